@@ -1,0 +1,57 @@
+// clip_kernels.h -- launchers of the gfx950 CLIP encoder kernels (internal; public ABI: include/clipx.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clipx {
+
+typedef __bf16 bf16;
+
+enum GemmEpilogue {
+  EPI_BIAS_BF16 = 0,        // out bf16 [M,N] = acc + bias                       (QKV projection)
+  EPI_BIAS_QGELU_BF16 = 1,  // out bf16 = quick_gelu(acc + bias)                 (fc1, OpenAI CLIP)
+  EPI_BIAS_GELU_BF16 = 2,   // out bf16 = gelu_erf(acc + bias)                   (fc1, open_clip LAION)
+  EPI_BIAS_RESID_F32 = 3,   // out f32 [M,N] += acc + bias   (in place residual) (out_proj, fc2)
+  EPI_TABLE_F32 = 4         // out f32 = acc + table[m % T][n]                   (patch embed + cls/pos)
+};
+
+struct GemmArgs {
+  const bf16* A;      // activations [M, K] row-major
+  const bf16* W;      // weights     [N, K] row-major (torch Linear layout)
+  const float* bias;  // [N] or null
+  void* out;          // [M, N] bf16 or f32
+  const float* table; // [T, N] (EPI_TABLE_F32)
+  int T;
+  int M, N, K;        // N % 128 == 0, K % 64 == 0
+  int epi;
+  int variant;        // 0 = register-staged LDS fill, 1 = global_load_lds
+};
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// x f32 [M, d] -> y (bf16 or f32) [M, d]; one wave per row; d % 256 == 0, d <= 2048
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, int M,
+                            int d, float eps, hipStream_t st);
+
+// pixels -> bf16 patch matrix [B*T, Kp] (row b*T is the all-zero class-token row; k = c*P*P + iy*P + ix)
+// fmt 0: f32 NCHW already normalised (the reference's `image_tensor`); fmt 1: u8 NHWC, normalised here
+hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int Kp, const float* mean,
+                         const float* inv_std, bf16* out, hipStream_t st);
+
+// qkv bf16 [B*T, 3*H*64] -> out bf16 [B*T, H*64]; softmax(q k^T / 8 [+ causal]) v, head dim 64
+hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st);
+
+// ids int32 [B, T] -> x f32 [B*T, d] = tok_emb[id] + pos_emb[t]
+hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T,
+                             int d, int vocab, hipStream_t st);
+
+// pooled row (CLS, or argmax(ids) for text) -> LayerNorm -> @ proj^T [E, d] -> / L2 norm -> fp16 [B, E]
+hipError_t launch_tail(const float* x, const int32_t* ids_or_null, const float* gamma, const float* beta,
+                       const bf16* proj, uint16_t* out_f16, float* out_f32_or_null, int B, int T, int d, int E,
+                       float eps, hipStream_t st);
+
+hipError_t launch_f32_to_bf16(const float* in, bf16* out, int64_t n, hipStream_t st);
+// conv weight [width, 3*P*P] f32 -> bf16 [width, Kp] zero padded
+hipError_t launch_pad_rows_bf16(const float* in, bf16* out, int rows, int k, int kp, hipStream_t st);
+
+}  // namespace clipx

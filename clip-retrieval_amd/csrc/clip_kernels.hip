@@ -1,0 +1,656 @@
+// clip_kernels.hip -- gfx950 kernels of the CLIP encoder forward (encode half of the hot path).
+//
+// These replace the torch ops executed inside `model.encode_image` / `model.encode_text`, called by the
+// reference at clip_retrieval/clip_inference/mapper.py:57,65 (and clip_back.py:230,244):
+//   conv1 patch-embed, class/pos embedding, ln_pre, L x { LN, QKV, MHA, out_proj(+res), LN, fc1+GELU, fc2(+res) },
+//   ln_post/ln_final, pooling, projection, L2 normalise, fp16 cast (mapper.py:58-59,66-67).
+// Numerics: bf16 MFMA operands, fp32 accumulation; the residual stream, LayerNorm statistics and softmax
+// stay in fp32 (SURVEY 7 "hard parts": 1e-3 cosine bar across 24-32 layers).
+//
+// HBM layouts
+//   activations  x    f32  [B*T, d]   residual stream (row = b*T + t)
+//                xn   bf16 [B*T, d]   LayerNorm output = GEMM operand
+//                qkv  bf16 [B*T, 3d]  (q | k | v, each [H][64])
+//                h    bf16 [B*T, mlp]
+//   weights      W    bf16 [N, K]     torch nn.Linear layout ("B^T"): both GEMM operands are K-contiguous
+//
+// GEMM: out[m, n] = sum_k A[m,k] W[n,k].  128x128x64 tiles, 4 waves (2x2), v_mfma_f32_32x32x16_bf16 with the
+// WEIGHT rows as the MFMA A operand and the activation rows as the B operand, so a lane's accumulator holds
+// four consecutive n of one m: epilogue stores are 8 B (bf16) / 16 B (f32) instead of 2-byte scatters.
+// LDS image per operand: [128 rows][8 chunks of 16 B], chunk position XOR ((row>>1)&7): ds_read_b128 fragment
+// reads of 16 rows at one k-chunk hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "clip_kernels.h"
+
+namespace clipx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ float quick_gelu(float v) { return v / (1.f + __expf(-1.702f * v)); }
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+
+// =============================================================================================
+// GEMM
+// =============================================================================================
+constexpr int G_TM = 128, G_TN = 128, G_BK = 64;
+constexpr int G_STAGE_BYTES = (G_TM + G_TN) * G_BK * 2;  // 32 KiB
+constexpr int G_GROUP_M = 8;
+
+template <int EPI, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                          const float* __restrict__ bias, void* __restrict__ outp,
+                                                          const float* __restrict__ table, int T, int M, int N,
+                                                          int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int wn = w & 1, wm = w >> 1;
+  const int hb = lane >> 5, l31 = lane & 31;
+
+  // ---- block -> tile: XCD-contiguous runs (block b executes on XCD b%8), grouped 8 m-tiles x all n-tiles
+  const int ntm = (M + G_TM - 1) / G_TM, ntn = N / G_TN;
+  const int nblk = ntm * ntn;
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int per_group = G_GROUP_M * ntn;
+  const int grp = logical / per_group, within = logical - grp * per_group;
+  const int gm0 = grp * G_GROUP_M;
+  const int gsz = (ntm - gm0) < G_GROUP_M ? (ntm - gm0) : G_GROUP_M;
+  const int tm = gm0 + within % gsz, tn = within / gsz;
+  const int m0 = tm * G_TM, n0 = tn * G_TN;
+
+  // ---- staging map: wave w fills rows [32w, 32w+32) of both operand tiles, 8 rows (1 KiB) per instruction
+  const bf16* gW[4];
+  const bf16* gA[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (w * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int am = m0 + row;
+    am = am < M ? am : M - 1;
+    gW[i] = W + (size_t)(n0 + row) * K + c * 8;
+    gA[i] = A + (size_t)am * K + c * 8;
+  }
+  const int stage_off = (w * 4) * 1024;  // + i*1024 (+ lane*16)
+
+  // ---- fragment read offsets (bytes inside an operand tile), one per k-step of the BK=64 slab
+  int foff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) foff[kk] = l31 * 128 + (((2 * kk + hb) ^ ((l31 >> 1) & 7)) << 4);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / G_BK;
+
+  auto compute = [&](int buf) {
+    const unsigned char* sW = smem + buf * G_STAGE_BYTES + (wn * 64) * 128;
+    const unsigned char* sA = smem + buf * G_STAGE_BYTES + G_TN * G_BK * 2 + (wm * 64) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 wf[2], af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sW + i * 32 * 128 + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) af[j] = *reinterpret_cast<const bf16x8*>(sA + j * 32 * 128 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (GLDS) {
+    auto issue = [&](int t, int buf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned char* dW = smem + buf * G_STAGE_BYTES + stage_off + i * 1024;
+        unsigned char* dA = dW + G_TN * G_BK * 2;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gW[i] + (size_t)t * G_BK), (lds_ptr_t)dW, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA[i] + (size_t)t * G_BK), (lds_ptr_t)dA, 16, 0, 0);
+      }
+    };
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+      compute(t & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // register-staged fill (T14 split): global loads for tile t+1 are issued before the MFMAs of tile t
+    // and written to LDS after them, so HBM/L2 latency hides under the compute
+    uint4 rw0, rw1, rw2, rw3, ra0, ra1, ra2, ra3;
+#define G_LOAD(t)                                                             \
+  {                                                                           \
+    rw0 = *reinterpret_cast<const uint4*>(gW[0] + (size_t)(t) * G_BK);        \
+    rw1 = *reinterpret_cast<const uint4*>(gW[1] + (size_t)(t) * G_BK);        \
+    rw2 = *reinterpret_cast<const uint4*>(gW[2] + (size_t)(t) * G_BK);        \
+    rw3 = *reinterpret_cast<const uint4*>(gW[3] + (size_t)(t) * G_BK);        \
+    ra0 = *reinterpret_cast<const uint4*>(gA[0] + (size_t)(t) * G_BK);        \
+    ra1 = *reinterpret_cast<const uint4*>(gA[1] + (size_t)(t) * G_BK);        \
+    ra2 = *reinterpret_cast<const uint4*>(gA[2] + (size_t)(t) * G_BK);        \
+    ra3 = *reinterpret_cast<const uint4*>(gA[3] + (size_t)(t) * G_BK);        \
+  }
+#define G_STORE(buf)                                                                        \
+  {                                                                                         \
+    unsigned char* dW = smem + (buf) * G_STAGE_BYTES + stage_off + lane * 16;               \
+    *reinterpret_cast<uint4*>(dW) = rw0;                                                    \
+    *reinterpret_cast<uint4*>(dW + 1024) = rw1;                                             \
+    *reinterpret_cast<uint4*>(dW + 2048) = rw2;                                             \
+    *reinterpret_cast<uint4*>(dW + 3072) = rw3;                                             \
+    *reinterpret_cast<uint4*>(dW + G_TN * G_BK * 2) = ra0;                                  \
+    *reinterpret_cast<uint4*>(dW + G_TN * G_BK * 2 + 1024) = ra1;                           \
+    *reinterpret_cast<uint4*>(dW + G_TN * G_BK * 2 + 2048) = ra2;                           \
+    *reinterpret_cast<uint4*>(dW + G_TN * G_BK * 2 + 3072) = ra3;                           \
+  }
+    G_LOAD(0)
+    G_STORE(0)
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) G_LOAD(t + 1)
+      compute(t & 1);
+      if (t + 1 < nk) G_STORE((t + 1) & 1)
+      __syncthreads();
+    }
+#undef G_LOAD
+#undef G_STORE
+  }
+
+  // ---- epilogue: lane (m = l31, n = (r&3) + 8*(r>>2) + 4*hb) of each 32x32 sub-tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + l31;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * hb;
+        float4 v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (EPI != EPI_TABLE_F32) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        if (EPI == EPI_BIAS_QGELU_BF16) { v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w); }
+        if (EPI == EPI_BIAS_GELU_BF16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+          bf16x4 o;
+          o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp) + (size_t)m * N + n) = o;
+        } else if (EPI == EPI_BIAS_RESID_F32) {
+          float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n);
+          float4 o = *p;
+          o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+          *p = o;
+        } else {  // EPI_TABLE_F32
+          const float4 t4 = *reinterpret_cast<const float4*>(table + (size_t)(m % T) * N + n);
+          v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+static hipError_t launch_gemm_epi(const GemmArgs& g, hipStream_t st) {
+  const int ntm = (g.M + G_TM - 1) / G_TM, ntn = g.N / G_TN;
+  const dim3 grid(ntm * ntn), block(256);
+  const size_t smem = 2 * G_STAGE_BYTES;
+  if (g.variant == 1) {
+    auto kern = gemm_bf16_kernel<EPI, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K);
+  } else {
+    auto kern = gemm_bf16_kernel<EPI, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+  if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
+  switch (g.epi) {
+    case EPI_BIAS_BF16: return launch_gemm_epi<EPI_BIAS_BF16>(g, st);
+    case EPI_BIAS_QGELU_BF16: return launch_gemm_epi<EPI_BIAS_QGELU_BF16>(g, st);
+    case EPI_BIAS_GELU_BF16: return launch_gemm_epi<EPI_BIAS_GELU_BF16>(g, st);
+    case EPI_BIAS_RESID_F32: return launch_gemm_epi<EPI_BIAS_RESID_F32>(g, st);
+    case EPI_TABLE_F32: return launch_gemm_epi<EPI_TABLE_F32>(g, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// =============================================================================================
+// LayerNorm: one wave per row, fp32 statistics (two-pass in registers)
+// =============================================================================================
+template <int NV, bool OUT_BF16>  // d = NV * 256
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, void* __restrict__ y, int M,
+                                                       float eps) {
+  constexpr int d = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    v[e] = xr[lane + 64 * e];
+    s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    const float a = v[e].x - mean, b = v[e].y - mean, c = v[e].z - mean, dd = v[e].w - mean;
+    q += (a * a + b * b) + (c * c + dd * dd);
+  }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.f / sqrtf(q * (1.f / d) + eps);
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    const int c4 = lane + 64 * e;
+    const float4 g4 = reinterpret_cast<const float4*>(gamma)[c4];
+    const float4 b4 = reinterpret_cast<const float4*>(beta)[c4];
+    float4 o;
+    o.x = (v[e].x - mean) * rstd * g4.x + b4.x;
+    o.y = (v[e].y - mean) * rstd * g4.y + b4.y;
+    o.z = (v[e].z - mean) * rstd * g4.z + b4.z;
+    o.w = (v[e].w - mean) * rstd * g4.w + b4.w;
+    if (OUT_BF16) {
+      bf16x4 ob;
+      ob[0] = (bf16)o.x; ob[1] = (bf16)o.y; ob[2] = (bf16)o.z; ob[3] = (bf16)o.w;
+      reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(y) + (size_t)row * d)[c4] = ob;
+    } else {
+      reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (size_t)row * d)[c4] = o;
+    }
+  }
+}
+
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, int M, int d,
+                            float eps, hipStream_t st) {
+  if (M <= 0) return hipSuccess;
+  const dim3 grid((M + 3) / 4), block(256);
+#define LN_CASE(NV)                                                                                           \
+  case NV * 256:                                                                                              \
+    if (out_bf16) hipLaunchKernelGGL((layernorm_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, y, M, eps); \
+    else hipLaunchKernelGGL((layernorm_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, y, M, eps);    \
+    break;
+  switch (d) {
+    LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef LN_CASE
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// im2col: pixels -> bf16 patch rows (+ the all-zero class-token row), 8 k per thread (16-B stores)
+// =============================================================================================
+template <int FMT>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ pixels, int B, int S, int P, int Kp,
+                                                    float m0, float m1, float m2, float i0, float i1, float i2,
+                                                    bf16* __restrict__ out) {
+  const int gdim = S / P, T = gdim * gdim + 1, PP = P * P, K = 3 * PP, nch = Kp / 8;
+  const int64_t total = (int64_t)B * T * nch;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % nch);
+    const int64_t row = idx / nch;
+    const int t = (int)(row % T), b = (int)(row / T);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = ch * 8 + e;
+      float v = 0.f;
+      if (t > 0 && k < K) {
+        const int c = k / PP, rem = k - c * PP;
+        const int iy = rem / P, ix = rem - iy * P;
+        const int py = (t - 1) / gdim, px = (t - 1) - py * gdim;
+        const int yy = py * P + iy, xx = px * P + ix;
+        if (FMT == 0) {
+          v = reinterpret_cast<const float*>(pixels)[(((size_t)b * 3 + c) * S + yy) * S + xx];
+        } else {
+          const float u = (float)reinterpret_cast<const unsigned char*>(pixels)[(((size_t)b * S + yy) * S + xx) * 3 + c];
+          const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), inv = c == 0 ? i0 : (c == 1 ? i1 : i2);
+          v = (u * (1.f / 255.f) - mean) * inv;
+        }
+      }
+      o[e] = (bf16)v;
+    }
+    *reinterpret_cast<bf16x8*>(out + (size_t)row * Kp + ch * 8) = o;
+  }
+}
+
+hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int Kp, const float* mean,
+                         const float* inv_std, bf16* out, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  const int gdim = S / P, T = gdim * gdim + 1;
+  const int64_t total = (int64_t)B * T * (Kp / 8);
+  const int blocks = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+  if (fmt == 0)
+    hipLaunchKernelGGL(im2col_kernel<0>, dim3(blocks), dim3(256), 0, st, pixels, B, S, P, Kp, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, out);
+  else
+    hipLaunchKernelGGL(im2col_kernel<1>, dim3(blocks), dim3(256), 0, st, pixels, B, S, P, Kp, mean[0], mean[1], mean[2],
+                       inv_std[0], inv_std[1], inv_std[2], out);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Attention (head dim 64): one workgroup per (batch, head); K (row-major, swizzled) and V^T in LDS.
+//   S^T = K Q^T   (MFMA A = K rows, B = Q rows): a lane holds 16 keys x NKB blocks of ONE query column
+//   softmax over the lane's registers + one exchange with lane^32; P stays in registers as the B operand
+//   O^T = V^T P^T (MFMA A = V^T rows from LDS, B = P): a lane ends with 4 consecutive d of its query -> 8-B stores
+// The MFMA contraction index of the PV product is a permutation of the key index (the order in which the
+// S^T accumulator registers hold keys); V^T fragments are read with the same permutation, so no lane
+// exchange is needed between the two products.
+// =============================================================================================
+constexpr int ATT_DH = 64;
+
+template <int NKB, int NW, int QPW, bool CAUSAL>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
+                                                           int H, float scale_log2e) {
+  constexpr int TP = NKB * 32;
+  constexpr int VT_STRIDE = TP * 2 + 8;  // bytes per V^T row: odd multiple of 8 -> conflict-free ds_read_b64
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;                 // [TP][128 B], chunk ^ ((key>>1)&7)
+  unsigned char* sVt = smem + TP * 128;     // [64][VT_STRIDE]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int hb = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int ld = 3 * H * ATT_DH;  // qkv row stride (elements)
+  const bf16* qbase = qkv + (size_t)b * T * ld + h * ATT_DH;
+  const bf16* kbase = qbase + H * ATT_DH;
+  const bf16* vbase = qbase + 2 * H * ATT_DH;
+
+  // ---- stage K: 8 lanes cover one key's 128 B
+  for (int i = tid; i < TP * 8; i += NW * 64) {
+    const int key = i >> 3, c = i & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (key < T) v = *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + c * 8);
+    *reinterpret_cast<uint4*>(sK + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = v;
+  }
+  // ---- stage V transposed: a thread takes keys (2kp, 2kp+1) x 8 d and writes 8 packed key-pairs
+  for (int i = tid; i < (TP / 2) * 8; i += NW * 64) {
+    const int kp = i >> 3, c = i & 7;
+    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+    uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = make_uint4(0u, 0u, 0u, 0u);
+    if (k0 < T) v0 = *reinterpret_cast<const uint4*>(vbase + (size_t)k0 * ld + c * 8);
+    if (k1 < T) v1 = *reinterpret_cast<const uint4*>(vbase + (size_t)k1 * ld + c * 8);
+    const unsigned a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const unsigned lo = (a0[jj] & 0xffffu) | (a1[jj] << 16);         // d = 8c + 2jj
+      const unsigned hi = (a0[jj] >> 16) | (a1[jj] & 0xffff0000u);     // d = 8c + 2jj + 1
+      *reinterpret_cast<unsigned*>(sVt + (8 * c + 2 * jj) * VT_STRIDE + kp * 4) = lo;
+      *reinterpret_cast<unsigned*>(sVt + (8 * c + 2 * jj + 1) * VT_STRIDE + kp * 4) = hi;
+    }
+  }
+  __syncthreads();
+
+  const int ksw = (l31 >> 1) & 7;
+#pragma unroll 1
+  for (int qi = 0; qi < QPW; ++qi) {
+    const int qb = w * QPW + qi;
+    if (qb >= NKB) break;
+    const int qpos = qb * 32 + l31;
+    // Q fragments straight from HBM (B operand: lane (q = l31, hb) holds Q[q][16s + 8hb .. +8])
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (qpos < T) v = *reinterpret_cast<const uint4*>(qbase + (size_t)qpos * ld + 16 * s + 8 * hb);
+      qf[s] = *reinterpret_cast<bf16x8*>(&v);
+    }
+    f32x16 sacc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * 128 + (((2 * s + hb) ^ ksw) << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+    // ---- softmax over keys (registers of this lane + lane^32)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+        const bool ok = key < T && (!CAUSAL || key <= qpos);
+        sacc[kb][r] = ok ? sacc[kb][r] : -INFINITY;
+        mx = fmaxf(mx, sacc[kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (mx == -INFINITY) mx = 0.f;  // padded query rows
+    float sum = 0.f;
+    bf16x8 pf[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f((sacc[kb][r] - mx) * scale_log2e);
+        sum += p;
+        pf[kb][r >> 3][r & 7] = (bf16)p;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+
+    // ---- O^T = V^T P^T
+    f32x16 oacc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          // lane (d = 32nb + l31, hb): keys kb*32 + 16*s2 + 4hb + {0..3} and + 8 + {0..3}
+          const unsigned char* vp = sVt + (32 * nb + l31) * VT_STRIDE + (kb * 32 + 16 * s2 + 4 * hb) * 2;
+          const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+          const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+          uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[kb][s2], oacc[nb], 0, 0, 0);
+        }
+    // ---- store: lane owns query qpos, d = 32nb + 8g + 4hb + {0..3}
+    if (qpos < T) {
+      bf16* orow = out + ((size_t)b * T + qpos) * (H * ATT_DH) + h * ATT_DH;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nb][4 * g + e] * inv);
+          *reinterpret_cast<bf16x4*>(orow + 32 * nb + 8 * g + 4 * hb) = o;
+        }
+    }
+  }
+}
+
+template <int NKB, int NW, int QPW>
+static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st) {
+  const size_t smem = (size_t)NKB * 32 * 128 + (size_t)64 * (NKB * 64 + 8);
+  const float scale_log2e = 0.125f * 1.4426950408889634f;
+  const dim3 grid(B * H), block(NW * 64);
+  if (causal) {
+    auto kern = attention_kernel<NKB, NW, QPW, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e);
+  } else {
+    auto kern = attention_kernel<NKB, NW, QPW, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  const int nkb = (T + 31) / 32;
+  switch (nkb) {
+    case 1: return launch_attention_cfg<1, 1, 1>(qkv, out, B, T, H, causal, st);
+    case 2: return launch_attention_cfg<2, 2, 1>(qkv, out, B, T, H, causal, st);   // ViT-B/32 image (T=50)
+    case 3: return launch_attention_cfg<3, 3, 1>(qkv, out, B, T, H, causal, st);   // text (T=77)
+    case 4: return launch_attention_cfg<4, 4, 1>(qkv, out, B, T, H, causal, st);
+    case 5: return launch_attention_cfg<5, 3, 2>(qkv, out, B, T, H, causal, st);
+    case 6: return launch_attention_cfg<6, 3, 2>(qkv, out, B, T, H, causal, st);
+    case 7: return launch_attention_cfg<7, 4, 2>(qkv, out, B, T, H, causal, st);   // ViT-B/16 image (T=197)
+    case 8: return launch_attention_cfg<8, 4, 2>(qkv, out, B, T, H, causal, st);
+    case 9: return launch_attention_cfg<9, 3, 3>(qkv, out, B, T, H, causal, st);   // ViT-L/14, H/14 image (T=257)
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// =============================================================================================
+// text embedding gather
+// =============================================================================================
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
+                                                        const float* __restrict__ pos, float* __restrict__ x, int BT,
+                                                        int T, int d, int vocab) {
+  const int d4 = d / 4;
+  const int64_t total = (int64_t)BT * d4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % d4);
+    const int row = (int)(idx / d4);
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float4 a = reinterpret_cast<const float4*>(tok + (size_t)id * d)[c];
+    const float4 p = reinterpret_cast<const float4*>(pos + (size_t)(row % T) * d)[c];
+    reinterpret_cast<float4*>(x + (size_t)row * d)[c] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T, int d,
+                             int vocab, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  const int64_t total = (int64_t)B * T * (d / 4);
+  const int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(text_embed_kernel, dim3(blocks), dim3(256), 0, st, ids, tok_emb, pos_emb, x, B * T, T, d, vocab);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// tail: pool -> LayerNorm -> projection -> L2 normalise -> fp16   (mapper.py:58-59, 66-67)
+// =============================================================================================
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const bf16* __restrict__ proj, uint16_t* __restrict__ out_f16,
+                                                  float* __restrict__ out_f32, int T, int d, int E, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* y = reinterpret_cast<float*>(smem);  // [d]
+  float* o = y + d;                           // [E]
+  float* red = o + E;                         // [4]   (all LDS in the one dynamic region: guide G17)
+  int* s_posp = reinterpret_cast<int*>(red + 4);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int best = 0;
+    if (ids) {  // EOT token = highest id; first occurrence (torch.argmax semantics of the reference model)
+      int bv = ids[(size_t)b * T];
+      for (int t = 1; t < T; ++t) {
+        const int v = ids[(size_t)b * T + t];
+        if (v > bv) { bv = v; best = t; }
+      }
+    }
+    *s_posp = best;
+  }
+  __syncthreads();
+  const float* xr = x + ((size_t)b * T + *s_posp) * d;
+  float s = 0.f;
+  for (int c = tid; c < d; c += 256) { y[c] = xr[c]; s += y[c]; }
+  const float mean = block_sum_256(s, red) / d;
+  float q = 0.f;
+  for (int c = tid; c < d; c += 256) { const float a = y[c] - mean; q += a * a; }
+  const float rstd = 1.f / sqrtf(block_sum_256(q, red) / d + eps);
+  for (int c = tid; c < d; c += 256) y[c] = (y[c] - mean) * rstd * gamma[c] + beta[c];
+  __syncthreads();
+  float ss = 0.f;
+  for (int e = tid; e < E; e += 256) {
+    const bf16x8* pr = reinterpret_cast<const bf16x8*>(proj + (size_t)e * d);
+    float acc = 0.f;
+    for (int c8 = 0; c8 < d / 8; ++c8) {
+      const bf16x8 pw = pr[c8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += y[c8 * 8 + j] * (float)pw[j];
+    }
+    o[e] = acc;
+    ss += acc * acc;
+  }
+  const float nrm = sqrtf(block_sum_256(ss, red));
+  for (int e = tid; e < E; e += 256) {
+    const float v = o[e] / nrm;  // no epsilon: mapper.py:58 divides by the raw norm
+    const _Float16 hv = (_Float16)v;
+    out_f16[(size_t)b * E + e] = *reinterpret_cast<const uint16_t*>(&hv);
+    if (out_f32) out_f32[(size_t)b * E + e] = v;
+  }
+}
+
+hipError_t launch_tail(const float* x, const int32_t* ids_or_null, const float* gamma, const float* beta, const bf16* proj,
+                       uint16_t* out_f16, float* out_f32_or_null, int B, int T, int d, int E, float eps, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  const size_t smem = (size_t)(d + E + 8) * sizeof(float);
+  hipLaunchKernelGGL(tail_kernel, dim3(B), dim3(256), smem, st, x, ids_or_null, gamma, beta, proj, out_f16,
+                     out_f32_or_null, T, d, E, eps);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// weight conversion
+// =============================================================================================
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (bf16)in[i];
+}
+hipError_t launch_f32_to_bf16(const float* in, bf16* out, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+__global__ void pad_rows_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, int rows, int k, int kp) {
+  const int64_t total = (int64_t)rows * kp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / kp), c = (int)(i % kp);
+    out[i] = c < k ? (bf16)in[(size_t)r * k + c] : (bf16)0.f;
+  }
+}
+hipError_t launch_pad_rows_bf16(const float* in, bf16* out, int rows, int k, int kp, hipStream_t st) {
+  hipLaunchKernelGGL(pad_rows_bf16_kernel, dim3(1024), dim3(256), 0, st, in, out, rows, k, kp);
+  return hipGetLastError();
+}
+
+}  // namespace clipx

@@ -1,0 +1,529 @@
+// clipx_api.hip -- host side of the C ABI declared in include/clipx.h (encode half of the hot path).
+//
+// Stands in for `model.encode_image` / `model.encode_text` + normalise + fp16 as called by
+// ClipMapper.__call__ (reference clip_retrieval/clip_inference/mapper.py:49-78).  Owns the bf16/f32
+// weights in HBM, one activation workspace sized for `max_batch`, a compute stream, a copy stream
+// and two pinned staging slots (H2D of chunk n+1 overlaps the kernels of chunk n).
+// There is deliberately no CPU compute path: without a gfx950 device every entry point fails.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/clipx.h"
+#include "clip_kernels.h"
+
+using namespace clipx;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return fail(_e == hipErrorOutOfMemory ? CLIPX_E_NOMEM : CLIPX_E_HIP,                \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+  } while (0)
+
+extern "C" const char* clipx_last_error(void) { return g_err.c_str(); }
+
+namespace {
+
+struct LayerW {
+  const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;  // into the f32 device blob
+  bf16 *qkv_w, *out_w, *fc1_w, *fc2_w;                                          // bf16 copies
+};
+
+struct Tower {
+  int width = 0, layers = 0, heads = 0, mlp = 0, T = 0;
+  std::vector<LayerW> L;
+  const float *lnf_w = nullptr, *lnf_b = nullptr;  // ln_post / ln_final
+  bf16* proj = nullptr;                            // [embed, width]
+};
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int kind;
+  double flops;
+};
+
+}  // namespace
+
+struct clipx_handle {
+  clipx_model_desc desc{};
+  int device = 0;
+  int max_batch = 256;
+  int gemm_variant = 1;
+  std::mutex mu;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+
+  float* blob_dev = nullptr;  // the whole f32 blob (LayerNorm params, biases, embeddings live here)
+  std::vector<void*> owned;   // every other device allocation
+  Tower vis, txt;
+  int Kp = 0, PP3 = 0;
+  bf16* conv_w = nullptr;       // [v_width, Kp]
+  float* clspos = nullptr;      // [T_v, v_width]: row 0 = class + pos[0], row t = pos[t]
+  const float *ln_pre_w = nullptr, *ln_pre_b = nullptr;
+  const float *tok_emb = nullptr, *txt_pos = nullptr;
+  float *mean_dev = nullptr;
+
+  // activation workspace (shared by both towers)
+  float* x = nullptr;
+  bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;
+
+  // host hand-over: two slots
+  void* pin_in[2] = {nullptr, nullptr};
+  void* pin_out[2] = {nullptr, nullptr};
+  void* dev_in[2] = {nullptr, nullptr};
+  uint16_t* dev_out[2] = {nullptr, nullptr};
+  size_t in_slot_bytes = 0, out_slot_bytes = 0;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+
+  bool prof = false;
+  std::vector<ProfEvent> prof_events;
+};
+
+static int dev_alloc(clipx_handle* h, void** p, size_t bytes) {
+  HIPCHK(hipMalloc(p, bytes));
+  h->owned.push_back(*p);
+  return 0;
+}
+
+extern "C" size_t clipx_blob_floats(const clipx_model_desc* d) {
+  if (!d) return 0;
+  auto layer = [](size_t w, size_t mlp) {
+    return 2 * w + 3 * w * w + 3 * w + w * w + w + 2 * w + mlp * w + mlp + w * mlp + w;
+  };
+  const size_t g = d->image_size / d->patch_size, Tv = g * g + 1;
+  const size_t w = d->v_width, tw = d->t_width, E = d->embed_dim;
+  size_t n = w * 3 * d->patch_size * d->patch_size + w + Tv * w + 2 * w;
+  n += (size_t)d->v_layers * layer(w, d->v_mlp) + 2 * w + E * w;
+  n += (size_t)d->vocab * tw + (size_t)d->ctx_len * tw;
+  n += (size_t)d->t_layers * layer(tw, d->t_mlp) + 2 * tw + E * tw;
+  return n;
+}
+
+static int check_desc(const clipx_model_desc* d) {
+  if (d->image_size <= 0 || d->patch_size <= 0 || d->image_size % d->patch_size) return fail(CLIPX_E_ARG, "image_size must be a multiple of patch_size");
+  if (d->v_width % 256 || d->t_width % 256) return fail(CLIPX_E_UNSUPPORTED, "tower widths must be multiples of 256");
+  if (d->v_width / d->v_heads != 64 || d->t_width / d->t_heads != 64 || d->v_width % d->v_heads || d->t_width % d->t_heads)
+    return fail(CLIPX_E_UNSUPPORTED, "this build has attention kernels for head dimension 64 only");
+  if (d->v_mlp % 128 || d->t_mlp % 128) return fail(CLIPX_E_UNSUPPORTED, "mlp widths must be multiples of 128");
+  const int g = d->image_size / d->patch_size;
+  if (g * g + 1 > 288 || d->ctx_len > 288) return fail(CLIPX_E_UNSUPPORTED, "sequence longer than 288 tokens");
+  if (d->embed_dim <= 0 || d->embed_dim % 8) return fail(CLIPX_E_ARG, "embed_dim must be a multiple of 8");
+  if (d->act != CLIPX_ACT_QUICK_GELU && d->act != CLIPX_ACT_GELU) return fail(CLIPX_E_ARG, "unknown activation");
+  if (d->v_layers <= 0 || d->t_layers <= 0 || d->vocab <= 0 || d->ctx_len <= 0) return fail(CLIPX_E_ARG, "bad layer/vocab/context size");
+  return 0;
+}
+
+// carve one transformer tower's per-layer parameters out of the device blob, converting matrices to bf16
+static int carve_layers(clipx_handle* h, Tower& t, float*& p) {
+  const size_t w = t.width, mlp = t.mlp;
+  t.L.resize(t.layers);
+  for (int l = 0; l < t.layers; ++l) {
+    LayerW& L = t.L[l];
+    L.ln1_w = p; p += w;
+    L.ln1_b = p; p += w;
+    const float* qkv_w32 = p; p += 3 * w * w;
+    L.qkv_b = p; p += 3 * w;
+    const float* out_w32 = p; p += w * w;
+    L.out_b = p; p += w;
+    L.ln2_w = p; p += w;
+    L.ln2_b = p; p += w;
+    const float* fc1_w32 = p; p += mlp * w;
+    L.fc1_b = p; p += mlp;
+    const float* fc2_w32 = p; p += w * mlp;
+    L.fc2_b = p; p += w;
+    int r;
+    if ((r = dev_alloc(h, (void**)&L.qkv_w, 3 * w * w * sizeof(bf16)))) return r;
+    if ((r = dev_alloc(h, (void**)&L.out_w, w * w * sizeof(bf16)))) return r;
+    if ((r = dev_alloc(h, (void**)&L.fc1_w, mlp * w * sizeof(bf16)))) return r;
+    if ((r = dev_alloc(h, (void**)&L.fc2_w, w * mlp * sizeof(bf16)))) return r;
+    HIPCHK(launch_f32_to_bf16(qkv_w32, L.qkv_w, (int64_t)(3 * w * w), h->stream));
+    HIPCHK(launch_f32_to_bf16(out_w32, L.out_w, (int64_t)(w * w), h->stream));
+    HIPCHK(launch_f32_to_bf16(fc1_w32, L.fc1_w, (int64_t)(mlp * w), h->stream));
+    HIPCHK(launch_f32_to_bf16(fc2_w32, L.fc2_w, (int64_t)(w * mlp), h->stream));
+  }
+  return 0;
+}
+
+static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
+  const clipx_model_desc& d = h->desc;
+  const int g = d.image_size / d.patch_size;
+  Tower& V = h->vis;
+  Tower& X = h->txt;
+  V.width = d.v_width; V.layers = d.v_layers; V.heads = d.v_heads; V.mlp = d.v_mlp; V.T = g * g + 1;
+  X.width = d.t_width; X.layers = d.t_layers; X.heads = d.t_heads; X.mlp = d.t_mlp; X.T = d.ctx_len;
+  h->PP3 = 3 * d.patch_size * d.patch_size;
+  h->Kp = (h->PP3 + 63) / 64 * 64;
+  const size_t E = d.embed_dim;
+
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc((void**)&h->blob_dev, blob_floats * sizeof(float)));
+  HIPCHK(hipMemcpy(h->blob_dev, blob, blob_floats * sizeof(float), hipMemcpyHostToDevice));
+
+  int r;
+  float* p = h->blob_dev;
+  // ---- vision
+  const float* conv32 = p; p += (size_t)V.width * h->PP3;
+  const float* cls = p; p += V.width;
+  const float* vpos = p; p += (size_t)V.T * V.width;
+  h->ln_pre_w = p; p += V.width;
+  h->ln_pre_b = p; p += V.width;
+  if ((r = dev_alloc(h, (void**)&h->conv_w, (size_t)V.width * h->Kp * sizeof(bf16)))) return r;
+  HIPCHK(launch_pad_rows_bf16(conv32, h->conv_w, V.width, h->PP3, h->Kp, h->stream));
+  if ((r = dev_alloc(h, (void**)&h->clspos, (size_t)V.T * V.width * sizeof(float)))) return r;
+  HIPCHK(hipMemcpyAsync(h->clspos, vpos, (size_t)V.T * V.width * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  {  // row 0 += class embedding (host arithmetic on a tiny row, then upload)
+    const size_t off_cls = (size_t)(cls - h->blob_dev), off_pos = (size_t)(vpos - h->blob_dev);
+    std::vector<float> row0(V.width);
+    for (int i = 0; i < V.width; ++i) row0[i] = blob[off_cls + i] + blob[off_pos + i];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->clspos, row0.data(), V.width * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if ((r = carve_layers(h, V, p))) return r;
+  V.lnf_w = p; p += V.width;
+  V.lnf_b = p; p += V.width;
+  const float* vproj32 = p; p += E * V.width;
+  if ((r = dev_alloc(h, (void**)&V.proj, E * V.width * sizeof(bf16)))) return r;
+  HIPCHK(launch_f32_to_bf16(vproj32, V.proj, (int64_t)(E * V.width), h->stream));
+  // ---- text
+  h->tok_emb = p; p += (size_t)d.vocab * X.width;
+  h->txt_pos = p; p += (size_t)X.T * X.width;
+  if ((r = carve_layers(h, X, p))) return r;
+  X.lnf_w = p; p += X.width;
+  X.lnf_b = p; p += X.width;
+  const float* tproj32 = p; p += E * X.width;
+  if ((r = dev_alloc(h, (void**)&X.proj, E * X.width * sizeof(bf16)))) return r;
+  HIPCHK(launch_f32_to_bf16(tproj32, X.proj, (int64_t)(E * X.width), h->stream));
+  if ((size_t)(p - h->blob_dev) != blob_floats) return fail(CLIPX_E_ARG, "internal: blob carve does not match clipx_blob_floats");
+
+  // ---- workspace
+  const size_t Bm = h->max_batch;
+  const size_t rowsV = Bm * V.T, rowsX = Bm * X.T;
+  const size_t nx = std::max(rowsV * V.width, rowsX * X.width);
+  const size_t nqkv = std::max(rowsV * 3 * V.width, rowsX * 3 * X.width);
+  const size_t nh = std::max(rowsV * V.mlp, rowsX * X.mlp);
+  if ((r = dev_alloc(h, (void**)&h->x, nx * sizeof(float)))) return r;
+  if ((r = dev_alloc(h, (void**)&h->xn, nx * sizeof(bf16)))) return r;
+  if ((r = dev_alloc(h, (void**)&h->qkv, nqkv * sizeof(bf16)))) return r;
+  if ((r = dev_alloc(h, (void**)&h->att, nx * sizeof(bf16)))) return r;
+  if ((r = dev_alloc(h, (void**)&h->hbuf, nh * sizeof(bf16)))) return r;
+  if ((r = dev_alloc(h, (void**)&h->patches, rowsV * h->Kp * sizeof(bf16)))) return r;
+
+  // ---- host hand-over slots
+  h->in_slot_bytes = std::max((size_t)Bm * 3 * d.image_size * d.image_size * sizeof(float), (size_t)Bm * d.ctx_len * sizeof(int32_t));
+  h->out_slot_bytes = Bm * E * sizeof(uint16_t);
+  for (int s = 0; s < 2; ++s) {
+    HIPCHK(hipHostMalloc(&h->pin_in[s], h->in_slot_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&h->pin_out[s], h->out_slot_bytes, hipHostMallocDefault));
+    if ((r = dev_alloc(h, &h->dev_in[s], h->in_slot_bytes))) return r;
+    if ((r = dev_alloc(h, (void**)&h->dev_out[s], h->out_slot_bytes))) return r;
+    HIPCHK(hipEventCreateWithFlags(&h->ev_copied[s], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, size_t blob_floats, int device,
+                            clipx_handle** out) {
+  if (!desc || !blob || !out) return fail(CLIPX_E_ARG, "null argument");
+  *out = nullptr;
+  int r = check_desc(desc);
+  if (r) return r;
+  if (blob_floats != clipx_blob_floats(desc)) return fail(CLIPX_E_ARG, "weight blob has the wrong number of floats for this model description");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(CLIPX_E_ARG, "no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(CLIPX_E_UNSUPPORTED, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  clipx_handle* h = new clipx_handle();
+  h->desc = *desc;
+  h->device = device;
+  const char* mb = getenv("CLIPX_MAX_BATCH");
+  if (mb && atoi(mb) > 0) h->max_batch = atoi(mb);
+  const char* gv = getenv("CLIPX_GEMM_VARIANT");
+  if (gv) h->gemm_variant = atoi(gv) ? 1 : 0;
+  r = create_impl(h, blob, blob_floats);
+  if (r) {
+    std::string keep = g_err;
+    clipx_destroy(h);
+    g_err = keep;
+    return r;
+  }
+  *out = h;
+  return CLIPX_OK;
+}
+
+extern "C" void clipx_destroy(clipx_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+  for (auto& e : h->prof_events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  for (void* p : h->owned) (void)hipFree(p);
+  if (h->blob_dev) (void)hipFree(h->blob_dev);
+  for (int s = 0; s < 2; ++s) {
+    if (h->pin_in[s]) (void)hipHostFree(h->pin_in[s]);
+    if (h->pin_out[s]) (void)hipHostFree(h->pin_out[s]);
+    if (h->ev_copied[s]) (void)hipEventDestroy(h->ev_copied[s]);
+    if (h->ev_done[s]) (void)hipEventDestroy(h->ev_done[s]);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  delete h;
+}
+
+extern "C" int clipx_max_batch(const clipx_handle* h) { return h ? h->max_batch : 0; }
+extern "C" int clipx_embed_dim(const clipx_handle* h) { return h ? h->desc.embed_dim : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers with optional event bracketing
+// ---------------------------------------------------------------------------------------------
+struct ProfScope {
+  clipx_handle* h;
+  hipStream_t st;
+  hipEvent_t a = nullptr, b = nullptr;
+  int kind;
+  double flops;
+  ProfScope(clipx_handle* h_, hipStream_t st_, int kind_, double flops_) : h(h_), st(st_), kind(kind_), flops(flops_) {
+    if (h->prof) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, st);
+    }
+  }
+  ~ProfScope() {
+    if (h->prof && a && b) {
+      (void)hipEventRecord(b, st);
+      h->prof_events.push_back({a, b, kind, flops});
+    }
+  }
+};
+
+static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* W, const float* bias, void* out,
+                    const float* table, int T, int M, int N, int K, int epi) {
+  GemmArgs g{};
+  g.A = A; g.W = W; g.bias = bias; g.out = out; g.table = table; g.T = T;
+  g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant;
+  ProfScope ps(h, st, 0, 2.0 * M * (double)N * K);
+  HIPCHK(launch_gemm(g, st));
+  return 0;
+}
+
+static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, int causal) {
+  const int M = B * t.T, w = t.width;
+  const float eps = h->desc.ln_eps;
+  const int act = h->desc.act == CLIPX_ACT_QUICK_GELU ? EPI_BIAS_QGELU_BF16 : EPI_BIAS_GELU_BF16;
+  for (int l = 0; l < t.layers; ++l) {
+    const LayerW& L = t.L[l];
+    int r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, L.ln1_w, L.ln1_b, h->xn, 1, M, w, eps, st)); }
+    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_b, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16))) return r;
+    { ProfScope ps(h, st, 1, 4.0 * B * t.heads * (double)t.T * t.T * 64); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, causal, st)); }
+    if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->x, nullptr, 1, M, w, w, EPI_BIAS_RESID_F32))) return r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, L.ln2_w, L.ln2_b, h->xn, 1, M, w, eps, st)); }
+    if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_b, h->hbuf, nullptr, 1, M, t.mlp, w, act))) return r;
+    if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->x, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_F32))) return r;
+  }
+  return 0;
+}
+
+// one chunk (B <= max_batch), everything on the device, asynchronous on `st`
+static int vision_chunk(clipx_handle* h, hipStream_t st, const void* pix_dev, int B, int fmt, uint16_t* out_f16,
+                        float* out_f32) {
+  const clipx_model_desc& d = h->desc;
+  const Tower& V = h->vis;
+  const int M = B * V.T;
+  float inv_std[3] = {1.f / d.pix_std[0], 1.f / d.pix_std[1], 1.f / d.pix_std[2]};
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_im2col(pix_dev, fmt, B, d.image_size, d.patch_size, h->Kp, d.pix_mean, inv_std, h->patches, st)); }
+  int r = run_gemm(h, st, h->patches, h->conv_w, nullptr, h->x, h->clspos, V.T, M, V.width, h->Kp, EPI_TABLE_F32);
+  if (r) return r;
+  { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, h->ln_pre_w, h->ln_pre_b, h->x, 0, M, V.width, d.ln_eps, st)); }
+  if ((r = run_layers(h, st, V, B, 0))) return r;
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, B, V.T, V.width, d.embed_dim, d.ln_eps, st)); }
+  return 0;
+}
+
+static int text_chunk(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32) {
+  const clipx_model_desc& d = h->desc;
+  const Tower& X = h->txt;
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, h->x, B, X.T, X.width, d.vocab, st)); }
+  int r = run_layers(h, st, X, B, 1);
+  if (r) return r;
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, B, X.T, X.width, d.embed_dim, d.ln_eps, st)); }
+  return 0;
+}
+
+static size_t pix_bytes_per_image(const clipx_model_desc& d, int fmt) {
+  const size_t px = (size_t)3 * d.image_size * d.image_size;
+  return fmt == CLIPX_PIX_F32_NCHW ? px * sizeof(float) : px;
+}
+
+extern "C" int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, int pix_fmt, uint16_t* out_f16_dev,
+                                         float* out_f32_or_null, void* stream) {
+  if (!h || !pixels_dev || !out_f16_dev || B < 0) return fail(CLIPX_E_ARG, "bad encode_image arguments");
+  if (pix_fmt != CLIPX_PIX_F32_NCHW && pix_fmt != CLIPX_PIX_U8_NHWC) return fail(CLIPX_E_ARG, "unknown pixel format");
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const size_t ib = pix_bytes_per_image(h->desc, pix_fmt), E = h->desc.embed_dim;
+  for (int o = 0; o < B; o += h->max_batch) {
+    const int nb = std::min(h->max_batch, B - o);
+    int r = vision_chunk(h, st, (const char*)pixels_dev + (size_t)o * ib, nb, pix_fmt, out_f16_dev + (size_t)o * E,
+                         out_f32_or_null ? out_f32_or_null + (size_t)o * E : nullptr);
+    if (r) return r;
+  }
+  return CLIPX_OK;
+}
+
+extern "C" int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,
+                                        float* out_f32_or_null, void* stream) {
+  if (!h || !ids_dev || !out_f16_dev || B < 0) return fail(CLIPX_E_ARG, "bad encode_text arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const size_t E = h->desc.embed_dim;
+  for (int o = 0; o < B; o += h->max_batch) {
+    const int nb = std::min(h->max_batch, B - o);
+    int r = text_chunk(h, st, ids_dev + (size_t)o * h->desc.ctx_len, nb, out_f16_dev + (size_t)o * E,
+                       out_f32_or_null ? out_f32_or_null + (size_t)o * E : nullptr);
+    if (r) return r;
+  }
+  return CLIPX_OK;
+}
+
+// Host-buffer path: chunks of max_batch flow through two slots.  The CPU fills slot s^1's pinned buffer
+// and the copy stream uploads it while the compute stream is still running the kernels of slot s.
+template <typename ChunkFn>
+static int host_pipeline(clipx_handle* h, const char* in, size_t in_bytes_per_item, int B, uint16_t* out, ChunkFn fn) {
+  const size_t E = h->desc.embed_dim;
+  const int nchunk = (B + h->max_batch - 1) / h->max_batch;
+  auto drain = [&](int c) -> int {  // copy chunk c's result out of its pinned slot
+    const int s = c & 1, o = c * h->max_batch, nb = std::min(h->max_batch, B - o);
+    HIPCHK(hipEventSynchronize(h->ev_done[s]));
+    memcpy(out + (size_t)o * E, h->pin_out[s], (size_t)nb * E * sizeof(uint16_t));
+    return 0;
+  };
+  for (int c = 0; c < nchunk; ++c) {
+    const int s = c & 1, o = c * h->max_batch, nb = std::min(h->max_batch, B - o);
+    int r;
+    if (c >= 2 && (r = drain(c - 2))) return r;  // slot s is free once chunk c-2 has been copied out
+    memcpy(h->pin_in[s], in + (size_t)o * in_bytes_per_item, (size_t)nb * in_bytes_per_item);
+    HIPCHK(hipMemcpyAsync(h->dev_in[s], h->pin_in[s], (size_t)nb * in_bytes_per_item, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(hipEventRecord(h->ev_copied[s], h->copy_stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copied[s], 0));
+    if ((r = fn(h->dev_in[s], nb, h->dev_out[s]))) return r;
+    HIPCHK(hipMemcpyAsync(h->pin_out[s], h->dev_out[s], (size_t)nb * E * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
+  }
+  for (int c = std::max(0, nchunk - 2); c < nchunk; ++c) {
+    int r = drain(c);
+    if (r) return r;
+  }
+  return 0;
+}
+
+extern "C" int clipx_encode_image(clipx_handle* h, const void* pixels, int B, int pix_fmt, uint16_t* out_f16) {
+  if (!h || (B > 0 && (!pixels || !out_f16)) || B < 0) return fail(CLIPX_E_ARG, "bad encode_image arguments");
+  if (pix_fmt != CLIPX_PIX_F32_NCHW && pix_fmt != CLIPX_PIX_U8_NHWC) return fail(CLIPX_E_ARG, "unknown pixel format");
+  if (B == 0) return CLIPX_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  return host_pipeline(h, (const char*)pixels, pix_bytes_per_image(h->desc, pix_fmt), B, out_f16,
+                       [&](void* din, int nb, uint16_t* dout) { return vision_chunk(h, h->stream, din, nb, pix_fmt, dout, nullptr); });
+}
+
+extern "C" int clipx_encode_text(clipx_handle* h, const int32_t* ids, int B, uint16_t* out_f16) {
+  if (!h || (B > 0 && (!ids || !out_f16)) || B < 0) return fail(CLIPX_E_ARG, "bad encode_text arguments");
+  if (B == 0) return CLIPX_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  return host_pipeline(h, (const char*)ids, (size_t)h->desc.ctx_len * sizeof(int32_t), B, out_f16,
+                       [&](void* din, int nb, uint16_t* dout) { return text_chunk(h, h->stream, (const int32_t*)din, nb, dout, nullptr); });
+}
+
+extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out,
+                                      int M, int N, int K, int epi, void* stream) {
+  if (!A_bf16 || !W_bf16 || !out || M <= 0 || N <= 0 || K <= 0) return fail(CLIPX_E_ARG, "bad gemm arguments");
+  if (epi < 0 || epi > 3 || !bias) return fail(CLIPX_E_ARG, "epi must be 0..3 and bias non-null");
+  if (N % 128 || K % 64) return fail(CLIPX_E_UNSUPPORTED, "N must be a multiple of 128 and K of 64");
+  HIPCHK(hipSetDevice(device));
+  GemmArgs g{};
+  g.A = (const bf16*)A_bf16; g.W = (const bf16*)W_bf16; g.bias = bias; g.out = out; g.table = nullptr; g.T = 1;
+  g.M = M; g.N = N; g.K = K; g.epi = epi;
+  const char* gv = getenv("CLIPX_GEMM_VARIANT");
+  g.variant = gv ? (atoi(gv) ? 1 : 0) : 1;
+  HIPCHK(launch_gemm(g, (hipStream_t)stream));
+  return CLIPX_OK;
+}
+
+extern "C" int clipx_attention_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int causal,
+                                      void* stream) {
+  if (!qkv_bf16 || !out_bf16 || B <= 0 || T <= 0 || H <= 0) return fail(CLIPX_E_ARG, "bad attention arguments");
+  if (T > 288) return fail(CLIPX_E_UNSUPPORTED, "sequence longer than 288 tokens");
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(launch_attention((const bf16*)qkv_bf16, (bf16*)out_bf16, B, T, H, causal, (hipStream_t)stream));
+  return CLIPX_OK;
+}
+
+extern "C" int clipx_layernorm_device(int device, const float* x, const float* gamma, const float* beta, void* y,
+                                      int out_bf16, int M, int d, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || M <= 0) return fail(CLIPX_E_ARG, "bad layernorm arguments");
+  if (d % 256 || d > 2048) return fail(CLIPX_E_UNSUPPORTED, "d must be a multiple of 256, <= 2048");
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(launch_layernorm(x, gamma, beta, y, out_bf16, M, d, eps, (hipStream_t)stream));
+  return CLIPX_OK;
+}
+
+extern "C" int clipx_profile_enable(clipx_handle* h, int on) {
+  if (!h) return fail(CLIPX_E_ARG, "handle is null");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->prof = on != 0;
+  return CLIPX_OK;
+}
+
+extern "C" int clipx_profile_get(clipx_handle* h, int kind, int64_t* launches, double* ms, double* flops) {
+  if (!h) return fail(CLIPX_E_ARG, "handle is null");
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  int64_t n = 0;
+  double t = 0.0, f = 0.0;
+  std::vector<ProfEvent> keep;
+  for (auto& e : h->prof_events) {
+    if (e.kind != kind) {
+      keep.push_back(e);
+      continue;
+    }
+    HIPCHK(hipEventSynchronize(e.b));
+    float dt = 0.f;
+    HIPCHK(hipEventElapsedTime(&dt, e.a, e.b));
+    t += dt;
+    f += e.flops;
+    ++n;
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  h->prof_events.swap(keep);
+  if (launches) *launches = n;
+  if (ms) *ms = t;
+  if (flops) *flops = f;
+  return CLIPX_OK;
+}

@@ -1,0 +1,52 @@
+// knn_kernels.h -- launchers of the gfx950 kNN kernels (internal; the public ABI is include/knnx.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace knnx {
+
+constexpr int KNN_NQ = 32;     // query columns of one scan (MFMA N dimension)
+constexpr int KNN_WAVES = 8;   // waves per workgroup, one 32-row tile each
+constexpr int KNN_WG = KNN_WAVES * 64;
+constexpr float KNN_LO_SCALE = 2048.f;
+constexpr float KNN_LO_INV = 1.f / 2048.f;
+constexpr int KNN_LDS_BYTES = 160 * 1024;
+
+struct ScanArgs {
+  const _Float16* X;
+  int64_t N;
+  int d;
+  const _Float16* qfrag;
+  int nq;
+  int k;
+  int cap;
+  int grid;
+  int mode;  // 0 top-k, 1 range
+  int nt;    // 1 = nontemporal X loads (A/B switch, KNNX_NT=1)
+  int* thr_g;
+  float* part_s;
+  uint32_t* part_i;
+  int* part_n;
+  float range_thr;
+  unsigned* range_cnt;
+  unsigned range_cap;
+  float* range_s;
+  uint32_t* range_i;
+};
+
+size_t scan_smem_bytes(int d, int cap);
+hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_g, unsigned* range_cnt,
+                       hipStream_t st);
+hipError_t launch_scan(const ScanArgs& a, hipStream_t st);
+hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
+                            int nq, int k, int64_t id_base, float* D, int64_t* I, hipStream_t st);
+hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
+                            int64_t* I, hipStream_t st);
+hipError_t launch_gather(const _Float16* X, int64_t N, int d, int64_t id_base, const int64_t* ids, int64_t n,
+                         float* out, hipStream_t st);
+hipError_t launch_f32_to_f16(const float* in, _Float16* out, int64_t n, hipStream_t st);
+hipError_t launch_range_sort(const float* rs, const uint32_t* ri, const unsigned* cnt, unsigned cap,
+                             const int64_t* lims, int64_t id_base, int nq, float* D, int64_t* I, hipStream_t st);
+hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st);
+
+}  // namespace knnx

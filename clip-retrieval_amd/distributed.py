@@ -1,0 +1,107 @@
+"""Multi-GPU layer: one process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI).
+
+  * encode half: replicas only.  Output partitions are dealt to ranks with the reference's rule
+    (`get_task_list`, clip_retrieval/clip_inference/slurm_worker.py:16-37); no collective.
+  * search half: the index is row-sharded (rank g holds rows [g*N/G, (g+1)*N/G), id_base = the first row).
+    Every rank scans its shard for the same queries, the per-shard top-k (k x 12 B per query) are exchanged
+    with ONE all-gather, and every rank merges P*k -> k with the (score desc, id asc) rule.  This is the
+    only exchange step on the path; the reference itself has none (single-process faiss).
+The merge runs in lib/libclipx.so (device kernel for CUDA tensors, C++ for host tensors under gloo).
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, load_library
+from .knn import merge_topk_host
+from .runner import get_task_list  # noqa: F401  (re-export: encode-side task split)
+
+
+def shard_rows(total_rows, world_size, rank):
+    """Contiguous row range of `rank` in a row-sharded index."""
+    lo = (total_rows * rank) // world_size
+    hi = (total_rows * (rank + 1)) // world_size
+    return lo, hi
+
+
+class ShardedIndex:
+    """faiss-shaped `search` over a row-sharded index; collective: every rank must call with the same queries."""
+
+    def __init__(self, local_index, group=None):
+        import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+
+        self.local = local_index
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.d = local_index.d
+
+    @property
+    def ntotal(self):
+        import torch  # pylint: disable=import-outside-toplevel
+        import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+
+        if self.world == 1:
+            return self.local.ntotal
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([self.local.ntotal], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def search(self, x, k):
+        """Host queries in, host results out (the clip_back call shape)."""
+        import torch  # pylint: disable=import-outside-toplevel
+        import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+
+        D, I = self.local.search(x, k)
+        if self.world == 1:
+            return D, I
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        Dt = torch.from_numpy(np.ascontiguousarray(D)).to(dev)
+        It = torch.from_numpy(np.ascontiguousarray(I)).to(dev)
+        n = Dt.shape[0]
+        # concatenated layout [world*n, k] (accepted by both gloo and RCCL), viewed as [world, n, k]
+        Dg = torch.empty((self.world * n, k), dtype=Dt.dtype, device=dev)
+        Ig = torch.empty((self.world * n, k), dtype=It.dtype, device=dev)
+        dist.all_gather_into_tensor(Dg, Dt, group=self.group)
+        dist.all_gather_into_tensor(Ig, It, group=self.group)
+        Dg, Ig = Dg.view(self.world, n, k), Ig.view(self.world, n, k)
+        if on_gpu:
+            Do, Io = self.merge_device(Dg, Ig, k)
+            return Do.cpu().numpy(), Io.cpu().numpy()
+        return merge_topk_host(Dg.numpy(), Ig.numpy(), k)
+
+    def search_device(self, q_cuda, k):
+        """CUDA tensors end to end: local scan -> all_gather (RCCL) -> merge kernel.  Returns (D, I) on the GPU."""
+        import torch  # pylint: disable=import-outside-toplevel
+        import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+
+        n = q_cuda.shape[0]
+        D = torch.empty((n, k), dtype=torch.float32, device=q_cuda.device)
+        I = torch.empty((n, k), dtype=torch.int64, device=q_cuda.device)
+        st = torch.cuda.current_stream(q_cuda.device).cuda_stream
+        self.local.search_device(q_cuda.data_ptr(), n, k, D.data_ptr(), I.data_ptr(), st)
+        if self.world == 1:
+            return D, I
+        Dg = torch.empty((self.world * n, k), dtype=torch.float32, device=q_cuda.device)
+        Ig = torch.empty((self.world * n, k), dtype=torch.int64, device=q_cuda.device)
+        dist.all_gather_into_tensor(Dg, D, group=self.group)
+        dist.all_gather_into_tensor(Ig, I, group=self.group)
+        return self.merge_device(Dg.view(self.world, n, k), Ig.view(self.world, n, k), k)
+
+    @staticmethod
+    def merge_device(Dg, Ig, k):
+        import torch  # pylint: disable=import-outside-toplevel
+
+        lib = load_library()
+        P, n, kk = Dg.shape
+        assert kk == k
+        Do = torch.empty((n, k), dtype=torch.float32, device=Dg.device)
+        Io = torch.empty((n, k), dtype=torch.int64, device=Dg.device)
+        st = torch.cuda.current_stream(Dg.device).cuda_stream
+        check(lib, lib.knnx_merge_topk_device(Dg.device.index or 0, C.c_void_p(Dg.data_ptr()), C.c_void_p(Ig.data_ptr()),
+                                              P, n, k, C.c_void_p(Do.data_ptr()), C.c_void_p(Io.data_ptr()),
+                                              C.c_void_p(st)), "knnx")
+        return Do, Io

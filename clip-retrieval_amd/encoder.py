@@ -1,0 +1,378 @@
+"""Host wrapper of the CLIP encoder C ABI (include/clipx.h): model descriptions, weight-blob assembly
+from the checkpoint formats `all_clip.load_clip` understands, and a `load_clip`-shaped factory.
+
+Reference seams mirrored here
+  * `load_clip(clip_model, use_jit, warmup_batch_size, clip_cache_path[, device]) -> (model, preprocess,
+    tokenizer)` as called at clip_retrieval/clip_inference/mapper.py:36-41, worker.py:52-57 and
+    clip_back.py:865-868; `model.encode_image(x)` / `model.encode_text(tok)` as used at mapper.py:57,65
+    and clip_back.py:230,244.
+All arithmetic happens in lib/libclipx.so on the GPU; this file only moves bytes and reshapes weights.
+"""
+
+import ctypes as C
+import os
+import threading
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._lib import ClipxModelDesc, HipLibraryError, check, load_library
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+PIX_F32_NCHW, PIX_U8_NHWC = 0, 1
+
+
+@dataclass(frozen=True)
+class ClipArch:
+    image_size: int = 224
+    patch_size: int = 14
+    v_width: int = 1024
+    v_layers: int = 24
+    v_heads: int = 16
+    v_mlp: int = 4096
+    ctx_len: int = 77
+    vocab: int = 49408
+    t_width: int = 768
+    t_layers: int = 12
+    t_heads: int = 12
+    t_mlp: int = 3072
+    embed_dim: int = 768
+    act: str = "quick_gelu"
+    ln_eps: float = 1e-5
+
+    @property
+    def v_tokens(self):
+        return (self.image_size // self.patch_size) ** 2 + 1
+
+    def to_desc(self):
+        d = ClipxModelDesc()
+        for f in ("image_size", "patch_size", "v_width", "v_layers", "v_heads", "v_mlp", "ctx_len", "vocab", "t_width",
+                  "t_layers", "t_heads", "t_mlp", "embed_dim"):
+            setattr(d, f, int(getattr(self, f)))
+        d.act = 0 if self.act == "quick_gelu" else 1
+        d.ln_eps = float(self.ln_eps)
+        d.pix_mean = (C.c_float * 3)(*CLIP_MEAN)
+        d.pix_std = (C.c_float * 3)(*CLIP_STD)
+        return d
+
+
+# the model names the reference passes as `clip_model` (main.py:88 default "ViT-B/32"; docs use L/14)
+ARCHS = {
+    "ViT-B/32": ClipArch(patch_size=32, v_width=768, v_layers=12, v_heads=12, v_mlp=3072, t_width=512, t_heads=8,
+                         t_mlp=2048, embed_dim=512),
+    "ViT-B/16": ClipArch(patch_size=16, v_width=768, v_layers=12, v_heads=12, v_mlp=3072, t_width=512, t_heads=8,
+                         t_mlp=2048, embed_dim=512),
+    "ViT-L/14": ClipArch(),
+    "open_clip:ViT-B-32": ClipArch(patch_size=32, v_width=768, v_layers=12, v_heads=12, v_mlp=3072, t_width=512,
+                                   t_heads=8, t_mlp=2048, embed_dim=512, act="gelu"),
+    "open_clip:ViT-L-14": ClipArch(act="gelu"),
+}
+
+
+def blob_floats(arch: ClipArch) -> int:
+    lib = load_library()
+    d = arch.to_desc()
+    return int(lib.clipx_blob_floats(C.byref(d)))
+
+
+# ----------------------------------------------------------------------------------------------
+# weight blobs
+# ----------------------------------------------------------------------------------------------
+def _cat(parts):
+    return np.concatenate([np.ascontiguousarray(p, dtype=np.float32).reshape(-1) for p in parts])
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy() if hasattr(t, "detach") else np.asarray(t, dtype=np.float32)
+
+
+def blob_from_openai_state_dict(sd, arch: ClipArch) -> np.ndarray:
+    """OpenAI `clip` / open_clip state-dict names (visual.conv1.weight, transformer.resblocks.N.attn.in_proj_weight,
+    ...).  `visual.proj` and `text_projection` are stored [width, embed] there and are transposed to the
+    library's [embed, width]."""
+    parts = []
+
+    def tower(prefix, n):
+        for l in range(n):
+            p = f"{prefix}.resblocks.{l}."
+            for k in ("ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                      "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                      "mlp.c_proj.weight", "mlp.c_proj.bias"):
+                parts.append(_np(sd[p + k]))
+
+    parts.append(_np(sd["visual.conv1.weight"]).reshape(arch.v_width, -1))
+    parts.append(_np(sd["visual.class_embedding"]))
+    parts.append(_np(sd["visual.positional_embedding"]))
+    parts += [_np(sd["visual.ln_pre.weight"]), _np(sd["visual.ln_pre.bias"])]
+    tower("visual.transformer", arch.v_layers)
+    parts += [_np(sd["visual.ln_post.weight"]), _np(sd["visual.ln_post.bias"])]
+    parts.append(_np(sd["visual.proj"]).T)
+    parts.append(_np(sd["token_embedding.weight"]))
+    parts.append(_np(sd["positional_embedding"]))
+    tower("transformer", arch.t_layers)
+    parts += [_np(sd["ln_final.weight"]), _np(sd["ln_final.bias"])]
+    parts.append(_np(sd["text_projection"]).T)
+    return _cat(parts)
+
+
+def blob_from_hf_state_dict(sd, arch: ClipArch) -> np.ndarray:
+    """HF `transformers.CLIPModel` names (the reference's `hf_clip:` models); q/k/v are stacked into the
+    in_proj layout."""
+    parts = []
+
+    def tower(prefix, n):
+        for l in range(n):
+            p = f"{prefix}.encoder.layers.{l}."
+            parts.extend([_np(sd[p + "layer_norm1.weight"]), _np(sd[p + "layer_norm1.bias"])])
+            parts.append(np.concatenate([_np(sd[p + f"self_attn.{x}_proj.weight"]) for x in "qkv"], 0))
+            parts.append(np.concatenate([_np(sd[p + f"self_attn.{x}_proj.bias"]) for x in "qkv"], 0))
+            parts.extend([_np(sd[p + "self_attn.out_proj.weight"]), _np(sd[p + "self_attn.out_proj.bias"]),
+                          _np(sd[p + "layer_norm2.weight"]), _np(sd[p + "layer_norm2.bias"]),
+                          _np(sd[p + "mlp.fc1.weight"]), _np(sd[p + "mlp.fc1.bias"]),
+                          _np(sd[p + "mlp.fc2.weight"]), _np(sd[p + "mlp.fc2.bias"])])
+
+    v, t = "vision_model", "text_model"
+    parts.append(_np(sd[v + ".embeddings.patch_embedding.weight"]).reshape(arch.v_width, -1))
+    parts.append(_np(sd[v + ".embeddings.class_embedding"]))
+    parts.append(_np(sd[v + ".embeddings.position_embedding.weight"]))
+    parts += [_np(sd[v + ".pre_layrnorm.weight"]), _np(sd[v + ".pre_layrnorm.bias"])]
+    tower(v, arch.v_layers)
+    parts += [_np(sd[v + ".post_layernorm.weight"]), _np(sd[v + ".post_layernorm.bias"])]
+    parts.append(_np(sd["visual_projection.weight"]))
+    parts.append(_np(sd[t + ".embeddings.token_embedding.weight"]))
+    parts.append(_np(sd[t + ".embeddings.position_embedding.weight"]))
+    tower(t, arch.t_layers)
+    parts += [_np(sd[t + ".final_layer_norm.weight"]), _np(sd[t + ".final_layer_norm.bias"])]
+    parts.append(_np(sd["text_projection.weight"]))
+    return _cat(parts)
+
+
+def random_blob(arch: ClipArch, seed: int = 0) -> np.ndarray:
+    """Random-init weights of the right shapes (benchmarks: no checkpoints offline).  Scales follow the
+    published CLIP initialisation (std width^-0.5 attention/proj, (2 width)^-0.5 fc, 0.02 embeddings).
+    Filled in place, segment by segment, straight into one preallocated blob."""
+    import torch  # pylint: disable=import-outside-toplevel
+
+    segs = []  # (count, std, offset_value)
+
+    def tower(w, mlp, n):
+        attn_std, proj_std, fc_std = w ** -0.5, (w ** -0.5) * ((2 * n) ** -0.5), (2 * w) ** -0.5
+        for _ in range(n):
+            segs.extend([(w, 0.05, 1.0), (w, 0.02, 0.0), (3 * w * w, attn_std, 0.0), (3 * w, 0.02, 0.0),
+                         (w * w, proj_std, 0.0), (w, 0.02, 0.0), (w, 0.05, 1.0), (w, 0.02, 0.0),
+                         (mlp * w, fc_std, 0.0), (mlp, 0.02, 0.0), (w * mlp, proj_std, 0.0), (w, 0.02, 0.0)])
+
+    w, tw, P, E = arch.v_width, arch.t_width, arch.patch_size, arch.embed_dim
+    segs.extend([(w * 3 * P * P, 0.02, 0.0), (w, w ** -0.5, 0.0), (arch.v_tokens * w, 0.02, 0.0), (w, 0.05, 1.0), (w, 0.02, 0.0)])
+    tower(w, arch.v_mlp, arch.v_layers)
+    segs.extend([(w, 0.05, 1.0), (w, 0.02, 0.0), (E * w, w ** -0.5, 0.0)])
+    segs.extend([(arch.vocab * tw, 0.02, 0.0), (arch.ctx_len * tw, 0.01, 0.0)])
+    tower(tw, arch.t_mlp, arch.t_layers)
+    segs.extend([(tw, 0.05, 1.0), (tw, 0.02, 0.0), (E * tw, tw ** -0.5, 0.0)])
+    total = sum(c for c, _, _ in segs)
+    g = torch.Generator().manual_seed(seed)
+    blob = torch.empty(total, dtype=torch.float32)
+    blob.normal_(0.0, 1.0, generator=g)
+    o = 0
+    for c, std, off in segs:
+        v = blob[o:o + c]
+        v.mul_(std)
+        if off:
+            v.add_(off)
+        o += c
+    return blob.numpy()
+
+
+def blob_from_checkpoint(path: str, arch: ClipArch) -> np.ndarray:
+    """A local checkpoint file: raw f32 blob (.bin/.npy), HF (.safetensors / state dict) or OpenAI/open_clip
+    state dict (.pt).  TorchScript archives (OpenAI's published files) are read through torch.jit.load."""
+    if path.endswith(".npy"):
+        return np.load(path).astype(np.float32).reshape(-1)
+    if path.endswith(".bin") and os.path.getsize(path) == 4 * blob_floats(arch):
+        return np.fromfile(path, dtype=np.float32)
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import load_file  # pylint: disable=import-outside-toplevel
+
+        sd = load_file(path)
+    else:
+        import torch  # pylint: disable=import-outside-toplevel
+
+        try:
+            sd = torch.jit.load(path, map_location="cpu").state_dict()
+        except RuntimeError:
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+            sd = sd.get("state_dict", sd)
+    if any(k.startswith("vision_model.") for k in sd):
+        return blob_from_hf_state_dict(sd, arch)
+    return blob_from_openai_state_dict(sd, arch)
+
+
+# ----------------------------------------------------------------------------------------------
+# the encoder object
+# ----------------------------------------------------------------------------------------------
+class ClipEncoder:
+    """One CLIP model resident on one GPU.  `encode_*` return fresh fp16 numpy arrays (unit L2 norm)."""
+
+    def __init__(self, arch: ClipArch, blob: np.ndarray, device: int = 0):
+        self._lib = load_library()
+        self.arch = arch
+        self.device = int(device)
+        blob = np.ascontiguousarray(blob, dtype=np.float32).reshape(-1)
+        desc = arch.to_desc()
+        want = int(self._lib.clipx_blob_floats(C.byref(desc)))
+        if blob.size != want:
+            raise ValueError(f"weight blob has {blob.size} floats, model needs {want}")
+        h = C.c_void_p()
+        check(self._lib, self._lib.clipx_create(C.byref(desc), blob.ctypes.data, blob.size, self.device, C.byref(h)), "clipx")
+        self._h = h
+        self.embed_dim = arch.embed_dim
+        self.max_batch = int(self._lib.clipx_max_batch(self._h))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.clipx_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+    # ---- host buffers (the ClipMapper path)
+    def encode_image(self, pixels) -> np.ndarray:
+        a = pixels.numpy() if hasattr(pixels, "numpy") else np.asarray(pixels)
+        S = self.arch.image_size
+        if a.dtype == np.uint8:
+            if a.ndim != 4 or a.shape[1:] != (S, S, 3):
+                raise ValueError(f"uint8 images must be [B,{S},{S},3] (NHWC), got {a.shape}")
+            fmt = PIX_U8_NHWC
+        else:
+            if a.ndim != 4 or a.shape[1:] != (3, S, S):
+                raise ValueError(f"float images must be [B,3,{S},{S}] (NCHW), got {a.shape}")
+            a = a.astype(np.float32, copy=False)
+            fmt = PIX_F32_NCHW
+        a = np.ascontiguousarray(a)
+        out = np.empty((a.shape[0], self.embed_dim), dtype=np.float16)
+        check(self._lib, self._lib.clipx_encode_image(self._h, a.ctypes.data, a.shape[0], fmt, out.ctypes.data), "clipx")
+        return out
+
+    def encode_text(self, ids) -> np.ndarray:
+        a = ids.numpy() if hasattr(ids, "numpy") else np.asarray(ids)
+        if a.ndim != 2 or a.shape[1] != self.arch.ctx_len:
+            raise ValueError(f"token ids must be [B,{self.arch.ctx_len}], got {a.shape}")
+        a = np.ascontiguousarray(a.astype(np.int32, copy=False))
+        out = np.empty((a.shape[0], self.embed_dim), dtype=np.float16)
+        check(self._lib, self._lib.clipx_encode_text(self._h, a.ctypes.data, a.shape[0], out.ctypes.data), "clipx")
+        return out
+
+    # ---- device buffers (benchmark; callers that stage their own input)
+    def encode_image_device(self, pix_ptr, B, fmt, out_f16_ptr, out_f32_ptr=None, stream=None):
+        check(self._lib, self._lib.clipx_encode_image_device(
+            self._h, C.c_void_p(int(pix_ptr)), int(B), int(fmt), C.c_void_p(int(out_f16_ptr)),
+            C.c_void_p(int(out_f32_ptr)) if out_f32_ptr else None, C.c_void_p(int(stream)) if stream else None), "clipx")
+
+    def encode_text_device(self, ids_ptr, B, out_f16_ptr, out_f32_ptr=None, stream=None):
+        check(self._lib, self._lib.clipx_encode_text_device(
+            self._h, C.c_void_p(int(ids_ptr)), int(B), C.c_void_p(int(out_f16_ptr)),
+            C.c_void_p(int(out_f32_ptr)) if out_f32_ptr else None, C.c_void_p(int(stream)) if stream else None), "clipx")
+
+    def profile(self, on):
+        check(self._lib, self._lib.clipx_profile_enable(self._h, 1 if on else 0), "clipx")
+
+    def profile_get(self, kind):
+        n, ms, fl = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+        check(self._lib, self._lib.clipx_profile_get(self._h, int(kind), C.byref(n), C.byref(ms), C.byref(fl)), "clipx")
+        return int(n.value), float(ms.value), float(fl.value)
+
+
+class _TorchModelFacade:
+    """The `model` object of `load_clip`: torch tensors in, torch float32 features out (already unit
+    norm, so the caller's `/= norm` of mapper.py:58 / clip_back.py:231 is a no-op up to rounding)."""
+
+    def __init__(self, enc: ClipEncoder):
+        self._enc = enc
+
+    def encode_image(self, x):
+        import torch  # pylint: disable=import-outside-toplevel
+
+        return torch.from_numpy(self._enc.encode_image(x.detach().cpu()).astype(np.float32))
+
+    def encode_text(self, tok):
+        import torch  # pylint: disable=import-outside-toplevel
+
+        return torch.from_numpy(self._enc.encode_text(tok.detach().cpu()).astype(np.float32))
+
+
+_registry = {}
+_registry_lock = threading.Lock()
+
+
+def register_encoder(name: str, encoder: ClipEncoder):
+    """Make an already-built encoder available as clip_model=`registered:<name>` (tests inject oracle weights)."""
+    with _registry_lock:
+        _registry[("registered:" + name, encoder.device)] = encoder
+
+
+def get_encoder(clip_model: str, clip_cache_path=None, device: int = 0) -> ClipEncoder:
+    """Resolve a `clip_model` string to a resident encoder; cached per (model, device) because the
+    reference constructs a ClipMapper per output partition (runner.py:31).
+
+      registered:<name>        an encoder passed to register_encoder()
+      random:<arch>[:seed]     random-init weights (benchmarks)
+      <arch>                   checkpoint `<clip_cache_path>/<arch with / -> ->.{pt,safetensors,bin,npy}`
+    """
+    key = (clip_model, int(device))
+    with _registry_lock:
+        if key in _registry:
+            return _registry[key]
+    if clip_model.startswith("registered:"):
+        raise KeyError(f"no encoder registered as {clip_model!r} on device {device}")
+    if clip_model.startswith("random:"):
+        parts = clip_model.split(":")
+        seed = int(parts[-1]) if parts[-1].isdigit() else 0
+        name = ":".join(parts[1:-1] if parts[-1].isdigit() else parts[1:])
+        arch = ARCHS[name]
+        enc = ClipEncoder(arch, random_blob(arch, seed), device)
+    else:
+        if clip_model not in ARCHS:
+            raise ValueError(f"unknown clip_model {clip_model!r}; known: {sorted(ARCHS)}")
+        arch = ARCHS[clip_model]
+        stem = clip_model.replace("open_clip:", "").replace("/", "-")
+        cands = []
+        if clip_cache_path:
+            if os.path.isfile(clip_cache_path):
+                cands.append(clip_cache_path)
+            cands += [os.path.join(clip_cache_path, stem + ext) for ext in (".pt", ".safetensors", ".bin", ".npy")]
+        path = next((c for c in cands if os.path.isfile(c)), None)
+        if path is None:
+            raise FileNotFoundError(
+                f"no checkpoint for {clip_model!r} (looked for {cands or 'nothing: clip_cache_path is unset'}); "
+                "this environment has no network, pass clip_cache_path=<local checkpoint>")
+        enc = ClipEncoder(arch, blob_from_checkpoint(path, arch), device)
+    with _registry_lock:
+        _registry[key] = enc
+    return enc
+
+
+def load_clip(clip_model="ViT-B/32", use_jit=True, warmup_batch_size=1, clip_cache_path=None, device=None):  # pylint: disable=unused-argument
+    """`all_clip.load_clip`-shaped factory -> (model, preprocess, tokenizer).
+
+    `preprocess` / `tokenizer` are the reference's CPU-side third-party callables (torchvision transform,
+    BPE tokenizer); they are not part of the accelerated path and are not re-implemented: both are None
+    here, and readers that need them take the ones from clip_retrieval_amd.reader.
+    """
+    dev = 0
+    if isinstance(device, int):
+        dev = device
+    elif isinstance(device, str) and ":" in device:
+        dev = int(device.split(":")[1])
+    enc = get_encoder(clip_model, clip_cache_path, dev)
+    if warmup_batch_size:
+        S = enc.arch.image_size
+        enc.encode_image(np.zeros((warmup_batch_size, 3, S, S), dtype=np.float32))
+        ids = np.zeros((warmup_batch_size, enc.arch.ctx_len), dtype=np.int32)
+        ids[:, 0], ids[:, 1] = enc.arch.vocab - 2, enc.arch.vocab - 1
+        enc.encode_text(ids)
+    return _TorchModelFacade(enc), None, None

@@ -1,0 +1,265 @@
+"""faiss-`Index`-shaped object over the MI355X kNN library (search half of the hot path).
+
+Mirrors exactly the part of the faiss Index API the reference exercises:
+  * `search_and_reconstruct(x, k) -> (D, I, R)`   clip_retrieval/clip_back.py:362
+  * `search(x, k) -> (D, I)`                      clip_retrieval/clip_filter.py:55
+  * `range_search(x, thresh) -> (lims, D, I)`     clip_retrieval/clip_filter.py:52, clip_back.py:294
+  * `.ntotal`, `.d`, `add(x)`, `reconstruct(i)`   ivf_metadata_ordering.py:51, clip_back.py:292-293
+so an instance can be dropped into `ClipResource.image_index` / `.text_index` (clip_back.py:781-782).
+`load_index` builds one from the `img_emb/*.npy` folder `clip inference` writes (writer.py:67-75),
+taking the place of clip_back.py:589-596 for our index type.
+
+Same argument meaning and error behaviour as faiss: float32 C-contiguous [n, d] queries (anything else
+raises like faiss' SWIG wrapper does), int64 labels, -1 / -FLT_MAX padding, exceptions on misuse.
+Thread-safe: clip_back serves each request on its own werkzeug thread with n=1 (clip_back.py:1018);
+concurrent callers are coalesced into one HBM scan of up to 32 queries by a leader/follower batcher.
+"""
+
+import ctypes as C
+import glob
+import os
+import threading
+
+import numpy as np
+
+from ._lib import HipLibraryError, check, load_library
+
+METRIC_INNER_PRODUCT = 0
+_SCAN_QUERIES = 32  # queries one HBM scan serves (KNN_NQ in csrc/knn_kernels.h)
+
+
+def _as_queries(x, d):
+    x = np.asarray(x)
+    if x.dtype != np.float32:
+        raise TypeError(f"queries must be float32 (got {x.dtype}); faiss raises the same way")
+    if x.ndim != 2 or x.shape[1] != d:
+        raise AssertionError(f"queries must have shape [n, {d}], got {x.shape}")
+    return np.ascontiguousarray(x)
+
+
+class Mi355xIndex:
+    """Flat inner-product index with fp16 rows resident in HBM (one GPU)."""
+
+    def __init__(self, d, device=0, id_base=0, coalesce=True):
+        self._lib = load_library()
+        self.d = int(d)
+        self._dpad = (self.d + 255) // 256 * 256  # kernels want d % 256 == 0; extra columns are zeros
+        self.device = int(device)
+        h = C.c_void_p()
+        check(self._lib, self._lib.knnx_create(self.device, self._dpad, METRIC_INNER_PRODUCT, C.byref(h)), "knnx")
+        self._h = h
+        self.metric_type = METRIC_INNER_PRODUCT
+        self.is_trained = True
+        if id_base:
+            check(self._lib, self._lib.knnx_set_id_base(self._h, int(id_base)), "knnx")
+        self._coalesce = coalesce
+        self._q_lock = threading.Lock()
+        self._pending = []  # [(k, query_row, slot)]
+        self._leader_active = False
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.knnx_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+    @property
+    def ntotal(self):
+        return int(self._lib.knnx_ntotal(self._h))
+
+    # ------------------------------------------------------------------ building
+    def reserve(self, n_rows):
+        check(self._lib, self._lib.knnx_reserve(self._h, int(n_rows)), "knnx")
+
+    def _pad(self, x):
+        if self._dpad == self.d:
+            return x
+        out = np.zeros((x.shape[0], self._dpad), dtype=x.dtype)
+        out[:, : self.d] = x
+        return out
+
+    def add(self, x):
+        """faiss Index.add: float32 (rounded to fp16 on the device) or float16 rows."""
+        x = np.asarray(x)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise AssertionError(f"add expects [n, {self.d}], got {x.shape}")
+        if x.dtype == np.float16:
+            x = np.ascontiguousarray(self._pad(x))
+            check(self._lib, self._lib.knnx_add_f16(self._h, x.ctypes.data, x.shape[0]), "knnx")
+        elif x.dtype == np.float32:
+            x = np.ascontiguousarray(self._pad(x))
+            check(self._lib, self._lib.knnx_add_f32(self._h, x.ctypes.data, x.shape[0]), "knnx")
+        else:
+            raise TypeError(f"add expects float32 or float16 rows, got {x.dtype}")
+
+    def attach_device_rows(self, dev_ptr, n_rows):
+        """Borrow fp16 rows already in HBM (e.g. a torch tensor's data_ptr()); caller keeps them alive."""
+        if self._dpad != self.d:
+            raise HipLibraryError("attached rows must already be padded to a multiple of 256 columns")
+        check(self._lib, self._lib.knnx_attach_device_f16(self._h, C.c_void_p(int(dev_ptr)), int(n_rows)), "knnx")
+
+    def synth_fill(self, n_rows, seed):
+        """Fill the index with the benchmark's synthetic corpus (oracle/knn_oracle.py:synth_rows)."""
+        if self._dpad != self.d:
+            raise HipLibraryError("synthetic fill needs d % 256 == 0")
+        check(self._lib, self._lib.knnx_synth_fill(self._h, int(n_rows), C.c_uint64(int(seed))), "knnx")
+
+    # ------------------------------------------------------------------ searching
+    def _search_raw(self, q, k, want_r):
+        n = q.shape[0]
+        qp = np.ascontiguousarray(self._pad(q))
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        R = np.empty((n, k, self._dpad), dtype=np.float32) if want_r else None
+        check(self._lib, self._lib.knnx_search(self._h, qp.ctypes.data, n, int(k), D.ctypes.data, I.ctypes.data,
+                                               R.ctypes.data if want_r else None), "knnx")
+        if want_r and self._dpad != self.d:
+            R = np.ascontiguousarray(R[:, :, : self.d])
+        return D, I, R
+
+    def _search_coalesced(self, q, k, want_r):
+        """n == 1 callers from many threads: the first becomes the leader and serves every query queued
+        while the GPU was busy, up to one scan's worth, in a single pass over HBM."""
+        slot = {"ev": threading.Event(), "out": None, "err": None}
+        with self._q_lock:
+            self._pending.append((k, want_r, q[0], slot))
+            lead = not self._leader_active
+            if lead:
+                self._leader_active = True
+        if not lead:
+            slot["ev"].wait()
+        else:
+            while True:
+                with self._q_lock:
+                    if not self._pending:
+                        self._leader_active = False
+                        break
+                    k0, r0 = self._pending[0][0], self._pending[0][1]
+                    take = [p for p in self._pending if p[0] == k0 and p[1] == r0][:_SCAN_QUERIES]
+                    taken = set(id(p) for p in take)
+                    self._pending = [p for p in self._pending if id(p) not in taken]
+                try:
+                    qq = np.stack([p[2] for p in take]).astype(np.float32)
+                    D, I, R = self._search_raw(qq, k0, r0)
+                    for j, p in enumerate(take):
+                        p[3]["out"] = (D[j:j + 1], I[j:j + 1], R[j:j + 1] if R is not None else None)
+                except Exception as e:  # pylint: disable=broad-except
+                    for p in take:
+                        p[3]["err"] = e
+                for p in take:
+                    p[3]["ev"].set()
+        if slot["err"] is not None:
+            raise slot["err"]
+        return slot["out"]
+
+    def _do_search(self, x, k, want_r):
+        if k <= 0:
+            raise AssertionError("k must be positive")
+        q = _as_queries(x, self.d)
+        if q.shape[0] == 0:
+            return (np.empty((0, k), np.float32), np.empty((0, k), np.int64),
+                    np.empty((0, k, self.d), np.float32) if want_r else None)
+        if self._coalesce and q.shape[0] == 1:
+            return self._search_coalesced(q, int(k), want_r)
+        return self._search_raw(q, int(k), want_r)
+
+    def search(self, x, k):
+        D, I, _ = self._do_search(x, k, False)
+        return D, I
+
+    def search_and_reconstruct(self, x, k):
+        return self._do_search(x, k, True)
+
+    def reconstruct(self, key):
+        return self.reconstruct_batch(np.asarray([key], dtype=np.int64))[0]
+
+    def reconstruct_batch(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        out = np.empty((keys.shape[0], self._dpad), dtype=np.float32)
+        check(self._lib, self._lib.knnx_reconstruct(self._h, keys.ctypes.data, keys.shape[0], out.ctypes.data), "knnx")
+        return np.ascontiguousarray(out[:, : self.d])
+
+    def range_search(self, x, thresh):
+        q = np.ascontiguousarray(self._pad(_as_queries(x, self.d)))
+        n = q.shape[0]
+        lims = np.zeros(n + 1, dtype=np.int64)
+        check(self._lib, self._lib.knnx_range_search(self._h, q.ctypes.data, n, C.c_float(thresh), lims.ctypes.data, None, None), "knnx")
+        total = int(lims[n])
+        D = np.empty(total, dtype=np.float32)
+        I = np.empty(total, dtype=np.int64)
+        if total:
+            check(self._lib, self._lib.knnx_range_search(self._h, q.ctypes.data, n, C.c_float(thresh), lims.ctypes.data,
+                                                         D.ctypes.data, I.ctypes.data), "knnx")
+        return lims, D, I
+
+    # ------------------------------------------------------------------ device-buffer path (bench, sharded search)
+    def search_device(self, q_ptr, n, k, D_ptr, I_ptr, stream=None):
+        check(self._lib, self._lib.knnx_search_device(self._h, C.c_void_p(int(q_ptr)), int(n), int(k), C.c_void_p(int(D_ptr)),
+                                                      C.c_void_p(int(I_ptr)), C.c_void_p(int(stream)) if stream else None), "knnx")
+
+    def profile(self, on):
+        check(self._lib, self._lib.knnx_profile_enable(self._h, 1 if on else 0), "knnx")
+
+    def profile_get(self):
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        check(self._lib, self._lib.knnx_profile_get(self._h, C.byref(n), C.byref(ms)), "knnx")
+        return int(n.value), float(ms.value)
+
+
+def merge_topk_host(D_parts, I_parts, k):
+    """[P, n, k] per-shard results with global ids -> [n, k]; host buffers (C++: knnx_merge_topk_host)."""
+    lib = load_library()
+    D_parts = np.ascontiguousarray(D_parts, dtype=np.float32)
+    I_parts = np.ascontiguousarray(I_parts, dtype=np.int64)
+    P, n, kk = D_parts.shape
+    assert kk == k and I_parts.shape == D_parts.shape
+    D = np.empty((n, k), dtype=np.float32)
+    I = np.empty((n, k), dtype=np.int64)
+    check(lib, lib.knnx_merge_topk_host(D_parts.ctypes.data, I_parts.ctypes.data, P, n, k, D.ctypes.data, I.ctypes.data), "knnx")
+    return D, I
+
+
+def embedding_files(folder):
+    """The `img_emb_*.npy` / `text_emb_*.npy` files of one `clip inference` output folder, in partition
+    order (zero-padded names sort correctly: writer.py:22,67)."""
+    files = sorted(glob.glob(os.path.join(folder, "*.npy")))
+    if not files:
+        raise ValueError(f"no .npy embedding files under {folder}")
+    return files
+
+
+def load_index(path, device=0, row_range=None, enable_faiss_memory_mapping=False):  # pylint: disable=unused-argument
+    """Build an HBM-resident flat index from a folder of fp16 `.npy` partitions.
+
+    Takes the place of clip_back.py:589-596 (`faiss.read_index`) for this index type; ids are the global
+    row order of the concatenated partitions = the metadata row order (clip_back.py:401-417).
+    `row_range=(lo, hi)` loads one shard of a row-sharded index and sets its id base to `lo`.
+    """
+    files = embedding_files(path)
+    shapes = []
+    for f in files:
+        a = np.load(f, mmap_mode="r")
+        if a.ndim != 2:
+            raise ValueError(f"{f}: expected a 2-D embedding matrix")
+        shapes.append(a.shape)
+    d = shapes[0][1]
+    if any(s[1] != d for s in shapes):
+        raise ValueError("embedding files disagree on the dimension")
+    total = sum(s[0] for s in shapes)
+    lo, hi = (0, total) if row_range is None else row_range
+    index = Mi355xIndex(d, device=device, id_base=lo)
+    index.reserve(max(hi - lo, 0))
+    start = 0
+    for f, s in zip(files, shapes):
+        a0, a1 = max(lo, start), min(hi, start + s[0])
+        if a1 > a0:
+            a = np.load(f, mmap_mode="r")[a0 - start:a1 - start]
+            index.add(np.ascontiguousarray(a) if a.dtype in (np.float16, np.float32) else np.asarray(a, dtype=np.float32))
+        start += s[0]
+    return index

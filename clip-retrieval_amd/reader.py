@@ -1,0 +1,232 @@
+"""Readers feeding the mapper: folder-of-files and webdataset-style tar shards ("next" row 8f-2).
+
+Same constructor arguments and batch dicts as the reference readers
+(clip_retrieval/clip_inference/reader.py:208-269): iterating yields
+  {"image_tensor": f32 [B,3,S,S], "image_filename": [str], "text_tokens": int [B,77], "text": [str],
+   "metadata": [str]}  (only the enabled keys)
+with the reference's skip-bad-sample behaviour (reader.py:100-104,142,180,187-189).
+Differences, stated: no `webdataset` / `torchvision` / DataLoader worker processes are used -- tar members
+are grouped by the webdataset key rule (basename up to the first dot) with `tarfile`, decoded with PIL on a
+thread pool, and collated into (pinned when a GPU is present) torch tensors.  `preprocess` defaults to a
+restatement of CLIP's transform (bicubic resize of the shorter side to S, centre crop, RGB, /255,
+mean/std); pass the real `preprocess`/`tokenizer` from the model package when they are available.
+"""
+
+import io
+import tarfile
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+CLIP_MEAN = np.asarray((0.48145466, 0.4578275, 0.40821073), dtype=np.float32)
+CLIP_STD = np.asarray((0.26862954, 0.26130258, 0.27577711), dtype=np.float32)
+IMAGE_EXTS = ("png", "jpg", "jpeg", "bmp", "webp")
+
+
+def clip_preprocess(image, size=224):
+    """PIL image -> f32 [3,size,size] (CLIP `_transform`: Resize(bicubic) -> CenterCrop -> RGB -> ToTensor -> Normalize)."""
+    from PIL import Image  # pylint: disable=import-outside-toplevel
+
+    w, h = image.size
+    if w <= h:
+        nw, nh = size, int(size * h / w)
+    else:
+        nw, nh = int(size * w / h), size
+    image = image.resize((nw, nh), Image.BICUBIC)
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+    image = image.crop((left, top, left + size, top + size)).convert("RGB")
+    x = np.asarray(image, dtype=np.float32) * np.float32(1.0 / 255.0)
+    x = (x - CLIP_MEAN) / CLIP_STD
+    return np.ascontiguousarray(x.transpose(2, 0, 1))
+
+
+class HashTokenizer:
+    """Deterministic stand-in for CLIP's BPE tokenizer, FOR SYNTHETIC DATA ONLY (the BPE merges file ships
+    inside the `clip` wheel, which is not available offline): words -> ids by FNV hash, SOT ... EOT, zero pad."""
+
+    def __init__(self, ctx_len=77, vocab=49408):
+        self.ctx_len, self.vocab = ctx_len, vocab
+
+    def __call__(self, texts):
+        import torch  # pylint: disable=import-outside-toplevel
+
+        out = torch.zeros(len(texts), self.ctx_len, dtype=torch.int64)
+        for i, t in enumerate(texts):
+            ids = []
+            for word in t.lower().split()[: self.ctx_len - 2]:
+                h = 2166136261
+                for ch in word.encode("utf-8"):
+                    h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+                ids.append(1 + h % (self.vocab - 3))
+            seq = [self.vocab - 2] + ids + [self.vocab - 1]
+            out[i, : len(seq)] = torch.tensor(seq)
+        return out
+
+
+def folder_to_keys(folder, enable_text=True, enable_image=True, enable_metadata=False):
+    """Sorted keys present in every enabled modality (reference reader.py:10-51: text keys win, then image)."""
+    root = Path(folder)
+
+    def index(exts):
+        found = {}
+        for ext in exts:
+            for variant in (ext, ext.upper()):
+                for p in root.glob(f"**/*.{variant}"):
+                    found[p.relative_to(root).with_suffix("").as_posix()] = p
+        return found
+
+    text_files = index(("txt",)) if enable_text else None
+    image_files = index(IMAGE_EXTS) if enable_image else None
+    metadata_files = index(("json",)) if enable_metadata else None
+    keys = None
+    for m in (text_files, image_files, metadata_files):
+        if m is not None:
+            keys = set(m) if keys is None else keys & set(m)
+    return sorted(keys or []), text_files, image_files, metadata_files
+
+
+def _collate(samples, enable_image, enable_text, enable_metadata, pin):
+    import torch  # pylint: disable=import-outside-toplevel
+
+    batch = {}
+    if enable_image:
+        t = torch.from_numpy(np.stack([s["image_tensor"] for s in samples]))
+        batch["image_tensor"] = t.pin_memory() if pin else t
+        batch["image_filename"] = [s["image_filename"] for s in samples]
+    if enable_text:
+        batch["text_tokens"] = torch.stack([s["text_tokens"] for s in samples])
+        batch["text"] = [s["text"] for s in samples]
+    if enable_metadata:
+        batch["metadata"] = [s["metadata"] for s in samples]
+    return batch
+
+
+class _BatchingReader:
+    def __init__(self, preprocess, tokenizer, batch_size, num_prepro_workers, enable_text, enable_image, enable_metadata):
+        self.preprocess = preprocess or clip_preprocess
+        self.tokenizer = tokenizer
+        self.batch_size = batch_size
+        self.workers = max(1, num_prepro_workers)
+        self.enable_text, self.enable_image, self.enable_metadata = enable_text, enable_image, enable_metadata
+        if enable_text and tokenizer is None:
+            raise ValueError("enable_text needs a tokenizer (pass the model package's, or HashTokenizer for synthetic data)")
+        try:
+            import torch  # pylint: disable=import-outside-toplevel
+
+            self.pin = torch.cuda.is_available()
+        except ImportError:
+            self.pin = False
+
+    def _decode(self, raw):
+        """raw: {"key", "image": bytes|None, "text": str|None, "metadata": str|None} -> sample dict or None"""
+        from PIL import Image, UnidentifiedImageError  # pylint: disable=import-outside-toplevel
+
+        out = {}
+        if self.enable_image:
+            try:
+                img = self.preprocess(Image.open(io.BytesIO(raw["image"])))
+            except (UnidentifiedImageError, OSError, ValueError) as e:
+                print(f"Failed to load image {raw['key']}. Error: {e}. Skipping.")
+                return None
+            out["image_tensor"] = img.numpy() if hasattr(img, "numpy") else np.asarray(img, dtype=np.float32)
+            out["image_filename"] = raw["key"]
+        if self.enable_text:
+            out["text"] = raw["text"]
+            out["text_tokens"] = self.tokenizer([raw["text"]])[0]
+        if self.enable_metadata:
+            out["metadata"] = raw["metadata"]
+        return out
+
+    def _raw_samples(self):
+        raise NotImplementedError
+
+    def __iter__(self):
+        with ThreadPoolExecutor(self.workers) as pool:
+            pending = []
+            for decoded in pool.map(self._decode, self._raw_samples()):
+                if decoded is None:
+                    continue
+                pending.append(decoded)
+                if len(pending) == self.batch_size:
+                    yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
+                    pending = []
+            if pending:
+                yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
+
+
+class FilesReader(_BatchingReader):
+    """Reads image / .txt / .json files sharing a stem from a folder tree."""
+
+    def __init__(self, sampler, preprocess, tokenizer, input_dataset, batch_size, num_prepro_workers,
+                 enable_text=True, enable_image=True, enable_metadata=False):
+        super().__init__(preprocess, tokenizer, batch_size, num_prepro_workers, enable_text, enable_image, enable_metadata)
+        keys, self.text_files, self.image_files, self.metadata_files = folder_to_keys(
+            input_dataset, enable_text, enable_image, enable_metadata)
+        self.keys = sampler(keys)
+
+    def _raw_samples(self):
+        for k in self.keys:
+            raw = {"key": k, "image": None, "text": None, "metadata": None}
+            if self.enable_image:
+                raw["key"] = str(self.image_files[k])
+                raw["image"] = self.image_files[k].read_bytes()
+            if self.enable_text:
+                raw["text"] = self.text_files[k].read_text()
+            if self.enable_metadata:
+                raw["metadata"] = self.metadata_files[k].read_text()
+            yield raw
+
+
+class WebdatasetReader(_BatchingReader):
+    """Reads webdataset-format tar shards: consecutive members sharing `<key>.` form one sample."""
+
+    def __init__(self, sampler, preprocess, tokenizer, input_dataset, batch_size, num_prepro_workers,
+                 enable_text=True, enable_image=True, enable_metadata=False, wds_image_key="jpg",
+                 wds_caption_key="txt", cache_path=None):
+        del cache_path  # shards are read in place
+        super().__init__(preprocess, tokenizer, batch_size, num_prepro_workers, enable_text, enable_image, enable_metadata)
+        shards = [input_dataset] if isinstance(input_dataset, str) else list(input_dataset)
+        self.shards = sampler(shards)
+        self.image_key, self.caption_key = wds_image_key, wds_caption_key
+
+    def _emit(self, key, fields):
+        if self.enable_image and self.image_key not in fields:
+            return None
+        if self.enable_text and self.caption_key not in fields:
+            return None
+        if self.enable_metadata and "json" not in fields:
+            return None
+        return {"key": key, "image": fields.get(self.image_key),
+                "text": fields[self.caption_key].decode("utf-8") if self.enable_text else None,
+                "metadata": fields["json"].decode("utf-8") if self.enable_metadata else None}
+
+    def _raw_samples(self):
+        for shard in self.shards:
+            try:
+                tf = tarfile.open(shard, "r|*")
+            except (tarfile.TarError, OSError) as e:
+                print(f"warn_and_continue: {shard}: {e}")
+                continue
+            with tf:
+                cur_key, fields = None, {}
+                try:
+                    for member in tf:
+                        if not member.isfile():
+                            continue
+                        base = member.name.rsplit("/", 1)
+                        stem, _, ext = base[-1].partition(".")
+                        key = (base[0] + "/" if len(base) == 2 else "") + stem
+                        if key != cur_key:
+                            if cur_key is not None:
+                                s = self._emit(cur_key, fields)
+                                if s is not None:
+                                    yield s
+                            cur_key, fields = key, {}
+                        fields[ext.lower()] = tf.extractfile(member).read()
+                except (tarfile.TarError, OSError) as e:
+                    print(f"warn_and_continue: {shard}: {e}")
+                if cur_key is not None:
+                    s = self._emit(cur_key, fields)
+                    if s is not None:
+                        yield s

@@ -1,0 +1,126 @@
+/*
+ * clipx.h -- C ABI of the MI355X-native CLIP encoder (encode half of the hot path).
+ *
+ * This is the boundary a clip-retrieval maintainer binds (ctypes stub in INTEGRATION.md) to
+ * replace the two model calls inside `ClipMapper.__call__`
+ * (reference clip_retrieval/clip_inference/mapper.py:57 `self.model_img(...)`, :65
+ * `self.model_txt(...)`) together with the normalise + fp16 cast that follows them
+ * (mapper.py:58-59, 66-67), and the B=1 query encodes of `KnnService.compute_query`
+ * (clip_back.py:230, 244).  Plain pointers and sizes only; no torch types.  Every function
+ * returns 0 or a negative CLIPX_E_* code and never throws; clipx_last_error() is thread-local.
+ *
+ * Arithmetic: bf16 MFMA operands with fp32 accumulation; residual stream, LayerNorm and
+ * softmax in fp32.  Outputs are unit-L2-norm rows rounded to IEEE fp16, exactly the
+ * `image_embs` / `text_embs` arrays the reference writer stores (writer.py:67-75).
+ */
+#ifndef CLIPX_H
+#define CLIPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct clipx_handle clipx_handle;
+
+enum {
+  CLIPX_OK = 0,
+  CLIPX_E_ARG = -1,
+  CLIPX_E_HIP = -2,
+  CLIPX_E_NOMEM = -3,
+  CLIPX_E_STATE = -4,
+  CLIPX_E_UNSUPPORTED = -5
+};
+
+#define CLIPX_ACT_QUICK_GELU 0 /* OpenAI CLIP checkpoints (x * sigmoid(1.702 x)) */
+#define CLIPX_ACT_GELU 1       /* open_clip LAION checkpoints (erf GELU)         */
+
+#define CLIPX_PIX_F32_NCHW 0 /* f32 [B,3,S,S], already mean/std normalised: the reference's item["image_tensor"] */
+#define CLIPX_PIX_U8_NHWC 1  /* u8  [B,S,S,3] raw RGB; /255, mean/std normalised on the device               */
+
+/* Architecture of one CLIP model = what `all_clip.load_clip(clip_model)` resolves a name to
+ * (mapper.py:36-41).  Head dimension (width / heads) must be 64 in this build. */
+typedef struct clipx_model_desc {
+  int image_size;   /* 224 */
+  int patch_size;   /* 14 (L/14), 32 (B/32), 16 (B/16) */
+  int v_width;      /* 1024 */
+  int v_layers;     /* 24 */
+  int v_heads;      /* 16 */
+  int v_mlp;        /* 4096 */
+  int ctx_len;      /* 77 */
+  int vocab;        /* 49408 */
+  int t_width;      /* 768 */
+  int t_layers;     /* 12 */
+  int t_heads;      /* 12 */
+  int t_mlp;        /* 3072 */
+  int embed_dim;    /* 768 */
+  int act;          /* CLIPX_ACT_* */
+  float ln_eps;     /* 1e-5 */
+  float pix_mean[3];/* CLIP mean (0.48145466, 0.4578275, 0.40821073) -- used by CLIPX_PIX_U8_NHWC */
+  float pix_std[3]; /* CLIP std  (0.26862954, 0.26130258, 0.27577711) */
+} clipx_model_desc;
+
+/* Number of floats in the weight blob for `desc` (see the order below). */
+size_t clipx_blob_floats(const clipx_model_desc* desc);
+
+/* Create an encoder on HIP device `device` from a host f32 weight blob.  Blob order, all
+ * row-major, torch `nn.Linear` [out, in] weights:
+ *   vision:  conv1.weight [v_width, 3*P*P]; class_embedding [v_width]; positional_embedding [T_v, v_width];
+ *            ln_pre.{w,b}; per layer { ln_1.{w,b}; in_proj_weight [3w, w] (q|k|v); in_proj_bias [3w];
+ *            out_proj.{weight [w,w], bias}; ln_2.{w,b}; c_fc.{weight [mlp,w], bias}; c_proj.{weight [w,mlp], bias} };
+ *            ln_post.{w,b}; visual projection [embed_dim, v_width]
+ *   text:    token_embedding [vocab, t_width]; positional_embedding [ctx_len, t_width]; per layer (same as above);
+ *            ln_final.{w,b}; text projection [embed_dim, t_width]
+ * (T_v = (image_size/patch_size)^2 + 1).  The blob is consumed during the call. */
+int clipx_create(const clipx_model_desc* desc, const float* blob, size_t blob_floats, int device,
+                 clipx_handle** out);
+void clipx_destroy(clipx_handle* h);
+
+/* model.encode_image(x) + `/= norm` + `.to(float16)` (mapper.py:57-59).  pixels: host pointer,
+ * layout per pix_fmt; out_f16: host [B, embed_dim] IEEE fp16 bits.  Any B >= 1 (chunked internally). */
+int clipx_encode_image(clipx_handle* h, const void* pixels, int B, int pix_fmt, uint16_t* out_f16);
+
+/* model.encode_text(tokens) + normalise + fp16 (mapper.py:65-67).  ids: host int32 [B, ctx_len]
+ * (SOT ... EOT 0 0 ..; the pooled position is argmax(ids) like the reference model). */
+int clipx_encode_text(clipx_handle* h, const int32_t* ids, int B, uint16_t* out_f16);
+
+/* Same with every buffer already resident in HBM (benchmark path, and callers that do their own
+ * hipMemcpyAsync double-buffering).  `stream` is a hipStream_t (NULL = the handle's stream);
+ * asynchronous on that stream.  out_f32_or_null: optional f32 [B, embed_dim] copy of the
+ * normalised embedding before the fp16 rounding (parity tests measure cosine on it). */
+int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, int pix_fmt, uint16_t* out_f16_dev,
+                              float* out_f32_or_null, void* stream);
+int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,
+                             float* out_f32_or_null, void* stream);
+
+/* Largest batch one launch sequence handles (workspace is sized for it at create time;
+ * CLIPX_MAX_BATCH env var, default 256).  Bigger B is processed in chunks of this size. */
+int clipx_max_batch(const clipx_handle* h);
+int clipx_embed_dim(const clipx_handle* h);
+
+/* Raw bf16 GEMM of this library (out[m,n] = sum_k A[m,k] W[n,k] + bias[n]), device pointers;
+ * exposed so tests and bench.py can check / time the dominant kernel in isolation.
+ * epi: 0 bias->bf16, 1 bias+quick_gelu->bf16, 2 bias+gelu->bf16, 3 f32 out += acc+bias. */
+int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M,
+                           int N, int K, int epi, void* stream);
+
+/* The attention and LayerNorm kernels in isolation (device pointers), for per-kernel parity tests:
+ * qkv bf16 [B*T, 3*H*64] -> out bf16 [B*T, H*64];  x f32 [M, d] -> y (bf16 if out_bf16 else f32). */
+int clipx_attention_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int causal,
+                           void* stream);
+int clipx_layernorm_device(int device, const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
+                           int M, int d, float eps, void* stream);
+
+/* Live per-kernel timing for bench.py: when enabled every launch is bracketed by hipEvents on
+ * its stream.  kind: 0 gemm, 1 attention, 2 layernorm, 3 other.  get() sums and resets. */
+int clipx_profile_enable(clipx_handle* h, int on);
+int clipx_profile_get(clipx_handle* h, int kind, int64_t* launches, double* ms, double* flops);
+
+const char* clipx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPX_H */

@@ -1,0 +1,109 @@
+/*
+ * knnx.h -- C ABI of the MI355X-native inner-product kNN (search half of the hot path).
+ *
+ * This is the boundary a clip-retrieval maintainer binds (ctypes stub in INTEGRATION.md)
+ * to replace the faiss `Index` object held in `ClipResource.image_index/.text_index`
+ * (reference clip_retrieval/clip_back.py:781-782, built by `load_index` :589-596).
+ * Each entry point names the reference call it stands in for.  Plain pointers and
+ * sizes only; no torch / faiss types.  All functions return 0 on success or a negative
+ * KNNX_E_* code; knnx_last_error() gives a thread-local message.  Nothing throws.
+ *
+ * Index rows are stored as fp16 [ntotal, d] row-major, resident in HBM.  Scores are
+ * the fp32 inner product of the fp16 row with the fp32 query (query split hi/lo into
+ * two fp16 MFMA operands, fp32 accumulate).  Result order: score descending, ties by
+ * ascending id; missing results are id -1 / score -FLT_MAX (faiss IP padding).
+ */
+#ifndef KNNX_H
+#define KNNX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct knnx_index knnx_index;
+
+enum {
+  KNNX_OK = 0,
+  KNNX_E_ARG = -1,        /* bad argument (null, d unsupported, k out of range ...) */
+  KNNX_E_HIP = -2,        /* a HIP runtime call failed (message has the hipError) */
+  KNNX_E_NOMEM = -3,      /* device allocation failed / capacity exceeded */
+  KNNX_E_STATE = -4,      /* call not valid in this state (e.g. add on an attached index) */
+  KNNX_E_UNSUPPORTED = -5 /* valid request this build has no kernel for */
+};
+
+#define KNNX_METRIC_INNER_PRODUCT 0 /* faiss.METRIC_INNER_PRODUCT; the only metric clip_back uses */
+#define KNNX_MAX_K_FAST 64          /* k <= 64: single-scan LDS candidate queues               */
+#define KNNX_MAX_K 16384            /* 64 < k <= 16384: two-scan threshold select              */
+
+/* faiss.IndexFlatIP(d) / faiss.read_index(...) (clip_back.py:589-596).  `device` is the HIP
+ * ordinal.  d must be a multiple of 256 and <= 1024 (CLIP embedding widths 512/768/1024). */
+int knnx_create(int device, int d, int metric, knnx_index** out);
+void knnx_destroy(knnx_index* ix);
+
+/* Pre-size the HBM arena for n_rows rows (one hipMalloc; 288 GB parts leave no room to
+ * grow by doubling).  Optional: add() grows geometrically if it was not called. */
+int knnx_reserve(knnx_index* ix, int64_t n_rows);
+
+/* faiss Index.add(x): append n rows.  Host pointers (pageable ok).  _f16 takes the exact
+ * bytes of an `img_emb_*.npy` payload (clip_inference/writer.py:67-75); _f32 rounds to fp16
+ * on the device. ids are implicit: id_base + row ordinal. */
+int knnx_add_f16(knnx_index* ix, const uint16_t* rows, int64_t n);
+int knnx_add_f32(knnx_index* ix, const float* rows, int64_t n);
+
+/* Borrow n rows of fp16 already resident in HBM (caller keeps ownership; used by the
+ * benchmark's on-device generator and by shard loaders that hipMemcpy themselves). */
+int knnx_attach_device_f16(knnx_index* ix, const void* dev_rows, int64_t n);
+
+/* Global id of local row 0 (row-sharded multi-GPU index: shard g has id_base = g*N/G). */
+int knnx_set_id_base(knnx_index* ix, int64_t id_base);
+
+/* faiss Index.ntotal / Index.d (ivf_metadata_ordering.py:51). */
+int64_t knnx_ntotal(const knnx_index* ix);
+int knnx_dim(const knnx_index* ix);
+
+/* faiss Index.search(x, k) (clip_filter.py:55) and Index.search_and_reconstruct(x, k)
+ * (clip_back.py:362).  q: host f32 [n, d] C-contiguous.  D: f32 [n, k], I: int64 [n, k],
+ * R (may be NULL): f32 [n, k, d] (rows of id -1 are filled with 0xFF bytes like faiss).
+ * Re-entrant; concurrent callers are serialised on the index's stream. */
+int knnx_search(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I, float* R);
+
+/* Same with every buffer already in HBM (benchmark / all-gather path).  `stream` is a
+ * hipStream_t (NULL = the index's own stream).  Asynchronous on that stream. */
+int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int k, float* D_dev,
+                       int64_t* I_dev, void* stream);
+
+/* faiss Index.reconstruct_batch: ids are global; out f32 [n, d]; id -1 -> 0xFF fill. */
+int knnx_reconstruct(knnx_index* ix, const int64_t* ids, int64_t n, float* out);
+
+/* faiss Index.range_search(x, thresh) (clip_filter.py:52; clip_back.py:294 on k<=3000 rows):
+ * all rows with <q,x> > thresh.  Two calls: pass I=D=NULL to get lims[n+1] (prefix counts),
+ * then call again with buffers of lims[n] entries.  Ids ascending inside each query. */
+int knnx_range_search(knnx_index* ix, const float* q, int n, float thresh, int64_t* lims,
+                      float* D, int64_t* I);
+
+/* Merge P per-shard results ([P, n, k] each, already global ids) into the top-k [n, k];
+ * the step after the RCCL all-gather of a row-sharded index.  Device buffers. */
+int knnx_merge_topk_device(int device, const float* D_parts, const int64_t* I_parts, int P, int n,
+                           int k, float* D_out, int64_t* I_out, void* stream);
+/* Same merge on host buffers (single process owning several devices; gloo tests). */
+int knnx_merge_topk_host(const float* D_parts, const int64_t* I_parts, int P, int n, int k,
+                         float* D_out, int64_t* I_out);
+
+/* Live kernel timing for bench.py: when enabled, every scan launch is bracketed with
+ * hipEvents on its own stream; get returns launches and summed milliseconds, then resets. */
+int knnx_profile_enable(knnx_index* ix, int on);
+int knnx_profile_get(knnx_index* ix, int64_t* scan_launches, double* scan_ms);
+
+/* Fill n rows of an attached/reserved arena with the benchmark's synthetic corpus:
+ * row r = L2-normalised N(0,1)^d from a counter-based hash of (seed, r, col), rounded to
+ * fp16.  Re-derivable on the CPU (oracle/knn_oracle.py:synth_rows). */
+int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed);
+
+const char* knnx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNNX_H */

@@ -1,0 +1,161 @@
+"""CPU oracle for the search half of the hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Restates the faiss calls the reference makes (faiss-cpu>=1.7.2,<2, requirements.txt:8 -- a C++ wheel
+that is NOT vendored in /root/reference and not installed here, so its published semantics are
+restated in numpy and anchored on the reference's call sites):
+  * `index.search_and_reconstruct(query, k)`   clip_retrieval/clip_back.py:362  (consumed :364-379)
+  * `index.search(x, k)`                       clip_retrieval/clip_filter.py:55
+  * `index.range_search(x, thr)`               clip_retrieval/clip_filter.py:52, clip_back.py:294
+  * `faiss.IndexFlatIP(d).add(x)`              clip_retrieval/clip_back.py:292-293
+IndexFlatIP semantics: score = <q, x> in fp32; results sorted by descending score; int64 labels;
+when fewer than k rows exist the tail is label -1 / distance -FLT_MAX (faiss' CMin<float>::neutral()).
+faiss leaves the order of exactly-tied scores unspecified; this oracle (and the HIP kernels) fix it to
+ascending id so that id SETS and ORDER are both comparable.
+
+The index stores rows as fp16 (the `img_emb_*.npy` files of clip_inference/writer.py:67-75 are fp16);
+scores are fp32 accumulations of fp32(x_fp16) * q_fp32.
+
+PARITY UNPINNED: no reference test asserts anything about search results (tests/test_end2end.py:119
+checks only HTTP 200), and faiss itself cannot be run here.
+"""
+
+import numpy as np
+
+NEG = np.float32(-3.4028234663852886e38)  # -FLT_MAX
+
+
+class FlatIPOracle:
+    """numpy IndexFlatIP over fp16-stored rows."""
+
+    def __init__(self, d: int):
+        self.d = d
+        self.rows = np.zeros((0, d), dtype=np.float16)
+
+    @property
+    def ntotal(self):
+        return self.rows.shape[0]
+
+    def add(self, x):
+        x = np.asarray(x)
+        assert x.ndim == 2 and x.shape[1] == self.d
+        self.rows = np.concatenate([self.rows, x.astype(np.float16)], axis=0)
+
+    def scores(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.empty((q.shape[0], self.ntotal), dtype=np.float32)
+        step = 262144
+        for o in range(0, self.ntotal, step):
+            out[:, o:o + step] = q @ self.rows[o:o + step].astype(np.float32).T
+        return out
+
+    def search(self, q, k: int):
+        s = self.scores(q)
+        n = s.shape[0]
+        D = np.full((n, k), NEG, dtype=np.float32)
+        I = np.full((n, k), -1, dtype=np.int64)
+        for i in range(n):
+            # score descending, id ascending: lexsort's last key is the primary one
+            order = np.lexsort((np.arange(self.ntotal), -s[i].astype(np.float64)))[:k]
+            D[i, :len(order)] = s[i, order]
+            I[i, :len(order)] = order
+        return D, I
+
+    def reconstruct_batch(self, ids):
+        ids = np.asarray(ids, dtype=np.int64)
+        out = np.empty((len(ids), self.d), dtype=np.float32)
+        ok = ids >= 0
+        out[ok] = self.rows[ids[ok]].astype(np.float32)
+        out[~ok] = np.frombuffer(b"\xff" * 4, dtype=np.float32)[0]  # faiss memset(-1): NaN pattern
+        return out
+
+    def search_and_reconstruct(self, q, k: int):
+        D, I = self.search(q, k)
+        R = self.reconstruct_batch(I.reshape(-1)).reshape(I.shape[0], k, self.d)
+        return D, I, R
+
+    def range_search(self, q, thresh: float):
+        s = self.scores(q)
+        lims = [0]
+        Ds, Is = [], []
+        for i in range(s.shape[0]):
+            hit = np.nonzero(s[i] > np.float32(thresh))[0]  # ascending ids, like a flat scan
+            Ds.append(s[i, hit])
+            Is.append(hit.astype(np.int64))
+            lims.append(lims[-1] + len(hit))
+        return (np.asarray(lims, dtype=np.int64),
+                np.concatenate(Ds).astype(np.float32) if Ds else np.zeros(0, np.float32),
+                np.concatenate(Is) if Is else np.zeros(0, np.int64))
+
+
+def merge_topk(D_parts, I_parts, k: int):
+    """[P, n, k] per-shard results (global ids) -> top-k per query; the step after the all-gather."""
+    D_parts = np.asarray(D_parts, dtype=np.float32)
+    I_parts = np.asarray(I_parts, dtype=np.int64)
+    P, n, kk = D_parts.shape
+    D = np.full((n, k), NEG, dtype=np.float32)
+    I = np.full((n, k), -1, dtype=np.int64)
+    for i in range(n):
+        d = D_parts[:, i, :].reshape(-1)
+        ids = I_parts[:, i, :].reshape(-1)
+        ok = ids >= 0
+        d, ids = d[ok], ids[ok]
+        order = np.lexsort((ids, -d.astype(np.float64)))[:k]
+        D[i, :len(order)] = d[order]
+        I[i, :len(order)] = ids[order]
+    return D, I
+
+
+def topk_sets_equal(I_a, D_a, I_b, D_b, tol: float = 2e-6):
+    """Identical id sets per query, except that entries whose score is within `tol` of the k-th score
+    may be exchanged (fp32 summation order differs between numpy's BLAS and the MFMA k-loop)."""
+    problems = []
+    for i in range(I_a.shape[0]):
+        a, b = set(I_a[i].tolist()), set(I_b[i].tolist())
+        if a == b:
+            continue
+        kth = min(D_a[i, -1], D_b[i, -1])
+        diff = a ^ b
+        sa = {int(x): float(s) for x, s in zip(I_a[i], D_a[i])}
+        sb = {int(x): float(s) for x, s in zip(I_b[i], D_b[i])}
+        for x in diff:
+            s = sa.get(x, sb.get(x))
+            if abs(s - kth) > tol * max(1.0, abs(kth)):
+                problems.append((i, x, s, float(kth)))
+    return problems
+
+
+# ----------------------------------------------------------------------------------------------
+# the synthetic corpus of bench.py / the full-scale parity test, bit-identical to knn_synth_kernel
+# ----------------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def synth_rows(rows, d: int, seed: int) -> np.ndarray:
+    """fp16 [len(rows), d]: row r = fp16(fp32(v / sqrt(sum v^2))), v = Irwin-Hall(4) of a splitmix64 hash."""
+    rows = np.asarray(rows, dtype=np.uint64).reshape(-1, 1)
+    cols = np.arange(d, dtype=np.uint64).reshape(1, -1)
+    with np.errstate(over="ignore"):
+        idx = rows * np.uint64(d) + cols
+        h = _mix64(np.uint64(seed) ^ (idx * np.uint64(0x9E3779B97F4A7C15)))
+    v = ((h & np.uint64(0xFFFF)) + ((h >> np.uint64(16)) & np.uint64(0xFFFF)) + ((h >> np.uint64(32)) & np.uint64(0xFFFF))
+         + (h >> np.uint64(48))).astype(np.int64) - 131070
+    ss = (v * v).sum(axis=1, keepdims=True)
+    scale = 1.0 / np.sqrt(ss.astype(np.float64))
+    return (v.astype(np.float64) * scale).astype(np.float32).astype(np.float16)
+
+
+def planted_queries(row_ids, d: int, seed: int, noise: float = 0.1, qseed: int = 4) -> np.ndarray:
+    """q_j = normalise(X[row_j] + noise * eps): the planted neighbour of q_j is row_j."""
+    x = synth_rows(row_ids, d, seed).astype(np.float32)
+    rng = np.random.default_rng(qseed)
+    q = x + noise * rng.standard_normal(x.shape).astype(np.float32) / np.sqrt(np.float32(d))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32)

@@ -1,0 +1,233 @@
+"""GPU parity tests of the encode half: HIP kernels through the C ABI vs the fp32 CPU oracle.
+Bar (north_star): cosine(oracle fp32, ours) >= 1 - 1e-3 per sample.  Per-kernel tests use a plain torch
+fp32 reference of the same op (floating-point kernels), with tolerances stated inline."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+COS_BAR = 1.0 - 1e-3
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import clip_retrieval_amd
+
+    return clip_retrieval_amd.load_library()
+
+
+# ------------------------------------------------------------------------------------------ per-kernel
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(257, 128, 64), (514, 1024, 1024), (1000, 2304, 768), (130, 768, 3072), (65, 128, 640)])
+def test_gemm_epilogues(lib, variant, M, N, K):
+    """out = A W^T + b with bf16 operands: reference is the fp32 matmul of the SAME bf16-rounded operands,
+    so only accumulation order differs (tol 2e-3 * |row| scale for bf16 outputs = 1 bf16 ulp + sum noise)."""
+    from clip_retrieval_amd._lib import check
+
+    os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    # asymmetric, row/col dependent structure so a transposed or permuted tile cannot pass
+    A[:, 0] += torch.arange(M, device="cuda").to(torch.bfloat16) * 0.01
+    W[:, 1] += torch.arange(N, device="cuda").to(torch.bfloat16) * 0.003
+    bias = torch.randn(N, generator=g).cuda()
+    ref = A.float() @ W.float().T + bias
+    for epi in (0, 1, 2, 3):
+        if epi == 3:
+            out = torch.randn(M, N, generator=g).cuda()
+            want = out + ref
+        else:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            want = ref if epi == 0 else (ref * torch.sigmoid(1.702 * ref) if epi == 1 else torch.nn.functional.gelu(ref))
+        check(lib, lib.clipx_gemm_bf16_device(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(out), M, N, K, epi, None), "clipx")
+        torch.cuda.synchronize()
+        err = (out.float() - want).abs()
+        tol = 1e-3 + (4e-3 * want.abs() if epi != 3 else 1e-4 * want.abs())
+        bad = (err > tol).nonzero()
+        assert bad.numel() == 0, (f"variant={variant} epi={epi} M={M} N={N} K={K}: {bad.shape[0]} bad, "
+                                  f"first {bad[:4].tolist()} max err {err.max().item():.4g}")
+    os.environ.pop("CLIPX_GEMM_VARIANT")
+
+
+@pytest.mark.parametrize("d", [512, 768, 1024, 1280])
+def test_layernorm(lib, d):
+    from clip_retrieval_amd._lib import check
+
+    M = 1031
+    g = torch.Generator().manual_seed(d)
+    x = (torch.randn(M, d, generator=g) * 3 + 0.7).cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    want = torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5)
+    y32 = torch.empty_like(x)
+    check(lib, lib.clipx_layernorm_device(0, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y32), 0, M, d, C.c_float(1e-5), None), "clipx")
+    y16 = torch.empty(M, d, dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.clipx_layernorm_device(0, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y16), 1, M, d, C.c_float(1e-5), None), "clipx")
+    torch.cuda.synchronize()
+    assert (y32 - want).abs().max() < 2e-5
+    assert (y16.float() - want).abs().max() < 0.02  # one bf16 ulp at |y| <= 4
+
+
+@pytest.mark.parametrize("B,T,H,causal", [(2, 257, 16, 0), (3, 77, 12, 1), (2, 50, 12, 0), (1, 197, 12, 0), (2, 77, 8, 1), (1, 1, 1, 0)])
+def test_attention(lib, B, T, H, causal):
+    """softmax(q k^T / 8 [+causal]) v per head; reference in fp32 on the same bf16 inputs.  Output is bf16 and P
+    is rounded to bf16 before the PV product: tol 1e-2 absolute on O(1) values."""
+    from clip_retrieval_amd._lib import check
+
+    g = torch.Generator().manual_seed(T * 31 + H)
+    qkv = (torch.randn(B * T, 3 * H * 64, generator=g)).to(torch.bfloat16).cuda()
+    qkv[:, : H * 64] *= 2.0  # sharper softmax
+    out = torch.empty(B * T, H * 64, dtype=torch.bfloat16, device="cuda")
+    check(lib, lib.clipx_attention_device(0, _ptr(qkv), _ptr(out), B, T, H, causal, None), "clipx")
+    torch.cuda.synchronize()
+    q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), device="cuda").triu_(1)
+    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    err = (out.float() - want).abs()
+    assert err.max() < 2e-2, f"B={B} T={T} H={H} causal={causal}: max err {err.max().item():.4g} at {err.argmax().item()}"
+    assert err.mean() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------ whole encoder
+def _product_arch(arch):
+    from clip_retrieval_amd.encoder import ClipArch
+
+    return ClipArch(**{k: getattr(arch, k) for k in ClipArch.__dataclass_fields__})
+
+
+@pytest.fixture(scope="module", params=["tiny-B/32", "tiny-L/14"])
+def tiny(request):
+    from clip_retrieval_amd.encoder import ClipEncoder
+    from oracle.clip_oracle import ARCHS, HFClipOracle
+
+    arch = ARCHS[request.param]
+    oracle = HFClipOracle(arch, seed=0)
+    enc = ClipEncoder(_product_arch(arch), oracle.export_blob(), 0)
+    yield request.param, arch, oracle, enc
+    enc.close()
+
+
+@pytest.mark.parametrize("B", [1, 2, 5])
+def test_encoder_parity_vs_oracle(tiny, B):
+    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    u8 = synth_pixels_u8(B, seed=B)
+    pix = normalise_u8_nhwc(u8)
+    ids = synth_tokens(B, seed=10 + B)
+    want_i16, want_i32 = mapper_semantics(oracle.encode_image(torch.from_numpy(pix)))
+    want_t16, want_t32 = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
+    got_i = enc.encode_image(pix)
+    got_t = enc.encode_text(ids)
+    assert got_i.dtype == np.float16 and got_i.shape == (B, arch.embed_dim) and got_i.flags["C_CONTIGUOUS"]
+    ci, ct = _cos(got_i, want_i32), _cos(got_t, want_t32)
+    assert ci.min() >= COS_BAR, f"{name} image cos {ci}"
+    assert ct.min() >= COS_BAR, f"{name} text cos {ct}"
+    assert np.allclose(np.linalg.norm(got_i.astype(np.float32), axis=1), 1, atol=2e-3)
+    assert np.abs(got_i.astype(np.float32) - want_i16.astype(np.float32)).max() < 0.02
+    # the raw-uint8 entry point normalises on the device and must land on the same embedding
+    got_u8 = enc.encode_image(u8)
+    assert _cos(got_u8, got_i).min() > 1 - 1e-4
+
+
+def test_device_path_and_fp16_rounding(tiny):
+    """Device-buffer entry points: the fp16 result is exactly the RNE rounding of the fp32 normalised row."""
+    from oracle.clip_oracle import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    B = 3
+    pix = torch.from_numpy(normalise_u8_nhwc(synth_pixels_u8(B, seed=77))).cuda()
+    ids = torch.from_numpy(synth_tokens(B, seed=78)).cuda()
+    o16 = torch.empty(B, arch.embed_dim, dtype=torch.float16, device="cuda")
+    o32 = torch.empty(B, arch.embed_dim, dtype=torch.float32, device="cuda")
+    enc.encode_image_device(pix.data_ptr(), B, 0, o16.data_ptr(), o32.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(o32.to(torch.float16), o16)
+    assert torch.allclose(o32.norm(dim=-1), torch.ones(B, device="cuda"), atol=1e-5)
+    assert np.array_equal(o16.cpu().numpy(), enc.encode_image(pix.cpu().numpy()))  # host path == device path, bitwise
+    enc.encode_text_device(ids.data_ptr(), B, o16.data_ptr(), o32.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(o32.to(torch.float16), o16)
+    assert np.array_equal(o16.cpu().numpy(), enc.encode_text(ids.cpu().numpy()))
+
+
+def test_chunked_batches_equal_unchunked(tiny):
+    """B larger than the workspace batch goes through the two-slot pinned pipeline in chunks."""
+    from clip_retrieval_amd.encoder import ClipEncoder
+    from oracle.clip_oracle import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    pix, ids = normalise_u8_nhwc(synth_pixels_u8(7, seed=5)), synth_tokens(7, seed=6)
+    os.environ["CLIPX_MAX_BATCH"] = "2"
+    try:
+        small = ClipEncoder(_product_arch(arch), oracle.export_blob(), 0)
+    finally:
+        os.environ.pop("CLIPX_MAX_BATCH")
+    assert small.max_batch == 2
+    assert np.array_equal(small.encode_image(pix), enc.encode_image(pix))
+    assert np.array_equal(small.encode_text(ids), enc.encode_text(ids))
+    small.close()
+
+
+def test_clip_mapper_drop_in(tiny):
+    """The reference's mapper test (tests/test_clip_inference/test_mapper.py:20-38: row count + float16) on batches
+    of 2 and 1, plus the value check the reference never had."""
+    from clip_retrieval_amd.encoder import register_encoder
+    from clip_retrieval_amd.mapper import ClipMapper
+    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    register_encoder("tiny-under-test", enc)
+    mapper = ClipMapper(enable_image=True, enable_text=True, enable_metadata=True, use_mclip=False,
+                        clip_model="registered:tiny-under-test", use_jit=True, mclip_model="", warmup_batch_size=1)
+    for B in (2, 1):
+        pix = torch.from_numpy(normalise_u8_nhwc(synth_pixels_u8(B, seed=20 + B)))
+        ids = torch.from_numpy(synth_tokens(B, seed=30 + B)).long()
+        item = {"image_tensor": pix, "text_tokens": ids, "image_filename": [f"{i}.jpg" for i in range(B)],
+                "text": [f"t{i}" for i in range(B)], "metadata": ["{}"] * B}
+        out = mapper(item)
+        assert set(out) == {"image_embs", "text_embs", "image_filename", "text", "metadata"}
+        assert out["image_embs"].shape[0] == B and out["image_embs"].dtype == np.float16
+        assert out["text_embs"].shape[0] == B and out["text_embs"].dtype == np.float16
+        assert out["image_filename"] == item["image_filename"] and out["text"] == item["text"]
+        _, w32 = mapper_semantics(oracle.encode_image(pix))
+        assert _cos(out["image_embs"], w32).min() >= COS_BAR
+        _, w32 = mapper_semantics(oracle.encode_text(ids))
+        assert _cos(out["text_embs"], w32).min() >= COS_BAR
+    off = ClipMapper(True, False, False, False, "registered:tiny-under-test", True, "", warmup_batch_size=0)
+    o = off({"image_tensor": pix, "image_filename": ["a"]})
+    assert o["text_embs"] is None and o["metadata"] is None and o["image_embs"].shape == (1, arch.embed_dim)
+    with pytest.raises(NotImplementedError):
+        ClipMapper(True, True, False, True, "registered:tiny-under-test", True, "x")
+
+
+def test_full_depth_vit_l14_parity():
+    """The BASELINE config's model at full depth (24 + 12 layers), small batch: the oracle needs ~1 s per image."""
+    from clip_retrieval_amd.encoder import ClipEncoder
+    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    arch = ARCHS["ViT-L/14"]
+    oracle = HFClipOracle(arch, seed=0)
+    enc = ClipEncoder(_product_arch(arch), oracle.export_blob(), 0)
+    pix = normalise_u8_nhwc(synth_pixels_u8(3, seed=1))
+    ids = synth_tokens(6, seed=2)
+    _, wi = mapper_semantics(oracle.encode_image(torch.from_numpy(pix)))
+    _, wt = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
+    ci, ct = _cos(enc.encode_image(pix), wi), _cos(enc.encode_text(ids), wt)
+    enc.close()
+    assert ci.min() >= COS_BAR, f"ViT-L/14 image cos {ci}"
+    assert ct.min() >= COS_BAR, f"ViT-L/14 text cos {ct}"

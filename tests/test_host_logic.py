@@ -1,0 +1,195 @@
+"""Host-side mirrors of the reference interfaces vs golden vectors produced by the reference's own code
+(tests/golden/make_golden.py) and vs the expectations of the reference's tests."""
+import hashlib
+import io
+import json
+import os
+import tarfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_host_logic.json")))
+
+
+def test_sampler_matches_reference_runner():
+    from clip_retrieval_amd.runner import Sampler
+
+    for g in GOLD["sampler"]:
+        items = [f"k{i:03d}" for i in range(g["n"])]
+        assert Sampler(g["id"], g["count"])(items) == g["out"]
+
+
+def test_get_task_list_matches_reference_tests():
+    from clip_retrieval_amd.runner import get_task_list
+
+    for g in GOLD["get_task_list"]:
+        for r, want in enumerate(g["out"]):
+            assert get_task_list(g["num_tasks"], g["world_size"], r, -1) == want
+    # every task exactly once for any split
+    for n in range(0, 40):
+        for w in range(1, 9):
+            got = sum((get_task_list(n, w, r) for r in range(w)), [])
+            assert got == list(range(n))
+
+
+def test_writer_bytes_match_reference_writer(tmp_path):
+    import pandas as pd
+    from clip_retrieval_amd.writer import NumpyWriter
+
+    for g in GOLD["writer"]:
+        out = tmp_path / f"p{g['partition_id']}"
+        w = NumpyWriter(g["partition_id"], str(out), True, True, True, g["partition_count"])
+        for b in g["batches"]:
+            b = dict(b)
+            b["image_embs"] = np.asarray(b["image_embs"], dtype=np.float16)
+            b["text_embs"] = np.asarray(b["text_embs"], dtype=np.float16)
+            w(b)
+        w.flush()
+        seen = {}
+        for root, _, names in os.walk(out):
+            for name in names:
+                seen[os.path.relpath(os.path.join(root, name), out)] = os.path.join(root, name)
+        assert sorted(seen) == sorted(g["files"])
+        for rel, want in g["files"].items():
+            if rel.endswith(".npy"):
+                assert hashlib.sha256(open(seen[rel], "rb").read()).hexdigest() == want, rel
+            else:
+                df = pd.read_parquet(seen[rel])
+                assert list(df.columns) == want["columns"]
+                assert json.loads(df.to_json(orient="records")) == want["rows"]
+
+
+def test_writer_empty_partition_writes_nothing(tmp_path):
+    from clip_retrieval_amd.writer import NumpyWriter
+
+    w = NumpyWriter(0, str(tmp_path), True, True, False, 4)
+    w.flush()
+    assert not list((tmp_path / "img_emb").glob("*"))
+
+
+def test_normalized_zero_guard():
+    from clip_retrieval_amd.mapper import normalized
+
+    a = np.array([[3.0, 4.0], [0.0, 0.0]], dtype=np.float32)
+    n = normalized(a)
+    assert np.allclose(n[0], [0.6, 0.8]) and np.array_equal(n[1], [0, 0])
+
+
+def _jpeg(w, h, seed):
+    from PIL import Image
+
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), rng.integers(0, 255, (h, w))], -1).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format="JPEG")
+    return buf.getvalue()
+
+
+@pytest.fixture()
+def image_folder(tmp_path):
+    # same population as the reference fixture folder: 7 JPEGs of assorted sizes (test_reader.py:58)
+    sizes = [(123, 456), (208, 495), (321, 421), (389, 535), (416, 264), (456, 123), (524, 316)]
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i, (w, h) in enumerate(sizes):
+        (d / f"{w}_{h}.jpg").write_bytes(_jpeg(w, h, i))
+    return str(d)
+
+
+@pytest.fixture()
+def tar_shards(tmp_path):
+    # same member counts as the reference tars: 4 + 3 + 2 + 2 images (test_reader.py:60)
+    paths, k = [], 0
+    for t, n in enumerate([4, 3, 2, 2]):
+        p = tmp_path / f"image{t + 1}.tar"
+        with tarfile.open(p, "w") as tf:
+            for _ in range(n):
+                data = _jpeg(200 + 10 * k, 150 + 7 * k, k)
+                ti = tarfile.TarInfo(f"{k:05d}.jpg")
+                ti.size = len(data)
+                tf.addfile(ti, io.BytesIO(data))
+                cap = f"caption number {k}".encode()
+                ti = tarfile.TarInfo(f"{k:05d}.txt")
+                ti.size = len(cap)
+                tf.addfile(ti, io.BytesIO(cap))
+                k += 1
+        paths.append(str(p))
+    return paths
+
+
+def test_files_reader_batch_shapes(image_folder):
+    """Reference expectation: 7 images, 2 partitions, batch 2 -> [[2,2],[2,1]] (test_reader.py:58-59)."""
+    from clip_retrieval_amd.reader import FilesReader
+    from clip_retrieval_amd.runner import Sampler
+
+    got = []
+    for pid in range(2):
+        r = FilesReader(Sampler(pid, 2), None, None, image_folder, 2, 2, enable_text=False, enable_image=True)
+        batches = list(r)
+        got.append([b["image_tensor"].shape[0] for b in batches])
+        assert all(tuple(b["image_tensor"].shape[1:]) == (3, 224, 224) for b in batches)
+        assert all(str(b["image_tensor"].dtype) == "torch.float32" for b in batches)
+    assert got == [[2, 2], [2, 1]]
+
+
+def test_webdataset_reader_batch_shapes(tar_shards):
+    """Reference expectation: 11 images in 4 tars, 2 partitions, batch 2 -> [[2,2,2],[2,2,1]] (test_reader.py:60-61)."""
+    from clip_retrieval_amd.reader import HashTokenizer, WebdatasetReader
+    from clip_retrieval_amd.runner import Sampler
+
+    got = []
+    for pid in range(2):
+        r = WebdatasetReader(Sampler(pid, 2), None, HashTokenizer(), tar_shards, 2, 2, enable_text=True, enable_image=True)
+        batches = list(r)
+        got.append([b["image_tensor"].shape[0] for b in batches])
+        for b in batches:
+            assert b["text_tokens"].shape[1] == 77 and len(b["text"]) == b["image_tensor"].shape[0]
+            assert int(b["text_tokens"][0].max()) == 49407  # EOT is the highest id
+    assert got == [[2, 2, 2], [2, 2, 1]]
+
+
+def test_reader_skips_corrupt_image(tmp_path, image_folder):
+    from clip_retrieval_amd.reader import FilesReader
+    from clip_retrieval_amd.runner import Sampler
+
+    (tmp_path / "imgs" / "000_bad.jpg").write_bytes(b"not a jpeg")
+    r = FilesReader(Sampler(0, 1), None, None, image_folder, 4, 1, enable_text=False, enable_image=True)
+    assert sum(b["image_tensor"].shape[0] for b in r) == 7
+
+
+def test_runner_with_stub_mapper_writes_reference_layout(tmp_path, image_folder):
+    """Runner + reader + writer plumbing with a stub mapper (the real one needs the GPU):
+    partition 0 of 2 over 7 images -> img_emb_0.npy with 4 rows (reference test_runner.py:76-77)."""
+    from clip_retrieval_amd.reader import FilesReader
+    from clip_retrieval_amd.runner import NullLogger, Runner
+    from clip_retrieval_amd.writer import NumpyWriter
+
+    class StubMapper:
+        def __call__(self, item):
+            n = item["image_tensor"].shape[0]
+            return {"image_embs": np.ones((n, 8), np.float16), "text_embs": None,
+                    "image_filename": item["image_filename"], "text": None, "metadata": None}
+
+    out = tmp_path / "out"
+    logs = {}
+
+    def logger_builder(i):
+        logs[i] = NullLogger(i)
+        return logs[i]
+
+    runner = Runner(
+        reader_builder=lambda s: FilesReader(s, None, None, image_folder, 2, 1, enable_text=False, enable_image=True),
+        mapper_builder=StubMapper,
+        writer_builder=lambda i: NumpyWriter(i, str(out), False, True, False, 2),
+        logger_builder=logger_builder,
+        output_partition_count=2,
+    )
+    runner(0)
+    runner(1)
+    assert np.load(out / "img_emb" / "img_emb_0.npy").shape == (4, 8)
+    assert np.load(out / "img_emb" / "img_emb_1.npy").shape == (3, 8)
+    keys = {"start_time", "end_time", "read_duration", "inference_duration", "write_duration", "total_duration", "sample_count"}
+    assert all(set(r) == keys for r in logs[0].records) and sum(r["sample_count"] for r in logs[0].records) == 4

@@ -1,0 +1,253 @@
+"""GPU parity tests of the search half: HIP kernels (through the C ABI / faiss-shaped wrapper) vs the numpy oracle.
+Bar (north_star): identical top-k id sets on the same index; scores are fp32 so they are compared to 1e-5 and
+ids at the k-th boundary may swap only when their scores differ by < 2e-6 (fp32 summation order)."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NEG = np.float32(-3.4028234663852886e38)
+
+
+def _data(n, d, seed, normalise=True):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    if normalise and n:
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float16)
+
+
+def _queries(nq, d, seed, x=None):
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    if x is not None and len(x):
+        pick = rng.integers(0, len(x), nq)
+        q = x[pick].astype(np.float32) + 0.3 * q / np.sqrt(d)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return q.astype(np.float32)
+
+
+def _check(D, I, Do, Io, ctx):
+    from oracle.knn_oracle import topk_sets_equal
+
+    assert D.shape == Do.shape and I.shape == Io.shape and I.dtype == np.int64 and D.dtype == np.float32, ctx
+    valid = Io >= 0
+    assert np.array_equal(I >= 0, valid), f"{ctx}: -1 padding differs"
+    assert (D[~valid] == NEG).all(), f"{ctx}: padding score"
+    assert np.allclose(D[valid], Do[valid], rtol=0, atol=1e-5), f"{ctx}: max score err {np.abs(D[valid]-Do[valid]).max()}"
+    for i in range(D.shape[0]):
+        dv = D[i][I[i] >= 0]
+        assert (np.diff(dv) <= 0).all(), f"{ctx}: query {i} not sorted by descending score"
+    bad = topk_sets_equal(I, D, Io, Do)
+    assert not bad, f"{ctx}: id sets differ beyond near-ties: {bad[:5]}"
+    exact = float((I == Io).mean())
+    assert exact > 0.98, f"{ctx}: only {exact:.3f} of positions identical"
+
+
+@pytest.mark.parametrize("n,d", [(1, 256), (31, 768), (33, 768), (1000, 768), (4097, 512), (70001, 768), (5000, 1024)])
+def test_flat_topk_parity(n, d):
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    x = _data(n, d, seed=n)
+    o = FlatIPOracle(d)
+    o.add(x)
+    ix = Mi355xIndex(d)
+    ix.add(x)
+    assert ix.ntotal == n
+    for nq, k in [(1, 40), (3, 1), (32, 10), (33, 64), (70, 40)]:
+        q = _queries(nq, d, seed=k + nq, x=x)
+        D, I = ix.search(q, k)
+        Do, Io = o.search(q, k)
+        _check(D, I, Do, Io, f"n={n} d={d} nq={nq} k={k}")
+    ix.close()
+
+
+def test_exact_ties_are_ordered_by_id():
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 768
+    base = _data(300, d, seed=5)
+    x = np.concatenate([base, base[:50], base[:50]])  # every one of the first 50 rows appears 3 times
+    o, ix = FlatIPOracle(d), Mi355xIndex(d)
+    o.add(x)
+    ix.add(x)
+    q = base[:8].astype(np.float32)
+    D, I = ix.search(q, 40)
+    Do, Io = o.search(q, 40)
+    assert np.array_equal(I, Io), "tied scores must come back in ascending id order"
+    assert np.array_equal(D, Do) or np.allclose(D, Do, atol=1e-6)
+    for i in range(8):
+        assert I[i, :3].tolist() == [i, 300 + i, 350 + i]
+
+
+def test_fewer_rows_than_k_and_empty_index():
+    from clip_retrieval_amd.knn import Mi355xIndex
+
+    ix = Mi355xIndex(768)
+    q = _queries(2, 768, 1)
+    D, I = ix.search(q, 5)
+    assert (I == -1).all() and (D == NEG).all()
+    x = _data(3, 768, 2)
+    ix.add(x)
+    D, I, R = ix.search_and_reconstruct(q, 8)
+    assert (I[:, 3:] == -1).all() and (I[:, :3] >= 0).all() and sorted(I[0, :3].tolist()) == [0, 1, 2]
+    assert np.array_equal(R[0, 0], x[I[0, 0]].astype(np.float32))
+    assert np.isnan(R[:, 3:]).all()  # faiss memset(-1) pattern
+
+
+def test_add_in_pieces_f32_and_reconstruct():
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 512
+    x = _data(5000, d, 9)
+    ix, o = Mi355xIndex(d), FlatIPOracle(d)
+    ix.add(x[:1234])
+    ix.add(x[1234:1300].astype(np.float32))  # f32 rows are rounded to fp16 on the device
+    ix.add(x[1300:])
+    o.add(x)
+    q = _queries(5, d, 3, x)
+    D, I, R = ix.search_and_reconstruct(q, 40)
+    Do, Io, Ro = o.search_and_reconstruct(q, 40)
+    _check(D, I, Do, Io, "pieces")
+    assert np.array_equal(R, x[I].astype(np.float32))
+    assert np.array_equal(ix.reconstruct(4999), x[4999].astype(np.float32))
+
+
+def test_dimension_not_multiple_of_256_is_padded():
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 640
+    x = _data(3000, d, 11)
+    ix, o = Mi355xIndex(d), FlatIPOracle(d)
+    ix.add(x)
+    o.add(x)
+    q = _queries(4, d, 5, x)
+    D, I, R = ix.search_and_reconstruct(q, 40)
+    Do, Io = o.search(q, 40)
+    _check(D, I, Do, Io, "d=640")
+    assert R.shape == (4, 40, d)
+
+
+def test_range_search_parity():
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 768
+    x = _data(20000, d, 21)
+    ix, o = Mi355xIndex(d), FlatIPOracle(d)
+    ix.add(x)
+    o.add(x)
+    q = _queries(35, d, 7, x)
+    for thr in (0.94, 0.1, 0.05):
+        lims, D, I = ix.range_search(q, thr)
+        lo, Do, Io = o.range_search(q, thr)
+        s = o.scores(q)
+        # rows whose score is within fp32 noise of the threshold may fall either side
+        for i in range(q.shape[0]):
+            a, b = set(I[lims[i]:lims[i + 1]].tolist()), set(Io[lo[i]:lo[i + 1]].tolist())
+            for r in a ^ b:
+                assert abs(s[i, r] - thr) < 2e-6, (thr, i, r, s[i, r])
+            assert (np.diff(I[lims[i]:lims[i + 1]]) > 0).all(), "ids ascending within a query"
+        assert lims[0] == 0 and lims[-1] == len(D) == len(I)
+
+
+@pytest.mark.parametrize("k", [65, 200, 3000])
+def test_large_k_parity(k):
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 768
+    x = _data(20000, d, 31)
+    ix, o = Mi355xIndex(d), FlatIPOracle(d)
+    ix.add(x)
+    o.add(x)
+    q = _queries(2, d, 13, x)
+    D, I = ix.search(q, k)
+    Do, Io = o.search(q, k)
+    _check(D, I, Do, Io, f"k={k}")
+
+
+def test_synthetic_corpus_is_bit_identical_to_the_cpu_derivation():
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import synth_rows
+
+    d, n, seed = 768, 200_000, 3
+    ix = Mi355xIndex(d)
+    ix.synth_fill(n, seed)
+    rows = np.array([0, 1, 63, 64, 4097, 199_999], dtype=np.int64)
+    got = ix.reconstruct_batch(rows)
+    want = synth_rows(rows, d, seed).astype(np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_full_scale_properties_planted_neighbours():
+    """Size-independent checks on a corpus the oracle cannot scan in seconds (4 M x 768 = 6 GB):
+    every planted neighbour is the top hit, scores agree with an fp32 recomputation of the returned rows,
+    and results are independent of how queries are batched."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import planted_queries, synth_rows
+
+    d, n, seed = 768, 4_000_000, 3
+    ix = Mi355xIndex(d)
+    ix.synth_fill(n, seed)
+    rng = np.random.default_rng(0)
+    planted = np.sort(rng.choice(n, 48, replace=False))
+    planted[0], planted[-1] = 0, n - 1
+    q = planted_queries(planted, d, seed)
+    D, I = ix.search(q, 40)
+    assert np.array_equal(I[:, 0], planted)
+    assert (np.diff(D, axis=1) <= 0).all() and (I >= 0).all() and (I < n).all()
+    for i in (0, 17, 47):  # recompute the scores of the returned rows from the CPU derivation of the corpus
+        rows = synth_rows(I[i], d, seed).astype(np.float32)
+        assert np.allclose(rows @ q[i], D[i], atol=1e-5)
+        assert len(set(I[i].tolist())) == 40
+    D1, I1 = ix.search(q[:1], 40)
+    assert np.array_equal(I1[0], I[0]) and np.allclose(D1[0], D[0], atol=1e-6)
+
+
+def test_concurrent_single_query_callers_are_coalesced_correctly():
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 768
+    x = _data(30000, d, 41)
+    ix, o = Mi355xIndex(d), FlatIPOracle(d)
+    ix.add(x)
+    o.add(x)
+    q = _queries(24, d, 17, x)
+    Do, Io = o.search(q, 40)
+    out, errs = [None] * 24, []
+
+    def call(i):
+        try:
+            out[i] = ix.search_and_reconstruct(q[i:i + 1], 40)
+        except Exception as e:  # pylint: disable=broad-except
+            errs.append(e)
+
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(24)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(24):
+        D, I, R = out[i]
+        _check(D, I, Do[i:i + 1], Io[i:i + 1], f"thread {i}")
+        assert np.array_equal(R[0], x[I[0]].astype(np.float32))
+
+
+def test_bad_arguments_raise_like_faiss():
+    from clip_retrieval_amd import HipLibraryError
+    from clip_retrieval_amd.knn import Mi355xIndex
+
+    ix = Mi355xIndex(768)
+    with pytest.raises(TypeError):
+        ix.search(np.zeros((1, 768), np.float64), 4)
+    with pytest.raises(AssertionError):
+        ix.search(np.zeros((1, 512), np.float32), 4)
+    with pytest.raises(HipLibraryError):
+        ix.search(np.zeros((1, 768), np.float32), 20000)

@@ -1,0 +1,117 @@
+"""The oracle checked against itself and against the fixtures that exist (parity is otherwise unpinned:
+the reference's tests assert shapes only, see oracle/*.py headers)."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_hf_model_and_functional_restatement_agree():
+    from oracle.clip_oracle import (ARCHS, HFClipOracle, functional_encode_image, functional_encode_text,
+                                    normalise_u8_nhwc, synth_pixels_u8, synth_tokens, unpack_blob)
+
+    for name in ("tiny-B/32",):
+        arch = ARCHS[name]
+        o = HFClipOracle(arch, seed=0)
+        W = unpack_blob(o.export_blob(), arch)
+        pix = torch.from_numpy(normalise_u8_nhwc(synth_pixels_u8(2)))
+        ids = torch.from_numpy(synth_tokens(3))
+        a, b = o.encode_image(pix), functional_encode_image(W, arch, pix)
+        assert (a - b).abs().max() < 1e-4 * a.abs().max()
+        a, b = o.encode_text(ids), functional_encode_text(W, arch, ids)
+        assert (a - b).abs().max() < 1e-4 * a.abs().max()
+
+
+def test_product_blob_builder_matches_oracle_export():
+    """encoder.blob_from_hf_state_dict (product host code) == oracle export, element for element."""
+    from clip_retrieval_amd.encoder import ARCHS as PARCHS, ClipArch, blob_from_hf_state_dict
+    from oracle.clip_oracle import ARCHS, HFClipOracle
+
+    arch = ARCHS["tiny-B/32"]
+    o = HFClipOracle(arch, seed=3)
+    parch = ClipArch(**{k: getattr(arch, k) for k in ClipArch.__dataclass_fields__})
+    got = blob_from_hf_state_dict(o.model.state_dict(), parch)
+    assert np.array_equal(got, o.export_blob())
+    assert PARCHS["ViT-L/14"].v_tokens == 257
+
+
+def test_openai_key_mapping_roundtrip():
+    """An OpenAI-named state dict built from the same tensors gives the same blob (proj transposes included)."""
+    from clip_retrieval_amd.encoder import ClipArch, blob_from_openai_state_dict
+    from oracle.clip_oracle import ARCHS, HFClipOracle
+
+    arch = ARCHS["tiny-B/32"]
+    o = HFClipOracle(arch, seed=4)
+    sd = o.model.state_dict()
+    oa = {"visual.conv1.weight": sd["vision_model.embeddings.patch_embedding.weight"],
+          "visual.class_embedding": sd["vision_model.embeddings.class_embedding"],
+          "visual.positional_embedding": sd["vision_model.embeddings.position_embedding.weight"],
+          "visual.ln_pre.weight": sd["vision_model.pre_layrnorm.weight"], "visual.ln_pre.bias": sd["vision_model.pre_layrnorm.bias"],
+          "visual.ln_post.weight": sd["vision_model.post_layernorm.weight"], "visual.ln_post.bias": sd["vision_model.post_layernorm.bias"],
+          "visual.proj": sd["visual_projection.weight"].T, "token_embedding.weight": sd["text_model.embeddings.token_embedding.weight"],
+          "positional_embedding": sd["text_model.embeddings.position_embedding.weight"],
+          "ln_final.weight": sd["text_model.final_layer_norm.weight"], "ln_final.bias": sd["text_model.final_layer_norm.bias"],
+          "text_projection": sd["text_projection.weight"].T}
+    for hf, pre, n in (("vision_model", "visual.transformer", arch.v_layers), ("text_model", "transformer", arch.t_layers)):
+        for l in range(n):
+            s, d = f"{hf}.encoder.layers.{l}.", f"{pre}.resblocks.{l}."
+            oa[d + "attn.in_proj_weight"] = torch.cat([sd[s + f"self_attn.{x}_proj.weight"] for x in "qkv"])
+            oa[d + "attn.in_proj_bias"] = torch.cat([sd[s + f"self_attn.{x}_proj.bias"] for x in "qkv"])
+            for a, b in (("self_attn.out_proj", "attn.out_proj"), ("layer_norm1", "ln_1"), ("layer_norm2", "ln_2"),
+                         ("mlp.fc1", "mlp.c_fc"), ("mlp.fc2", "mlp.c_proj")):
+                oa[d + b + ".weight"], oa[d + b + ".bias"] = sd[s + a + ".weight"], sd[s + a + ".bias"]
+    parch = ClipArch(**{k: getattr(arch, k) for k in ClipArch.__dataclass_fields__})
+    assert np.array_equal(blob_from_openai_state_dict(oa, parch), o.export_blob())
+
+
+def test_mapper_semantics():
+    from oracle.clip_oracle import mapper_semantics
+
+    f = torch.tensor([[3.0, 4.0, 0.0], [1.0, 1.0, 1.0]])
+    h, f32 = mapper_semantics(f)
+    assert h.dtype == np.float16 and np.allclose(np.linalg.norm(f32, axis=1), 1.0, atol=1e-6)
+    assert np.allclose(h[0], [0.6, 0.8, 0.0], atol=1e-3)
+
+
+def test_flops_table_matches_survey():
+    from oracle.clip_oracle import ARCHS, FLOPS, tower_gflop
+
+    for name in ("ViT-L/14", "ViT-B/32"):
+        img, txt = tower_gflop(ARCHS[name])
+        assert abs(img - FLOPS[name]["image"]) < 0.01 and abs(txt - FLOPS[name]["text"]) < 0.01
+
+
+def test_knn_oracle_semantics():
+    from oracle.knn_oracle import NEG, FlatIPOracle
+
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((50, 16)).astype(np.float32)
+    o = FlatIPOracle(16)
+    o.add(x)
+    o.add(x[:3])  # exact duplicates -> exact score ties, id order must decide
+    q = x[:2].copy()
+    D, I, R = o.search_and_reconstruct(q, 60)
+    assert D.shape == (2, 60) and I.dtype == np.int64 and R.shape == (2, 60, 16)
+    assert (I[:, 53:] == -1).all() and (D[:, 53:] == NEG).all() and np.isnan(R[:, 53:]).all()
+    assert (np.diff(D[:, :53], axis=1) <= 0).all()
+    for i in range(2):  # the duplicate pair (i, 50+i) ties exactly and appears in id order
+        pos = {int(v): j for j, v in enumerate(I[i])}
+        assert pos[i] + 1 == pos[50 + i] and D[i, pos[i]] == D[i, pos[50 + i]]
+    lims, Dr, Ir = o.range_search(q, 0.5)
+    assert lims[0] == 0 and lims[-1] == len(Dr) == len(Ir) and (Dr > 0.5).all()
+    assert (np.diff(Ir[lims[0]:lims[1]]) > 0).all()
+    # brute-force cross-check in float64
+    s = (q.astype(np.float64) @ o.rows.astype(np.float64).T)
+    assert set(I[0, :10].tolist()) == set(np.argsort(-s[0], kind="stable")[:10].tolist())
+
+
+def test_synth_rows_properties():
+    from oracle.knn_oracle import planted_queries, synth_rows
+
+    x = synth_rows(np.arange(64), 256, seed=3)
+    assert x.dtype == np.float16 and x.shape == (64, 256)
+    assert np.allclose(np.linalg.norm(x.astype(np.float32), axis=1), 1.0, atol=2e-3)
+    again = synth_rows([5, 63], 256, seed=3)
+    assert np.array_equal(again, x[[5, 63]])  # any row is re-derivable on its own
+    assert not np.array_equal(synth_rows([5], 256, seed=4), x[[5]])
+    q = planted_queries([7, 9], 256, seed=3)
+    assert np.argmax(q @ x.astype(np.float32).T, axis=1).tolist() == [7, 9]
