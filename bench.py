@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--knn-queries", type=int, default=32)
     ap.add_argument("--knn-scans", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0: skip)")
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="torch threads of the CPU baseline (all 256 cores of the GPU box oversubscribe torch's CPU GEMMs: 0.07 samples/s)")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
 
@@ -85,7 +87,8 @@ def main():
     if want_cpu or want_parity:
         from oracle.clip_oracle import ARCHS as OARCHS, HFClipOracle
 
-        oracle = HFClipOracle(OARCHS[args.model], seed=0, threads=os.cpu_count())
+        cpu_threads = min(os.cpu_count() or 1, args.cpu_threads)
+        oracle = HFClipOracle(OARCHS[args.model], seed=0, threads=cpu_threads)
         oracle.load_blob(blob)
     del blob
 
@@ -166,14 +169,14 @@ def main():
     if want_cpu:
         from oracle.clip_oracle import mapper_semantics
 
-        cb = 8
+        cb = 4
         done, t1 = 0, time.perf_counter()
         while time.perf_counter() - t1 < args.cpu_seconds and done < B:
             mapper_semantics(oracle.encode_image(torch.from_numpy(pix_host[done:done + cb])))
             mapper_semantics(oracle.encode_text(torch.from_numpy(ids_host[done:done + cb])))
             done += cb
         el = time.perf_counter() - t1
-        cpu = {"value": round(done / el, 3), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+        cpu = {"value": round(done / el, 3), "unit": "samples/s", "cores": cpu_threads, "kind": "port",
                "sample": f"{done} of the {B} image+text pairs of one step, fp32, torch CPU ({el:.1f} s)"}
     del oracle
 

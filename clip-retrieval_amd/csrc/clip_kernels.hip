@@ -367,8 +367,8 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 constexpr int ATT_DH = 64;
 
 template <int NKB, int NW, int QPW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
-                                                           int H, float scale_log2e) {
+__global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
+                                                              int H, float scale_log2e) {
   constexpr int TP = NKB * 32;
   constexpr int VT_STRIDE = TP * 2 + 8;  // bytes per V^T row: odd multiple of 8 -> conflict-free ds_read_b64
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -421,51 +421,53 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16* __restri
       if (qpos < T) v = *reinterpret_cast<const uint4*>(qbase + (size_t)qpos * ld + 16 * s + 8 * hb);
       qf[s] = *reinterpret_cast<bf16x8*>(&v);
     }
+    // ---- S^T blocks; causal rows never look right of the diagonal block (wave-uniform skip)
     f32x16 sacc[NKB];
+    float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      if (!CAUSAL || kb <= qb) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * 128 + (((2 * s + hb) ^ ksw) << 4));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * 128 + (((2 * s + hb) ^ ksw) << 4));
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+        }
       }
+      // masking is needed only in the last key block (padding past T) and, for causal, on/after the diagonal
+      if (kb == NKB - 1 || CAUSAL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+          const bool ok = key < T && (!CAUSAL || key <= qpos);
+          sacc[kb][r] = ok ? sacc[kb][r] : -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
     }
-    // ---- softmax over keys (registers of this lane + lane^32)
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
-        const bool ok = key < T && (!CAUSAL || key <= qpos);
-        sacc[kb][r] = ok ? sacc[kb][r] : -INFINITY;
-        mx = fmaxf(mx, sacc[kb][r]);
-      }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (mx == -INFINITY) mx = 0.f;  // padded query rows
-    float sum = 0.f;
-    bf16x8 pf[NKB][2];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = exp2f((sacc[kb][r] - mx) * scale_log2e);
-        sum += p;
-        pf[kb][r >> 3][r & 7] = (bf16)p;
-      }
-    sum += __shfl_xor(sum, 32);
-    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    const float nmx = -mx * scale_log2e;
 
-    // ---- O^T = V^T P^T
+    // ---- per key block: P = exp2(S*c - m*c) -> bf16 (stays in registers as the B operand), then O^T += V^T P^T
+    float sum = 0.f;
     f32x16 oacc[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (CAUSAL && kb > qb) continue;
+      bf16x8 pf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], scale_log2e, nmx));
+        sum += p;
+        pf[r >> 3][r & 7] = (bf16)p;
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -475,8 +477,11 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16* __restri
           const uint2 lo = *reinterpret_cast<const uint2*>(vp);
           const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
           uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[kb][s2], oacc[nb], 0, 0, 0);
+          oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[s2], oacc[nb], 0, 0, 0);
         }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
     // ---- store: lane owns query qpos, d = 32nb + 8g + 4hb + {0..3}
     if (qpos < T) {
       bf16* orow = out + ((size_t)b * T + qpos) * (H * ATT_DH) + h * ATT_DH;

@@ -282,103 +282,110 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// merge of P sorted partial lists per query -> final top-k (also used after the all-gather)
+// merge of P partial top-k lists per query -> final top-k (also used after the all-gather)
 //   in:  ps [P, nq_stride, kin] scores, pi ids (u32 local or i64 global), pn [P, nq_stride] counts
-//        (pn == nullptr: every list is full unless id < 0)
-//   out: D [nq, k], I [nq, k] (id_base added for u32 inputs); padding -FLT_MAX / -1
+//        (pn == nullptr: an entry is valid iff its id >= 0)
+//   out: D [nq, k], I [nq, k] (id_base added for u32 inputs); padding -FLT_MAX / -1.   k <= 64.
+// Selection is exact and data-independent in cost: the order-encoded scores of all P*kin candidates sit in
+// LDS; a 32-step bisection finds the k-th largest value V, a second bisection over ids resolves ties at V
+// (ascending id), the exactly-k selected entries are compacted and rank-sorted.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_count_256(int v, int* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
 template <typename IdT>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ ps, const IdT* __restrict__ pi,
                                                        const int* __restrict__ pn, int P, int nq_stride, int kin,
                                                        int k, int64_t id_base, float* __restrict__ D,
                                                        int64_t* __restrict__ I) {
-  constexpr int SCAP = 4096;
-  __shared__ float s_s[SCAP];
-  __shared__ long long s_i[SCAP];
-  __shared__ int s_red[256];
-  __shared__ int s_cnt;
+  extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
+  unsigned* s_u = reinterpret_cast<unsigned*>(merge_smem);             // [P*kin] order-encoded score, 0 = empty
+  const int ncand = P * kin;
+  long long* sel_i = reinterpret_cast<long long*>(s_u + ((ncand + 3) & ~3));  // [64], 16-B aligned
+  float* sel_s = reinterpret_cast<float*>(sel_i + 64);                        // [64]
+  int* red = reinterpret_cast<int*>(sel_s + 64);                              // [4] + counter
   const int qq = blockIdx.x, tid = threadIdx.x;
 
-  auto list_n = [&](int p) -> int {
-    if (pn) return pn[p * nq_stride + qq];
-    // no count array: a list ends at the first negative id
-    const IdT* ids = pi + ((size_t)p * nq_stride + qq) * kin;
-    int n = 0;
-    while (n < kin && (long long)ids[n] >= 0) ++n;
-    return n;
-  };
+  auto gidx = [&](int c) -> size_t { return ((size_t)(c / kin) * nq_stride + qq) * kin + (c % kin); };
+  auto get_id = [&](int c) -> long long { return (long long)pi[gidx(c)] + id_base; };
 
-  // T* = max over lists of the list's k-th best: nothing below it can be in the global top-k
-  int t = enc_f(-INFINITY);
-  for (int p = tid; p < P; p += 256) {
-    const int n = list_n(p);
-    if (n >= k) {
-      const int e = enc_f(ps[((size_t)p * nq_stride + qq) * kin + (k - 1)]);
-      t = e > t ? e : t;
+  int mine = 0;
+  for (int c = tid; c < ncand; c += 256) {
+    const int p = c / kin, j = c - p * kin;
+    const size_t g = ((size_t)p * nq_stride + qq) * kin + j;
+    bool ok;
+    if (pn) ok = j < pn[p * nq_stride + qq];
+    else ok = (long long)pi[g] >= 0;
+    unsigned u = 0;
+    if (ok) {
+      u = (unsigned)enc_f(ps[g]) ^ 0x80000000u;  // unsigned order == float order
+      if (u == 0) u = 1;                         // (only a -NaN payload; keeps 0 = "empty")
     }
+    s_u[c] = u;
+    mine += ok ? 1 : 0;
   }
-  s_red[tid] = t;
-  if (tid == 0) s_cnt = 0;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) s_red[tid] = s_red[tid] > s_red[tid + o] ? s_red[tid] : s_red[tid + o];
-    __syncthreads();
-  }
-  const float T = dec_f(s_red[0]);
-
-  // gather survivors
-  for (int p = 0; p < P; ++p) {
-    const int n = list_n(p);
-    const size_t base = ((size_t)p * nq_stride + qq) * kin;
-    for (int j = tid; j < n; j += 256) {
-      const float s = ps[base + j];
-      if (s >= T) {
-        const int pos = atomicAdd(&s_cnt, 1);
-        if (pos < SCAP) { s_s[pos] = s; s_i[pos] = (long long)pi[base + j] + id_base; }
+  if (tid == 0) red[4] = 0;
+  const int ntot = block_count_256(mine, red);
+  const int kk = ntot < k ? ntot : k;
+  if (kk > 0) {
+    // V = kk-th largest encoded score
+    unsigned V = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned cand = V | (1u << bit);
+      int c = 0;
+      for (int e = tid; e < ncand; e += 256) c += s_u[e] >= cand ? 1 : 0;
+      if (block_count_256(c, red) >= kk) V = cand;
+    }
+    int cg = 0, ce = 0;
+    for (int e = tid; e < ncand; e += 256) { cg += s_u[e] > V ? 1 : 0; ce += s_u[e] == V ? 1 : 0; }
+    const int m1 = block_count_256(cg, red);
+    const int ceq = block_count_256(ce, red);
+    const int t = kk - m1;  // entries to take among the ties at V, smallest ids first
+    long long X = 0x7fffffffffffffffll;
+    if (ceq > t) {
+      X = 0;
+      for (int bit = 62; bit >= 0; --bit) {
+        const long long hi = X | ((1ll << bit) - 1);  // largest id with this prefix and the bit clear
+        int c = 0;
+        for (int e = tid; e < ncand; e += 256)
+          if (s_u[e] == V) c += get_id(e) <= hi ? 1 : 0;
+        if (block_count_256(c, red) < t) X |= (1ll << bit);
       }
     }
-  }
-  __syncthreads();
-  const int ns = s_cnt;
-  if (ns <= SCAP) {
-    for (int e = tid; e < ns; e += 256) {
-      const float se = s_s[e];
-      const long long ie = s_i[e];
+    // compact the exactly-kk selected entries
+    for (int e = tid; e < ncand; e += 256) {
+      const unsigned u = s_u[e];
+      bool take = u > V;
+      long long id = 0;
+      if (u >= V && u != 0) {
+        id = get_id(e);
+        if (u == V) take = id <= X;
+      }
+      if (take) {
+        const int pos = atomicAdd(&red[4], 1);
+        if (pos < 64) { sel_s[pos] = ps[gidx(e)]; sel_i[pos] = id; }
+      }
+    }
+    __syncthreads();
+    if (tid < kk) {
+      const float se = sel_s[tid];
+      const long long ie = sel_i[tid];
       int r = 0;
-      for (int j = 0; j < ns; ++j) {
-        const float sj = s_s[j];
-        const long long ij = s_i[j];
+      for (int j = 0; j < kk; ++j) {
+        const float sj = sel_s[j];
+        const long long ij = sel_i[j];
         r += ((sj > se) || (sj == se && ij < ie)) ? 1 : 0;
       }
-      if (r < k) { D[(size_t)qq * k + r] = se; I[(size_t)qq * k + r] = ie; }
+      D[(size_t)qq * k + r] = se;
+      I[(size_t)qq * k + r] = ie;
     }
-    for (int j = (ns < k ? ns : k) + tid; j < k; j += 256) { D[(size_t)qq * k + j] = -FLT_MAX; I[(size_t)qq * k + j] = -1; }
-  } else {
-    // massive-tie fallback: rank straight out of global memory (slow, exact)
-    int total = 0;
-    for (int p = 0; p < P; ++p) {
-      const int n = list_n(p);
-      const size_t base = ((size_t)p * nq_stride + qq) * kin;
-      for (int j = tid; j < n; j += 256) {
-        const float se = ps[base + j];
-        if (!(se >= T)) continue;
-        const long long ie = (long long)pi[base + j] + id_base;
-        int r = 0;
-        for (int p2 = 0; p2 < P && r < k; ++p2) {
-          const int n2 = list_n(p2);
-          const size_t b2 = ((size_t)p2 * nq_stride + qq) * kin;
-          for (int j2 = 0; j2 < n2; ++j2) {
-            const float sj = ps[b2 + j2];
-            const long long ij = (long long)pi[b2 + j2] + id_base;
-            r += ((sj > se) || (sj == se && ij < ie)) ? 1 : 0;
-          }
-        }
-        if (r < k) { D[(size_t)qq * k + r] = se; I[(size_t)qq * k + r] = ie; }
-      }
-      total += n;
-    }
-    (void)total;  // ns > SCAP >= k here, so no padding is needed
   }
+  for (int j = kk + tid; j < k; j += 256) { D[(size_t)qq * k + j] = -FLT_MAX; I[(size_t)qq * k + j] = -1; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -460,7 +467,11 @@ __global__ __launch_bounds__(256) void knn_synth_kernel(_Float16* __restrict__ X
 #pragma unroll
   for (int e = 0; e < MAXE; ++e) {
     const int c = e * 64 + lane;
-    if (c < d) X[(size_t)r * d + c] = (_Float16)(float)((double)v[e] * scale);
+    if (c < d) {
+      float f = (float)((double)v[e] * scale);
+      asm volatile("" : "+v"(f));  // keep the two roundings (f64->f32, f32->f16) separate: hipcc otherwise folds them
+      X[(size_t)r * d + c] = (_Float16)f;
+    }
   }
 }
 
@@ -506,14 +517,23 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
 
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
                             int nq, int k, int64_t id_base, float* D, int64_t* I, hipStream_t st) {
-  hipLaunchKernelGGL(knn_merge_kernel<uint32_t>, dim3(nq), dim3(256), 0, st, ps, pi, pn, P, nq_stride, kin, k,
-                     id_base, D, I);
+  if (k > 64) return hipErrorInvalidValue;
+  const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
+  auto kern = knn_merge_kernel<uint32_t>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, D, I);
   return hipGetLastError();
 }
 hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
                             int64_t* I, hipStream_t st) {
-  hipLaunchKernelGGL(knn_merge_kernel<int64_t>, dim3(nq), dim3(256), 0, st, ps, pi, (const int*)nullptr, P, nq,
-                     kin, k, (int64_t)0, D, I);
+  if (k > 64) return hipErrorInvalidValue;
+  const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
+  if (smem > (size_t)KNN_LDS_BYTES) return hipErrorInvalidValue;
+  auto kern = knn_merge_kernel<int64_t>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, (const int*)nullptr, P, nq, kin, k, (int64_t)0, D, I);
   return hipGetLastError();
 }
 hipError_t launch_gather(const _Float16* X, int64_t N, int d, int64_t id_base, const int64_t* ids, int64_t n,

@@ -1,0 +1,80 @@
+"""Per-kernel micro-benchmark (for rocprofv3 --pmc passes and A/B of kernel variants): launches the dominant
+kernels at their BASELINE shapes a few times each.  Usage: python tools/microbench.py [gemm] [attn] [knn] [ln]"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import clip_retrieval_amd  # noqa: E402
+from clip_retrieval_amd._lib import check  # noqa: E402
+
+lib = clip_retrieval_amd.load_library()
+what = set(sys.argv[1:]) or {"gemm", "attn", "knn", "ln"}
+REPS = int(os.environ.get("MB_REPS", "5"))
+P = lambda t: C.c_void_p(t.data_ptr())
+
+
+def timed(name, fn, flops=None, nbytes=None):
+    fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    st = torch.cuda.current_stream()
+    ev[0].record(st)
+    for _ in range(REPS):
+        fn()
+    ev[1].record(st)
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / REPS
+    extra = ""
+    if flops:
+        extra += f"  {flops / ms / 1e9:8.1f} TFLOP/s"
+    if nbytes:
+        extra += f"  {nbytes / ms / 1e6:8.1f} GB/s"
+    print(f"{name:48s} {ms * 1e3:9.1f} us{extra}", flush=True)
+
+
+st = torch.cuda.current_stream().cuda_stream
+if "gemm" in what:
+    M = 256 * 257
+    for variant in ([0, 1] if os.environ.get("MB_BOTH") else [1]):
+        os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
+        for (name, N, K, epi) in [("qkv  65792x3072x1024", 3072, 1024, 0), ("out  65792x1024x1024", 1024, 1024, 3),
+                                  ("fc1  65792x4096x1024", 4096, 1024, 1), ("fc2  65792x1024x4096", 1024, 4096, 3),
+                                  ("txt-fc1 19712x3072x768", 3072, 768, 1)]:
+            m = 19712 if name.startswith("txt") else M
+            A = (torch.randn(m, K, device="cuda") * 0.5).to(torch.bfloat16)
+            W = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+            b = torch.randn(N, device="cuda")
+            out = torch.zeros(m, N, device="cuda", dtype=torch.float32 if epi == 3 else torch.bfloat16)
+            timed(f"gemm v{variant} {name}", lambda: check(lib, lib.clipx_gemm_bf16_device(0, P(A), P(W), P(b), P(out), m, N, K, epi, C.c_void_p(st)), "clipx"),
+                  flops=2.0 * m * N * K)
+if "attn" in what:
+    for (B, T, H, causal) in [(256, 257, 16, 0), (256, 77, 12, 1)]:
+        qkv = torch.randn(B * T, 3 * H * 64, device="cuda").to(torch.bfloat16)
+        out = torch.empty(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
+        timed(f"attention B={B} T={T} H={H} causal={causal}",
+              lambda: check(lib, lib.clipx_attention_device(0, P(qkv), P(out), B, T, H, causal, C.c_void_p(st)), "clipx"),
+              flops=4.0 * B * H * T * T * 64)
+if "ln" in what:
+    M, d = 256 * 257, 1024
+    x = torch.randn(M, d, device="cuda")
+    g, b = torch.ones(d, device="cuda"), torch.zeros(d, device="cuda")
+    y = torch.empty(M, d, device="cuda", dtype=torch.bfloat16)
+    timed("layernorm 65792x1024 f32->bf16", lambda: check(lib, lib.clipx_layernorm_device(0, P(x), P(g), P(b), P(y), 1, M, d, C.c_float(1e-5), C.c_void_p(st)), "clipx"),
+          nbytes=M * d * 6.0)
+if "knn" in what:
+    from clip_retrieval_amd.knn import Mi355xIndex
+
+    rows = int(os.environ.get("MB_KNN_ROWS", "20000000"))
+    ix = Mi355xIndex(768)
+    ix.synth_fill(rows, 3)
+    for nq in (1, 32):
+        q = torch.nn.functional.normalize(torch.randn(nq, 768, device="cuda"), dim=1)
+        D = torch.empty(nq, 40, device="cuda")
+        I = torch.empty(nq, 40, device="cuda", dtype=torch.int64)
+        timed(f"knn search_device rows={rows} nq={nq} k=40 (prep+scan+merge)",
+              lambda: ix.search_device(q.data_ptr(), nq, 40, D.data_ptr(), I.data_ptr(), st), nbytes=rows * 768 * 2.0)
