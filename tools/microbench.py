@@ -37,7 +37,12 @@ def timed(name, fn, flops=None, nbytes=None):
     print(f"{name:48s} {ms * 1e3:9.1f} us{extra}", flush=True)
 
 
-st = torch.cuda.current_stream().cuda_stream
+# a non-default torch stream: the C ABI treats stream == NULL as "use the handle's own stream", which
+# torch.cuda.Event on the default stream would not see
+_stream = torch.cuda.Stream()
+torch.cuda.set_stream(_stream)
+st = _stream.cuda_stream
+assert st != 0
 if "gemm" in what:
     M = 256 * 257
     for variant in ([0, 1] if os.environ.get("MB_BOTH") else [1]):
