@@ -23,17 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "clip_kernels.h"
+#include "gemm_common.h"
 
 namespace clipx {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ float quick_gelu(float v) { return v / (1.f + __expf(-1.702f * v)); }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
 // =============================================================================================
 // GEMM
@@ -46,7 +38,7 @@ template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int M, int N,
-                                                          int K) {
+                                                          int K, int row0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -181,27 +173,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16* __restric
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * hb;
-        float4 v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        if (EPI != EPI_TABLE_F32) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        }
-        if (EPI == EPI_BIAS_QGELU_BF16) { v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w); }
-        if (EPI == EPI_BIAS_GELU_BF16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-        if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16) {
-          bf16x4 o;
-          o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp) + (size_t)m * N + n) = o;
-        } else if (EPI == EPI_BIAS_RESID_F32) {
-          float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n);
-          float4 o = *p;
-          o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-          *p = o;
-        } else {  // EPI_TABLE_F32
-          const float4 t4 = *reinterpret_cast<const float4*>(table + (size_t)(m % T) * N + n);
-          v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n) = v;
-        }
+        const float4 v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, row0);
       }
     }
   }
@@ -216,18 +189,17 @@ static hipError_t launch_gemm_epi(const GemmArgs& g, hipStream_t st) {
     auto kern = gemm_bf16_kernel<EPI, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0);
   } else {
     auto kern = gemm_bf16_kernel<EPI, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
-  if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
+static hipError_t launch_gemm128(const GemmArgs& g, hipStream_t st) {
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_gemm_epi<EPI_BIAS_BF16>(g, st);
     case EPI_BIAS_QGELU_BF16: return launch_gemm_epi<EPI_BIAS_QGELU_BF16>(g, st);
@@ -236,6 +208,52 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
     case EPI_TABLE_F32: return launch_gemm_epi<EPI_TABLE_F32>(g, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+// How many 256-row m-tiles go to the persistent 256x256 kernel (variant 2); the rest (ragged rows and the m-tiles
+// that would only add a mostly-empty extra round over the CUs) goes to the 128x128 kernel.  ViT-L/14 at bs=256 has
+// M = 257 * 256: 256 m-tiles fill the 256 CUs in whole rounds, the 257th (the class-token rows' worth) is peeled.
+int gemm256_bulk_mtiles(int M, int N, int n_cu) {
+  const int mt = M / 256, nt = N / 256;
+  if (mt <= 0 || nt <= 0) return 0;
+  const int cu = (n_cu > 0 ? n_cu : 256) & ~7;
+  int best = mt;
+  double best_cost = 1e30;
+  for (int peel = 0; peel <= 8 && peel < mt; ++peel) {
+    const int bulk = mt - peel;
+    const int rounds = (bulk * nt + cu - 1) / cu;
+    // cost in units of one 256x256 tile on one CU; peeled rows run as 128x128 tiles, two resident per CU, at
+    // roughly 0.6x the per-CU rate of the big kernel
+    const double rest = (double)(peel * 4 * nt) / (2.0 * cu);
+    const double cost = rounds + (peel ? 0.25 * (rest > 1.0 ? rest : 1.0) / 0.6 : 0.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = bulk; }
+  }
+  return best;
+}
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+  if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
+  if ((g.variant == 2 || g.variant == 3) && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
+    const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
+    if (bulk > 0) {
+      GemmArgs b = g;
+      b.M = bulk * 256;
+      hipError_t e = g.variant == 3 ? launch_gemm256sp(b, g.n_cu, st) : launch_gemm256(b, g.n_cu, st);
+      if (e != hipSuccess) return e;
+      if (b.M == g.M) return hipSuccess;
+      GemmArgs r = g;  // remaining rows [bulk*256, M)
+      r.variant = 1;
+      r.A = g.A + (size_t)b.M * g.K;
+      r.M = g.M - b.M;
+      const size_t esz = (g.epi == EPI_BIAS_RESID_F32 || g.epi == EPI_TABLE_F32) ? 4 : 2;
+      r.out = reinterpret_cast<char*>(g.out) + (size_t)b.M * g.N * esz;
+      r.row0 = g.row0 + b.M;
+      return launch_gemm128(r, st);
+    }
+  }
+  GemmArgs r = g;
+  if (r.variant >= 2) r.variant = 1;
+  return launch_gemm128(r, st);
 }
 
 // =============================================================================================

@@ -61,7 +61,8 @@ struct clipx_handle {
   clipx_model_desc desc{};
   int device = 0;
   int max_batch = 256;
-  int gemm_variant = 1;
+  int gemm_variant = 3;
+  int n_cu = 256;
   std::mutex mu;
   hipStream_t stream = nullptr, copy_stream = nullptr;
 
@@ -257,7 +258,8 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   const char* mb = getenv("CLIPX_MAX_BATCH");
   if (mb && atoi(mb) > 0) h->max_batch = atoi(mb);
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
-  if (gv) h->gemm_variant = atoi(gv) ? 1 : 0;
+  if (gv) h->gemm_variant = std::min(3, std::max(0, atoi(gv)));
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r = create_impl(h, blob, blob_floats);
   if (r) {
     std::string keep = g_err;
@@ -322,7 +324,7 @@ static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* 
                     const float* table, int T, int M, int N, int K, int epi) {
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.table = table; g.T = T;
-  g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant;
+  g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant; g.n_cu = h->n_cu; g.row0 = 0;
   ProfScope ps(h, st, 0, 2.0 * M * (double)N * K);
   HIPCHK(launch_gemm(g, st));
   return 0;
@@ -470,7 +472,11 @@ extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void
   g.A = (const bf16*)A_bf16; g.W = (const bf16*)W_bf16; g.bias = bias; g.out = out; g.table = nullptr; g.T = 1;
   g.M = M; g.N = N; g.K = K; g.epi = epi;
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
-  g.variant = gv ? (atoi(gv) ? 1 : 0) : 1;
+  g.variant = gv ? std::min(3, std::max(0, atoi(gv))) : 3;
+  int ncu = 0;
+  HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+  g.n_cu = ncu;
+  g.row0 = 0;
   HIPCHK(launch_gemm(g, (hipStream_t)stream));
   return CLIPX_OK;
 }

@@ -1,0 +1,51 @@
+// gemm_common.h -- device-side pieces shared by the two bf16 GEMM kernels (clip_kernels.hip: 128x128 tile,
+// gemm256.hip: persistent 256x256 ping-pong).  Internal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "clip_kernels.h"
+
+namespace clipx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ float quick_gelu(float v) { return v / (1.f + __expf(-1.702f * v)); }
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+
+// One accumulator quad of the transposed-product layout both kernels use (MFMA A operand = weight rows, B operand
+// = activation rows): the lane owns output row m and four consecutive columns n..n+3.
+template <int EPI>
+__device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, const float* __restrict__ bias,
+                                                void* __restrict__ outp, const float* __restrict__ table, int T,
+                                                int row0 = 0) {
+  if (EPI != EPI_TABLE_F32) {
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+  }
+  if (EPI == EPI_BIAS_QGELU_BF16) { v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w); }
+  if (EPI == EPI_BIAS_GELU_BF16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+    bf16x4 o;
+    o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp) + (size_t)m * N + n) = o;
+  } else if (EPI == EPI_BIAS_RESID_F32) {
+    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n);
+    float4 o = *p;
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    *p = o;
+  } else {  // EPI_TABLE_F32
+    const float4 t4 = *reinterpret_cast<const float4*>(table + (size_t)((m + row0) % T) * N + n);
+    v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n) = v;
+  }
+}
+
+// bulk-tile launcher of gemm256.hip: rows [0, g.M) must be a multiple of 256, N % 256 == 0, K % 128 == 0
+hipError_t launch_gemm256(const GemmArgs& g, int n_cu, hipStream_t st);    // variant 2: ping-pong schedule
+hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st);  // variant 3: one barrier per K-tile
+
+}  // namespace clipx

@@ -29,25 +29,32 @@ def lib():
 
 
 # ------------------------------------------------------------------------------------------ per-kernel
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(257, 128, 64), (514, 1024, 1024), (1000, 2304, 768), (130, 768, 3072), (65, 128, 640)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(257, 128, 64), (514, 1024, 1024), (1000, 2304, 768), (130, 768, 3072), (65, 128, 640),
+                                   (33357, 512, 128), (65792, 1024, 1024), (2048, 4096, 1024), (19712, 768, 3072)])
 def test_gemm_epilogues(lib, variant, M, N, K):
     """out = A W^T + b with bf16 operands: reference is the fp32 matmul of the SAME bf16-rounded operands,
-    so only accumulation order differs (tol 2e-3 * |row| scale for bf16 outputs = 1 bf16 ulp + sum noise)."""
+    so only accumulation order differs (tol 2e-3 * |row| scale for bf16 outputs = 1 bf16 ulp + sum noise).
+    variant 2 = persistent 256x256 ping-pong kernel for the whole m-tiles + 128x128 kernel for the peeled rows;
+    (33357,512,128): 260 tiles -> two tiles per workgroup with K = one iteration; (65792,1024,1024): the ViT-L/14
+    bs=256 out_proj shape (4 tiles per workgroup + 256 peeled rows)."""
     from clip_retrieval_amd._lib import check
 
+    if variant < 2 and M > 20000:
+        pytest.skip("large shapes exercise the persistent kernel's multi-tile stream only")
+
     os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
-    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
-    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
-    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    A = (torch.randn(M, K, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
     # asymmetric, row/col dependent structure so a transposed or permuted tile cannot pass
     A[:, 0] += torch.arange(M, device="cuda").to(torch.bfloat16) * 0.01
     W[:, 1] += torch.arange(N, device="cuda").to(torch.bfloat16) * 0.003
-    bias = torch.randn(N, generator=g).cuda()
+    bias = torch.randn(N, generator=g, device="cuda")
     ref = A.float() @ W.float().T + bias
     for epi in (0, 1, 2, 3):
         if epi == 3:
-            out = torch.randn(M, N, generator=g).cuda()
+            out = torch.randn(M, N, generator=g, device="cuda")
             want = out + ref
         else:
             out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")

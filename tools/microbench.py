@@ -43,20 +43,52 @@ _stream = torch.cuda.Stream()
 torch.cuda.set_stream(_stream)
 st = _stream.cuda_stream
 assert st != 0
+def time_once(fn, reps):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    s_ = torch.cuda.current_stream()
+    ev[0].record(s_)
+    for _ in range(reps):
+        fn()
+    ev[1].record(s_)
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / reps
+
+
 if "gemm" in what:
+    # A/B of GEMM variants: shapes outer, variants interleaved inside each round (same clocks / thermal state),
+    # median over MB_ROUNDS rounds.  MB_VARIANTS = "1,3" or "3:flags" entries (CLIPX_GEMM_FLAGS).
     M = 256 * 257
-    for variant in ([0, 1] if os.environ.get("MB_BOTH") else [1]):
-        os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
-        for (name, N, K, epi) in [("qkv  65792x3072x1024", 3072, 1024, 0), ("out  65792x1024x1024", 1024, 1024, 3),
-                                  ("fc1  65792x4096x1024", 4096, 1024, 1), ("fc2  65792x1024x4096", 1024, 4096, 3),
-                                  ("txt-fc1 19712x3072x768", 3072, 768, 1)]:
-            m = 19712 if name.startswith("txt") else M
-            A = (torch.randn(m, K, device="cuda") * 0.5).to(torch.bfloat16)
-            W = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
-            b = torch.randn(N, device="cuda")
-            out = torch.zeros(m, N, device="cuda", dtype=torch.float32 if epi == 3 else torch.bfloat16)
-            timed(f"gemm v{variant} {name}", lambda: check(lib, lib.clipx_gemm_bf16_device(0, P(A), P(W), P(b), P(out), m, N, K, epi, C.c_void_p(st)), "clipx"),
-                  flops=2.0 * m * N * K)
+    vspecs = os.environ.get("MB_VARIANTS", "1,3").split(",")
+    rounds = int(os.environ.get("MB_ROUNDS", "5"))
+    for (name, N, K, epi) in [("qkv  65792x3072x1024", 3072, 1024, 0), ("out  65792x1024x1024", 1024, 1024, 3),
+                              ("fc1  65792x4096x1024", 4096, 1024, 1), ("fc2  65792x1024x4096", 1024, 4096, 3),
+                              ("txt-fc1 19712x3072x768", 3072, 768, 1)]:
+        if os.environ.get("MB_GEMM") and not name.startswith(os.environ["MB_GEMM"]):
+            continue
+        m = 19712 if name.startswith("txt") else M
+        A = (torch.randn(m, K, device="cuda") * 0.5).to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda")
+        out = torch.zeros(m, N, device="cuda", dtype=torch.float32 if epi == 3 else torch.bfloat16)
+        call = lambda: check(lib, lib.clipx_gemm_bf16_device(0, P(A), P(W), P(b), P(out), m, N, K, epi, C.c_void_p(st)), "clipx")
+
+        def setv(vspec):
+            os.environ["CLIPX_GEMM_VARIANT"] = vspec.split(":")[0]
+            if ":" in vspec:
+                os.environ["CLIPX_GEMM_FLAGS"] = vspec.split(":")[1]
+            else:
+                os.environ.pop("CLIPX_GEMM_FLAGS", None)
+
+        setv(vspecs[0])
+        time_once(call, 30)  # clock ramp
+        res = {v: [] for v in vspecs}
+        for _ in range(rounds):
+            for v in vspecs:
+                setv(v)
+                res[v].append(time_once(call, REPS))
+        for v in vspecs:
+            ms = sorted(res[v])[len(res[v]) // 2]
+            print(f"gemm v{v:5s} {name:26s} {ms * 1e3:9.1f} us  {2.0 * m * N * K / ms / 1e9:8.1f} TFLOP/s   (min {min(res[v]) * 1e3:.1f})", flush=True)
 if "attn" in what:
     for (B, T, H, causal) in [(256, 257, 16, 0), (256, 77, 12, 1)]:
         qkv = torch.randn(B * T, 3 * H * 64, device="cuda").to(torch.bfloat16)
