@@ -25,6 +25,18 @@ BF16_PEAK_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0      # HBM3E spec
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 --pmc passes of this same command, collected
+    by tools/gpu_round.sh (separate passes, kernel-trace only) and summarised by tools/traffic_summary.py into
+    profiles/traffic.json; None when that file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            k = json.load(f)["kernels"][kernel]
+        return int(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,8 +143,8 @@ def main():
         prof[name] = {"launches": n, "ms": round(ms, 3), "tflops": (fl / (ms * 1e-3) / 1e12) if ms > 0 and fl > 0 else None}
     g = prof["gemm"]
     gemm_tflops = g["tflops"] or 0.0
-    roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(gemm_tflops, 1), "peak": BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(gemm_tflops / BF16_PEAK_TFLOPS, 4), "traffic": None,
+    roofline = {"bound": "mfma", "kernel": "gemm256sp_kernel (+ gemm_bf16_kernel on the peeled 257th m-tile)", "achieved": round(gemm_tflops, 1), "peak": BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(gemm_tflops / BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm"),
                 "launches": g["launches"], "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 4)}
 
     # image-only / text-only rates (untimed extras)
@@ -221,7 +233,8 @@ def main():
                "rows_per_gpu": rows, "total_rows": rows * world, "d": d, "k": k, "queries_per_scan": nq,
                "ms_per_batch": round(dk / args.knn_scans * 1e3, 3), "planted_neighbour_top1": hit,
                "roofline": {"bound": "hbm", "kernel": "knn_scan_kernel", "achieved": round(scan_gbs, 1), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                            "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
+                            "traffic": pmc_traffic("knn_scan_kernel") if rows == 100_000_000 else None,
                             "launches": nl, "avg_launch_ms": round(scan_ms, 4),
                             "algorithmic_bytes_per_launch": rows * d * 2}}
         ix.close()

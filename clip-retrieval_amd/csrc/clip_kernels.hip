@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "clip_kernels.h"
 #include "gemm_common.h"
 
@@ -384,8 +385,11 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 // =============================================================================================
 constexpr int ATT_DH = 64;
 
-template <int NKB, int NW, int QPW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
+// RECOMP: S^T blocks are computed twice (pass 1: row max only, pass 2: exp + PV) instead of being kept in
+// NKB*16 registers.  The matrix pipe has slack (16 % busy at T=257) and the register saving (247 -> ~100 VGPRs) lets
+// 9 one-query-block waves per workgroup x 2 workgroups = 18 waves share a CU and split the K/V staging 9 ways.
+template <int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP>
+__global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
                                                               int H, float scale_log2e) {
   constexpr int TP = NKB * 32;
   constexpr int VT_STRIDE = TP * 2 + 8;  // bytes per V^T row: odd multiple of 8 -> conflict-free ds_read_b64
@@ -400,57 +404,93 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16* __res
   const bf16* kbase = qbase + H * ATT_DH;
   const bf16* vbase = qbase + 2 * H * ATT_DH;
 
-  // ---- stage K: 8 lanes cover one key's 128 B
-  for (int i = tid; i < TP * 8; i += NW * 64) {
-    const int key = i >> 3, c = i & 7;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (key < T) v = *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + c * 8);
-    *reinterpret_cast<uint4*>(sK + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = v;
+  // ---- Q fragments of every query block of this wave, requested before the K/V staging so that their HBM
+  // latency hides under it (B operand: lane (q = l31, hb) holds Q[q][16s + 8hb .. +8])
+  bf16x8 qf_all[QPW][4];
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) {
+    const int qpos = (w * QPW + qi) * 32 + l31;
+    const int qrow = qpos < T ? qpos : T - 1;  // padded query rows compute on a valid row and are never stored
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 v = *reinterpret_cast<const uint4*>(qbase + (size_t)qrow * ld + 16 * s + 8 * hb);
+      qf_all[qi][s] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  }
+
+  // ---- stage K: 8 lanes cover one key's 128 B.  Loads are unconditional (row clamped, zeroed after) and issued as
+  // one batch: a per-element `if (key < T) load` makes hipcc branch around every load and drain vmcnt(0) each time.
+  {
+    constexpr int KIT = (TP * 8 + NW * 64 - 1) / (NW * 64);
+    uint4 kv[KIT];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int i = tid + it * NW * 64;
+      int key = i >> 3;
+      key = key < T ? key : T - 1;
+      kv[it] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + (i & 7) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int i = tid + it * NW * 64;
+      const int key = i >> 3, c = i & 7;
+      if (i < TP * 8) {
+        const uint4 v = key < T ? kv[it] : make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(sK + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = v;
+      }
+    }
   }
   // ---- stage V transposed: a thread takes keys (2kp, 2kp+1) x 8 d and writes 8 packed key-pairs
-  for (int i = tid; i < (TP / 2) * 8; i += NW * 64) {
-    const int kp = i >> 3, c = i & 7;
-    const int k0 = 2 * kp, k1 = 2 * kp + 1;
-    uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = make_uint4(0u, 0u, 0u, 0u);
-    if (k0 < T) v0 = *reinterpret_cast<const uint4*>(vbase + (size_t)k0 * ld + c * 8);
-    if (k1 < T) v1 = *reinterpret_cast<const uint4*>(vbase + (size_t)k1 * ld + c * 8);
-    const unsigned a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+  {
+    constexpr int VIT = ((TP / 2) * 8 + NW * 64 - 1) / (NW * 64);
+    uint4 v0s[VIT], v1s[VIT];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const unsigned lo = (a0[jj] & 0xffffu) | (a1[jj] << 16);         // d = 8c + 2jj
-      const unsigned hi = (a0[jj] >> 16) | (a1[jj] & 0xffff0000u);     // d = 8c + 2jj + 1
-      *reinterpret_cast<unsigned*>(sVt + (8 * c + 2 * jj) * VT_STRIDE + kp * 4) = lo;
-      *reinterpret_cast<unsigned*>(sVt + (8 * c + 2 * jj + 1) * VT_STRIDE + kp * 4) = hi;
+    for (int it = 0; it < VIT; ++it) {
+      const int i = tid + it * NW * 64;
+      const int kp = i >> 3, c = i & 7;
+      const int k0 = 2 * kp < T ? 2 * kp : T - 1, k1 = 2 * kp + 1 < T ? 2 * kp + 1 : T - 1;
+      v0s[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)k0 * ld + c * 8);
+      v1s[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)k1 * ld + c * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int i = tid + it * NW * 64;
+      const int kp = i >> 3, c = i & 7;
+      if (i < (TP / 2) * 8) {
+        const uint4 v0 = 2 * kp < T ? v0s[it] : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 v1 = 2 * kp + 1 < T ? v1s[it] : make_uint4(0u, 0u, 0u, 0u);
+        const unsigned a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const unsigned lo = (a0[jj] & 0xffffu) | (a1[jj] << 16);         // d = 8c + 2jj
+          const unsigned hi = (a0[jj] >> 16) | (a1[jj] & 0xffff0000u);     // d = 8c + 2jj + 1
+          *reinterpret_cast<unsigned*>(sVt + (8 * c + 2 * jj) * VT_STRIDE + kp * 4) = lo;
+          *reinterpret_cast<unsigned*>(sVt + (8 * c + 2 * jj + 1) * VT_STRIDE + kp * 4) = hi;
+        }
+      }
     }
   }
   __syncthreads();
 
   const int ksw = (l31 >> 1) & 7;
-#pragma unroll 1
+#pragma unroll
   for (int qi = 0; qi < QPW; ++qi) {
     const int qb = w * QPW + qi;
     if (qb >= NKB) break;
     const int qpos = qb * 32 + l31;
-    // Q fragments straight from HBM (B operand: lane (q = l31, hb) holds Q[q][16s + 8hb .. +8])
     bf16x8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (qpos < T) v = *reinterpret_cast<const uint4*>(qbase + (size_t)qpos * ld + 16 * s + 8 * hb);
-      qf[s] = *reinterpret_cast<bf16x8*>(&v);
-    }
+    for (int s = 0; s < 4; ++s) qf[s] = qf_all[qi][s];
     // ---- S^T blocks; causal rows never look right of the diagonal block (wave-uniform skip)
-    f32x16 sacc[NKB];
-    float mx = -INFINITY;
+    auto s_block = [&](int kb) -> f32x16 {
+      f32x16 sb;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) sb[r] = 0.f;
       if (!CAUSAL || kb <= qb) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * 128 + (((2 * s + hb) ^ ksw) << 4));
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+          sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sb, 0, 0, 0);
         }
       }
       // masking is needed only in the last key block (padding past T) and, for causal, on/after the diagonal
@@ -459,11 +499,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16* __res
         for (int r = 0; r < 16; ++r) {
           const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
           const bool ok = key < T && (!CAUSAL || key <= qpos);
-          sacc[kb][r] = ok ? sacc[kb][r] : -INFINITY;
+          sb[r] = ok ? sb[r] : -INFINITY;
         }
       }
+      return sb;
+    };
+    f32x16 sacc[RECOMP ? 1 : NKB];
+    float mx = -INFINITY;
+#pragma unroll(RECOMP ? 1 : NKB)
+    for (int kb = 0; kb < NKB; ++kb) {
+      const f32x16 sb = s_block(kb);
+      if (!RECOMP) sacc[kb] = sb;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sb[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (mx == -INFINITY) mx = 0.f;  // padded query rows
@@ -476,13 +524,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16* __res
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
-#pragma unroll
+#pragma unroll(RECOMP ? 1 : NKB)
     for (int kb = 0; kb < NKB; ++kb) {
       if (CAUSAL && kb > qb) continue;
       bf16x8 pf[2];
+      const f32x16 sb = RECOMP ? s_block(kb) : sacc[RECOMP ? 0 : kb];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][r], scale_log2e, nmx));
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[r], scale_log2e, nmx));
         sum += p;
         pf[r >> 3][r & 7] = (bf16)p;
       }
@@ -516,18 +565,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16* __res
   }
 }
 
-template <int NKB, int NW, int QPW>
+template <int NKB, int NW, int QPW, bool RECOMP = false>
 static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st) {
   const size_t smem = (size_t)NKB * 32 * 128 + (size_t)64 * (NKB * 64 + 8);
   const float scale_log2e = 0.125f * 1.4426950408889634f;
   const dim3 grid(B * H), block(NW * 64);
   if (causal) {
-    auto kern = attention_kernel<NKB, NW, QPW, true>;
+    auto kern = attention_kernel<NKB, NW, QPW, true, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e);
   } else {
-    auto kern = attention_kernel<NKB, NW, QPW, false>;
+    auto kern = attention_kernel<NKB, NW, QPW, false, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e);
@@ -545,9 +594,13 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
     case 4: return launch_attention_cfg<4, 4, 1>(qkv, out, B, T, H, causal, st);
     case 5: return launch_attention_cfg<5, 3, 2>(qkv, out, B, T, H, causal, st);
     case 6: return launch_attention_cfg<6, 3, 2>(qkv, out, B, T, H, causal, st);
-    case 7: return launch_attention_cfg<7, 4, 2>(qkv, out, B, T, H, causal, st);   // ViT-B/16 image (T=197)
+    case 7: return launch_attention_cfg<7, 7, 1, true>(qkv, out, B, T, H, causal, st);   // ViT-B/16 image (T=197)
     case 8: return launch_attention_cfg<8, 4, 2>(qkv, out, B, T, H, causal, st);
-    case 9: return launch_attention_cfg<9, 3, 3>(qkv, out, B, T, H, causal, st);   // ViT-L/14, H/14 image (T=257)
+    case 9: {  // ViT-L/14, H/14 image (T=257)
+      static const int cfg = getenv("CLIPX_ATT_CFG") ? atoi(getenv("CLIPX_ATT_CFG")) : 0;
+      if (cfg == 1) return launch_attention_cfg<9, 9, 1, true>(qkv, out, B, T, H, causal, st);
+      return launch_attention_cfg<9, 3, 3>(qkv, out, B, T, H, causal, st);
+    }
     default: return hipErrorInvalidValue;
   }
 }

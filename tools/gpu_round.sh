@@ -1,6 +1,7 @@
 #!/bin/bash
-# One GPU visit: parity tests, the default bench line, a rocprofv3 kernel-trace of the same command, microbench.
-# usage (on the GPU box, from the repo root): bash tools/gpu_round.sh <tag> [quick]
+# One GPU visit: parity tests, microbench, the default bench line, a rocprofv3 kernel-trace of the same command and
+# the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) that bench.py's `traffic` fields
+# come from.   usage (on the GPU box, from the repo root): bash tools/gpu_round.sh <tag> [quick]
 set -u
 TAG=${1:-rX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,10 +11,15 @@ cd $ROOT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu_$TAG.log
 tail -3 $OUT/pytest_gpu_$TAG.log
-timeout 600 python tools/microbench.py > $OUT/microbench_$TAG.log 2>&1; cat $OUT/microbench_$TAG.log
+MB_VARIANTS=1,2,3 timeout 600 python tools/microbench.py > $OUT/microbench_$TAG.log 2>&1; cat $OUT/microbench_$TAG.log
 if [ "${2:-}" != "quick" ]; then
   ( time timeout 900 python bench.py ) > $OUT/bench_$TAG.log 2>&1; tail -5 $OUT/bench_$TAG.log
   cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --cpu-seconds 0 --no-parity > $OUT/rocprof_$TAG.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${c}_$TAG -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --knn-scans 3 --cpu-seconds 0 --no-parity > $OUT/pmc_${c}_$TAG.log 2>&1
+  done
+  cd $ROOT
+  python3 tools/traffic_summary.py $OUT/pmc_FETCH_SIZE_$TAG/p_counter_collection.csv $OUT/pmc_WRITE_SIZE_$TAG/p_counter_collection.csv > $OUT/traffic_$TAG.json; cat $OUT/traffic_$TAG.json
   ls -R $OUT/prof_$TAG | head
 fi
