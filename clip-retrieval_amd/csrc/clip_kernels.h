@@ -45,8 +45,8 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int Kp, const float* mean,
                          const float* inv_std, bf16* out, hipStream_t st);
 
-// qkv bf16 [B*T, 3*H*64] -> out bf16 [B*T, H*64]; softmax(q k^T / 8 [+ causal]) v, head dim 64
-hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st);
+// qkv bf16 [B*T, 3*H*dh] -> out bf16 [B*T, H*dh]; softmax(q k^T / sqrt(dh) [+ causal]) v, head dim dh = 64 or 80
+hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st);
 
 // ids int32 [B, T] -> x f32 [B*T, d] = tok_emb[id] + pos_emb[t]
 hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T,

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include "clip_kernels.h"
 #include "gemm_common.h"
 
@@ -375,79 +376,85 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 }
 
 // =============================================================================================
-// Attention (head dim 64): one workgroup per (batch, head); K (row-major, swizzled) and V^T in LDS.
+// Attention (head dim DH = 64 or 80): one workgroup per (batch, head); K (row-major) and V^T in LDS.
 //   S^T = K Q^T   (MFMA A = K rows, B = Q rows): a lane holds 16 keys x NKB blocks of ONE query column
 //   softmax over the lane's registers + one exchange with lane^32; P stays in registers as the B operand
 //   O^T = V^T P^T (MFMA A = V^T rows from LDS, B = P): a lane ends with 4 consecutive d of its query -> 8-B stores
 // The MFMA contraction index of the PV product is a permutation of the key index (the order in which the
 // S^T accumulator registers hold keys); V^T fragments are read with the same permutation, so no lane
 // exchange is needed between the two products.
+// LDS images: K rows of DH*2 bytes; DH=64: 128-B rows with the 16-B chunk position XOR ((key>>1)&7); DH=80 (ViT-H/14):
+// rows padded to 176 B = 11 chunks, 11 is odd so 16 consecutive rows hit 16 distinct 16-B slots without a swizzle.
+// V^T has DV = DH rounded up to 32 rows (rows >= DH are zero: the third 32-row output block of DH=80 is half padding).
+// RECOMP: S^T blocks are computed twice (pass 1: row max only, pass 2: exp + PV) instead of being kept in NKB*16
+// registers, for configurations where one query block per wave and many waves per workgroup pay.
 // =============================================================================================
-constexpr int ATT_DH = 64;
-
-// RECOMP: S^T blocks are computed twice (pass 1: row max only, pass 2: exp + PV) instead of being kept in
-// NKB*16 registers.  The matrix pipe has slack (16 % busy at T=257) and the register saving (247 -> ~100 VGPRs) lets
-// 9 one-query-block waves per workgroup x 2 workgroups = 18 waves share a CU and split the K/V staging 9 ways.
-template <int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP>
+template <int DH, int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP>
 __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
                                                               int H, float scale_log2e) {
   constexpr int TP = NKB * 32;
+  constexpr int CH = DH / 8;                      // 16-B chunks per key row
+  constexpr int KS = DH / 16;                     // MFMA k-steps of the QK^T product
+  constexpr int KROW = DH == 64 ? 128 : 176;      // bytes per K row in LDS
+  constexpr int DV = (DH + 31) / 32 * 32, NB = DV / 32;
   constexpr int VT_STRIDE = TP * 2 + 8;  // bytes per V^T row: odd multiple of 8 -> conflict-free ds_read_b64
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sK = smem;                 // [TP][128 B], chunk ^ ((key>>1)&7)
-  unsigned char* sVt = smem + TP * 128;     // [64][VT_STRIDE]
+  unsigned char* sK = smem;                 // [TP][KROW]
+  unsigned char* sVt = smem + TP * KROW;    // [DV][VT_STRIDE]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int hb = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int ld = 3 * H * ATT_DH;  // qkv row stride (elements)
-  const bf16* qbase = qkv + (size_t)b * T * ld + h * ATT_DH;
-  const bf16* kbase = qbase + H * ATT_DH;
-  const bf16* vbase = qbase + 2 * H * ATT_DH;
+  const int ld = 3 * H * DH;  // qkv row stride (elements)
+  const bf16* qbase = qkv + (size_t)b * T * ld + h * DH;
+  const bf16* kbase = qbase + H * DH;
+  const bf16* vbase = qbase + 2 * H * DH;
+  auto kchunk = [](int key, int c) -> int { return DH == 64 ? (c ^ ((key >> 1) & 7)) : c; };
 
   // ---- Q fragments of every query block of this wave, requested before the K/V staging so that their HBM
   // latency hides under it (B operand: lane (q = l31, hb) holds Q[q][16s + 8hb .. +8])
-  bf16x8 qf_all[QPW][4];
+  bf16x8 qf_all[QPW][KS];
 #pragma unroll
   for (int qi = 0; qi < QPW; ++qi) {
     const int qpos = (w * QPW + qi) * 32 + l31;
     const int qrow = qpos < T ? qpos : T - 1;  // padded query rows compute on a valid row and are never stored
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const uint4 v = *reinterpret_cast<const uint4*>(qbase + (size_t)qrow * ld + 16 * s + 8 * hb);
       qf_all[qi][s] = *reinterpret_cast<const bf16x8*>(&v);
     }
   }
 
-  // ---- stage K: 8 lanes cover one key's 128 B.  Loads are unconditional (row clamped, zeroed after) and issued as
+  // ---- stage K: CH lanes cover one key's row.  Loads are unconditional (row clamped, zeroed after) and issued as
   // one batch: a per-element `if (key < T) load` makes hipcc branch around every load and drain vmcnt(0) each time.
   {
-    constexpr int KIT = (TP * 8 + NW * 64 - 1) / (NW * 64);
+    constexpr int KIT = (TP * CH + NW * 64 - 1) / (NW * 64);
     uint4 kv[KIT];
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
       const int i = tid + it * NW * 64;
-      int key = i >> 3;
+      int key = i / CH;
+      const int c = i - key * CH;
       key = key < T ? key : T - 1;
-      kv[it] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + (i & 7) * 8);
+      kv[it] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + c * 8);
     }
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
       const int i = tid + it * NW * 64;
-      const int key = i >> 3, c = i & 7;
-      if (i < TP * 8) {
+      const int key = i / CH, c = i - key * CH;
+      if (i < TP * CH) {
         const uint4 v = key < T ? kv[it] : make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint4*>(sK + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = v;
+        *reinterpret_cast<uint4*>(sK + key * KROW + (kchunk(key, c) << 4)) = v;
       }
     }
   }
   // ---- stage V transposed: a thread takes keys (2kp, 2kp+1) x 8 d and writes 8 packed key-pairs
   {
-    constexpr int VIT = ((TP / 2) * 8 + NW * 64 - 1) / (NW * 64);
+    constexpr int VIT = ((TP / 2) * CH + NW * 64 - 1) / (NW * 64);
     uint4 v0s[VIT], v1s[VIT];
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
       const int i = tid + it * NW * 64;
-      const int kp = i >> 3, c = i & 7;
+      const int kp = i / CH, c = i - kp * CH;
       const int k0 = 2 * kp < T ? 2 * kp : T - 1, k1 = 2 * kp + 1 < T ? 2 * kp + 1 : T - 1;
       v0s[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)k0 * ld + c * 8);
       v1s[it] = *reinterpret_cast<const uint4*>(vbase + (size_t)k1 * ld + c * 8);
@@ -455,8 +462,8 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 #pragma unroll
     for (int it = 0; it < VIT; ++it) {
       const int i = tid + it * NW * 64;
-      const int kp = i >> 3, c = i & 7;
-      if (i < (TP / 2) * 8) {
+      const int kp = i / CH, c = i - kp * CH;
+      if (i < (TP / 2) * CH) {
         const uint4 v0 = 2 * kp < T ? v0s[it] : make_uint4(0u, 0u, 0u, 0u);
         const uint4 v1 = 2 * kp + 1 < T ? v1s[it] : make_uint4(0u, 0u, 0u, 0u);
         const unsigned a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
@@ -469,6 +476,12 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
         }
       }
     }
+    if (DV > DH) {  // zero rows DH .. DV-1 of V^T
+      for (int i = tid; i < (DV - DH) * (TP / 2); i += NW * 64) {
+        const int r = i / (TP / 2), kp = i - r * (TP / 2);
+        *reinterpret_cast<unsigned*>(sVt + (DH + r) * VT_STRIDE + kp * 4) = 0u;
+      }
+    }
   }
   __syncthreads();
 
@@ -478,9 +491,9 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
     const int qb = w * QPW + qi;
     if (qb >= NKB) break;
     const int qpos = qb * 32 + l31;
-    bf16x8 qf[4];
+    bf16x8 qf[KS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = qf_all[qi][s];
+    for (int s = 0; s < KS; ++s) qf[s] = qf_all[qi][s];
     // ---- S^T blocks; causal rows never look right of the diagonal block (wave-uniform skip)
     auto s_block = [&](int kb) -> f32x16 {
       f32x16 sb;
@@ -488,8 +501,9 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
       for (int r = 0; r < 16; ++r) sb[r] = 0.f;
       if (!CAUSAL || kb <= qb) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * 128 + (((2 * s + hb) ^ ksw) << 4));
+        for (int s = 0; s < KS; ++s) {
+          const int c = 2 * s + hb;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * KROW + ((DH == 64 ? (c ^ ksw) : c) << 4));
           sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sb, 0, 0, 0);
         }
       }
@@ -519,9 +533,9 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 
     // ---- per key block: P = exp2(S*c - m*c) -> bf16 (stays in registers as the B operand), then O^T += V^T P^T
     float sum = 0.f;
-    f32x16 oacc[2];
+    f32x16 oacc[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
 #pragma unroll(RECOMP ? 1 : NKB)
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
           // lane (d = 32nb + l31, hb): keys kb*32 + 16*s2 + 4hb + {0..3} and + 8 + {0..3}
           const unsigned char* vp = sVt + (32 * nb + l31) * VT_STRIDE + (kb * 32 + 16 * s2 + 4 * hb) * 2;
           const uint2 lo = *reinterpret_cast<const uint2*>(vp);
@@ -551,11 +565,12 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     // ---- store: lane owns query qpos, d = 32nb + 8g + 4hb + {0..3}
     if (qpos < T) {
-      bf16* orow = out + ((size_t)b * T + qpos) * (H * ATT_DH) + h * ATT_DH;
+      bf16* orow = out + ((size_t)b * T + qpos) * (H * DH) + h * DH;
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          if (32 * nb + 8 * g >= DH) continue;  // padded d of the last block (compile time)
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nb][4 * g + e] * inv);
@@ -565,18 +580,19 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
   }
 }
 
-template <int NKB, int NW, int QPW, bool RECOMP = false>
+template <int DH, int NKB, int NW, int QPW, bool RECOMP = false>
 static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st) {
-  const size_t smem = (size_t)NKB * 32 * 128 + (size_t)64 * (NKB * 64 + 8);
-  const float scale_log2e = 0.125f * 1.4426950408889634f;
+  constexpr int KROW = DH == 64 ? 128 : 176, DV = (DH + 31) / 32 * 32;
+  const size_t smem = (size_t)NKB * 32 * KROW + (size_t)DV * (NKB * 64 + 8);
+  const float scale_log2e = (1.f / sqrtf((float)DH)) * 1.4426950408889634f;
   const dim3 grid(B * H), block(NW * 64);
   if (causal) {
-    auto kern = attention_kernel<NKB, NW, QPW, true, RECOMP>;
+    auto kern = attention_kernel<DH, NKB, NW, QPW, true, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e);
   } else {
-    auto kern = attention_kernel<NKB, NW, QPW, false, RECOMP>;
+    auto kern = attention_kernel<DH, NKB, NW, QPW, false, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e);
@@ -584,23 +600,29 @@ static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T,
   return hipGetLastError();
 }
 
-hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st) {
+hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   const int nkb = (T + 31) / 32;
-  switch (nkb) {
-    case 1: return launch_attention_cfg<1, 1, 1>(qkv, out, B, T, H, causal, st);
-    case 2: return launch_attention_cfg<2, 2, 1>(qkv, out, B, T, H, causal, st);   // ViT-B/32 image (T=50)
-    case 3: return launch_attention_cfg<3, 3, 1>(qkv, out, B, T, H, causal, st);   // text (T=77)
-    case 4: return launch_attention_cfg<4, 4, 1>(qkv, out, B, T, H, causal, st);
-    case 5: return launch_attention_cfg<5, 3, 2>(qkv, out, B, T, H, causal, st);
-    case 6: return launch_attention_cfg<6, 3, 2>(qkv, out, B, T, H, causal, st);
-    case 7: return launch_attention_cfg<7, 7, 1, true>(qkv, out, B, T, H, causal, st);   // ViT-B/16 image (T=197)
-    case 8: return launch_attention_cfg<8, 4, 2>(qkv, out, B, T, H, causal, st);
-    case 9: {  // ViT-L/14, H/14 image (T=257)
-      static const int cfg = getenv("CLIPX_ATT_CFG") ? atoi(getenv("CLIPX_ATT_CFG")) : 0;
-      if (cfg == 1) return launch_attention_cfg<9, 9, 1, true>(qkv, out, B, T, H, causal, st);
-      return launch_attention_cfg<9, 3, 3>(qkv, out, B, T, H, causal, st);
+  if (dh == 80) {  // ViT-H/14 image tower (T = 257), ViT-bigG is dh 104: not built
+    switch (nkb) {
+      case 1: return launch_attention_cfg<80, 1, 1, 1>(qkv, out, B, T, H, causal, st);
+      case 2: return launch_attention_cfg<80, 2, 2, 1>(qkv, out, B, T, H, causal, st);
+      case 3: return launch_attention_cfg<80, 3, 3, 1>(qkv, out, B, T, H, causal, st);
+      case 9: return launch_attention_cfg<80, 9, 9, 1, true>(qkv, out, B, T, H, causal, st);
+      default: return hipErrorInvalidValue;
     }
+  }
+  if (dh != 64) return hipErrorInvalidValue;
+  switch (nkb) {
+    case 1: return launch_attention_cfg<64, 1, 1, 1>(qkv, out, B, T, H, causal, st);
+    case 2: return launch_attention_cfg<64, 2, 2, 1>(qkv, out, B, T, H, causal, st);   // ViT-B/32 image (T=50)
+    case 3: return launch_attention_cfg<64, 3, 3, 1>(qkv, out, B, T, H, causal, st);   // text (T=77)
+    case 4: return launch_attention_cfg<64, 4, 4, 1>(qkv, out, B, T, H, causal, st);
+    case 5: return launch_attention_cfg<64, 5, 3, 2>(qkv, out, B, T, H, causal, st);
+    case 6: return launch_attention_cfg<64, 6, 3, 2>(qkv, out, B, T, H, causal, st);
+    case 7: return launch_attention_cfg<64, 7, 4, 2>(qkv, out, B, T, H, causal, st);   // ViT-B/16 image (T=197)
+    case 8: return launch_attention_cfg<64, 8, 4, 2>(qkv, out, B, T, H, causal, st);
+    case 9: return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st);   // ViT-L/14 image (T=257)
     default: return hipErrorInvalidValue;
   }
 }

@@ -115,8 +115,10 @@ extern "C" size_t clipx_blob_floats(const clipx_model_desc* d) {
 static int check_desc(const clipx_model_desc* d) {
   if (d->image_size <= 0 || d->patch_size <= 0 || d->image_size % d->patch_size) return fail(CLIPX_E_ARG, "image_size must be a multiple of patch_size");
   if (d->v_width % 256 || d->t_width % 256) return fail(CLIPX_E_UNSUPPORTED, "tower widths must be multiples of 256");
-  if (d->v_width / d->v_heads != 64 || d->t_width / d->t_heads != 64 || d->v_width % d->v_heads || d->t_width % d->t_heads)
-    return fail(CLIPX_E_UNSUPPORTED, "this build has attention kernels for head dimension 64 only");
+  if (d->v_width % d->v_heads || d->t_width % d->t_heads) return fail(CLIPX_E_ARG, "width must be a multiple of heads");
+  const int vdh = d->v_width / d->v_heads, tdh = d->t_width / d->t_heads;
+  if ((vdh != 64 && vdh != 80) || (tdh != 64 && tdh != 80))
+    return fail(CLIPX_E_UNSUPPORTED, "this build has attention kernels for head dimensions 64 and 80 only");
   if (d->v_mlp % 128 || d->t_mlp % 128) return fail(CLIPX_E_UNSUPPORTED, "mlp widths must be multiples of 128");
   const int g = d->image_size / d->patch_size;
   if (g * g + 1 > 288 || d->ctx_len > 288) return fail(CLIPX_E_UNSUPPORTED, "sequence longer than 288 tokens");
@@ -339,7 +341,7 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
     int r;
     { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, L.ln1_w, L.ln1_b, h->xn, 1, M, w, eps, st)); }
     if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_b, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16))) return r;
-    { ProfScope ps(h, st, 1, 4.0 * B * t.heads * (double)t.T * t.T * 64); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, causal, st)); }
+    { ProfScope ps(h, st, 1, 4.0 * B * t.heads * (double)t.T * t.T * (w / t.heads)); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st)); }
     if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->x, nullptr, 1, M, w, w, EPI_BIAS_RESID_F32))) return r;
     { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, L.ln2_w, L.ln2_b, h->xn, 1, M, w, eps, st)); }
     if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_b, h->hbuf, nullptr, 1, M, t.mlp, w, act))) return r;
@@ -486,7 +488,19 @@ extern "C" int clipx_attention_device(int device, const void* qkv_bf16, void* ou
   if (!qkv_bf16 || !out_bf16 || B <= 0 || T <= 0 || H <= 0) return fail(CLIPX_E_ARG, "bad attention arguments");
   if (T > 288) return fail(CLIPX_E_UNSUPPORTED, "sequence longer than 288 tokens");
   HIPCHK(hipSetDevice(device));
-  HIPCHK(launch_attention((const bf16*)qkv_bf16, (bf16*)out_bf16, B, T, H, causal, (hipStream_t)stream));
+  HIPCHK(launch_attention((const bf16*)qkv_bf16, (bf16*)out_bf16, B, T, H, 64, causal, (hipStream_t)stream));
+  return CLIPX_OK;
+}
+
+extern "C" int clipx_attention_dh_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int dh,
+                                         int causal, void* stream) {
+  if (!qkv_bf16 || !out_bf16 || B <= 0 || T <= 0 || H <= 0) return fail(CLIPX_E_ARG, "bad attention arguments");
+  if (T > 288) return fail(CLIPX_E_UNSUPPORTED, "sequence longer than 288 tokens");
+  if (dh != 64 && dh != 80) return fail(CLIPX_E_UNSUPPORTED, "head dimension must be 64 or 80");
+  HIPCHK(hipSetDevice(device));
+  hipError_t e = launch_attention((const bf16*)qkv_bf16, (bf16*)out_bf16, B, T, H, dh, causal, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue) return fail(CLIPX_E_UNSUPPORTED, "no attention kernel for this (T, head dimension)");
+  HIPCHK(e);
   return CLIPX_OK;
 }
 

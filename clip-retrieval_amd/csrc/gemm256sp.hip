@@ -39,8 +39,23 @@ constexpr int S_SCRATCH = 131072; // per-wave 4 KiB epilogue scratch starts here
 
 #define S_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// Output stores are write-through and do not keep their lines in the XCD's L2 (sc1): one tile round writes
+// 32 CUs x 128 KiB = the whole 4 MiB L2 of an XCD, and with plain stores that round evicts the operand panels the
+// next K-tiles re-read (measured: the stores alone cost 24 % of the QKV GEMM, 215 k of 888 k cycles).  flags bit 2
+// switches back to plain stores for A/B.  (s_nop 1: the data registers must not be rewritten before the store read them.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(void* p, uint4 v, bool plain) {
+  if (plain) {
+    *reinterpret_cast<uint4*>(p) = v;
+  } else {
+    const u32x4 r = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+  }
+}
+
 // DBG (ablation, EPI_BIAS_BF16 only; garbage results): 1 = no staging, 3 = no staging and no ds_reads,
-// 5 = normal main loop, no epilogue stores
+// 5 = normal main loop, no epilogue at all; 6 = epilogue without its global stores; 7 = XCD x starts x/8 of a tile
+// period late (tests whether the tile-boundary cost is the chip-wide simultaneous store burst)
 template <int EPI, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
@@ -68,6 +83,11 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   };
   int m0, n0;
   if (!tile_of(0, m0, n0)) return;  // before any barrier
+  if (DBG == 7) {
+    const long long t0 = __builtin_readcyclecounter();  // s_memtime: shader-clock ticks
+    const long long wait = (long long)xcd * (K >> 6) * 420;  // (K/64 K-tiles) * ~3300 cycles / 8 per XCD step
+    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
 
   // ---- staging: wave w fills rows [32w, 32w+32) of both operands, 8 rows (1 KiB) per instruction
   // (piece 4w + j = rows 32w + 8j .. +8).  Source chunk = LDS chunk position ^ ((row>>1)&7); rows 8 apart flip bit 2
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   // and may stay in flight: vmcnt(S_EPI_ST).  (An L2 prefetch of the K-tile 4 ahead was tried and measured neutral:
   // the exposed staging time is LDS-DMA throughput, not HBM latency -- staging an L2-resident K-tile costs the same.)
   constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
-  constexpr int S_EPI_ST = DBG == 5 ? 0 : (OUT_BF16 ? 16 : 32);  // f32: 32 loads + 32 stores follow; 32 youngest = stores
+  constexpr int S_EPI_ST = (DBG == 5 || DBG == 6) ? 0 : (OUT_BF16 ? 16 : 32);  // f32: 32 loads + 32 stores follow; 32 youngest = stores
 
   // ---- prologue: K-tiles 0, 1 of the first tile; K-tile 0 landed + first fragment set read
   stage(curM, curN, 0);
@@ -255,7 +275,8 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
           for (int i = 0; i < 4; ++i) {
             const int row = 8 * i + rrow;
             const uint4 q = *reinterpret_cast<const uint4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4));
-            *reinterpret_cast<uint4*>(yo + (size_t)(mt * 32 + row) * N + rch * 8) = q;
+            if (DBG != 6) store16_wt(yo + (size_t)(mt * 32 + row) * N + rch * 8, q, flags & 4);
+            else asm volatile("" ::"v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
           }
         }
       } else {
@@ -298,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                 q.x += bq.x; q.y += bq.y; q.z += bq.z; q.w += bq.w;
               }
               q.x = ext[i].x + q.x; q.y = ext[i].y + q.y; q.z = ext[i].z + q.z; q.w = ext[i].w + q.w;
-              *reinterpret_cast<float4*>(xo + (size_t)(mt * 32 + row) * N + nt * 32 + rch * 4) = q;
+              store16_wt(xo + (size_t)(mt * 32 + row) * N + nt * 32 + rch * 4, make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)), flags & 4);
             }
           }
       }
@@ -327,7 +348,7 @@ template <int EPI, int DBG = 0>
 static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   const size_t smem = S_SCRATCH + 8 * 4096;  // 160 KiB: the whole LDS of the CU
   auto kern = gemm256sp_kernel<EPI, DBG>;
-  const char* fl = getenv("CLIPX_GEMM_FLAGS");  // bit 1: A/B switch, drain vmcnt(0) at every wait (no counted waits)
+  const char* fl = getenv("CLIPX_GEMM_FLAGS");  // A/B switches: bit 1 = drain vmcnt(0) at every wait, bit 2 = plain (L2-resident) output stores
   const int flags = fl ? atoi(fl) : 0;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
@@ -346,6 +367,8 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 1) return launch_sp_epi<EPI_BIAS_BF16, 1>(g, grid, st);
     if (d == 3) return launch_sp_epi<EPI_BIAS_BF16, 3>(g, grid, st);
     if (d == 5) return launch_sp_epi<EPI_BIAS_BF16, 5>(g, grid, st);
+    if (d == 6) return launch_sp_epi<EPI_BIAS_BF16, 6>(g, grid, st);
+    if (d == 7) return launch_sp_epi<EPI_BIAS_BF16, 7>(g, grid, st);
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);

@@ -67,6 +67,9 @@ ARCHS = {
     "open_clip:ViT-B-32": ClipArch(patch_size=32, v_width=768, v_layers=12, v_heads=12, v_mlp=3072, t_width=512,
                                    t_heads=8, t_mlp=2048, embed_dim=512, act="gelu"),
     "open_clip:ViT-L-14": ClipArch(act="gelu"),
+    # LAION ViT-H/14 (the 1024-d model of docs/laion5B_h14_back.md; BASELINE config 5): image heads are 80 wide
+    "open_clip:ViT-H-14": ClipArch(v_width=1280, v_layers=32, v_heads=16, v_mlp=5120, t_width=1024, t_layers=24,
+                                   t_heads=16, t_mlp=4096, embed_dim=1024, act="gelu"),
 }
 
 

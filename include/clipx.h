@@ -41,7 +41,7 @@ enum {
 #define CLIPX_PIX_U8_NHWC 1  /* u8  [B,S,S,3] raw RGB; /255, mean/std normalised on the device               */
 
 /* Architecture of one CLIP model = what `all_clip.load_clip(clip_model)` resolves a name to
- * (mapper.py:36-41).  Head dimension (width / heads) must be 64 in this build. */
+ * (mapper.py:36-41).  Head dimension (width / heads) must be 64 or 80 (ViT-H/14) in this build. */
 typedef struct clipx_model_desc {
   int image_size;   /* 224 */
   int patch_size;   /* 14 (L/14), 32 (B/32), 16 (B/16) */
@@ -110,6 +110,9 @@ int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, c
  * qkv bf16 [B*T, 3*H*64] -> out bf16 [B*T, H*64];  x f32 [M, d] -> y (bf16 if out_bf16 else f32). */
 int clipx_attention_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int causal,
                            void* stream);
+/* Same for head dimension dh = 64 or 80 (ViT-H/14 image tower: 1280 / 16): qkv [B*T, 3*H*dh] -> out [B*T, H*dh]. */
+int clipx_attention_dh_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int dh,
+                              int causal, void* stream);
 int clipx_layernorm_device(int device, const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
                            int M, int d, float eps, void* stream);
 

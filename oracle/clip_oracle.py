@@ -65,7 +65,11 @@ ARCHS = {
                          t_mlp=2048, embed_dim=512),
     "ViT-L/14": ClipArch(),
     # reduced-depth shapes for fast tests (same widths/heads as the real towers, fewer layers)
+    "ViT-H/14": ClipArch(v_width=1280, v_layers=32, v_heads=16, v_mlp=5120, t_width=1024, t_layers=24, t_heads=16,
+                         t_mlp=4096, embed_dim=1024, act="gelu"),
     "tiny-L/14": ClipArch(v_layers=2, t_layers=2),
+    "tiny-H/14": ClipArch(v_width=1280, v_layers=2, v_heads=16, v_mlp=5120, t_width=1024, t_layers=2, t_heads=16,
+                          t_mlp=4096, embed_dim=1024, act="gelu"),
     "tiny-B/32": ClipArch(patch_size=32, v_width=768, v_layers=2, v_heads=12, v_mlp=3072, t_width=512, t_heads=8,
                           t_mlp=2048, t_layers=2, embed_dim=512),
 }

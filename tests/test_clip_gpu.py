@@ -87,25 +87,30 @@ def test_layernorm(lib, d):
     assert (y16.float() - want).abs().max() < 0.02  # one bf16 ulp at |y| <= 4
 
 
-@pytest.mark.parametrize("B,T,H,causal", [(2, 257, 16, 0), (3, 77, 12, 1), (2, 50, 12, 0), (1, 197, 12, 0), (2, 77, 8, 1), (1, 1, 1, 0)])
-def test_attention(lib, B, T, H, causal):
-    """softmax(q k^T / 8 [+causal]) v per head; reference in fp32 on the same bf16 inputs.  Output is bf16 and P
-    is rounded to bf16 before the PV product: tol 1e-2 absolute on O(1) values."""
+@pytest.mark.parametrize("B,T,H,dh,causal", [(2, 257, 16, 64, 0), (3, 77, 12, 64, 1), (2, 50, 12, 64, 0), (1, 197, 12, 64, 0),
+                                              (2, 77, 8, 64, 1), (1, 1, 1, 64, 0), (2, 257, 16, 80, 0), (2, 77, 4, 80, 1),
+                                              (1, 33, 2, 80, 0)])
+def test_attention(lib, B, T, H, dh, causal):
+    """softmax(q k^T / sqrt(dh) [+causal]) v per head; reference in fp32 on the same bf16 inputs.  Output is bf16 and
+    P is rounded to bf16 before the PV product: tol 1e-2 absolute on O(1) values.  dh = 80 is the ViT-H/14 image tower."""
     from clip_retrieval_amd._lib import check
 
     g = torch.Generator().manual_seed(T * 31 + H)
-    qkv = (torch.randn(B * T, 3 * H * 64, generator=g)).to(torch.bfloat16).cuda()
-    qkv[:, : H * 64] *= 2.0  # sharper softmax
-    out = torch.empty(B * T, H * 64, dtype=torch.bfloat16, device="cuda")
-    check(lib, lib.clipx_attention_device(0, _ptr(qkv), _ptr(out), B, T, H, causal, None), "clipx")
+    qkv = (torch.randn(B * T, 3 * H * dh, generator=g)).to(torch.bfloat16).cuda()
+    qkv[:, : H * dh] *= 2.0  # sharper softmax
+    out = torch.empty(B * T, H * dh, dtype=torch.bfloat16, device="cuda")
+    if dh == 64:
+        check(lib, lib.clipx_attention_device(0, _ptr(qkv), _ptr(out), B, T, H, causal, None), "clipx")
+    else:
+        check(lib, lib.clipx_attention_dh_device(0, _ptr(qkv), _ptr(out), B, T, H, dh, causal, None), "clipx")
     torch.cuda.synchronize()
-    q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
-    s = (q @ k.transpose(-1, -2)) * 0.125
+    q, k, v = qkv.float().view(B, T, 3, H, dh).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
     if causal:
         s = s + torch.full((T, T), float("-inf"), device="cuda").triu_(1)
-    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, H * dh)
     err = (out.float() - want).abs()
-    assert err.max() < 2e-2, f"B={B} T={T} H={H} causal={causal}: max err {err.max().item():.4g} at {err.argmax().item()}"
+    assert err.max() < 2e-2, f"B={B} T={T} H={H} dh={dh} causal={causal}: max err {err.max().item():.4g} at {err.argmax().item()}"
     assert err.mean() < 2e-3
 
 
@@ -116,7 +121,7 @@ def _product_arch(arch):
     return ClipArch(**{k: getattr(arch, k) for k in ClipArch.__dataclass_fields__})
 
 
-@pytest.fixture(scope="module", params=["tiny-B/32", "tiny-L/14"])
+@pytest.fixture(scope="module", params=["tiny-B/32", "tiny-L/14", "tiny-H/14"])
 def tiny(request):
     from clip_retrieval_amd.encoder import ClipEncoder
     from oracle.clip_oracle import ARCHS, HFClipOracle
