@@ -49,6 +49,9 @@ SIGNATURES = {
     "knnx_search_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "knnx_reconstruct": (C.c_int, [_P, _P, C.c_int64, _P]),
     "knnx_range_search": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P, _P]),
+    "knnx_ivf_set_lists": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "knnx_ivf_set_nprobe": (C.c_int, [_P, C.c_int]),
+    "knnx_ivf_nlist": (C.c_int, [_P]),
     "knnx_merge_topk_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "knnx_merge_topk_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "knnx_profile_enable": (C.c_int, [_P, C.c_int]),

@@ -32,6 +32,9 @@ struct ScanArgs {
   unsigned range_cap;
   float* range_s;
   uint32_t* range_i;
+  // IVF: walk this work list of {tile, query mask, valid rows, -} items instead of all tiles (null = flat scan)
+  const uint4* work;
+  const unsigned* nwork;
 };
 
 size_t scan_smem_bytes(int d, int cap);
@@ -39,7 +42,17 @@ hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* 
                        hipStream_t st);
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st);
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
-                            int nq, int k, int64_t id_base, float* D, int64_t* I, hipStream_t st);
+                            int nq, int k, int64_t id_base, const int64_t* idmap_or_null, float* D, int64_t* I,
+                            hipStream_t st);
+// IVF-Flat helpers (see knn_kernels.hip)
+hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
+                               const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
+                               hipStream_t st);
+hipError_t launch_ivf_relayout(const _Float16* src, _Float16* dst, int d, int nlist, const int64_t* src0, const unsigned* tile0,
+                               const unsigned* ntile, const unsigned* size, const int64_t* ids, int64_t id_lo, int64_t n_ids,
+                               int64_t* idmap, uint32_t* inv, hipStream_t st);
+hipError_t launch_gather_inv(const _Float16* X, int d, int64_t id_lo, int64_t n_ids, const uint32_t* inv, const int64_t* ids,
+                             int64_t n, float* out, hipStream_t st);
 hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
                             int64_t* I, hipStream_t st);
 hipError_t launch_gather(const _Float16* X, int64_t N, int d, int64_t id_base, const int64_t* ids, int64_t n,

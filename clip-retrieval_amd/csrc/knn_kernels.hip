@@ -133,12 +133,16 @@ __device__ __forceinline__ void prune_query(const ScanSmem& sm, int qq, int cap,
   if (lane == 0) sm.cnt[qq] = n < k ? n : k;
 }
 
-template <int NCH, int MODE, bool NT>  // NCH = d/128 (even); MODE 0 = top-k, 1 = range; NT = nontemporal loads
+// IVF = true: instead of all row tiles 0..N/32, the waves walk a WORK LIST of 32-row tiles (the tiles of the inverted
+// lists probed by at least one query of this scan, built by ivf_expand_kernel); item = {tile, query mask, valid rows}:
+// a lane (= query column) only admits a score when its query probes that tile's list -- exactly the candidate set
+// faiss IndexIVFFlat scans for that query -- and row ids are positions in the list-sorted arena (mapped back by idmap).
+template <int NCH, int MODE, bool NT, bool IVF>  // NCH = d/128 (even); MODE 0 = top-k, 1 = range; NT = nontemporal loads
 __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     const _Float16* __restrict__ X, int64_t N, const _Float16* __restrict__ qfrag, int nq, int k, int cap,
     int* __restrict__ thr_g, float* __restrict__ part_s, uint32_t* __restrict__ part_i, int* __restrict__ part_n,
     float range_thr, unsigned* __restrict__ range_cnt, unsigned range_cap, float* __restrict__ range_s,
-    uint32_t* __restrict__ range_i) {
+    uint32_t* __restrict__ range_i, const uint4* __restrict__ work, const unsigned* __restrict__ nwork_ptr) {
   constexpr int D = NCH * 128;
   constexpr int KS = D / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -158,13 +162,23 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
   }
   __syncthreads();
 
-  const int64_t ntile = (N + 31) >> 5;
+  const int64_t ntile = IVF ? (int64_t)*nwork_ptr : (N + 31) >> 5;  // IVF: number of work items
   const int64_t ngroup = (ntile + KNN_WAVES - 1) / KNN_WAVES;
 
   half8 a0[8], a1[8];
+  auto item_of = [&](int64_t grp) -> uint4 {  // IVF work item of this wave in group `grp` (wave-uniform address)
+    const int64_t idx = grp * KNN_WAVES + w;
+    return (grp < ngroup && idx < ntile) ? work[idx] : make_uint4(0u, 0u, 0u, 0u);
+  };
+  uint4 it_cur = make_uint4(0u, 0u, 0u, 0u), it_nxt = it_cur, it_n2 = it_cur;  // items are fetched two groups ahead
   auto row_ptr = [&](int64_t grp) -> const half8* {
-    int64_t row = (grp * KNN_WAVES + w) * 32 + q;
-    row = row < N ? row : N - 1;
+    int64_t row;
+    if (IVF) {
+      row = (int64_t)it_nxt.x * 32 + q;  // the arena is padded to whole tiles: always in range
+    } else {
+      row = (grp * KNN_WAVES + w) * 32 + q;
+      row = row < N ? row : N - 1;
+    }
     return reinterpret_cast<const half8*>(X + (size_t)row * D) + hb;
   };
   auto load_chunk = [&](half8 (&buf)[8], const half8* xp, int c) {
@@ -175,11 +189,20 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
   };
 
   int64_t grp = blockIdx.x;
+  if (IVF) {  // row_ptr() addresses the tile of it_nxt
+    it_nxt = item_of(grp);
+    it_n2 = item_of(grp + gridDim.x);
+  }
   const half8* xp = row_ptr(grp < ngroup ? grp : 0);
   if (grp < ngroup) load_chunk(a0, xp, 0);
 
   for (int rnd = 0; grp < ngroup; grp += gridDim.x, ++rnd) {
     const int64_t gnext = grp + gridDim.x;
+    if (IVF) {
+      it_cur = it_nxt;
+      it_nxt = it_n2;
+      it_n2 = item_of(gnext + gridDim.x);
+    }
     const half8* xnext = row_ptr(gnext < ngroup ? gnext : grp);
     float16v acc_h, acc_l;
 #pragma unroll
@@ -203,7 +226,10 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     xp = xnext;
 
     // ---- filter: lane (q, hb) owns rows row0 + (r&3) + 8*(r>>2) + 4*hb of query q
-    const int64_t row0 = (grp * KNN_WAVES + w) * 32 + 4 * hb;
+    const int64_t row0 = (IVF ? (int64_t)it_cur.x : grp * KNN_WAVES + w) * 32 + 4 * hb;
+    // IVF: rows of this tile beyond the list's size are padding; the query must probe the tile's list
+    const int64_t row_lim = IVF ? (int64_t)it_cur.x * 32 + (int64_t)it_cur.z : N;
+    const bool q_ok = q < nq && (!IVF || ((it_cur.y >> q) & 1u));
     float sc[16];
     unsigned pend = 0;
     if (MODE == 0) {
@@ -212,7 +238,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
       for (int r = 0; r < 16; ++r) {
         sc[r] = acc_h[r] + acc_l[r] * KNN_LO_INV;
         const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-        if (sc[r] >= thr && row < N && q < nq) pend |= 1u << r;
+        if (sc[r] >= thr && row < row_lim && q_ok) pend |= 1u << r;
       }
       const int par = rnd & 1;
       for (;;) {
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
       for (int r = 0; r < 16; ++r) {
         const float s = acc_h[r] + acc_l[r] * KNN_LO_INV;
         const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-        if (s > range_thr && row < N && q < nq) {
+        if (s > range_thr && row < row_lim && q_ok) {
           const unsigned pos = atomicAdd(&range_cnt[q], 1u);
           if (pos < range_cap) {
             range_s[(size_t)q * range_cap + pos] = s;
@@ -301,8 +327,8 @@ __device__ __forceinline__ int block_count_256(int v, int* red) {
 template <typename IdT>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ ps, const IdT* __restrict__ pi,
                                                        const int* __restrict__ pn, int P, int nq_stride, int kin,
-                                                       int k, int64_t id_base, float* __restrict__ D,
-                                                       int64_t* __restrict__ I) {
+                                                       int k, int64_t id_base, const int64_t* __restrict__ idmap,
+                                                       float* __restrict__ D, int64_t* __restrict__ I) {
   extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
   unsigned* s_u = reinterpret_cast<unsigned*>(merge_smem);             // [P*kin] order-encoded score, 0 = empty
   const int ncand = P * kin;
@@ -312,7 +338,10 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
   const int qq = blockIdx.x, tid = threadIdx.x;
 
   auto gidx = [&](int c) -> size_t { return ((size_t)(c / kin) * nq_stride + qq) * kin + (c % kin); };
-  auto get_id = [&](int c) -> long long { return (long long)pi[gidx(c)] + id_base; };
+  // IVF: candidate ids are positions in the list-sorted arena; idmap gives the id the row was added with
+  auto get_id = [&](int c) -> long long {
+    return idmap ? (long long)idmap[(size_t)pi[gidx(c)]] : (long long)pi[gidx(c)] + id_base;
+  };
 
   int mine = 0;
   for (int c = tid; c < ncand; c += 256) {
@@ -476,6 +505,116 @@ __global__ __launch_bounds__(256) void knn_synth_kernel(_Float16* __restrict__ X
 }
 
 // ---------------------------------------------------------------------------------------------
+// IVF-Flat (faiss IndexIVFFlat semantics, inner product): coarse quantiser = the same flat scan over the centroid
+// matrix; the kernels below turn its [nq, nprobe] list ids into the work list the IVF scan walks.
+//   list l occupies tiles [tile0[l], tile0[l] + ntile[l]) of the list-sorted, tile-padded arena; size[l] rows are real.
+// ---------------------------------------------------------------------------------------------
+__global__ void ivf_mark_kernel(const int64_t* __restrict__ Ic, int nq, int nprobe, int nlist, unsigned* __restrict__ masks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * nprobe) return;
+  const int64_t l = Ic[i];
+  if (l >= 0 && l < nlist) atomicOr(&masks[l], 1u << (i / nprobe));
+}
+
+// single workgroup: exclusive prefix sum of (mask[l] ? ntile[l] : 0) -> off[l]; total -> *nwork
+__global__ __launch_bounds__(1024) void ivf_offsets_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ ntile,
+                                                          int nlist, unsigned* __restrict__ off, unsigned* __restrict__ nwork) {
+  __shared__ unsigned red[1024];
+  __shared__ unsigned carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nlist; base += 1024) {
+    const int l = base + tid;
+    const unsigned v = (l < nlist && masks[l]) ? ntile[l] : 0u;
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+      const unsigned t = tid >= o ? red[tid - o] : 0u;
+      __syncthreads();
+      red[tid] += t;
+      __syncthreads();
+    }
+    if (l < nlist) off[l] = carry + red[tid] - v;
+    __syncthreads();
+    if (tid == 1023) carry += red[1023];
+    __syncthreads();
+  }
+  if (tid == 0) *nwork = carry;
+}
+
+// one workgroup per list: writes the list's tiles into the work list
+__global__ __launch_bounds__(256) void ivf_expand_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ tile0,
+                                                        const unsigned* __restrict__ ntile, const unsigned* __restrict__ size,
+                                                        const unsigned* __restrict__ off, uint4* __restrict__ work) {
+  const int l = blockIdx.x;
+  const unsigned m = masks[l];
+  if (!m) return;
+  const unsigned nt = ntile[l], t0 = tile0[l], o = off[l], sz = size[l];
+  for (unsigned t = threadIdx.x; t < nt; t += 256) {
+    const unsigned valid = (t + 1 < nt) ? 32u : sz - 32u * (nt - 1);
+    work[o + t] = make_uint4(t0 + t, m, valid, 0u);
+  }
+}
+
+// one workgroup per list: copy its rows from the unpadded (list-grouped) arena to the tile-padded one, zero the pad
+// rows, and lay down idmap (-1 on pad rows) and the inverse map id -> padded row
+__global__ __launch_bounds__(256) void ivf_relayout_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, int d,
+                                                          const int64_t* __restrict__ src0, const unsigned* __restrict__ tile0,
+                                                          const unsigned* __restrict__ ntile, const unsigned* __restrict__ size,
+                                                          const int64_t* __restrict__ ids, int64_t id_lo, int64_t n_ids,
+                                                          int64_t* __restrict__ idmap, uint32_t* __restrict__ inv) {
+  const int l = blockIdx.x;
+  const int64_t s0 = src0[l];
+  const size_t r0 = (size_t)tile0[l] * 32, nrow = (size_t)ntile[l] * 32, sz = size[l];
+  const int d8 = d / 8;
+  const uint4* sp = reinterpret_cast<const uint4*>(src + (size_t)s0 * d);
+  uint4* dp = reinterpret_cast<uint4*>(dst + r0 * d);
+  for (size_t i = threadIdx.x; i < nrow * d8; i += 256) dp[i] = (i / d8) < sz ? sp[i] : make_uint4(0u, 0u, 0u, 0u);
+  for (size_t r = threadIdx.x; r < nrow; r += 256) {
+    const int64_t id = r < sz ? ids[s0 + r] : -1;
+    idmap[r0 + r] = id;
+    if (id >= id_lo && id - id_lo < n_ids) inv[id - id_lo] = (uint32_t)(r0 + r);
+  }
+}
+
+// reconstruct for IVF: ids -> padded arena rows through the inverse map
+__global__ void knn_gather_rows_inv_kernel(const _Float16* __restrict__ X, int d, int64_t id_lo, int64_t n_ids,
+                                           const uint32_t* __restrict__ inv, const int64_t* __restrict__ ids, int64_t n,
+                                           float* __restrict__ out) {
+  const int64_t i = blockIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  const bool ok = id >= id_lo && id - id_lo < n_ids;
+  const size_t r = ok ? inv[id - id_lo] : 0;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)i * d + c] = ok ? (float)X[r * d + c] : __int_as_float(-1);
+}
+
+hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
+                               const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
+                               hipStream_t st) {
+  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nlist * sizeof(unsigned), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ivf_mark_kernel, dim3((nq * nprobe + 255) / 256), dim3(256), 0, st, Ic, nq, nprobe, nlist, masks);
+  hipLaunchKernelGGL(ivf_offsets_kernel, dim3(1), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3(nlist), dim3(256), 0, st, masks, tile0, ntile, size, off, work);
+  return hipGetLastError();
+}
+hipError_t launch_ivf_relayout(const _Float16* src, _Float16* dst, int d, int nlist, const int64_t* src0, const unsigned* tile0,
+                               const unsigned* ntile, const unsigned* size, const int64_t* ids, int64_t id_lo, int64_t n_ids,
+                               int64_t* idmap, uint32_t* inv, hipStream_t st) {
+  hipLaunchKernelGGL(ivf_relayout_kernel, dim3(nlist), dim3(256), 0, st, src, dst, d, src0, tile0, ntile, size, ids, id_lo,
+                     n_ids, idmap, inv);
+  return hipGetLastError();
+}
+hipError_t launch_gather_inv(const _Float16* X, int d, int64_t id_lo, int64_t n_ids, const uint32_t* inv, const int64_t* ids,
+                             int64_t n, float* out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(knn_gather_rows_inv_kernel, dim3((unsigned)n), dim3(256), 0, st, X, d, id_lo, n_ids, inv, ids, n, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers (declared in knn_kernels.h)
 // ---------------------------------------------------------------------------------------------
 size_t scan_smem_bytes(int d, int cap) { return (size_t)d * 128 + (size_t)KNN_NQ * cap * 8 + KNN_NQ * 8 + 16; }
@@ -486,18 +625,18 @@ hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* 
   return hipGetLastError();
 }
 
-template <int MODE, bool NT>
+template <int MODE, bool NT, bool IVF = false>
 static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
   const size_t smem = scan_smem_bytes(a.d, a.cap);
 #define KNN_LAUNCH(NCH)                                                                                         \
   {                                                                                                             \
-    auto kern = knn_scan_kernel<NCH, MODE, NT>;                                                                     \
+    auto kern = knn_scan_kernel<NCH, MODE, NT, IVF>;                                                                   \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                  \
     if (e != hipSuccess) return e;                                                                              \
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(KNN_WG), smem, st, a.X, a.N, a.qfrag, a.nq, a.k, a.cap,         \
                        a.thr_g, a.part_s, a.part_i, a.part_n, a.range_thr, a.range_cnt, a.range_cap, a.range_s, \
-                       a.range_i);                                                                              \
+                       a.range_i, a.work, a.nwork);                                                             \
     return hipGetLastError();                                                                                   \
   }
   switch (a.d) {
@@ -511,18 +650,20 @@ static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
+  if (a.work) return a.mode == 0 ? launch_scan_mode<0, false, true>(a, st) : hipErrorInvalidValue;
   if (a.mode == 0) return a.nt ? launch_scan_mode<0, true>(a, st) : launch_scan_mode<0, false>(a, st);
   return launch_scan_mode<1, false>(a, st);
 }
 
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
-                            int nq, int k, int64_t id_base, float* D, int64_t* I, hipStream_t st) {
+                            int nq, int k, int64_t id_base, const int64_t* idmap, float* D, int64_t* I,
+                            hipStream_t st) {
   if (k > 64) return hipErrorInvalidValue;
   const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
   auto kern = knn_merge_kernel<uint32_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, D, I);
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I);
   return hipGetLastError();
 }
 hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
@@ -533,7 +674,8 @@ hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, i
   auto kern = knn_merge_kernel<int64_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, (const int*)nullptr, P, nq, kin, k, (int64_t)0, D, I);
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, (const int*)nullptr, P, nq, kin, k, (int64_t)0,
+                     (const int64_t*)nullptr, D, I);
   return hipGetLastError();
 }
 hipError_t launch_gather(const _Float16* X, int64_t N, int d, int64_t id_base, const int64_t* ids, int64_t n,

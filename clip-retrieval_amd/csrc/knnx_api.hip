@@ -63,6 +63,17 @@ struct knnx_index {
   void* pin = nullptr;
   size_t pin_bytes = 0;
 
+  // IVF-Flat state (knnx_ivf_set_lists): rows live list-sorted and tile-padded in `rows`; see knn_kernels.hip
+  int ivf_nlist = 0, ivf_nprobe = 1;
+  knnx_index* cent = nullptr;  // coarse quantiser: a flat index over the fp16 centroids
+  unsigned *ivf_tile0 = nullptr, *ivf_ntile = nullptr, *ivf_size = nullptr, *ivf_masks = nullptr, *ivf_off = nullptr,
+           *ivf_nwork = nullptr;
+  uint4* ivf_work = nullptr;
+  int64_t* ivf_idmap = nullptr;  // padded arena row -> id (-1 on pad rows)
+  uint32_t* ivf_inv = nullptr;   // id - id_base -> padded arena row
+  int64_t* ivf_Ic = nullptr;     // [KNN_NQ, KNNX_MAX_K_FAST] coarse result
+  float* ivf_Dc = nullptr;
+
   int nt_loads = 0;
   bool prof = false;
   int64_t prof_launches = 0;
@@ -155,6 +166,19 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->range_cnt);
   if (ix->range_s) hipFree(ix->range_s);
   if (ix->range_i) hipFree(ix->range_i);
+  if (ix->cent) knnx_destroy(ix->cent);
+  hipSetDevice(ix->device);
+  hipFree(ix->ivf_tile0);
+  hipFree(ix->ivf_ntile);
+  hipFree(ix->ivf_size);
+  hipFree(ix->ivf_masks);
+  hipFree(ix->ivf_off);
+  hipFree(ix->ivf_nwork);
+  hipFree(ix->ivf_work);
+  hipFree(ix->ivf_idmap);
+  hipFree(ix->ivf_inv);
+  hipFree(ix->ivf_Ic);
+  hipFree(ix->ivf_Dc);
   if (ix->pin) hipHostFree(ix->pin);
   for (auto& ev : ix->prof_events) {
     hipEventDestroy(ev.first);
@@ -207,6 +231,7 @@ static int add_common(knnx_index* ix, const void* rows, int64_t n, bool is_f32) 
   std::lock_guard<std::mutex> lk(ix->mu);
   if (set_dev(ix)) return KNNX_E_HIP;
   if (ix->borrowed) return fail(KNNX_E_STATE, "add() on an index that borrows device rows");
+  if (ix->ivf_nlist) return fail(KNNX_E_STATE, "add() after knnx_ivf_set_lists (rebuild the index instead)");
   if (ix->ntotal + n > ix->capacity) {
     int64_t want = std::max<int64_t>(ix->ntotal + n, ix->capacity + ix->capacity / 2);
     int r = grow(ix, want);
@@ -277,10 +302,19 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
                      hipStream_t st) {
   const int cap = scan_cap(ix->d, k);
   if (cap < 0) return fail(KNNX_E_UNSUPPORTED, "k too large for the LDS queues at this d");
+  if (ix->ivf_nlist) {
+    // coarse quantiser: top-nprobe centroids per query (the same flat scan over the [nlist, d] centroid rows), then
+    // the work list = tiles of every list probed by at least one of the <= 32 queries, each with its query mask
+    const int np = std::min(ix->ivf_nprobe, ix->ivf_nlist);
+    int r = scan_topk(ix->cent, q_dev, nq, np, ix->ivf_Dc, ix->ivf_Ic, st);
+    if (r) return r;
+    HIPCHK(launch_ivf_worklist(ix->ivf_Ic, nq, np, ix->ivf_nlist, ix->ivf_masks, ix->ivf_tile0, ix->ivf_ntile, ix->ivf_size,
+                               ix->ivf_off, ix->ivf_work, ix->ivf_nwork, st));
+  }
   HIPCHK(launch_prep(q_dev, nq, ix->d, ix->qfrag, ix->thr_g, nullptr, st));
   ScanArgs a{};
   a.X = ix->rows;
-  a.N = ix->ntotal;
+  a.N = ix->ivf_nlist ? ix->capacity : ix->ntotal;
   a.d = ix->d;
   a.qfrag = ix->qfrag;
   a.nq = nq;
@@ -293,6 +327,8 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
   a.part_s = ix->part_s;
   a.part_i = ix->part_i;
   a.part_n = ix->part_n;
+  a.work = ix->ivf_nlist ? ix->ivf_work : nullptr;
+  a.nwork = ix->ivf_nwork;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->prof) {
     HIPCHK(hipEventCreate(&e0));
@@ -304,8 +340,8 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
     HIPCHK(hipEventRecord(e1, st));
     ix->prof_events.emplace_back(e0, e1);
   }
-  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ, k, nq, k, ix->id_base, D_out,
-                          I_out, st));
+  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ, k, nq, k, ix->id_base,
+                          ix->ivf_nlist ? ix->ivf_idmap : nullptr, D_out, I_out, st));
   return 0;
 }
 
@@ -352,6 +388,7 @@ static int search_large_k_locked(knnx_index* ix, const float* q, int n, int k, f
 extern "C" int knnx_search(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I, float* R) {
   if (!ix || (n > 0 && (!q || !D || !I)) || n < 0 || k <= 0) return fail(KNNX_E_ARG, "bad search arguments");
   if (k > KNNX_MAX_K) return fail(KNNX_E_UNSUPPORTED, "k > 16384 is not implemented");
+  if (ix->ivf_nlist && k > KNNX_MAX_K_FAST) return fail(KNNX_E_UNSUPPORTED, "IVF search supports k <= 64");
   if (n == 0) return KNNX_OK;
   {
     std::lock_guard<std::mutex> lk(ix->mu);
@@ -380,7 +417,9 @@ extern "C" int knnx_reconstruct(knnx_index* ix, const int64_t* ids, int64_t n, f
   for (int64_t o = 0; o < n && e == hipSuccess; o += chunk) {
     const int64_t m = std::min(chunk, n - o);
     e = hipMemcpyAsync(ids_dev, ids + o, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream);
-    if (e == hipSuccess) e = launch_gather(ix->rows, ix->ntotal, ix->d, ix->id_base, ids_dev, m, out_dev, ix->stream);
+    if (e == hipSuccess)
+      e = ix->ivf_nlist ? launch_gather_inv(ix->rows, ix->d, ix->id_base, ix->ntotal, ix->ivf_inv, ids_dev, m, out_dev, ix->stream)
+                        : launch_gather(ix->rows, ix->ntotal, ix->d, ix->id_base, ids_dev, m, out_dev, ix->stream);
     if (e == hipSuccess)
       e = hipMemcpyAsync(out + (size_t)o * ix->d, out_dev, (size_t)m * ix->d * sizeof(float), hipMemcpyDeviceToHost,
                          ix->stream);
@@ -483,6 +522,7 @@ extern "C" int knnx_range_search(knnx_index* ix, const float* q, int n, float th
                                  int64_t* I) {
   if (!ix || !lims || (n > 0 && !q) || n < 0) return fail(KNNX_E_ARG, "bad range_search arguments");
   if ((D == nullptr) != (I == nullptr)) return fail(KNNX_E_ARG, "D and I must both be null or both be set");
+  if (ix->ivf_nlist) return fail(KNNX_E_UNSUPPORTED, "range_search on an IVF index is not implemented");
   std::lock_guard<std::mutex> lk(ix->mu);
   if (set_dev(ix)) return KNNX_E_HIP;
   const bool fill = D != nullptr;
@@ -569,6 +609,87 @@ static int search_large_k_locked(knnx_index* ix, const float* q, int n, int k, f
   }
   return KNNX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// IVF-Flat
+// ---------------------------------------------------------------------------------------------
+extern "C" int knnx_ivf_set_lists(knnx_index* ix, int nlist, const uint16_t* centroids_f16, const int64_t* list_sizes,
+                                  const int64_t* ids) {
+  if (!ix || nlist <= 0 || !centroids_f16 || !list_sizes || !ids) return fail(KNNX_E_ARG, "bad ivf_set_lists arguments");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (set_dev(ix)) return KNNX_E_HIP;
+  if (ix->borrowed) return fail(KNNX_E_STATE, "IVF needs an index that owns its rows");
+  if (ix->ivf_nlist) return fail(KNNX_E_STATE, "lists are already set");
+  std::vector<int64_t> src0(nlist);
+  std::vector<unsigned> tile0(nlist), ntile(nlist), size(nlist);
+  int64_t run = 0, tiles = 0;
+  for (int l = 0; l < nlist; ++l) {
+    if (list_sizes[l] < 0) return fail(KNNX_E_ARG, "negative list size");
+    src0[l] = run;
+    size[l] = (unsigned)list_sizes[l];
+    ntile[l] = (unsigned)((list_sizes[l] + 31) / 32);
+    tile0[l] = (unsigned)tiles;
+    run += list_sizes[l];
+    tiles += ntile[l];
+  }
+  if (run != ix->ntotal) return fail(KNNX_E_ARG, "list sizes do not add up to ntotal (add the rows list by list first)");
+  if (tiles * 32 > (int64_t)0xffffffffll) return fail(KNNX_E_UNSUPPORTED, "more than 2^32 padded rows per device");
+  for (int64_t i = 0; i < run; ++i)
+    if (ids[i] < ix->id_base || ids[i] - ix->id_base >= run) return fail(KNNX_E_ARG, "ids must be a permutation of [id_base, id_base + ntotal)");
+  const int64_t prow = std::max<int64_t>(tiles * 32, 32);
+  _Float16* dst = nullptr;
+  int64_t* ids_dev = nullptr;
+  int64_t* src0_dev = nullptr;
+  HIPCHK(hipMalloc(&dst, (size_t)prow * ix->d * sizeof(_Float16)));
+  hipError_t e = hipMalloc(&ids_dev, (size_t)std::max<int64_t>(run, 1) * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&src0_dev, nlist * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_tile0, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_ntile, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_size, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_masks, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_off, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_nwork, sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_work, (size_t)std::max<int64_t>(tiles, 1) * sizeof(uint4));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_idmap, (size_t)prow * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_inv, (size_t)std::max<int64_t>(run, 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_Ic, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_Dc, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(ids_dev, ids, (size_t)run * sizeof(int64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(src0_dev, src0.data(), nlist * sizeof(int64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ix->ivf_tile0, tile0.data(), nlist * sizeof(unsigned), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ix->ivf_ntile, ntile.data(), nlist * sizeof(unsigned), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ix->ivf_size, size.data(), nlist * sizeof(unsigned), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = launch_ivf_relayout(ix->rows, dst, ix->d, nlist, src0_dev, ix->ivf_tile0, ix->ivf_ntile, ix->ivf_size, ids_dev,
+                            ix->id_base, run, ix->ivf_idmap, ix->ivf_inv, ix->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+  hipFree(ids_dev);
+  hipFree(src0_dev);
+  if (e != hipSuccess) {
+    hipFree(dst);
+    return fail(e == hipErrorOutOfMemory ? KNNX_E_NOMEM : KNNX_E_HIP, std::string("ivf_set_lists: ") + hipGetErrorString(e));
+  }
+  if (ix->rows) hipFree(ix->rows);
+  ix->rows = dst;
+  ix->capacity = prow;
+  int r = knnx_create(ix->device, ix->d, KNNX_METRIC_INNER_PRODUCT, &ix->cent);
+  if (r) return r;
+  r = knnx_add_f16(ix->cent, centroids_f16, nlist);
+  if (r) return r;
+  ix->ivf_nlist = nlist;
+  ix->ivf_nprobe = std::min(ix->ivf_nprobe, nlist);
+  return KNNX_OK;
+}
+
+extern "C" int knnx_ivf_set_nprobe(knnx_index* ix, int nprobe) {
+  if (!ix) return fail(KNNX_E_ARG, "index is null");
+  if (nprobe < 1 || nprobe > KNNX_MAX_K_FAST) return fail(KNNX_E_UNSUPPORTED, "nprobe must be in 1..64");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  ix->ivf_nprobe = nprobe;
+  return KNNX_OK;
+}
+
+extern "C" int knnx_ivf_nlist(const knnx_index* ix) { return ix ? ix->ivf_nlist : 0; }
 
 extern "C" int knnx_merge_topk_device(int device, const float* D_parts, const int64_t* I_parts, int P, int n, int k,
                                       float* D_out, int64_t* I_out, void* stream) {

@@ -110,6 +110,31 @@ class Mi355xIndex:
             raise HipLibraryError("synthetic fill needs d % 256 == 0")
         check(self._lib, self._lib.knnx_synth_fill(self._h, int(n_rows), C.c_uint64(int(seed))), "knnx")
 
+    # ------------------------------------------------------------------ IVF-Flat
+    def set_ivf_lists(self, centroids, list_sizes, ids):
+        """Turn the index into a faiss-IndexIVFFlat-shaped one.  The rows must have been add()ed grouped by list;
+        `centroids` [nlist, d] (stored fp16), `list_sizes` [nlist], `ids` [ntotal] = the id of every added row."""
+        c = np.ascontiguousarray(self._pad(np.asarray(centroids).astype(np.float16)))
+        sizes = np.ascontiguousarray(list_sizes, dtype=np.int64)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        if c.shape[0] != sizes.shape[0] or ids.shape[0] != self.ntotal:
+            raise AssertionError("centroids/list_sizes/ids disagree with the index")
+        check(self._lib, self._lib.knnx_ivf_set_lists(self._h, c.shape[0], c.ctypes.data, sizes.ctypes.data, ids.ctypes.data), "knnx")
+
+    @property
+    def nlist(self):
+        return int(self._lib.knnx_ivf_nlist(self._h))
+
+    @property
+    def nprobe(self):
+        return getattr(self, "_nprobe", 1)
+
+    @nprobe.setter
+    def nprobe(self, v):
+        """faiss `extract_index_ivf(index).nprobe = v` (clip_back.py:357-369)."""
+        check(self._lib, self._lib.knnx_ivf_set_nprobe(self._h, int(v)), "knnx")
+        self._nprobe = int(v)
+
     # ------------------------------------------------------------------ searching
     def _search_raw(self, q, k, want_r):
         n = q.shape[0]
@@ -262,4 +287,67 @@ def load_index(path, device=0, row_range=None, enable_faiss_memory_mapping=False
             a = np.load(f, mmap_mode="r")[a0 - start:a1 - start]
             index.add(np.ascontiguousarray(a) if a.dtype in (np.float16, np.float32) else np.asarray(a, dtype=np.float32))
         start += s[0]
+    return index
+
+
+# ------------------------------------------------------------------------------------------------------------
+# IVF-Flat index build (BASELINE config 5; takes the place of the autofaiss call of clip_index.py:12-66 for this
+# index type).  Build-time only: Lloyd iterations whose assignment step is the library's own flat scan over the
+# centroid rows (k = 1), centroid means on the host.
+# ------------------------------------------------------------------------------------------------------------
+def _assign(cent_index, x_f16, batch=8192):
+    out = np.empty(x_f16.shape[0], dtype=np.int64)
+    for o in range(0, x_f16.shape[0], batch):
+        _, I = cent_index.search(np.ascontiguousarray(x_f16[o:o + batch], dtype=np.float32), 1)
+        out[o:o + batch] = I[:, 0]
+    return out
+
+
+def train_ivf_centroids(x_f16, nlist, niter=8, seed=0, device=0, max_points_per_centroid=256):
+    """k-means with inner-product assignment (faiss Clustering with an IndexFlatIP quantiser): returns fp16 [nlist, d]."""
+    x_f16 = np.asarray(x_f16)
+    rng = np.random.default_rng(seed)
+    n, d = x_f16.shape
+    if n < nlist:
+        raise ValueError(f"need at least nlist={nlist} training rows, got {n}")
+    take = min(n, nlist * max_points_per_centroid)
+    sample = x_f16[np.sort(rng.choice(n, take, replace=False))] if take < n else x_f16
+    cent = sample[rng.choice(sample.shape[0], nlist, replace=False)].astype(np.float32)
+    s32 = sample.astype(np.float32)
+    for _ in range(niter):
+        ci = Mi355xIndex(d, device=device, coalesce=False)
+        ci.add(cent.astype(np.float16))
+        a = _assign(ci, sample)
+        ci.close()
+        sums = np.zeros((nlist, d), dtype=np.float64)
+        np.add.at(sums, a, s32)
+        cnt = np.bincount(a, minlength=nlist)
+        empty = cnt == 0
+        cent = (sums / np.maximum(cnt, 1)[:, None]).astype(np.float32)
+        if empty.any():  # re-seed empty clusters on random points (faiss splits big clusters; any re-seed is valid)
+            cent[empty] = s32[rng.choice(s32.shape[0], int(empty.sum()), replace=False)]
+    return cent.astype(np.float16)
+
+
+def build_ivf_index(x_f16, nlist, nprobe=16, niter=8, seed=0, device=0, id_base=0, centroids=None):
+    """fp16 rows [N, d] -> HBM-resident IVF-Flat index (ids = id_base + row number, like the flat index)."""
+    x_f16 = np.ascontiguousarray(np.asarray(x_f16).astype(np.float16))
+    n, d = x_f16.shape
+    if centroids is None:
+        centroids = train_ivf_centroids(x_f16, nlist, niter=niter, seed=seed, device=device)
+    centroids = np.asarray(centroids).astype(np.float16)
+    ci = Mi355xIndex(d, device=device, coalesce=False)
+    ci.add(centroids)
+    lists = _assign(ci, x_f16)
+    ci.close()
+    order = np.argsort(lists, kind="stable")
+    sizes = np.bincount(lists, minlength=nlist).astype(np.int64)
+    index = Mi355xIndex(d, device=device, id_base=id_base)
+    index.reserve(n)
+    step = 1 << 18
+    for o in range(0, n, step):
+        index.add(x_f16[order[o:o + step]])
+    index.set_ivf_lists(centroids, sizes, order.astype(np.int64) + id_base)
+    index.nprobe = min(nprobe, nlist)
+    index.ivf_lists = lists  # kept for tests / recall measurement
     return index

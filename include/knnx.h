@@ -83,6 +83,18 @@ int knnx_reconstruct(knnx_index* ix, const int64_t* ids, int64_t n, float* out);
 int knnx_range_search(knnx_index* ix, const float* q, int n, float thresh, int64_t* lims,
                       float* D, int64_t* I);
 
+/* faiss IndexIVFFlat(quantizer=IndexFlatIP, d, nlist, METRIC_INNER_PRODUCT) (the index family of BASELINE config 5;
+ * the reference gets its indices from autofaiss, clip_index.py:12-66).  Protocol: knnx_add_* the rows GROUPED BY LIST
+ * (list 0 first), then call knnx_ivf_set_lists once: centroids fp16 [nlist, d] (the coarse quantiser is a flat scan
+ * over them), list_sizes [nlist], ids [ntotal] = the id each added row carries (a permutation of
+ * [id_base, id_base + ntotal)).  Afterwards knnx_search* probe the nprobe lists whose centroids score highest for the
+ * query (faiss `nprobe`, clip_back.py:357-369) and return exactly the top-k of those lists' rows; k <= 64,
+ * nprobe <= 64; range_search and add are refused on an IVF index. */
+int knnx_ivf_set_lists(knnx_index* ix, int nlist, const uint16_t* centroids_f16, const int64_t* list_sizes,
+                       const int64_t* ids);
+int knnx_ivf_set_nprobe(knnx_index* ix, int nprobe);
+int knnx_ivf_nlist(const knnx_index* ix);
+
 /* Merge P per-shard results ([P, n, k] each, already global ids) into the top-k [n, k];
  * the step after the RCCL all-gather of a row-sharded index.  Device buffers. */
 int knnx_merge_topk_device(int device, const float* D_parts, const int64_t* I_parts, int P, int n,

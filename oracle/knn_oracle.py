@@ -89,6 +89,34 @@ class FlatIPOracle:
                 np.concatenate(Is) if Is else np.zeros(0, np.int64))
 
 
+class IVFFlatOracle:
+    """numpy faiss.IndexIVFFlat(IndexFlatIP(d), d, nlist, METRIC_INNER_PRODUCT) over fp16-stored rows and fp16-stored
+    centroids: coarse = the `nprobe` centroids with the largest <q, c> (ties by ascending list id), candidates = the
+    rows assigned to those lists, result = their top-k by (score desc, id asc).  The assignment is an INPUT (any
+    assignment is a valid IVF index); faiss call shape: clip_back.py:357-369 sets `nprobe` on such an index."""
+
+    def __init__(self, d, centroids_f16, lists, rows_f16):
+        self.d = d
+        self.cent = np.asarray(centroids_f16).astype(np.float16)
+        self.lists = np.asarray(lists, dtype=np.int64)
+        self.rows = np.asarray(rows_f16).astype(np.float16)
+
+    def search(self, q, k: int, nprobe: int):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        cs = q @ self.cent.astype(np.float32).T
+        n = q.shape[0]
+        D = np.full((n, k), NEG, dtype=np.float32)
+        I = np.full((n, k), -1, dtype=np.int64)
+        for i in range(n):
+            probes = np.lexsort((np.arange(cs.shape[1]), -cs[i].astype(np.float64)))[:nprobe]
+            cand = np.nonzero(np.isin(self.lists, probes))[0]
+            sc = self.rows[cand].astype(np.float32) @ q[i]
+            order = np.lexsort((cand, -sc.astype(np.float64)))[:k]
+            D[i, :len(order)] = sc[order]
+            I[i, :len(order)] = cand[order]
+        return D, I
+
+
 def merge_topk(D_parts, I_parts, k: int):
     """[P, n, k] per-shard results (global ids) -> top-k per query; the step after the all-gather."""
     D_parts = np.asarray(D_parts, dtype=np.float32)

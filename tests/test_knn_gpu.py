@@ -251,3 +251,58 @@ def test_bad_arguments_raise_like_faiss():
         ix.search(np.zeros((1, 512), np.float32), 4)
     with pytest.raises(HipLibraryError):
         ix.search(np.zeros((1, 768), np.float32), 20000)
+
+
+# ------------------------------------------------------------------------------------------ IVF-Flat (BASELINE config 5)
+@pytest.mark.parametrize("n,d,nlist,nprobe", [(20000, 768, 64, 8), (5000, 1024, 16, 16), (3000, 512, 100, 1), (40, 768, 8, 3)])
+def test_ivf_flat_parity(n, d, nlist, nprobe):
+    """IVF search = exactly the top-k of the rows in the nprobe best lists (faiss IndexIVFFlat semantics), compared with
+    the numpy oracle on the SAME centroids and assignment; nprobe = nlist must reproduce the flat result."""
+    from clip_retrieval_amd.knn import Mi355xIndex, build_ivf_index
+    from oracle.knn_oracle import FlatIPOracle, IVFFlatOracle
+
+    x = _data(n, d, seed=n + nlist)
+    rng = np.random.default_rng(nlist)
+    cent = x[rng.choice(n, nlist, replace=False)]  # fixed centroids: the build's k-means is not what is under test here
+    ix = build_ivf_index(x, nlist, nprobe=nprobe, centroids=cent)
+    assert ix.ntotal == n and ix.nlist == nlist
+    o = IVFFlatOracle(d, cent, ix.ivf_lists, x)
+    for nq, k in [(1, 40), (7, 10), (32, 64), (45, 40)]:
+        q = _queries(nq, d, seed=k + nq, x=x)
+        D, I = ix.search(q, k)
+        Do, Io = o.search(q, k, nprobe)
+        _check(D, I, Do, Io, f"ivf n={n} d={d} nlist={nlist} nprobe={nprobe} nq={nq} k={k}")
+    # reconstruct goes through the inverse id map
+    q = _queries(3, d, seed=3, x=x)
+    D, I, R = ix.search_and_reconstruct(q, 5)
+    ok = I >= 0
+    assert np.array_equal(R[ok], x[I[ok]].astype(np.float32))
+    if nlist <= 64:
+        ix.nprobe = nlist
+        f = FlatIPOracle(d)
+        f.add(x)
+        D, I = ix.search(q, 40)
+        Do, Io = f.search(q, 40)
+        _check(D, I, Do, Io, "ivf with nprobe = nlist equals flat")
+    ix.close()
+
+
+def test_ivf_trained_recall():
+    """k-means centroids from the library's own assignment scan: recall@10 vs exact flat on clustered data."""
+    from clip_retrieval_amd.knn import build_ivf_index
+    from oracle.knn_oracle import FlatIPOracle
+
+    rng = np.random.default_rng(0)
+    d, nclu = 256, 32
+    centers = rng.standard_normal((nclu, d)).astype(np.float32)
+    x = centers[rng.integers(0, nclu, 30000)] + 0.35 * rng.standard_normal((30000, d)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
+    ix = build_ivf_index(x, nlist=32, nprobe=4, niter=6)
+    f = FlatIPOracle(d)
+    f.add(x)
+    q = _queries(64, d, seed=1, x=x)
+    _, I = ix.search(q, 10)
+    _, Io = f.search(q, 10)
+    recall = np.mean([len(set(I[i]) & set(Io[i])) / 10 for i in range(64)])
+    assert recall > 0.9, recall
+    ix.close()
