@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--knn-rows", type=int, default=-1, help="index rows per GPU (-1: 100M, 125M at 8 GPUs; 0: skip)")
-    ap.add_argument("--knn-queries", type=int, default=32)
+    ap.add_argument("--knn-queries", type=int, default=64, help="queries per batch (64 = one wide scan; 32 = one exact scan)")
     ap.add_argument("--knn-scans", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0: skip)")
     ap.add_argument("--cpu-threads", type=int, default=32,

@@ -5,7 +5,10 @@
 
 namespace knnx {
 
-constexpr int KNN_NQ = 32;     // query columns of one scan (MFMA N dimension)
+constexpr int KNN_NQ = 32;     // query columns of one exact scan (MFMA N dimension)
+constexpr int KNN_NQ_MAX = 64; // queries of one wide scan (two 32-column blocks, fp16-hi scores + exact re-scoring)
+constexpr int KNN_WIDE_KW = 64;   // candidates per query the wide scan keeps
+constexpr int KNN_WIDE_MAX_K = 48;  // largest k it serves (needs a gap between the k-th exact and the 64th approx score)
 constexpr int KNN_WAVES = 8;   // waves per workgroup, one 32-row tile each
 constexpr int KNN_WG = KNN_WAVES * 64;
 constexpr float KNN_LO_SCALE = 2048.f;
@@ -35,15 +38,23 @@ struct ScanArgs {
   // IVF: walk this work list of {tile, query mask, valid rows, -} items instead of all tiles (null = flat scan)
   const uint4* work;
   const unsigned* nwork;
+  int wide;              // 1: QB = 2 wide scan (64 queries, approximate scores; flat top-k only)
+  const unsigned* gate;  // run only if *gate != 0 (null: always)
 };
 
-size_t scan_smem_bytes(int d, int cap);
-hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_g, unsigned* range_cnt,
-                       hipStream_t st);
+size_t scan_smem_bytes(int d, int cap, int nq_slots);
+hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_g, unsigned* range_cnt, int wide,
+                       const unsigned* gate, hipStream_t st);
+hipError_t launch_maxnorm(const _Float16* X, int64_t n, int d, int* maxnorm_enc, hipStream_t st);
+hipError_t launch_rescore(const _Float16* X, int d, const float* q, const int64_t* cand, const float* approx, int nq, int kw,
+                          int k, int64_t id_base, const int* maxnorm_enc, float* D, int64_t* I, unsigned* need, unsigned* gate,
+                          hipStream_t st);
+hipError_t launch_select(const unsigned* need, int q0, int nq, int k, const float* Dfb, const int64_t* Ifb, float* D, int64_t* I,
+                         hipStream_t st);
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st);
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
                             int nq, int k, int64_t id_base, const int64_t* idmap_or_null, float* D, int64_t* I,
-                            hipStream_t st);
+                            const unsigned* gate_or_null, hipStream_t st);
 // IVF-Flat helpers (see knn_kernels.hip)
 hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
                                const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,

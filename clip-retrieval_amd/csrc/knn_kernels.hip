@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <algorithm>
 #include "knn_kernels.h"
 
 namespace knnx {
@@ -49,9 +50,11 @@ __device__ __forceinline__ bool better(float sa, uint32_t ia, float sb, uint32_t
 // ---------------------------------------------------------------------------------------------
 // query preparation: f32 [nq, d] -> hi/lo fp16 MFMA fragments; resets the per-scan global state
 // ---------------------------------------------------------------------------------------------
+// wide = 1: slot 1 holds the fp16 hi part of query n + 32 instead of the lo part of query n (QB = 2 scan)
 __global__ void knn_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
                                         _Float16* __restrict__ qfrag, int* __restrict__ thr_g,
-                                        unsigned* __restrict__ range_cnt) {
+                                        unsigned* __restrict__ range_cnt, int wide, const unsigned* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   const int s = blockIdx.x;  // k-step
   const int lane = threadIdx.x;
   const int n = lane & 31, h = lane >> 5;
@@ -62,14 +65,15 @@ __global__ void knn_prep_queries_kernel(const float* __restrict__ q, int nq, int
     const float v = (n < nq) ? q[(size_t)n * d + kk] : 0.f;
     const _Float16 vh = (_Float16)v;
     hi[j] = vh;
-    lo[j] = (_Float16)((v - (float)vh) * KNN_LO_SCALE);
+    if (wide) lo[j] = (n + 32 < nq) ? (_Float16)q[(size_t)(n + 32) * d + kk] : (_Float16)0.f;
+    else lo[j] = (_Float16)((v - (float)vh) * KNN_LO_SCALE);
   }
   half8* out = reinterpret_cast<half8*>(qfrag);
   out[(size_t)(s * 2 + 0) * 64 + lane] = hi;
   out[(size_t)(s * 2 + 1) * 64 + lane] = lo;
-  if (s == 0 && lane < KNN_NQ) {
+  if (s == 0 && lane < KNN_NQ_MAX) {
     thr_g[lane] = enc_f(-INFINITY);
-    if (range_cnt) range_cnt[lane] = 0u;
+    if (range_cnt && lane < KNN_NQ) range_cnt[lane] = 0u;
   }
 }
 
@@ -86,19 +90,19 @@ struct ScanSmem {
   int* flag;         // [4]
 };
 
-__device__ __forceinline__ ScanSmem carve(unsigned char* base, int d, int cap) {
+__device__ __forceinline__ ScanSmem carve(unsigned char* base, int d, int cap, int nqs) {
   ScanSmem s;
   size_t off = 0;
   s.qf = reinterpret_cast<half8*>(base + off);
   off += (size_t)d * 128;  // (d/16) * 2 * 64 * 16 B
   s.cand_s = reinterpret_cast<float*>(base + off);
-  off += (size_t)KNN_NQ * cap * 4;
+  off += (size_t)nqs * cap * 4;
   s.cand_i = reinterpret_cast<uint32_t*>(base + off);
-  off += (size_t)KNN_NQ * cap * 4;
+  off += (size_t)nqs * cap * 4;
   s.cnt = reinterpret_cast<int*>(base + off);
-  off += KNN_NQ * 4;
+  off += nqs * 4;
   s.thr = reinterpret_cast<int*>(base + off);
-  off += KNN_NQ * 4;
+  off += nqs * 4;
   s.flag = reinterpret_cast<int*>(base + off);
   return s;
 }
@@ -137,16 +141,25 @@ __device__ __forceinline__ void prune_query(const ScanSmem& sm, int qq, int cap,
 // lists probed by at least one query of this scan, built by ivf_expand_kernel); item = {tile, query mask, valid rows}:
 // a lane (= query column) only admits a score when its query probes that tile's list -- exactly the candidate set
 // faiss IndexIVFFlat scans for that query -- and row ids are positions in the list-sorted arena (mapped back by idmap).
-template <int NCH, int MODE, bool NT, bool IVF>  // NCH = d/128 (even); MODE 0 = top-k, 1 = range; NT = nontemporal loads
+// QB = 2 ("wide" scan): the two MFMA B operands are the fp16 HI parts of queries 0..31 and 32..63 instead of the hi / lo
+// parts of queries 0..31: the same instruction stream and the same HBM bytes serve 64 queries, with scores that are off
+// by at most |q - fp16(q)| * |x|.  The caller asks for the best kw > k rows by that approximate score, re-scores them
+// exactly (knn_rescore_kernel) and PROVES the top-k exact from the gap between the kw-th approximate and the k-th exact
+// score, falling back to the QB = 1 scan for a query whose gap is too small.  `gate`: run only if *gate != 0.
+template <int NCH, int MODE, bool NT, bool IVF, int QB>  // NCH = d/128 (even); MODE 0 = top-k, 1 = range; NT = nontemporal loads
 __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     const _Float16* __restrict__ X, int64_t N, const _Float16* __restrict__ qfrag, int nq, int k, int cap,
     int* __restrict__ thr_g, float* __restrict__ part_s, uint32_t* __restrict__ part_i, int* __restrict__ part_n,
     float range_thr, unsigned* __restrict__ range_cnt, unsigned range_cap, float* __restrict__ range_s,
-    uint32_t* __restrict__ range_i, const uint4* __restrict__ work, const unsigned* __restrict__ nwork_ptr) {
+    uint32_t* __restrict__ range_i, const uint4* __restrict__ work, const unsigned* __restrict__ nwork_ptr,
+    const unsigned* __restrict__ gate) {
   constexpr int D = NCH * 128;
   constexpr int KS = D / 16;
+  constexpr int NQ = 32 * QB;  // queries (= queues, thresholds) of this scan
+  static_assert(QB == 1 || (MODE == 0 && !IVF), "the wide scan exists for the flat top-k mode only");
+  if (gate && *gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const ScanSmem sm = carve(smem_raw, D, cap);
+  const ScanSmem sm = carve(smem_raw, D, cap, NQ);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     const uint4* src = reinterpret_cast<const uint4*>(qfrag);
     uint4* dst = reinterpret_cast<uint4*>(sm.qf);
     for (int i = tid; i < KS * 2 * 64; i += KNN_WG) dst[i] = src[i];
-    if (tid < KNN_NQ) { sm.cnt[tid] = 0; sm.thr[tid] = enc_f(-INFINITY); }
+    if (tid < NQ) { sm.cnt[tid] = 0; sm.thr[tid] = enc_f(-INFINITY); }
     if (tid < 4) sm.flag[tid] = 0;
   }
   __syncthreads();
@@ -230,27 +243,34 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     // IVF: rows of this tile beyond the list's size are padding; the query must probe the tile's list
     const int64_t row_lim = IVF ? (int64_t)it_cur.x * 32 + (int64_t)it_cur.z : N;
     const bool q_ok = q < nq && (!IVF || ((it_cur.y >> q) & 1u));
-    float sc[16];
-    unsigned pend = 0;
+    float sc[16 * QB];
+    unsigned pend = 0;  // bit r + 16*blk: score r of query q + 32*blk still has to be queued
     if (MODE == 0) {
-      const float thr = dec_f(sm.thr[q]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sc[r] = acc_h[r] + acc_l[r] * KNN_LO_INV;
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-        if (sc[r] >= thr && row < row_lim && q_ok) pend |= 1u << r;
+      for (int blk = 0; blk < QB; ++blk) {
+        const int qq = q + 32 * blk;
+        const float thr = dec_f(sm.thr[qq]);
+        const bool ok_q = QB == 1 ? q_ok : qq < nq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = QB == 1 ? acc_h[r] + acc_l[r] * KNN_LO_INV : (blk == 0 ? acc_h[r] : acc_l[r]);
+          sc[16 * blk + r] = v;
+          const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+          if (v >= thr && row < row_lim && ok_q) pend |= 1u << (16 * blk + r);
+        }
       }
       const int par = rnd & 1;
       for (;;) {
         bool ovf = false;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (pend & (1u << r)) {
-            const int pos = atomicAdd(&sm.cnt[q], 1);
+        for (int b = 0; b < 16 * QB; ++b) {
+          if (pend & (1u << b)) {
+            const int qq = q + 32 * (b >> 4), r = b & 15;
+            const int pos = atomicAdd(&sm.cnt[qq], 1);
             if (pos < cap) {
-              sm.cand_s[(size_t)q * cap + pos] = sc[r];
-              sm.cand_i[(size_t)q * cap + pos] = (uint32_t)(row0 + (r & 3) + 8 * (r >> 2));
-              pend &= ~(1u << r);
+              sm.cand_s[(size_t)qq * cap + pos] = sc[b];
+              sm.cand_i[(size_t)qq * cap + pos] = (uint32_t)(row0 + (r & 3) + 8 * (r >> 2));
+              pend &= ~(1u << b);
             } else {
               ovf = true;
             }
@@ -259,17 +279,20 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
         if (ovf) sm.flag[par] = 1;
         __syncthreads();  // (A) every append of this attempt has landed
         if (sm.flag[par] == 0) break;
-        for (int qq = w; qq < KNN_NQ; qq += KNN_WAVES) prune_query(sm, qq, cap, k, lane, thr_g);
+        for (int qq = w; qq < NQ; qq += KNN_WAVES) prune_query(sm, qq, cap, k, lane, thr_g);
         __syncthreads();  // (B) queues pruned, everyone has read flag[par]
         if (tid == 0) sm.flag[par] = 0;
         __syncthreads();  // (C) flag cleared before anyone appends again
-        const float thr2 = dec_f(sm.thr[q]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if ((pend & (1u << r)) && !(sc[r] >= thr2)) pend &= ~(1u << r);
+        for (int blk = 0; blk < QB; ++blk) {
+          const float thr2 = dec_f(sm.thr[q + 32 * blk]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if ((pend & (1u << (16 * blk + r))) && !(sc[16 * blk + r] >= thr2)) pend &= ~(1u << (16 * blk + r));
+        }
       }
       // every 4th round pull the other workgroups' thresholds (lower bounds, monotone)
-      if ((rnd & 3) == 3 && w == 0 && lane < KNN_NQ) {
+      if ((rnd & 3) == 3 && w == 0 && lane < NQ) {
         const int g = __hip_atomic_load(&thr_g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicMax(&sm.thr[lane], g);
       }
@@ -291,19 +314,19 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
 
   if (MODE == 0) {
     __syncthreads();
-    for (int qq = w; qq < KNN_NQ; qq += KNN_WAVES) prune_query(sm, qq, cap, k, lane, thr_g);
+    for (int qq = w; qq < NQ; qq += KNN_WAVES) prune_query(sm, qq, cap, k, lane, thr_g);
     __syncthreads();
     // publish this workgroup's sorted lists
-    for (int i = tid; i < KNN_NQ * k; i += KNN_WG) {
+    for (int i = tid; i < NQ * k; i += KNN_WG) {
       const int qq = i / k, j = i - qq * k;
       const int n = sm.cnt[qq];
-      const size_t o = ((size_t)blockIdx.x * KNN_NQ + qq) * k + j;
+      const size_t o = ((size_t)blockIdx.x * NQ + qq) * k + j;
       if (j < n) {
         part_s[o] = sm.cand_s[(size_t)qq * cap + j];
         part_i[o] = sm.cand_i[(size_t)qq * cap + j];
       }
     }
-    if (tid < KNN_NQ) part_n[blockIdx.x * KNN_NQ + tid] = sm.cnt[tid];
+    if (tid < NQ) part_n[blockIdx.x * NQ + tid] = sm.cnt[tid];
   }
 }
 
@@ -328,7 +351,9 @@ template <typename IdT>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ ps, const IdT* __restrict__ pi,
                                                        const int* __restrict__ pn, int P, int nq_stride, int kin,
                                                        int k, int64_t id_base, const int64_t* __restrict__ idmap,
-                                                       float* __restrict__ D, int64_t* __restrict__ I) {
+                                                       float* __restrict__ D, int64_t* __restrict__ I,
+                                                       const unsigned* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
   unsigned* s_u = reinterpret_cast<unsigned*>(merge_smem);             // [P*kin] order-encoded score, 0 = empty
   const int ncand = P * kin;
@@ -505,6 +530,116 @@ __global__ __launch_bounds__(256) void knn_synth_kernel(_Float16* __restrict__ X
 }
 
 // ---------------------------------------------------------------------------------------------
+// wide-scan support: largest row norm of the index, exact re-scoring + proof, gates and selection
+// ---------------------------------------------------------------------------------------------
+// maxnorm (order-encoded float, atomicMax) = max over rows of |x|_2: the bound |<x, q_lo>| <= |q_lo| * maxnorm
+__global__ __launch_bounds__(256) void knn_maxnorm_kernel(const _Float16* __restrict__ X, int64_t n, int d, int* __restrict__ maxnorm) {
+  const int lane = threadIdx.x & 63;
+  float best = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+    const half8* xr = reinterpret_cast<const half8*>(X + (size_t)r * d);
+    float ss = 0.f;
+    for (int c = lane; c < d / 8; c += 64) {
+      const half8 v = xr[c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    best = fmaxf(best, ss);
+  }
+  if (lane == 0) atomicMax(maxnorm, enc_f(sqrtf(best) * 1.0001f));
+}
+
+// One workgroup per query.  cand [nq, kw]: rows (id_base NOT added) of the kw best APPROXIMATE scores, approx [nq, kw]
+// those scores (descending; -1 / -FLT_MAX padding).  Re-scores every candidate exactly (fp32 FMA of fp32(x) and the
+// fp32 query), writes the top-k by (score desc, id asc) and need[q] = 1 when exactness cannot be proven:
+//   every row outside the candidates has hi-score <= approx[kw-1], hence exact score <= approx[kw-1] + eps with
+//   eps = |q - fp16(q)|_2 * maxnorm; if that is < the k-th exact score among the candidates, no outsider belongs to
+//   the exact top-k.  (Fewer than kw candidates = the whole index was a candidate.)
+__global__ __launch_bounds__(256) void knn_rescore_kernel(const _Float16* __restrict__ X, int d, const float* __restrict__ q,
+                                                         const int64_t* __restrict__ cand, const float* __restrict__ approx,
+                                                         int kw, int k, int64_t id_base, const int* __restrict__ maxnorm,
+                                                         float* __restrict__ D, int64_t* __restrict__ I,
+                                                         unsigned* __restrict__ need) {
+  __shared__ float s_sc[64];
+  __shared__ long long s_id[64];
+  __shared__ float s_red[4];
+  const int qq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* qv = q + (size_t)qq * d;
+  // |q - fp16(q)|^2
+  float e2 = 0.f;
+  for (int c = tid; c < d; c += 256) {
+    const float v = qv[c];
+    const float r = v - (float)(_Float16)v;
+    e2 += r * r;
+  }
+  for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+  if (lane == 0) s_red[w] = e2;
+  for (int j = w; j < kw; j += 4) {
+    const int64_t row = cand[(size_t)qq * kw + j];
+    float acc = 0.f;
+    if (row >= 0) {
+      const _Float16* xr = X + (size_t)row * d;
+      for (int c = lane; c < d; c += 64) acc = __builtin_fmaf((float)xr[c], qv[c], acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+      s_sc[j] = row >= 0 ? acc : -FLT_MAX;
+      s_id[j] = row >= 0 ? row + id_base : -1;
+    }
+  }
+  __syncthreads();
+  if (tid < kw) {
+    const float se = s_sc[tid];
+    const long long ie = s_id[tid];
+    int r = 0, nvalid = 0;
+    for (int j = 0; j < kw; ++j) {
+      const float sj = s_sc[j];
+      const long long ij = s_id[j];
+      nvalid += ij >= 0 ? 1 : 0;
+      if (ij >= 0 && ie >= 0) r += ((sj > se) || (sj == se && ij < ie)) ? 1 : 0;
+      else if (ij >= 0 && ie < 0) r += 1;  // invalid entries sort last
+      else if (ij < 0 && ie < 0) r += j < tid ? 1 : 0;
+    }
+    if (r < k) {
+      D[(size_t)qq * k + r] = ie >= 0 ? se : -FLT_MAX;
+      I[(size_t)qq * k + r] = ie;
+    }
+    if (r == (k < nvalid ? k : nvalid) - 1 || (nvalid == 0 && tid == 0)) {
+      // this thread holds the k-th best exact score (or the last valid one)
+      const float eps = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]) * dec_f(*maxnorm);
+      const bool all_in = nvalid < kw;  // the index has fewer than kw rows for this query: nothing is outside
+      const float a_last = approx[(size_t)qq * kw + kw - 1];
+      const bool proven = all_in || (nvalid >= k && a_last + eps < se);
+      need[qq] = proven ? 0u : 1u;
+    }
+  }
+}
+
+// gate[b] = any(need[32b .. 32b+31]) for the two 32-query halves of a wide scan
+__global__ void knn_gates_kernel(const unsigned* __restrict__ need, int nq, unsigned* __restrict__ gate) {
+  const int lane = threadIdx.x;  // 64 threads
+  const unsigned v = lane < nq ? need[lane] : 0u;
+  const unsigned long long m = __ballot(v != 0);
+  if (lane == 0) {
+    gate[0] = (unsigned)(m & 0xffffffffull) ? 1u : 0u;
+    gate[1] = (unsigned)(m >> 32) ? 1u : 0u;
+  }
+}
+
+// rows of queries with need[q] != 0 are replaced by the exact-scan result of their half
+__global__ void knn_select_kernel(const unsigned* __restrict__ need, int q0, int nq, int k, const float* __restrict__ Dfb,
+                                  const int64_t* __restrict__ Ifb, float* __restrict__ D, int64_t* __restrict__ I) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * k) return;
+  const int qq = i / k;
+  if (need[q0 + qq]) {
+    D[(size_t)(q0 + qq) * k + (i - qq * k)] = Dfb[i];
+    I[(size_t)(q0 + qq) * k + (i - qq * k)] = Ifb[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // IVF-Flat (faiss IndexIVFFlat semantics, inner product): coarse quantiser = the same flat scan over the centroid
 // matrix; the kernels below turn its [nq, nprobe] list ids into the work list the IVF scan walks.
 //   list l occupies tiles [tile0[l], tile0[l] + ntile[l]) of the list-sorted, tile-padded arena; size[l] rows are real.
@@ -617,26 +752,45 @@ hipError_t launch_gather_inv(const _Float16* X, int d, int64_t id_lo, int64_t n_
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (declared in knn_kernels.h)
 // ---------------------------------------------------------------------------------------------
-size_t scan_smem_bytes(int d, int cap) { return (size_t)d * 128 + (size_t)KNN_NQ * cap * 8 + KNN_NQ * 8 + 16; }
+size_t scan_smem_bytes(int d, int cap, int nqs) { return (size_t)d * 128 + (size_t)nqs * cap * 8 + nqs * 8 + 16; }
 
-hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_g, unsigned* range_cnt,
-                       hipStream_t st) {
-  hipLaunchKernelGGL(knn_prep_queries_kernel, dim3(d / 16), dim3(64), 0, st, q_dev, nq, d, qfrag, thr_g, range_cnt);
+hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_g, unsigned* range_cnt, int wide,
+                       const unsigned* gate, hipStream_t st) {
+  hipLaunchKernelGGL(knn_prep_queries_kernel, dim3(d / 16), dim3(64), 0, st, q_dev, nq, d, qfrag, thr_g, range_cnt, wide, gate);
+  return hipGetLastError();
+}
+hipError_t launch_maxnorm(const _Float16* X, int64_t n, int d, int* maxnorm, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  const int64_t blocks = std::min<int64_t>((n + 3) / 4, 8192);
+  hipLaunchKernelGGL(knn_maxnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, X, n, d, maxnorm);
+  return hipGetLastError();
+}
+hipError_t launch_rescore(const _Float16* X, int d, const float* q, const int64_t* cand, const float* approx, int nq, int kw,
+                          int k, int64_t id_base, const int* maxnorm, float* D, int64_t* I, unsigned* need, unsigned* gate,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(knn_rescore_kernel, dim3(nq), dim3(256), 0, st, X, d, q, cand, approx, kw, k, id_base, maxnorm, D, I, need);
+  hipLaunchKernelGGL(knn_gates_kernel, dim3(1), dim3(64), 0, st, need, nq, gate);
+  return hipGetLastError();
+}
+hipError_t launch_select(const unsigned* need, int q0, int nq, int k, const float* Dfb, const int64_t* Ifb, float* D, int64_t* I,
+                         hipStream_t st) {
+  if (nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(knn_select_kernel, dim3((nq * k + 255) / 256), dim3(256), 0, st, need, q0, nq, k, Dfb, Ifb, D, I);
   return hipGetLastError();
 }
 
-template <int MODE, bool NT, bool IVF = false>
+template <int MODE, bool NT, bool IVF = false, int QB = 1>
 static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
-  const size_t smem = scan_smem_bytes(a.d, a.cap);
+  const size_t smem = scan_smem_bytes(a.d, a.cap, 32 * QB);
 #define KNN_LAUNCH(NCH)                                                                                         \
   {                                                                                                             \
-    auto kern = knn_scan_kernel<NCH, MODE, NT, IVF>;                                                                   \
+    auto kern = knn_scan_kernel<NCH, MODE, NT, IVF, QB>;                                                                   \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                  \
     if (e != hipSuccess) return e;                                                                              \
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(KNN_WG), smem, st, a.X, a.N, a.qfrag, a.nq, a.k, a.cap,         \
                        a.thr_g, a.part_s, a.part_i, a.part_n, a.range_thr, a.range_cnt, a.range_cap, a.range_s, \
-                       a.range_i, a.work, a.nwork);                                                             \
+                       a.range_i, a.work, a.nwork, a.gate);                                                     \
     return hipGetLastError();                                                                                   \
   }
   switch (a.d) {
@@ -650,6 +804,7 @@ static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
+  if (a.wide) return (a.mode == 0 && !a.work) ? launch_scan_mode<0, false, false, 2>(a, st) : hipErrorInvalidValue;
   if (a.work) return a.mode == 0 ? launch_scan_mode<0, false, true>(a, st) : hipErrorInvalidValue;
   if (a.mode == 0) return a.nt ? launch_scan_mode<0, true>(a, st) : launch_scan_mode<0, false>(a, st);
   return launch_scan_mode<1, false>(a, st);
@@ -657,13 +812,13 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
 
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
                             int nq, int k, int64_t id_base, const int64_t* idmap, float* D, int64_t* I,
-                            hipStream_t st) {
+                            const unsigned* gate, hipStream_t st) {
   if (k > 64) return hipErrorInvalidValue;
   const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
   auto kern = knn_merge_kernel<uint32_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I);
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I, gate);
   return hipGetLastError();
 }
 hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
@@ -675,7 +830,7 @@ hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, i
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, (const int*)nullptr, P, nq, kin, k, (int64_t)0,
-                     (const int64_t*)nullptr, D, I);
+                     (const int64_t*)nullptr, D, I, (const unsigned*)nullptr);
   return hipGetLastError();
 }
 hipError_t launch_gather(const _Float16* X, int64_t N, int d, int64_t id_base, const int64_t* ids, int64_t n,

@@ -45,7 +45,7 @@ struct knnx_index {
   hipStream_t stream = nullptr;
   std::mutex mu;
 
-  // per-scan scratch (sized for KNN_NQ queries, grid = n_cu workgroups, k <= KNNX_MAX_K_FAST)
+  // per-scan scratch (sized for KNN_NQ_MAX queries, grid = n_cu workgroups, k <= KNNX_MAX_K_FAST)
   _Float16* qfrag = nullptr;
   float* q_dev = nullptr;  // [KNN_NQ, d]
   int* thr_g = nullptr;
@@ -73,6 +73,16 @@ struct knnx_index {
   uint32_t* ivf_inv = nullptr;   // id - id_base -> padded arena row
   int64_t* ivf_Ic = nullptr;     // [KNN_NQ, KNNX_MAX_K_FAST] coarse result
   float* ivf_Dc = nullptr;
+
+  // wide scan (64 queries per pass): candidates, fallback results, proof flags; largest row norm (order-encoded)
+  int wide_ok = 1;             // KNNX_WIDE=0 disables
+  int* maxnorm = nullptr;
+  int64_t* wide_cand = nullptr;  // [64, 64]
+  float* wide_approx = nullptr;  // [64, 64]
+  unsigned* wide_need = nullptr; // [64]
+  unsigned* wide_gate = nullptr; // [2]
+  float* wide_Dfb = nullptr;     // [32, 64]
+  int64_t* wide_Ifb = nullptr;
 
   int nt_loads = 0;
   bool prof = false;
@@ -128,19 +138,29 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
   ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   const char* nt = getenv("KNNX_NT");
   ix->nt_loads = (nt && nt[0] == '1') ? 1 : 0;
+  const char* wd = getenv("KNNX_WIDE");
+  ix->wide_ok = (wd && wd[0] == '0') ? 0 : 1;
   const char* gr = getenv("KNNX_GRID");
   if (gr && atoi(gr) > 0) ix->n_cu = atoi(gr);
   hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
   const size_t G = (size_t)ix->n_cu;
   if (e == hipSuccess) e = hipMalloc(&ix->qfrag, (size_t)d * 128);
-  if (e == hipSuccess) e = hipMalloc(&ix->q_dev, (size_t)KNN_NQ * d * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&ix->thr_g, KNN_NQ * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&ix->part_s, G * KNN_NQ * KNNX_MAX_K_FAST * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&ix->part_i, G * KNN_NQ * KNNX_MAX_K_FAST * sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMalloc(&ix->part_n, G * KNN_NQ * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&ix->D_dev, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&ix->I_dev, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->q_dev, (size_t)KNN_NQ_MAX * d * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&ix->thr_g, KNN_NQ_MAX * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&ix->part_s, G * KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&ix->part_i, G * KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->part_n, G * KNN_NQ_MAX * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&ix->D_dev, (size_t)KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&ix->I_dev, (size_t)KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(int64_t));
   if (e == hipSuccess) e = hipMalloc(&ix->range_cnt, KNN_NQ * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->maxnorm, sizeof(int));
+  if (e == hipSuccess) e = hipMemset(ix->maxnorm, 0, sizeof(int));  // order-encoded +0.0f
+  if (e == hipSuccess) e = hipMalloc(&ix->wide_cand, (size_t)KNN_NQ_MAX * KNN_WIDE_KW * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->wide_approx, (size_t)KNN_NQ_MAX * KNN_WIDE_KW * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&ix->wide_need, KNN_NQ_MAX * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->wide_gate, 2 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->wide_Dfb, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&ix->wide_Ifb, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(int64_t));
   if (e != hipSuccess) {
     std::string m = std::string("knnx_create: ") + hipGetErrorString(e);
     knnx_destroy(ix);
@@ -164,6 +184,13 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->D_dev);
   hipFree(ix->I_dev);
   hipFree(ix->range_cnt);
+  hipFree(ix->maxnorm);
+  hipFree(ix->wide_cand);
+  hipFree(ix->wide_approx);
+  hipFree(ix->wide_need);
+  hipFree(ix->wide_gate);
+  hipFree(ix->wide_Dfb);
+  hipFree(ix->wide_Ifb);
   if (ix->range_s) hipFree(ix->range_s);
   if (ix->range_i) hipFree(ix->range_i);
   if (ix->cent) knnx_destroy(ix->cent);
@@ -255,6 +282,7 @@ static int add_common(knnx_index* ix, const void* rows, int64_t n, bool is_f32) 
     } else {
       e = hipMemcpyAsync(dst, ix->pin, bytes, hipMemcpyHostToDevice, ix->stream);
     }
+    if (e == hipSuccess) e = launch_maxnorm(dst, m, ix->d, ix->maxnorm, ix->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
     if (e != hipSuccess) {
       if (tmp32) hipFree(tmp32);
@@ -278,6 +306,10 @@ extern "C" int knnx_attach_device_f16(knnx_index* ix, const void* dev_rows, int6
   ix->borrowed = true;
   ix->capacity = n;
   ix->ntotal = n;
+  if (set_dev(ix)) return KNNX_E_HIP;
+  HIPCHK(hipMemsetAsync(ix->maxnorm, 0, sizeof(int), ix->stream));
+  HIPCHK(launch_maxnorm(ix->rows, n, ix->d, ix->maxnorm, ix->stream));
+  HIPCHK(hipStreamSynchronize(ix->stream));
   return KNNX_OK;
 }
 
@@ -292,6 +324,8 @@ extern "C" int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed) {
     return fail(KNNX_E_NOMEM, "attached arena is smaller than n");
   }
   HIPCHK(launch_synth(ix->rows, 0, n, ix->d, seed, ix->stream));
+  HIPCHK(hipMemsetAsync(ix->maxnorm, 0, sizeof(int), ix->stream));
+  HIPCHK(launch_maxnorm(ix->rows, n, ix->d, ix->maxnorm, ix->stream));
   HIPCHK(hipStreamSynchronize(ix->stream));
   ix->ntotal = n;
   return KNNX_OK;
@@ -299,7 +333,7 @@ extern "C" int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed) {
 
 // one scan of <= KNN_NQ queries already in HBM; results land in D_out/I_out (device, [nq, k])
 static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out,
-                     hipStream_t st) {
+                     hipStream_t st, const unsigned* gate = nullptr) {
   const int cap = scan_cap(ix->d, k);
   if (cap < 0) return fail(KNNX_E_UNSUPPORTED, "k too large for the LDS queues at this d");
   if (ix->ivf_nlist) {
@@ -311,8 +345,9 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
     HIPCHK(launch_ivf_worklist(ix->ivf_Ic, nq, np, ix->ivf_nlist, ix->ivf_masks, ix->ivf_tile0, ix->ivf_ntile, ix->ivf_size,
                                ix->ivf_off, ix->ivf_work, ix->ivf_nwork, st));
   }
-  HIPCHK(launch_prep(q_dev, nq, ix->d, ix->qfrag, ix->thr_g, nullptr, st));
+  HIPCHK(launch_prep(q_dev, nq, ix->d, ix->qfrag, ix->thr_g, nullptr, 0, gate, st));
   ScanArgs a{};
+  a.gate = gate;
   a.X = ix->rows;
   a.N = ix->ivf_nlist ? ix->capacity : ix->ntotal;
   a.d = ix->d;
@@ -330,6 +365,55 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
   a.work = ix->ivf_nlist ? ix->ivf_work : nullptr;
   a.nwork = ix->ivf_nwork;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool prof = ix->prof && !gate;  // gated fallback scans normally exit at once: not a scan launch worth timing
+  if (prof) {
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st));
+  }
+  HIPCHK(launch_scan(a, st));
+  if (prof) {
+    HIPCHK(hipEventRecord(e1, st));
+    ix->prof_events.emplace_back(e0, e1);
+  }
+  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ, k, nq, k, ix->id_base,
+                          ix->ivf_nlist ? ix->ivf_idmap : nullptr, D_out, I_out, gate, st));
+  return 0;
+}
+
+// LDS capacity of the 64-queue wide scan at this d
+static int wide_cap(int d) {
+  long avail = (long)KNN_LDS_BYTES - (long)d * 128 - KNN_NQ_MAX * 8 - 16;
+  int cap = (int)(avail / (KNN_NQ_MAX * 8));
+  cap = std::min(cap, 128) & ~1;
+  return cap >= KNN_WIDE_KW + 16 ? cap : -1;
+}
+static bool wide_usable(const knnx_index* ix, int nq, int k) {
+  return ix->wide_ok && !ix->ivf_nlist && nq > KNN_NQ && k <= KNN_WIDE_MAX_K && wide_cap(ix->d) > 0;
+}
+
+// one WIDE scan of 33..64 queries: approximate top-64 by fp16-hi score in ONE pass over HBM, exact re-scoring of the 64
+// candidates, proof of exactness per query; a query whose proof fails gets the exact 32-query scan of its half, which
+// is launched unconditionally but exits at once unless its gate was set by the proof kernel (no host round trip).
+static int scan_topk_wide(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st) {
+  const int cap = wide_cap(ix->d);
+  HIPCHK(launch_prep(q_dev, nq, ix->d, ix->qfrag, ix->thr_g, nullptr, 1, nullptr, st));
+  ScanArgs a{};
+  a.X = ix->rows;
+  a.N = ix->ntotal;
+  a.d = ix->d;
+  a.qfrag = ix->qfrag;
+  a.nq = nq;
+  a.k = KNN_WIDE_KW;
+  a.cap = cap;
+  a.grid = ix->n_cu;
+  a.mode = 0;
+  a.wide = 1;
+  a.thr_g = ix->thr_g;
+  a.part_s = ix->part_s;
+  a.part_i = ix->part_i;
+  a.part_n = ix->part_n;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->prof) {
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -340,8 +424,17 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
     HIPCHK(hipEventRecord(e1, st));
     ix->prof_events.emplace_back(e0, e1);
   }
-  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ, k, nq, k, ix->id_base,
-                          ix->ivf_nlist ? ix->ivf_idmap : nullptr, D_out, I_out, st));
+  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ_MAX, KNN_WIDE_KW, nq, KNN_WIDE_KW, 0, nullptr,
+                          ix->wide_approx, ix->wide_cand, nullptr, st));
+  HIPCHK(launch_rescore(ix->rows, ix->d, q_dev, ix->wide_cand, ix->wide_approx, nq, KNN_WIDE_KW, k, ix->id_base, ix->maxnorm,
+                        D_out, I_out, ix->wide_need, ix->wide_gate, st));
+  for (int half = 0; half < 2; ++half) {
+    const int q0 = half * KNN_NQ, n = std::min(KNN_NQ, nq - q0);
+    if (n <= 0) break;
+    int r = scan_topk(ix, q_dev + (size_t)q0 * ix->d, n, k, ix->wide_Dfb, ix->wide_Ifb, st, ix->wide_gate + half);
+    if (r) return r;
+    HIPCHK(launch_select(ix->wide_need, q0, n, k, ix->wide_Dfb, ix->wide_Ifb, D_out, I_out, st));
+  }
   return 0;
 }
 
@@ -352,10 +445,13 @@ extern "C" int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int
   std::lock_guard<std::mutex> lk(ix->mu);
   if (set_dev(ix)) return KNNX_E_HIP;
   hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
-  for (int o = 0; o < n; o += KNN_NQ) {
-    const int nq = std::min(KNN_NQ, n - o);
-    int r = scan_topk(ix, q_dev + (size_t)o * ix->d, nq, k, D_dev + (size_t)o * k, I_dev + (size_t)o * k, st);
+  for (int o = 0; o < n;) {
+    const bool wide = wide_usable(ix, n - o, k);
+    const int nq = std::min(wide ? KNN_NQ_MAX : KNN_NQ, n - o);
+    int r = wide ? scan_topk_wide(ix, q_dev + (size_t)o * ix->d, nq, k, D_dev + (size_t)o * k, I_dev + (size_t)o * k, st)
+                 : scan_topk(ix, q_dev + (size_t)o * ix->d, nq, k, D_dev + (size_t)o * k, I_dev + (size_t)o * k, st);
     if (r) return r;
+    o += nq;
   }
   return KNNX_OK;
 }
@@ -363,22 +459,24 @@ extern "C" int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int
 // k <= 64, host buffers; caller holds ix->mu
 static int search_fast_locked(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I) {
   hipStream_t st = ix->stream;
-  const size_t qb = (size_t)KNN_NQ * ix->d * sizeof(float);
-  const size_t db = (size_t)KNN_NQ * k * sizeof(float), ib = (size_t)KNN_NQ * k * sizeof(int64_t);
+  const size_t qb = (size_t)KNN_NQ_MAX * ix->d * sizeof(float);
+  const size_t db = (size_t)KNN_NQ_MAX * k * sizeof(float), ib = (size_t)KNN_NQ_MAX * k * sizeof(int64_t);
   int r = ensure_pin(ix, qb + db + ib);
   if (r) return r;
   char* pin = (char*)ix->pin;
-  for (int o = 0; o < n; o += KNN_NQ) {
-    const int nq = std::min(KNN_NQ, n - o);
+  for (int o = 0; o < n;) {
+    const bool wide = wide_usable(ix, n - o, k);
+    const int nq = std::min(wide ? KNN_NQ_MAX : KNN_NQ, n - o);
     memcpy(pin, q + (size_t)o * ix->d, (size_t)nq * ix->d * sizeof(float));
     HIPCHK(hipMemcpyAsync(ix->q_dev, pin, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
-    r = scan_topk(ix, ix->q_dev, nq, k, ix->D_dev, ix->I_dev, st);
+    r = wide ? scan_topk_wide(ix, ix->q_dev, nq, k, ix->D_dev, ix->I_dev, st) : scan_topk(ix, ix->q_dev, nq, k, ix->D_dev, ix->I_dev, st);
     if (r) return r;
     HIPCHK(hipMemcpyAsync(pin + qb, ix->D_dev, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(pin + qb + db, ix->I_dev, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(D + (size_t)o * k, pin + qb, (size_t)nq * k * sizeof(float));
     memcpy(I + (size_t)o * k, pin + qb + db, (size_t)nq * k * sizeof(int64_t));
+    o += nq;
   }
   return 0;
 }
@@ -448,7 +546,7 @@ static int range_scan(knnx_index* ix, const float* q_host, int nq, float thr, st
       HIPCHK(hipMalloc(&ix->range_i, ix->range_pool * sizeof(uint32_t)));
     }
     const unsigned cap = (unsigned)std::min<size_t>(ix->range_pool / (size_t)nq, 0xffffffffu);
-    HIPCHK(launch_prep(ix->q_dev, nq, ix->d, ix->qfrag, ix->thr_g, ix->range_cnt, st));
+    HIPCHK(launch_prep(ix->q_dev, nq, ix->d, ix->qfrag, ix->thr_g, ix->range_cnt, 0, nullptr, st));
     ScanArgs a{};
     a.X = ix->rows;
     a.N = ix->ntotal;

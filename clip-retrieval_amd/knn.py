@@ -25,7 +25,7 @@ import numpy as np
 from ._lib import HipLibraryError, check, load_library
 
 METRIC_INNER_PRODUCT = 0
-_SCAN_QUERIES = 32  # queries one HBM scan serves (KNN_NQ in csrc/knn_kernels.h)
+_SCAN_QUERIES = 64  # queries one HBM scan serves (KNN_NQ_MAX in csrc/knn_kernels.h: the wide scan)
 
 
 def _as_queries(x, d):

@@ -84,6 +84,30 @@ def test_exact_ties_are_ordered_by_id():
         assert I[i, :3].tolist() == [i, 300 + i, 350 + i]
 
 
+def test_wide_scan_64_queries_and_its_fallback():
+    """33..64 queries share ONE pass over HBM (fp16-hi scores + exact re-scoring of 64 candidates + proof).  Case 1:
+    ordinary data, every proof succeeds.  Case 2: each row exists 100 times, so the 64th approximate score equals the
+    k-th exact one, every proof fails and the gated exact scans must deliver the answer.  Both must equal the oracle."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 768
+    for name, x in (("plain", _data(50000, d, seed=11)), ("dups", np.tile(_data(300, d, seed=12), (100, 1)))):
+        o, ix = FlatIPOracle(d), Mi355xIndex(d)
+        o.add(x)
+        ix.add(x)
+        for nq, k in [(64, 40), (40, 10), (33, 48), (64, 1)]:
+            q = _queries(nq, d, seed=nq + k, x=x)
+            D, I = ix.search(q, k)
+            Do, Io = o.search(q, k)
+            if name == "dups":
+                assert np.array_equal(I, Io), f"{name} nq={nq} k={k}: ties must come back in ascending id order"
+                assert np.allclose(D, Do, atol=1e-5)
+            else:
+                _check(D, I, Do, Io, f"wide {name} nq={nq} k={k}")
+        ix.close()
+
+
 def test_fewer_rows_than_k_and_empty_index():
     from clip_retrieval_amd.knn import Mi355xIndex
 

@@ -109,7 +109,7 @@ if "knn" in what:
     rows = int(os.environ.get("MB_KNN_ROWS", "20000000"))
     ix = Mi355xIndex(768)
     ix.synth_fill(rows, 3)
-    for nq in (1, 32):
+    for nq in (1, 32, 64):
         q = torch.nn.functional.normalize(torch.randn(nq, 768, device="cuda"), dim=1)
         D = torch.empty(nq, 40, device="cuda")
         I = torch.empty(nq, 40, device="cuda", dtype=torch.int64)
