@@ -235,12 +235,13 @@ int gemm256_bulk_mtiles(int M, int N, int n_cu) {
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
-  if ((g.variant == 2 || g.variant == 3) && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
+  if (g.variant >= 2 && g.variant <= 4 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
     const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
     if (bulk > 0) {
       GemmArgs b = g;
       b.M = bulk * 256;
-      hipError_t e = g.variant == 3 ? launch_gemm256sp(b, g.n_cu, st) : launch_gemm256(b, g.n_cu, st);
+      hipError_t e = g.variant == 4 ? launch_gemm256r4(b, g.n_cu, st)
+                     : g.variant == 3 ? launch_gemm256sp(b, g.n_cu, st) : launch_gemm256(b, g.n_cu, st);
       if (e != hipSuccess) return e;
       if (b.M == g.M) return hipSuccess;
       GemmArgs r = g;  // remaining rows [bulk*256, M)

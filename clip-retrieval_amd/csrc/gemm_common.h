@@ -47,5 +47,6 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
 // bulk-tile launcher of gemm256.hip: rows [0, g.M) must be a multiple of 256, N % 256 == 0, K % 128 == 0
 hipError_t launch_gemm256(const GemmArgs& g, int n_cu, hipStream_t st);    // variant 2: ping-pong schedule
 hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st);  // variant 3: one barrier per K-tile
+hipError_t launch_gemm256r4(const GemmArgs& g, int n_cu, hipStream_t st);  // variant 4: 32-deep K-tiles, 4-deep DMA ring
 
 }  // namespace clipx

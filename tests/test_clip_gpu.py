@@ -29,7 +29,7 @@ def lib():
 
 
 # ------------------------------------------------------------------------------------------ per-kernel
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(257, 128, 64), (514, 1024, 1024), (1000, 2304, 768), (130, 768, 3072), (65, 128, 640),
                                    (33357, 512, 128), (65792, 1024, 1024), (2048, 4096, 1024), (19712, 768, 3072)])
 def test_gemm_epilogues(lib, variant, M, N, K):
