@@ -237,7 +237,10 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
   if (g.variant >= 2 && g.variant <= 4 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
     const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
-    if (bulk > 0) {
+    // small problems (query-side B = 1: M = 257 or 77 rows) would put one 256x256 tile on each of a handful of CUs;
+    // the 128x128 kernel gives them 4x the tiles.  Both kernels produce bit-identical rows.
+    const int cu = (g.n_cu > 0 ? g.n_cu : 256);
+    if (bulk > 0 && (int64_t)bulk * (g.N / 256) >= cu / 2) {
       GemmArgs b = g;
       b.M = bulk * 256;
       hipError_t e = g.variant == 4 ? launch_gemm256r4(b, g.n_cu, st)

@@ -13,7 +13,7 @@ import clip_retrieval_amd  # noqa: E402
 from clip_retrieval_amd._lib import check  # noqa: E402
 
 lib = clip_retrieval_amd.load_library()
-what = set(sys.argv[1:]) or {"gemm", "attn", "knn", "ln"}
+what = set(sys.argv[1:]) or {"gemm", "attn", "knn", "ln"}  # extra targets: ivf, b1
 REPS = int(os.environ.get("MB_REPS", "5"))
 P = lambda t: C.c_void_p(t.data_ptr())
 
@@ -115,3 +115,37 @@ if "knn" in what:
         I = torch.empty(nq, 40, device="cuda", dtype=torch.int64)
         timed(f"knn search_device rows={rows} nq={nq} k=40 (prep+scan+merge)",
               lambda: ix.search_device(q.data_ptr(), nq, 40, D.data_ptr(), I.data_ptr(), st), nbytes=rows * 768 * 2.0)
+
+if "ivf" in what:
+    # IVF-Flat search at moderate scale (built from host rows): bytes actually scanned = tiles of the probed lists
+    import numpy as np
+
+    from clip_retrieval_amd.knn import build_ivf_index
+
+    rows, d, nlist = int(os.environ.get("MB_IVF_ROWS", "2000000")), 768, int(os.environ.get("MB_IVF_NLIST", "1024"))
+    rng = np.random.default_rng(0)
+    centers = rng.standard_normal((nlist, d)).astype(np.float32)
+    x = centers[rng.integers(0, nlist, rows)] + 0.5 * rng.standard_normal((rows, d)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
+    t0 = time.perf_counter()
+    ix = build_ivf_index(x, nlist, nprobe=16, niter=4)
+    print(f"ivf build rows={rows} nlist={nlist}: {time.perf_counter() - t0:.1f} s (k-means 4 iters + assign + relayout)", flush=True)
+    for nq, nprobe in ((1, 16), (32, 16), (32, 64)):
+        ix.nprobe = nprobe
+        q = torch.from_numpy(x[rng.integers(0, rows, nq)].astype(np.float32)).cuda()
+        D = torch.empty(nq, 40, device="cuda")
+        I = torch.empty(nq, 40, device="cuda", dtype=torch.int64)
+        timed(f"ivf search rows={rows} nlist={nlist} nprobe={nprobe} nq={nq} k=40",
+              lambda: ix.search_device(q.data_ptr(), nq, 40, D.data_ptr(), I.data_ptr(), st))
+if "b1" in what:
+    # query-side latency (KnnService.compute_query, clip_back.py:207-255): ONE text / ONE image through the towers
+    from clip_retrieval_amd.encoder import ARCHS, ClipEncoder, random_blob
+    from clip_retrieval_amd.synth import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    arch = ARCHS["ViT-L/14"]
+    enc = ClipEncoder(arch, random_blob(arch, seed=0), 0)
+    pix = torch.from_numpy(normalise_u8_nhwc(synth_pixels_u8(1, arch.image_size, seed=1))).cuda()
+    ids = torch.from_numpy(synth_tokens(1, arch.ctx_len, arch.vocab, seed=2)).cuda()
+    o16 = torch.empty(1, arch.embed_dim, dtype=torch.float16, device="cuda")
+    timed("encode_image B=1 ViT-L/14 (device buffers)", lambda: enc.encode_image_device(pix.data_ptr(), 1, 0, o16.data_ptr(), None, st))
+    timed("encode_text  B=1 ViT-L/14 (device buffers)", lambda: enc.encode_text_device(ids.data_ptr(), 1, o16.data_ptr(), None, st))
