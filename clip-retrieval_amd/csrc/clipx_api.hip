@@ -61,6 +61,9 @@ struct clipx_handle {
   clipx_model_desc desc{};
   int device = 0;
   int max_batch = 256;
+  int host_chunk = 256;  // chunk of the host-buffer pipeline (H2D of chunk i+1 overlaps the kernels of chunk i); measured
+                         // at B=256: chunks of 32/64/128/256 -> 92/65/58/56.5 ms, small chunks lose more GEMM efficiency than
+                         // the overlap wins
   int gemm_variant = 3;
   int n_cu = 256;
   std::mutex mu;
@@ -259,6 +262,9 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   h->device = device;
   const char* mb = getenv("CLIPX_MAX_BATCH");
   if (mb && atoi(mb) > 0) h->max_batch = atoi(mb);
+  const char* hc = getenv("CLIPX_HOST_CHUNK");
+  if (hc && atoi(hc) > 0) h->host_chunk = atoi(hc);
+  h->host_chunk = std::min(h->host_chunk, h->max_batch);
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   if (gv) h->gemm_variant = std::min(4, std::max(0, atoi(gv)));
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -414,24 +420,35 @@ extern "C" int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev,
   return CLIPX_OK;
 }
 
-// Host-buffer path: chunks of max_batch flow through two slots.  The CPU fills slot s^1's pinned buffer
-// and the copy stream uploads it while the compute stream is still running the kernels of slot s.
+// Host-buffer path: chunks of `host_chunk` (default max_batch) samples flow through two slots.  The copy stream uploads chunk c+1 while
+// the compute stream still runs the kernels of chunk c.  Caller memory that is already page-locked (the reference's
+// DataLoader collates with pin_memory: reader.py:198) is uploaded straight from where it lies; pageable memory is
+// first copied into the slot's pinned buffer by the CPU.  Chunking never changes a row's result (test: bitwise).
 template <typename ChunkFn>
 static int host_pipeline(clipx_handle* h, const char* in, size_t in_bytes_per_item, int B, uint16_t* out, ChunkFn fn) {
   const size_t E = h->desc.embed_dim;
-  const int nchunk = (B + h->max_batch - 1) / h->max_batch;
+  const int CH = h->host_chunk;
+  const int nchunk = (B + CH - 1) / CH;
+  hipPointerAttribute_t attr;
+  bool pinned = false;
+  if (hipPointerGetAttributes(&attr, in) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
+  else (void)hipGetLastError();  // plain malloc memory: the query fails, which is the answer
   auto drain = [&](int c) -> int {  // copy chunk c's result out of its pinned slot
-    const int s = c & 1, o = c * h->max_batch, nb = std::min(h->max_batch, B - o);
+    const int s = c & 1, o = c * CH, nb = std::min(CH, B - o);
     HIPCHK(hipEventSynchronize(h->ev_done[s]));
     memcpy(out + (size_t)o * E, h->pin_out[s], (size_t)nb * E * sizeof(uint16_t));
     return 0;
   };
   for (int c = 0; c < nchunk; ++c) {
-    const int s = c & 1, o = c * h->max_batch, nb = std::min(h->max_batch, B - o);
+    const int s = c & 1, o = c * CH, nb = std::min(CH, B - o);
     int r;
     if (c >= 2 && (r = drain(c - 2))) return r;  // slot s is free once chunk c-2 has been copied out
-    memcpy(h->pin_in[s], in + (size_t)o * in_bytes_per_item, (size_t)nb * in_bytes_per_item);
-    HIPCHK(hipMemcpyAsync(h->dev_in[s], h->pin_in[s], (size_t)nb * in_bytes_per_item, hipMemcpyHostToDevice, h->copy_stream));
+    const char* src = in + (size_t)o * in_bytes_per_item;
+    if (!pinned) {
+      memcpy(h->pin_in[s], src, (size_t)nb * in_bytes_per_item);
+      src = (const char*)h->pin_in[s];
+    }
+    HIPCHK(hipMemcpyAsync(h->dev_in[s], src, (size_t)nb * in_bytes_per_item, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(hipEventRecord(h->ev_copied[s], h->copy_stream));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copied[s], 0));
     if ((r = fn(h->dev_in[s], nb, h->dev_out[s]))) return r;

@@ -149,3 +149,22 @@ if "b1" in what:
     o16 = torch.empty(1, arch.embed_dim, dtype=torch.float16, device="cuda")
     timed("encode_image B=1 ViT-L/14 (device buffers)", lambda: enc.encode_image_device(pix.data_ptr(), 1, 0, o16.data_ptr(), None, st))
     timed("encode_text  B=1 ViT-L/14 (device buffers)", lambda: enc.encode_text_device(ids.data_ptr(), 1, o16.data_ptr(), None, st))
+
+if "e2e" in what:
+    # host-buffer path of the C ABI (what ClipMapper.__call__ uses): f32 NCHW batch of 256 in host memory -> fp16 embeddings
+    import numpy as np
+
+    from clip_retrieval_amd.encoder import ARCHS, ClipEncoder, random_blob
+    from clip_retrieval_amd.synth import normalise_u8_nhwc, synth_pixels_u8
+
+    arch = ARCHS["ViT-L/14"]
+    enc = ClipEncoder(arch, random_blob(arch, seed=0), 0)
+    pix = normalise_u8_nhwc(synth_pixels_u8(256, arch.image_size, seed=1))
+    pinned = torch.from_numpy(pix).pin_memory()
+    for name, arr in (("pageable numpy", pix), ("page-locked torch tensor", pinned)):
+        enc.encode_image(arr)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            enc.encode_image(arr)
+        dt = (time.perf_counter() - t0) / 5
+        print(f"encode_image host path B=256 ({name}): {dt * 1e3:.1f} ms/batch = {256 / dt:.0f} images/s", flush=True)
