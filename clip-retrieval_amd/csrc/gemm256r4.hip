@@ -73,15 +73,20 @@ __global__ __launch_bounds__(512, 2) void gemm256r4_kernel(const bf16* __restric
   const int c0 = (lane & 3) ^ ((srow >> 2) & 3);
   const unsigned off0 = (unsigned)((srow * K + (c0 << 3)) * 2);
   const size_t jstep = (size_t)16 * K * 2;
-  auto stage = [&](const char* baseM, const char* baseN, int slot) {
+  // One K-tile = 4 DMA instructions per wave, issued as two halves (j = 0, 1: the wave's two 16-row pieces, M and N
+  // operand each).  Measured on gemm256sp (ablation DBG 8/9): the staging cost is ~19 cycles of address processing per
+  // DMA INSTRUCTION, independent of its size, and a burst of 8 per wave right behind the barrier blocks the issuing
+  // waves (in-order issue) while the queue drains.  So the halves are issued one k-step apart, each behind 8 MFMAs.
+  auto stage_half = [&](const char* baseM, const char* baseN, int slot, int j) {
     if (DBG == 1) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off0),
-                                       (lds_ptr_t)(smem + slot * R_OPB + (w * 2 + j) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off0),
-                                       (lds_ptr_t)(smem + R_NBASE + slot * R_OPB + (w * 2 + j) * 1024), 16, 0, 0);
-    }
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off0),
+                                     (lds_ptr_t)(smem + slot * R_OPB + (w * 2 + j) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off0),
+                                     (lds_ptr_t)(smem + R_NBASE + slot * R_OPB + (w * 2 + j) * 1024), 16, 0, 0);
+  };
+  auto stage = [&](const char* baseM, const char* baseN, int slot) {
+    stage_half(baseM, baseN, slot, 0);
+    stage_half(baseM, baseN, slot, 1);
   };
 
   // ---- fragment read addresses (LDS byte addresses), one per (operand, k-step of the 32-deep K-tile)
@@ -149,11 +154,15 @@ __global__ __launch_bounds__(512, 2) void gemm256r4_kernel(const bf16* __restric
   S_FENCE();
   S_READ(F0, 0, 0)
 
-  // VMEM bookkeeping (vmcnt retires in order; 4 DMA per wave per K-tile): at K-tile g's barrier "K-tile g+1 has landed"
-  // = vmcnt(8) in steady state (g+2, g+3 in flight).  After an epilogue its S_EPI_ST stores and the bias DMA are also
-  // younger than the awaited K-tile for the next three K-tiles (age 0, 1: + stores + bias; age 2: + stores).  When no
-  // further K-tile is staged (end of the stream) fewer DMAs are younger: drain.
+  // VMEM bookkeeping (vmcnt retires in order; 4 DMA per wave per K-tile, issued 2 + 2): at K-tile g's barrier "K-tile
+  // g+1 has landed" = vmcnt(8) in steady state (g+2, g+3 in flight).  After an epilogue its S_EPI_ST stores and the
+  // bias DMA are also younger than the awaited K-tile for the next two K-tiles (age 0, 1); from age 2 on the awaited
+  // K-tile's second half is itself younger than the stores.  When no further K-tile is staged (end of the stream)
+  // fewer DMAs are younger: drain.
   int age = 3;
+  bool pend = false;  // the second half of the last begun stage is still to be issued
+  const char* pendM = curM;
+  const char* pendN = curN;
   for (int j = 0;; ++j) {
     int nm0 = 0, nn0 = 0;
     const bool have_next = tile_of(j + 1, nm0, nn0);
@@ -169,19 +178,26 @@ __global__ __launch_bounds__(512, 2) void gemm256r4_kernel(const bf16* __restric
 
 #define S_KTILE(slot, bias_stmt)                                                                     \
   S_READ(F1, slot, 1)                                                                                \
+  if (pend) stage_half(pendM, pendN, ((slot) + 3) & 3, 1); /* 2nd half of the stage begun at the previous barrier */ \
+  pend = false;                                                                                      \
+  S_FENCE();                                                                                         \
   S_WAIT_PREV()                                                                                      \
   S_MFMA(F0)                                                                                         \
   S_FENCE();                                                                                         \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
   if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
   else if (age <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(8 + S_NB + S_EPI_ST) : "memory");     \
-  else if (age == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(8 + S_EPI_ST) : "memory");            \
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                              \
   S_FENCE();                                                                                         \
   __builtin_amdgcn_s_barrier();                                                                      \
   S_FENCE();                                                                                         \
   bias_stmt;                                                                                         \
-  if (more) stage(sM + (slot) * 64, sN + (slot) * 64, slot);                                         \
+  if (more) {                                                                                        \
+    pendM = sM + (slot) * 64;                                                                        \
+    pendN = sN + (slot) * 64;                                                                        \
+    pend = true;                                                                                     \
+    stage_half(pendM, pendN, slot, 0);                                                               \
+  }                                                                                                  \
   if ((slot) < 3 || more) { S_READ(F0, ((slot) + 1) & 3, 0) }                                        \
   S_FENCE();                                                                                         \
   S_MFMA(F1)                                                                                         \
@@ -197,8 +213,8 @@ __global__ __launch_bounds__(512, 2) void gemm256r4_kernel(const bf16* __restric
     // ---- epilogue of this output tile, transposed through the wave's LDS scratch (the next tile's first four
     // K-tiles are in flight / landed and its first fragment set is in F0)
     S_WAIT_ALL()  // the next tile's first fragment set must have landed before hipcc may move/spill its registers
-    // bias landed in the scratch: only the next tile's 4th K-tile (4 DMA) was issued after its DMA
-    if (have_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // bias landed in the scratch: only the first half of the next tile's 4th K-tile (2 DMA) was issued after its DMA
+    if (have_next) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_FENCE();
     if (DBG != 5) {

@@ -102,8 +102,16 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned off = (j & 1) ? offO : offE;
+      if (DBG == 9) {  // same instruction count, a quarter of the bytes
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off),
+                                         (lds_ptr_t)(smem + buf * S_OPB + (w * 4 + j) * 1024), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off),
+                                         (lds_ptr_t)(smem + S_NBASE + buf * S_OPB + (w * 4 + j) * 1024), 4, 0, 0);
+        continue;
+      }
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off),
                                        (lds_ptr_t)(smem + buf * S_OPB + (w * 4 + j) * 1024), 16, 0, 0);
+      if (DBG == 8) continue;  // half the bytes and half the instructions: M operand only
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off),
                                        (lds_ptr_t)(smem + S_NBASE + buf * S_OPB + (w * 4 + j) * 1024), 16, 0, 0);
     }
@@ -369,6 +377,8 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 5) return launch_sp_epi<EPI_BIAS_BF16, 5>(g, grid, st);
     if (d == 6) return launch_sp_epi<EPI_BIAS_BF16, 6>(g, grid, st);
     if (d == 7) return launch_sp_epi<EPI_BIAS_BF16, 7>(g, grid, st);
+    if (d == 8) return launch_sp_epi<EPI_BIAS_BF16, 8>(g, grid, st);
+    if (d == 9) return launch_sp_epi<EPI_BIAS_BF16, 9>(g, grid, st);
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);
