@@ -97,11 +97,18 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   const unsigned offE = (unsigned)((srow * K + (c0 << 3)) * 2);
   const unsigned offO = (unsigned)((srow * K + ((c0 ^ 4) << 3)) * 2);
   const size_t jstep = (size_t)8 * K * 2;
+  typedef unsigned dbg_u32x4 __attribute__((ext_vector_type(4)));
+  dbg_u32x4 dbg_sink = {0u, 0u, 0u, 0u};
   auto stage = [&](const char* baseM, const char* baseN, int buf) {
     if (DBG == 1 || DBG == 3) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned off = (j & 1) ? offO : offE;
+      if (DBG == 10) {  // the same loads into a (dummy) register instead of the LDS: is the per-instruction cost TA- or LDS-side?
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dbg_sink) : "v"(baseM + j * jstep + off) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dbg_sink) : "v"(baseN + j * jstep + off) : "memory");
+        continue;
+      }
       if (DBG == 9) {  // same instruction count, a quarter of the bytes
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off),
                                          (lds_ptr_t)(smem + buf * S_OPB + (w * 4 + j) * 1024), 4, 0, 0);
@@ -350,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     curM = nxtM;
     curN = nxtN;
   }
+  if (DBG == 10) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dbg_sink)::"memory");
 }
 
 template <int EPI, int DBG = 0>
@@ -379,6 +387,7 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 7) return launch_sp_epi<EPI_BIAS_BF16, 7>(g, grid, st);
     if (d == 8) return launch_sp_epi<EPI_BIAS_BF16, 8>(g, grid, st);
     if (d == 9) return launch_sp_epi<EPI_BIAS_BF16, 9>(g, grid, st);
+    if (d == 10) return launch_sp_epi<EPI_BIAS_BF16, 10>(g, grid, st);
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);

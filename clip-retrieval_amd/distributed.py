@@ -74,15 +74,23 @@ class ShardedIndex:
         return merge_topk_host(Dg.numpy(), Ig.numpy(), k)
 
     def search_device(self, q_cuda, k):
-        """CUDA tensors end to end: local scan -> all_gather (RCCL) -> merge kernel.  Returns (D, I) on the GPU."""
+        """CUDA tensors end to end: local scan -> all_gather (RCCL) -> merge kernel.  Returns (D, I) on the GPU.
+
+        The scan is launched on a dedicated torch side stream (the C ABI reads a NULL stream as "the index's own
+        stream", which torch's collectives would not be ordered against); the caller's current stream waits for it
+        before the all-gather reads the local results."""
         import torch  # pylint: disable=import-outside-toplevel
         import torch.distributed as dist  # pylint: disable=import-outside-toplevel
 
         n = q_cuda.shape[0]
         D = torch.empty((n, k), dtype=torch.float32, device=q_cuda.device)
         I = torch.empty((n, k), dtype=torch.int64, device=q_cuda.device)
-        st = torch.cuda.current_stream(q_cuda.device).cuda_stream
-        self.local.search_device(q_cuda.data_ptr(), n, k, D.data_ptr(), I.data_ptr(), st)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=q_cuda.device)
+        cur = torch.cuda.current_stream(q_cuda.device)
+        self._side.wait_stream(cur)  # q_cuda, D, I were produced / allocated on the caller's stream
+        self.local.search_device(q_cuda.data_ptr(), n, k, D.data_ptr(), I.data_ptr(), self._side.cuda_stream)
+        cur.wait_stream(self._side)
         if self.world == 1:
             return D, I
         Dg = torch.empty((self.world * n, k), dtype=torch.float32, device=q_cuda.device)
