@@ -18,9 +18,14 @@ What it restates (reference file:line)
         taking the flat weight blob the HIP library consumes (include/clipx.h).
     tests/test_oracle_clip.py checks the two against each other.
 
-PARITY UNPINNED: the reference's own tests assert only shape and dtype at this boundary
-(tests/test_clip_inference/test_mapper.py:37-38); its fixture pairs test_tensors/*.pkl ->
-test_embeddings/*.pkl need the real ViT-B/32 checkpoint, which is not available offline.
+PARITY PIN: tests/golden/reference_mapper_*.npz hold fp16 embeddings produced by the reference's own
+`ClipMapper.__call__` (mapper.py loaded by file path and run unmodified in the build container by
+tests/golden/make_golden_mapper.py; the absent `all_clip` wheel is stubbed by its hf_clip wrapper around
+`transformers.CLIPModel`, weights = this module's seeded random init); tests/test_oracle.py requires this oracle to
+reproduce them bit for bit, tests/test_clip_gpu.py holds the HIP path to cosine >= 1 - 1e-3 against them.
+STILL UNPINNED: real-checkpoint numbers -- the reference's own tests assert only shape and dtype at this boundary
+(tests/test_clip_inference/test_mapper.py:37-38) and its fixture pairs test_tensors/*.pkl -> test_embeddings/*.pkl
+need the OpenAI ViT-B/32 checkpoint, which is not available offline.
 """
 
 import math

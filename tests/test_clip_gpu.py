@@ -195,6 +195,29 @@ def test_chunked_batches_equal_unchunked(tiny):
     small.close()
 
 
+def test_mapper_vs_reference_clipmapper_golden(tiny):
+    """The HIP ClipMapper against fp16 embeddings produced by the reference's own ClipMapper code on the CPU
+    (tests/golden/make_golden_mapper.py): per-sample cosine >= 1 - 1e-3 (north_star bar), same shapes and dtype."""
+    from clip_retrieval_amd.encoder import register_encoder
+    from clip_retrieval_amd.mapper import ClipMapper
+    from oracle.clip_oracle import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_mapper_" + name.replace("/", "-") + ".npz"))
+    B = int(g["batch"])
+    register_encoder("golden:" + name, enc)
+    m = ClipMapper(True, True, True, False, "golden:" + name, False, "", warmup_batch_size=1)
+    pix = normalise_u8_nhwc(synth_pixels_u8(B, arch.image_size, seed=int(g["pixel_seed"])))
+    ids = synth_tokens(B, arch.ctx_len, arch.vocab, seed=int(g["token_seed"]))
+    out = m({"image_tensor": torch.from_numpy(pix), "text_tokens": torch.from_numpy(ids), "image_filename": ["a"] * B,
+             "text": ["b"] * B, "metadata": ["{}"] * B})
+    for key in ("image_embs", "text_embs"):
+        assert out[key].dtype == np.float16 and out[key].shape == g[key].shape
+        cos = _cos(out[key], g[key])
+        assert cos.min() >= COS_BAR, f"{name} {key}: cosine {cos}"
+        assert np.abs(out[key].astype(np.float32) - g[key].astype(np.float32)).max() < 2e-2
+
+
 def test_clip_mapper_drop_in(tiny):
     """The reference's mapper test (tests/test_clip_inference/test_mapper.py:20-38: row count + float16) on batches
     of 2 and 1, plus the value check the reference never had."""

@@ -115,3 +115,27 @@ def test_synth_rows_properties():
     assert not np.array_equal(synth_rows([5], 256, seed=4), x[[5]])
     q = planted_queries([7, 9], 256, seed=3)
     assert np.argmax(q @ x.astype(np.float32).T, axis=1).tolist() == [7, 9]
+
+
+@pytest.mark.parametrize("name", ["tiny-B/32", "tiny-L/14", "tiny-H/14"])
+def test_oracle_matches_reference_clipmapper_golden(name):
+    """PIN: tests/golden/reference_mapper_*.npz were produced by the reference's own ClipMapper.__call__
+    (clip_retrieval/clip_inference/mapper.py:49-78, executed unmodified by tests/golden/make_golden_mapper.py with the
+    absent all_clip wheel stubbed by its hf_clip wrapper around transformers.CLIPModel).  The oracle must reproduce them
+    bit for bit (same CPU fp32 model, same normalise + fp16 cast)."""
+    import os
+
+    import torch
+
+    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_mapper_" + name.replace("/", "-") + ".npz"))
+    arch = ARCHS[name]
+    B = int(g["batch"])
+    o = HFClipOracle(arch, seed=0)
+    pix = normalise_u8_nhwc(synth_pixels_u8(B, arch.image_size, seed=int(g["pixel_seed"])))
+    ids = synth_tokens(B, arch.ctx_len, arch.vocab, seed=int(g["token_seed"]))
+    img16, _ = mapper_semantics(o.encode_image(torch.from_numpy(pix)))
+    txt16, _ = mapper_semantics(o.encode_text(torch.from_numpy(ids)))
+    assert img16.dtype == np.float16 and np.array_equal(img16, g["image_embs"])
+    assert np.array_equal(txt16, g["text_embs"])
