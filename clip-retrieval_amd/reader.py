@@ -141,22 +141,32 @@ class _BatchingReader:
     def _raw_samples(self):
         raise NotImplementedError
 
+    # True: group `batch_size` RAW samples first and drop the failed ones from each group -- what the reference's
+    # FilesReader does (DataLoader batches dataset indices, its collate_fn then filters the `None`s: reader.py:187-189),
+    # so a failed image makes THAT batch short.  False: drop failed samples first, then batch -- the reference's
+    # webdataset pipeline (map(..., handler=warn_and_continue) before batching: reader.py:142-180).
+    batch_before_filter = False
+
     def __iter__(self):
         with ThreadPoolExecutor(self.workers) as pool:
-            pending = []
+            pending, taken = [], 0
             for decoded in pool.map(self._decode, self._raw_samples()):
-                if decoded is None:
-                    continue
-                pending.append(decoded)
-                if len(pending) == self.batch_size:
-                    yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
-                    pending = []
+                taken += 1
+                if decoded is not None:
+                    pending.append(decoded)
+                full = taken == self.batch_size if self.batch_before_filter else len(pending) == self.batch_size
+                if full:
+                    if pending:
+                        yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
+                    pending, taken = [], 0
             if pending:
                 yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
 
 
 class FilesReader(_BatchingReader):
     """Reads image / .txt / .json files sharing a stem from a folder tree."""
+
+    batch_before_filter = True
 
     def __init__(self, sampler, preprocess, tokenizer, input_dataset, batch_size, num_prepro_workers,
                  enable_text=True, enable_image=True, enable_metadata=False):

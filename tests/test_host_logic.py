@@ -193,3 +193,61 @@ def test_runner_with_stub_mapper_writes_reference_layout(tmp_path, image_folder)
     assert np.load(out / "img_emb" / "img_emb_1.npy").shape == (3, 8)
     keys = {"start_time", "end_time", "read_duration", "inference_duration", "write_duration", "total_duration", "sample_count"}
     assert all(set(r) == keys for r in logs[0].records) and sum(r["sample_count"] for r in logs[0].records) == 4
+
+
+def test_reader_runner_writer_match_reference_run(tmp_path):
+    """PIN of the plumbing on both sides of the mapper: tests/golden/reference_reader_runner.json was recorded by running
+    the reference's own FilesReader + Runner + NumpyWriter (tests/golden/make_golden_reader.py) over the deterministic
+    folder of tests/golden/reader_fixture.py.  Ours must yield the same batches (order, file names, bit-identical image
+    tensors, the corrupt image skipped) and write byte-identical .npy files and identical parquet rows."""
+    import hashlib
+    import sys
+
+    import pandas as pd
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from reader_fixture import ListLogger, StubMapper, make_folder
+
+    from clip_retrieval_amd.reader import FilesReader, HashTokenizer, clip_preprocess
+    from clip_retrieval_amd.runner import Runner
+    from clip_retrieval_amd.writer import NumpyWriter
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_reader_runner.json")) as f:
+        golden = json.load(f)
+    folder = make_folder(str(tmp_path / "in"))
+    out = str(tmp_path / "out")
+    seen = {}
+    preprocess = lambda im: torch.from_numpy(clip_preprocess(im))  # noqa: E731
+
+    class Recording:
+        def __init__(self, sampler):
+            self.inner = FilesReader(sampler, preprocess, HashTokenizer(), folder, 3, 0, enable_text=False, enable_image=True,
+                                     enable_metadata=False)
+            self.pid = sampler.output_partition_id
+
+        def __iter__(self):
+            for b in self.inner:
+                seen.setdefault(self.pid, []).append({
+                    "image_filename": [os.path.basename(p) for p in b["image_filename"]], "keys": sorted(b.keys()),
+                    "image_shape": list(b["image_tensor"].shape), "image_dtype": str(b["image_tensor"].dtype),
+                    "image_sha256": hashlib.sha256(b["image_tensor"].numpy().tobytes()).hexdigest()})
+                yield b
+
+    r = Runner(reader_builder=Recording, mapper_builder=StubMapper,
+               writer_builder=lambda i: NumpyWriter(i, out, False, True, False, 2), logger_builder=ListLogger,
+               output_partition_count=2)
+    for i in range(2):
+        r(i)
+    assert [seen.get(i, []) for i in range(2)] == golden["partitions"]
+    for rel, want in golden["files"].items():
+        p = os.path.join(out, rel)
+        assert os.path.exists(p), rel
+        if rel.endswith(".npy"):
+            assert hashlib.sha256(open(p, "rb").read()).hexdigest() == want, rel
+        else:
+            df = pd.read_parquet(p)
+            got_rows = json.loads(df.to_json(orient="records"))
+            # the reference stores absolute paths of its temporary folder: compare base names
+            strip = lambda rows: [{k: (os.path.basename(v) if k == "image_path" else v) for k, v in row.items()} for row in rows]  # noqa: E731
+            assert list(df.columns) == want["columns"] and strip(got_rows) == strip(want["rows"]), rel
