@@ -8,8 +8,8 @@
 // against 2048 of MFMA work, and the gap is the LATENCY of the LDS-DMA issued exactly one K-tile (2048 MFMA cycles)
 // earlier: 128 KiB of operand LDS only holds two 64-deep K-tiles.  Here the same 128 KiB are a ring of FOUR 32-deep
 // K-tiles, so a K-tile's DMA is issued three K-tiles (3072 MFMA cycles) before its first read:
-//     K-tile g, step 1:  lgkmcnt(0); vmcnt(8) [K-tile g+1 landed, g+2 and g+3 stay in flight]; s_barrier;
-//                        stage K-tile g+4 into the slot just released; ds_read step 0 of K-tile g+1; 8 MFMA
+//     K-tile g, step 1:  lgkmcnt(0); vmcnt(6) [K-tile g+1 landed, g+2 and half of g+3 stay in flight]; s_barrier;
+//                        ds_read step 0 of K-tile g+1; 8 MFMA with the last two DMAs of K-tile g+3 behind each four
 // at the price of one barrier per 32 k instead of per 64.  LDS rows are 64 B (4 chunks of 16 B), chunk position
 // XOR ((row>>2)&3): 16 consecutive rows x one k-chunk hit 16 distinct 16-B slots (conflict-free ds_read_b128).
 //
@@ -73,20 +73,25 @@ __global__ __launch_bounds__(512, 2) void gemm256r4_kernel(const bf16* __restric
   const int c0 = (lane & 3) ^ ((srow >> 2) & 3);
   const unsigned off0 = (unsigned)((srow * K + (c0 << 3)) * 2);
   const size_t jstep = (size_t)16 * K * 2;
-  // One K-tile = 4 DMA instructions per wave, issued as two halves (j = 0, 1: the wave's two 16-row pieces, M and N
-  // operand each).  Measured on gemm256sp (ablation DBG 8/9): the staging cost is ~19 cycles of address processing per
-  // DMA INSTRUCTION, independent of its size, and a burst of 8 per wave right behind the barrier blocks the issuing
-  // waves (in-order issue) while the queue drains.  So the halves are issued one k-step apart, each behind 8 MFMAs.
-  auto stage_half = [&](const char* baseM, const char* baseN, int slot, int j) {
+  // One K-tile = 4 DMA instructions per wave.  Measured on gemm256sp (ablations DBG 8/9/10): staging costs ~19 cycles per
+  // load INSTRUCTION on the CU's load path, whatever its size and whether it lands in LDS or VGPRs, and that time ADDS to
+  // the MFMA time instead of hiding under it when every wave issues its DMAs in one burst behind the barrier (the
+  // in-order waves sit in VMEM issue while the queue drains, nobody issues MFMAs).  Here the ring gives a stage two
+  // K-tiles of slack, so its four DMAs are issued ONE AT A TIME, each behind four MFMAs of the next K-tile.
+  // piece i of a K-tile's stage (one DMA instruction): i = 0, 1 -> M operand pieces j = 0, 1; i = 2, 3 -> N operand
+  auto stage_piece = [&](const char* baseM, const char* baseN, int slot, int i) {
     if (DBG == 1) return;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off0),
-                                     (lds_ptr_t)(smem + slot * R_OPB + (w * 2 + j) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off0),
-                                     (lds_ptr_t)(smem + R_NBASE + slot * R_OPB + (w * 2 + j) * 1024), 16, 0, 0);
+    const int j = i & 1;
+    if (i < 2)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off0),
+                                       (lds_ptr_t)(smem + slot * R_OPB + (w * 2 + j) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off0),
+                                       (lds_ptr_t)(smem + R_NBASE + slot * R_OPB + (w * 2 + j) * 1024), 16, 0, 0);
   };
   auto stage = [&](const char* baseM, const char* baseN, int slot) {
-    stage_half(baseM, baseN, slot, 0);
-    stage_half(baseM, baseN, slot, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece(baseM, baseN, slot, i);
   };
 
   // ---- fragment read addresses (LDS byte addresses), one per (operand, k-step of the 32-deep K-tile)
@@ -128,6 +133,19 @@ __global__ __launch_bounds__(512, 2) void gemm256r4_kernel(const bf16* __restric
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] =  \
       __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F[4 + ni]), __builtin_bit_cast(bf16x8, F[mi]), acc[mi][ni], 0, 0, 0);
 
+// 8 MFMAs of one k-step with one DMA piece behind each group of four
+#define S_MFMA_DMA(F, ok, pM, pN, slot, i0)                                                                        \
+  _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] =  \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F[4 + ni]), __builtin_bit_cast(bf16x8, F[mi]), acc[mi][ni], 0, 0, 0); \
+  S_FENCE();                                                                                                       \
+  if (ok) stage_piece(pM, pN, slot, i0);                                                                           \
+  S_FENCE();                                                                                                       \
+  _Pragma("unroll") for (int mi = 2; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] =  \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F[4 + ni]), __builtin_bit_cast(bf16x8, F[mi]), acc[mi][ni], 0, 0, 0); \
+  S_FENCE();                                                                                                       \
+  if (ok) stage_piece(pM, pN, slot, (i0) + 1);                                                                     \
+  S_FENCE();
+
   const char* curM = reinterpret_cast<const char*>(A) + (size_t)m0 * K * 2;
   const char* curN = reinterpret_cast<const char*>(W) + (size_t)n0 * K * 2;
   const int nk = K >> 5;  // 32-deep K-tiles per output tile (multiple of 4)
@@ -143,26 +161,23 @@ __global__ __launch_bounds__(512, 2) void gemm256r4_kernel(const bf16* __restric
                                      (lds_ptr_t)(smem + S_SCRATCH + w * 4096), 16, 0, 0);
   };
 
-  // ---- prologue: K-tiles 0..3 of the first tile; K-tile 0 landed + first fragment set read
+  // ---- prologue: K-tiles 0..2 of the first tile (K-tile 3 rides on K-tile 0's MFMAs); K-tile 0 landed + first fragments read
   stage(curM, curN, 0);
   stage(curM + 64, curN + 64, 1);
   stage(curM + 128, curN + 128, 2);
-  stage(curM + 192, curN + 192, 3);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   S_FENCE();
   __builtin_amdgcn_s_barrier();
   S_FENCE();
   S_READ(F0, 0, 0)
 
-  // VMEM bookkeeping (vmcnt retires in order; 4 DMA per wave per K-tile, issued 2 + 2): at K-tile g's barrier "K-tile
-  // g+1 has landed" = vmcnt(8) in steady state (g+2, g+3 in flight).  After an epilogue its S_EPI_ST stores and the
-  // bias DMA are also younger than the awaited K-tile for the next two K-tiles (age 0, 1); from age 2 on the awaited
-  // K-tile's second half is itself younger than the stores.  When no further K-tile is staged (end of the stream)
-  // fewer DMAs are younger: drain.
+  // VMEM bookkeeping (vmcnt retires in order).  The stage of K-tile x+3 (slot (x+3)&3 = (x-1)&3, released at K-tile
+  // x-1's barrier) rides on K-tile x's 16 MFMAs: pieces 0, 1 in step 0, pieces 2, 3 in step 1 (after the barrier).  At
+  // K-tile g's barrier "K-tile g+1 has landed" therefore leaves stage(g+2) (4) and the first two pieces of stage(g+3)
+  // in flight: vmcnt(6).  After an epilogue its S_EPI_ST stores and the bias DMA are also younger than the awaited
+  // K-tile for K-tile 0 of the new tile (age 0: 6 + bias + stores) and the stores for K-tile 1 (age 1: 6 + stores).  When
+  // the stream ends (nothing staged on this K-tile) fewer DMAs are younger: drain.
   int age = 3;
-  bool pend = false;  // the second half of the last begun stage is still to be issued
-  const char* pendM = curM;
-  const char* pendN = curN;
   for (int j = 0;; ++j) {
     int nm0 = 0, nn0 = 0;
     const bool have_next = tile_of(j + 1, nm0, nn0);
@@ -170,50 +185,42 @@ __global__ __launch_bounds__(512, 2) void gemm256r4_kernel(const bf16* __restric
     const char* nxtN = reinterpret_cast<const char*>(W) + (size_t)nn0 * K * 2;
 
     for (int t = 0; t < nk; t += 4) {
-      // K-tiles t..t+3 sit in slots 0..3; K-tile t+4+s is staged into slot s at K-tile t+s's barrier
+      // K-tiles t..t+3 sit in slots 0..3.  During K-tile t+s the stage of K-tile t+s+3 is issued into slot (s+3)&3:
+      // s = 0 -> K-tile t+3 of this group (slot 3); s = 1..3 -> K-tiles t+4.. of the next group / next tile (slots 0..2)
       const bool tail = t + 4 >= nk;
-      const bool more = !tail || have_next;
+      const bool more = !tail || have_next;  // K-tiles t+4.. exist in this block's stream
       const char* sM = tail ? nxtM : curM + (size_t)(t + 4) * 64;
       const char* sN = tail ? nxtN : curN + (size_t)(t + 4) * 64;
+      const char* s3M = curM + (size_t)(t + 3) * 64;  // K-tile t+3 (always exists: nk % 4 == 0)
+      const char* s3N = curN + (size_t)(t + 3) * 64;
 
-#define S_KTILE(slot, bias_stmt)                                                                     \
+#define S_KTILE(slot, ok, pM, pN, bias_stmt)                                                         \
   S_READ(F1, slot, 1)                                                                                \
-  if (pend) stage_half(pendM, pendN, ((slot) + 3) & 3, 1); /* 2nd half of the stage begun at the previous barrier */ \
-  pend = false;                                                                                      \
-  S_FENCE();                                                                                         \
   S_WAIT_PREV()                                                                                      \
-  S_MFMA(F0)                                                                                         \
-  S_FENCE();                                                                                         \
+  S_MFMA_DMA(F0, ok, pM, pN, ((slot) + 3) & 3, 0)                                                    \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
-  if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-  else if (age <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(8 + S_NB + S_EPI_ST) : "memory");     \
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                              \
+  if (!(ok)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+  else if (age == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(6 + S_NB + S_EPI_ST) : "memory");     \
+  else if (age == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(6 + S_EPI_ST) : "memory");            \
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                              \
   S_FENCE();                                                                                         \
   __builtin_amdgcn_s_barrier();                                                                      \
   S_FENCE();                                                                                         \
   bias_stmt;                                                                                         \
-  if (more) {                                                                                        \
-    pendM = sM + (slot) * 64;                                                                        \
-    pendN = sN + (slot) * 64;                                                                        \
-    pend = true;                                                                                     \
-    stage_half(pendM, pendN, slot, 0);                                                               \
-  }                                                                                                  \
   if ((slot) < 3 || more) { S_READ(F0, ((slot) + 1) & 3, 0) }                                        \
-  S_FENCE();                                                                                         \
-  S_MFMA(F1)                                                                                         \
-  S_FENCE();                                                                                         \
+  S_MFMA_DMA(F1, ok, pM, pN, ((slot) + 3) & 3, 2)                                                    \
   if (age < 3) ++age;
 
-      S_KTILE(0, (void)0)
-      S_KTILE(1, (void)0)
-      S_KTILE(2, (void)0)
-      S_KTILE(3, if (tail) load_bias())
+      S_KTILE(0, true, s3M, s3N, (void)0)
+      S_KTILE(1, more, sM, sN, (void)0)
+      S_KTILE(2, more, sM + 64, sN + 64, (void)0)
+      S_KTILE(3, more, sM + 128, sN + 128, if (tail) load_bias())
     }
 
     // ---- epilogue of this output tile, transposed through the wave's LDS scratch (the next tile's first four
     // K-tiles are in flight / landed and its first fragment set is in F0)
     S_WAIT_ALL()  // the next tile's first fragment set must have landed before hipcc may move/spill its registers
-    // bias landed in the scratch: only the first half of the next tile's 4th K-tile (2 DMA) was issued after its DMA
+    // bias landed in the scratch: only pieces 2, 3 of the next tile's K-tile 2 were issued after its DMA
     if (have_next) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_FENCE();
