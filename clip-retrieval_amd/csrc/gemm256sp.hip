@@ -99,11 +99,19 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   const size_t jstep = (size_t)8 * K * 2;
   typedef unsigned dbg_u32x4 __attribute__((ext_vector_type(4)));
   dbg_u32x4 dbg_sink = {0u, 0u, 0u, 0u};
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
   auto stage = [&](const char* baseM, const char* baseN, int buf) {
     if (DBG == 1 || DBG == 3) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned off = (j & 1) ? offO : offE;
+      if (DBG == 11) {  // as DBG 10 but SGPR base + 32-bit VGPR offset (saddr form): is the cost the 64-bit address transfer?
+        const char* bm = baseM + j * jstep;
+        const char* bn = baseN + j * jstep;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dbg_sink) : "v"(off), "s"(bm) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dbg_sink) : "v"(off), "s"(bn) : "memory");
+        continue;
+      }
       if (DBG == 10) {  // the same loads into a (dummy) register instead of the LDS: is the per-instruction cost TA- or LDS-side?
         asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dbg_sink) : "v"(baseM + j * jstep + off) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dbg_sink) : "v"(baseN + j * jstep + off) : "memory");
@@ -114,6 +122,17 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                                          (lds_ptr_t)(smem + buf * S_OPB + (w * 4 + j) * 1024), 4, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off),
                                          (lds_ptr_t)(smem + S_NBASE + buf * S_OPB + (w * 4 + j) * 1024), 4, 0, 0);
+        continue;
+      }
+      if (!(flags & 8)) {
+        // SGPR base + 32-bit VGPR offset ("saddr") form: half the per-lane address bits to move per DMA instruction
+        // (ablation DBG 11: -18 % of the per-instruction cost).  M0 (LDS destination) is written in the same statement.
+        const char* bm = baseM + j * jstep;
+        const char* bn = baseN + j * jstep;
+        const unsigned dm = lds_base + buf * S_OPB + (w * 4 + j) * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(bm), "s"(dm) : "memory");
+        if (DBG == 8) continue;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(bn), "s"(dm + S_NBASE) : "memory");
         continue;
       }
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off),
@@ -357,14 +376,14 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     curM = nxtM;
     curN = nxtN;
   }
-  if (DBG == 10) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dbg_sink)::"memory");
+  if (DBG == 10 || DBG == 11) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dbg_sink)::"memory");
 }
 
 template <int EPI, int DBG = 0>
 static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   const size_t smem = S_SCRATCH + 8 * 4096;  // 160 KiB: the whole LDS of the CU
   auto kern = gemm256sp_kernel<EPI, DBG>;
-  const char* fl = getenv("CLIPX_GEMM_FLAGS");  // A/B switches: bit 1 = drain vmcnt(0) at every wait, bit 2 = plain (L2-resident) output stores
+  const char* fl = getenv("CLIPX_GEMM_FLAGS");  // A/B switches: bit 1 = drain vmcnt(0) at every wait, bit 2 = plain (L2-resident) output stores, bit 3 = builtin (64-bit VGPR address) LDS-DMA
   const int flags = fl ? atoi(fl) : 0;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
@@ -388,6 +407,7 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 8) return launch_sp_epi<EPI_BIAS_BF16, 8>(g, grid, st);
     if (d == 9) return launch_sp_epi<EPI_BIAS_BF16, 9>(g, grid, st);
     if (d == 10) return launch_sp_epi<EPI_BIAS_BF16, 10>(g, grid, st);
+    if (d == 11) return launch_sp_epi<EPI_BIAS_BF16, 11>(g, grid, st);
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);
