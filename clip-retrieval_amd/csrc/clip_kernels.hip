@@ -36,8 +36,11 @@ constexpr int G_TM = 128, G_TN = 128, G_BK = 64;
 constexpr int G_STAGE_BYTES = (G_TM + G_TN) * G_BK * 2;  // 32 KiB
 constexpr int G_GROUP_M = 8;
 
-template <int EPI, bool GLDS>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+// DEEP (GLDS only): 4-deep LDS ring (128 KiB, one workgroup per CU) with the DMA of K-tile t+3 issued at K-tile t and ONE
+// barrier per K-tile.  For launches of few workgroups (the peeled 257th m-tile of ViT-L/14: 16..64 workgroups; B = 1
+// queries) nothing else runs on the CU to hide the DMA latency, and the 2-deep loop below then takes ~1.4 us per K-tile.
+template <int EPI, bool GLDS, bool DEEP = false>
+__global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int M, int N,
                                                           int K, int row0) {
@@ -116,6 +119,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16* __restric
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA[i] + (size_t)t * G_BK), (lds_ptr_t)dA, 16, 0, 0);
       }
     };
+    if (DEEP) {
+      // ring slot of K-tile t = t & 3; 8 DMA per thread per K-tile; K-tiles t+1, t+2 stay in flight across the barrier
+      issue(0, 0);
+      if (nk > 1) issue(1, 1);
+      if (nk > 2) issue(2, 2);
+      for (int t = 0; t < nk; ++t) {
+        const int rem = nk - 1 - t;  // K-tiles issued after K-tile t
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // K-tile t landed for every wave; every wave is done reading slot (t-1)&3
+        if (t + 3 < nk) issue(t + 3, (t + 3) & 3);
+        compute(t & 3);
+      }
+    } else {
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -124,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16* __restric
       compute(t & 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+    }
     }
   } else {
     // register-staged fill (T14 split): global loads for tile t+1 are issued before the MFMAs of tile t
@@ -187,7 +206,14 @@ static hipError_t launch_gemm_epi(const GemmArgs& g, hipStream_t st) {
   const int ntm = (g.M + G_TM - 1) / G_TM, ntn = g.N / G_TN;
   const dim3 grid(ntm * ntn), block(256);
   const size_t smem = 2 * G_STAGE_BYTES;
-  if (g.variant == 1) {
+  const int cu = g.n_cu > 0 ? g.n_cu : 256;
+  if (g.variant == 1 && (int)grid.x <= cu && g.K >= 4 * G_BK) {
+    auto kern = gemm_bf16_kernel<EPI, true, true>;
+    const size_t smem4 = 4 * G_STAGE_BYTES;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, smem4, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0);
+  } else if (g.variant == 1) {
     auto kern = gemm_bf16_kernel<EPI, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;

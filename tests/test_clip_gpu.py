@@ -205,8 +205,8 @@ def test_mapper_vs_reference_clipmapper_golden(tiny):
     name, arch, oracle, enc = tiny
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_mapper_" + name.replace("/", "-") + ".npz"))
     B = int(g["batch"])
-    register_encoder("golden:" + name, enc)
-    m = ClipMapper(True, True, True, False, "golden:" + name, False, "", warmup_batch_size=1)
+    register_encoder("golden-" + name, enc)
+    m = ClipMapper(True, True, True, False, "registered:golden-" + name, False, "", warmup_batch_size=1)
     pix = normalise_u8_nhwc(synth_pixels_u8(B, arch.image_size, seed=int(g["pixel_seed"])))
     ids = synth_tokens(B, arch.ctx_len, arch.vocab, seed=int(g["token_seed"]))
     out = m({"image_tensor": torch.from_numpy(pix), "text_tokens": torch.from_numpy(ids), "image_filename": ["a"] * B,

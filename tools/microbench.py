@@ -62,10 +62,12 @@ if "gemm" in what:
     rounds = int(os.environ.get("MB_ROUNDS", "5"))
     for (name, N, K, epi) in [("qkv  65792x3072x1024", 3072, 1024, 0), ("out  65792x1024x1024", 1024, 1024, 3),
                               ("fc1  65792x4096x1024", 4096, 1024, 1), ("fc2  65792x1024x4096", 1024, 4096, 3),
-                              ("txt-fc1 19712x3072x768", 3072, 768, 1)]:
+                              ("txt-fc1 19712x3072x768", 3072, 768, 1), ("peel-qkv 256x3072x1024", 3072, 1024, 0),
+                              ("peel-out 256x1024x1024", 1024, 1024, 3), ("peel-fc1 256x4096x1024", 4096, 1024, 1),
+                              ("peel-fc2 256x1024x4096", 1024, 4096, 3)]:
         if os.environ.get("MB_GEMM") and not name.startswith(os.environ["MB_GEMM"]):
             continue
-        m = 19712 if name.startswith("txt") else M
+        m = 19712 if name.startswith("txt") else (256 if name.startswith("peel") else M)
         A = (torch.randn(m, K, device="cuda") * 0.5).to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
         b = torch.randn(N, device="cuda")
