@@ -125,22 +125,35 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    enc.profile(True)
+    # timed region: only the dominant kernel family (GEMM, kind 0) is bracketed by hipEvents; the other kinds are
+    # timed in an extra, untimed pass below (event records are not free: ~2 % of the step when every launch has two)
+    PROF_GEMM, PROF_REST = 2, 4 | 8 | 16  # clipx_profile_enable masks: bit (kind + 1)
+    enc.profile(PROF_GEMM)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    enc.profile(False)
+    enc.profile(0)
     value = world * args.steps * B / dt
 
-    # per-kernel live timing (hipEvents on the launch stream, recorded inside the timed region)
+    # per-kernel live timing (hipEvents on the launch stream).  GEMM: recorded inside the timed region above.
     kinds = {"gemm": 0, "attention": 1, "layernorm": 2, "other": 3}
     prof = {}
+    n, ms, fl = enc.profile_get(0)
+    prof["gemm"] = {"launches": n, "ms": round(ms, 3), "tflops": (fl / (ms * 1e-3) / 1e12) if ms > 0 and fl > 0 else None, "steps": args.steps}
+    enc.profile(PROF_REST)
+    extra_steps = max(2, args.steps // 2)
+    for _ in range(extra_steps):
+        step()
+    barrier()
+    enc.profile(0)
     for name, kind in kinds.items():
+        if name == "gemm":
+            continue
         n, ms, fl = enc.profile_get(kind)
-        prof[name] = {"launches": n, "ms": round(ms, 3), "tflops": (fl / (ms * 1e-3) / 1e12) if ms > 0 and fl > 0 else None}
+        prof[name] = {"launches": n, "ms": round(ms, 3), "tflops": (fl / (ms * 1e-3) / 1e12) if ms > 0 and fl > 0 else None, "steps": extra_steps}
     g = prof["gemm"]
     gemm_tflops = g["tflops"] or 0.0
     roofline = {"bound": "mfma", "kernel": "gemm256sp_kernel (+ gemm_bf16_kernel on the peeled 257th m-tile)", "achieved": round(gemm_tflops, 1), "peak": BF16_PEAK_TFLOPS,
@@ -159,7 +172,7 @@ def main():
     e2e_tflops = value / world * (gf_img + gf_txt) / 1e3
     extras["end_to_end_tflops_per_gpu"] = round(e2e_tflops, 1)
     extras["end_to_end_frac_of_mfma_peak"] = round(e2e_tflops / BF16_PEAK_TFLOPS, 4)
-    extras["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
+    extras["kernel_ms_per_step"] = {k: round(v["ms"] / v["steps"], 3) for k, v in prof.items()}
 
     # ---- parity gate on the benchmark's own weights and inputs (oracle = checker)
     parity = None

@@ -91,7 +91,7 @@ struct clipx_handle {
   size_t in_slot_bytes = 0, out_slot_bytes = 0;
   hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
 
-  bool prof = false;
+  int prof = 0;  // bit k set: launches of kind k (0 gemm, 1 attention, 2 layernorm, 3 other) are bracketed by hipEvents
   std::vector<ProfEvent> prof_events;
 };
 
@@ -314,14 +314,14 @@ struct ProfScope {
   int kind;
   double flops;
   ProfScope(clipx_handle* h_, hipStream_t st_, int kind_, double flops_) : h(h_), st(st_), kind(kind_), flops(flops_) {
-    if (h->prof) {
+    if (h->prof & (1 << kind)) {
       (void)hipEventCreate(&a);
       (void)hipEventCreate(&b);
       (void)hipEventRecord(a, st);
     }
   }
   ~ProfScope() {
-    if (h->prof && a && b) {
+    if (a && b) {
       (void)hipEventRecord(b, st);
       h->prof_events.push_back({a, b, kind, flops});
     }
@@ -533,7 +533,7 @@ extern "C" int clipx_layernorm_device(int device, const float* x, const float* g
 extern "C" int clipx_profile_enable(clipx_handle* h, int on) {
   if (!h) return fail(CLIPX_E_ARG, "handle is null");
   std::lock_guard<std::mutex> lk(h->mu);
-  h->prof = on != 0;
+  h->prof = on == 1 ? 15 : ((on >> 1) & 15);  // 1 = every kind; otherwise bit (kind + 1) selects a kind
   return CLIPX_OK;
 }
 

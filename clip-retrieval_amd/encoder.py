@@ -282,7 +282,8 @@ class ClipEncoder:
             C.c_void_p(int(out_f32_ptr)) if out_f32_ptr else None, C.c_void_p(int(stream)) if stream else None), "clipx")
 
     def profile(self, on):
-        check(self._lib, self._lib.clipx_profile_enable(self._h, 1 if on else 0), "clipx")
+        """on: False/0 off, True/1 every kind, or a mask with bit (kind + 1): 2 gemm, 4 attention, 8 layernorm, 16 other."""
+        check(self._lib, self._lib.clipx_profile_enable(self._h, int(on)), "clipx")
 
     def profile_get(self, kind):
         n, ms, fl = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)

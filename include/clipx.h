@@ -116,8 +116,9 @@ int clipx_attention_dh_device(int device, const void* qkv_bf16, void* out_bf16, 
 int clipx_layernorm_device(int device, const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
                            int M, int d, float eps, void* stream);
 
-/* Live per-kernel timing for bench.py: when enabled every launch is bracketed by hipEvents on
- * its stream.  kind: 0 gemm, 1 attention, 2 layernorm, 3 other.  get() sums and resets. */
+/* Live per-kernel timing for bench.py: launches of the enabled kinds are bracketed by hipEvents on
+ * their stream.  kind: 0 gemm, 1 attention, 2 layernorm, 3 other.  on: 0 off, 1 all kinds, else a bit
+ * mask with bit (kind + 1): 2 = GEMMs only, 4 | 8 | 16 = everything but the GEMMs.  get() sums and resets. */
 int clipx_profile_enable(clipx_handle* h, int on);
 int clipx_profile_get(clipx_handle* h, int kind, int64_t* launches, double* ms, double* flops);
 
