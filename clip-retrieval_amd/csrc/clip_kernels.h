@@ -24,14 +24,14 @@ struct GemmArgs {
   int T;
   int M, N, K;        // N % 128 == 0, K % 64 == 0
   int epi;
-  int variant;        // 0 = 128x128 register-staged LDS fill, 1 = 128x128 global_load_lds, 2 / 3 = persistent 256x256
-                      // kernel (2: ping-pong gemm256.hip, 3: one-barrier-per-K-tile gemm256sp.hip) for the whole
-                      // 256-row m-tiles, 128x128 for the rest
-  int n_cu;           // compute units of the device (variant 2 launches one workgroup per CU); 0 = 256
+  int variant;        // 0 = 128x128 register-staged LDS fill, 1 = 128x128 global_load_lds, >= 2 (3 by convention, the
+                      // default) = persistent 256x256 kernel (gemm256sp.hip) for the whole 256-row m-tiles, 128x128
+                      // (variant 1) for the rest
+  int n_cu;           // compute units of the device (variant 3 launches one workgroup per CU); 0 = 256
   int row0;           // EPI_TABLE_F32: table row = (row0 + m) % T (set by the launcher when it splits M)
 };
 
-// number of 256-row m-tiles variant 2 hands to the 256x256 kernel for an [M, N] output
+// number of 256-row m-tiles variant 3 hands to the 256x256 kernel for an [M, N] output
 int gemm256_bulk_mtiles(int M, int N, int n_cu);
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);

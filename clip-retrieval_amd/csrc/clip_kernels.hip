@@ -238,7 +238,7 @@ static hipError_t launch_gemm128(const GemmArgs& g, hipStream_t st) {
   }
 }
 
-// How many 256-row m-tiles go to the persistent 256x256 kernel (variant 2); the rest (ragged rows and the m-tiles
+// How many 256-row m-tiles go to the persistent 256x256 kernel (variant 3); the rest (ragged rows and the m-tiles
 // that would only add a mostly-empty extra round over the CUs) goes to the 128x128 kernel.  ViT-L/14 at bs=256 has
 // M = 257 * 256: 256 m-tiles fill the 256 CUs in whole rounds, the 257th (the class-token rows' worth) is peeled.
 int gemm256_bulk_mtiles(int M, int N, int n_cu) {
@@ -261,7 +261,7 @@ int gemm256_bulk_mtiles(int M, int N, int n_cu) {
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
-  if (g.variant >= 2 && g.variant <= 4 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
+  if (g.variant >= 2 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
     const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
     // small problems (query-side B = 1: M = 257 or 77 rows) would put one 256x256 tile on each of a handful of CUs;
     // the 128x128 kernel gives them 4x the tiles.  Both kernels produce bit-identical rows.
@@ -269,8 +269,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (bulk > 0 && (int64_t)bulk * (g.N / 256) >= cu / 2) {
       GemmArgs b = g;
       b.M = bulk * 256;
-      hipError_t e = g.variant == 4 ? launch_gemm256r4(b, g.n_cu, st)
-                     : g.variant == 3 ? launch_gemm256sp(b, g.n_cu, st) : launch_gemm256(b, g.n_cu, st);
+      hipError_t e = launch_gemm256sp(b, g.n_cu, st);
       if (e != hipSuccess) return e;
       if (b.M == g.M) return hipSuccess;
       GemmArgs r = g;  // remaining rows [bulk*256, M)

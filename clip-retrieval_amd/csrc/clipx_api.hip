@@ -266,7 +266,7 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   if (hc && atoi(hc) > 0) h->host_chunk = atoi(hc);
   h->host_chunk = std::min(h->host_chunk, h->max_batch);
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
-  if (gv) h->gemm_variant = std::min(4, std::max(0, atoi(gv)));
+  if (gv) h->gemm_variant = std::min(3, std::max(0, atoi(gv)));
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r = create_impl(h, blob, blob_floats);
   if (r) {
@@ -491,7 +491,7 @@ extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void
   g.A = (const bf16*)A_bf16; g.W = (const bf16*)W_bf16; g.bias = bias; g.out = out; g.table = nullptr; g.T = 1;
   g.M = M; g.N = N; g.K = K; g.epi = epi;
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
-  g.variant = gv ? std::min(4, std::max(0, atoi(gv))) : 3;
+  g.variant = gv ? std::min(3, std::max(0, atoi(gv))) : 3;
   int ncu = 0;
   HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
   g.n_cu = ncu;

@@ -1,26 +1,26 @@
-// gemm256sp.hip -- persistent 256x256x64 software-pipelined bf16 GEMM for gfx950 (GemmArgs.variant == 3).
+// gemm256sp.hip -- persistent 256x256x64 software-pipelined bf16 GEMM for gfx950 (GemmArgs.variant == 3, the default).
 //
 //   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )        A bf16 [M, K] activations, W bf16 [N, K] (torch Linear)
 //
-// Same role and operand layout as gemm256.hip (the linear layers inside `model.encode_image/encode_text`, reference
-// clip_retrieval/clip_inference/mapper.py:57,65), different schedule.  Measured on MI355X the two-barriers-per-
-// 8-MFMA ping-pong of gemm256.hip tops out at ~50 % of the MFMA roof with NO memory traffic at all (barrier hand-off
-// latency per 256-cycle phase); this kernel synchronises ONCE per K-tile instead:
+// The linear layers inside `model.encode_image/encode_text` (reference clip_retrieval/clip_inference/mapper.py:57,65).
 //
-//   * one 512-thread workgroup per CU, persistent over output tiles as one continuous K-tile stream (as gemm256).
+//   * one 512-thread workgroup per CU, persistent over output tiles as one continuous K-tile stream.
 //   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 4x2 v_mfma_f32_32x32x16_bf16 tiles (128 accumulator VGPRs).
 //   * LDS: 2 K-tile buffers x (M operand 256 rows + N operand 256 rows) x 128 B = 128 KiB, filled by LDS-DMA
-//     (global_load_lds_dwordx4, 8 per wave per K-tile), chunk-XOR swizzled through the source address;
-//     + 32 KiB of per-wave scratch for the epilogue transposition = the CU's whole 160 KiB.
+//     (global_load_lds_dwordx4, 8 per wave per K-tile, SGPR base + one of four per-lane offsets, M0 = one s_add),
+//     chunk-XOR swizzled through the source address; + 32 KiB of per-wave scratch for the epilogue transposition.
 //   * per K-tile each wave runs 4 k-steps of {6 ds_read_b128 for the NEXT step, 8 MFMA of this step} from two
-//     register sets, so LDS latency is always covered by a step's MFMAs; the single s_barrier of the K-tile sits
-//     BEFORE the last step's MFMAs, with the reads of the next K-tile's first step issued right behind it:
+//     register sets; the single s_barrier of the K-tile sits BEFORE the last step's MFMAs:
 //         step 3:  lgkmcnt(0); vmcnt(0)  [K-tile g+1 landed]; s_barrier;
 //                  stage K-tile g+2 into the buffer just released; ds_read step 0 of K-tile g+1; 8 MFMA
-//     so the matrix pipe only sees the barrier's own hand-off latency once per 2048 pipe-cycles.
+//     Everything between the barrier and those MFMAs is on the critical path of all 8 waves at once, so the steady
+//     state is branch-free straight-line code: the first and last K-tile pair of a tile (epilogue bookkeeping, next
+//     tile's operands, bias) are separate copies of the K-tile body.
 //   * epilogue: accumulators (+bias, activation) are transposed through the wave's private LDS scratch so that
-//     every global access is 16 B per lane with 8 consecutive lanes covering one full 128-B line of a row
-//     (the MFMA layout itself gives 8-B pieces scattered over 32 rows per instruction).
+//     every global access is 16 B per lane with 8 consecutive lanes covering one full 128-B line of a row; the
+//     stores are SGPR-base + one VGPR offset and are never waited for (a CU stores ~20 B/clk: the 128 KiB of a bf16
+//     tile drain under the next tile's first K-tiles).  Measured with the phase timer (DBG 16): an earlier version whose
+//     address registers spilled paid an `s_waitcnt vmcnt(0)` per store = 17.7 k cycles per tile; now ~4 k.
 //
 // Requirements: M % 256 == 0, N % 256 == 0, K % 128 == 0 (the launcher in clip_kernels.hip peels ragged rows).
 
@@ -39,28 +39,20 @@ constexpr int S_SCRATCH = 131072; // per-wave 4 KiB epilogue scratch starts here
 
 #define S_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// Output stores are write-through and do not keep their lines in the XCD's L2 (sc1): one tile round writes
-// 32 CUs x 128 KiB = the whole 4 MiB L2 of an XCD, and with plain stores that round evicts the operand panels the
-// next K-tiles re-read (measured: the stores alone cost 24 % of the QKV GEMM, 215 k of 888 k cycles).  flags bit 2
-// switches back to plain stores for A/B.  (s_nop 1: the data registers must not be rewritten before the store read them.)
+// DBG 16: per-phase shader-cycle totals of every block's wave 0 (8 counters per block): [0] epilogues, [1] / [2] first and
+// second K-tile after an epilogue, [3] steady-state K-tiles, [4] last K-tile pair of a tile, [5] number of steady K-tiles,
+// [6] tiles, [7] whole kernel.  Read back with clipx_dbg_phase_cycles().
+__device__ long long g_sp_phase[2048 * 8];
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16_wt(void* p, uint4 v, bool plain) {
-  if (plain) {
-    *reinterpret_cast<uint4*>(p) = v;
-  } else {
-    const u32x4 r = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
-  }
-}
 
 // DBG (ablation, EPI_BIAS_BF16 only; garbage results): 1 = no staging, 3 = no staging and no ds_reads,
-// 5 = normal main loop, no epilogue at all; 6 = epilogue without its global stores; 7 = XCD x starts x/8 of a tile
-// period late (tests whether the tile-boundary cost is the chip-wide simultaneous store burst)
+// 5 = no epilogue at all, 6 = epilogue without its global stores, 16 = phase timer (correct results)
 template <int EPI, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
-                                                          int ntn, int flags) {
+                                                          int ntn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,7 +60,8 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   const int hb = lane >> 5, l31 = lane & 31;
   const int ntiles = ntm * ntn;
 
-  // ---- tile list of this block (same XCD-aware order as gemm256.hip)
+  // ---- tile list of this block, XCD-aware: the 32 workgroups of an XCD (blockIdx % 8) walk 8 m-tiles x all n-tiles of a
+  // group together, so the A panels and the W panels they share stay in that XCD's L2
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
   auto tile_of = [&](int j, int& m0, int& n0) -> bool {
     const int logical = (j * 8 + xcd) * cpx + idx;
@@ -83,65 +76,35 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   };
   int m0, n0;
   if (!tile_of(0, m0, n0)) return;  // before any barrier
-  if (DBG == 7) {
-    const long long t0 = __builtin_readcyclecounter();  // s_memtime: shader-clock ticks
-    const long long wait = (long long)xcd * (K >> 6) * 420;  // (K/64 K-tiles) * ~3300 cycles / 8 per XCD step
-    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-  }
 
-  // ---- staging: wave w fills rows [32w, 32w+32) of both operands, 8 rows (1 KiB) per instruction
-  // (piece 4w + j = rows 32w + 8j .. +8).  Source chunk = LDS chunk position ^ ((row>>1)&7); rows 8 apart flip bit 2
-  // of that key, so even and odd j use two per-lane offsets.
+  // ---- staging: wave w fills rows [32w, 32w+32) of both operands, 8 rows (1 KiB) per instruction (piece 4w + j =
+  // rows 32w + 8j .. +8).  Source chunk = LDS chunk position ^ ((row>>1)&7).  One per-lane byte offset per piece
+  // (both operands are [rows, K] row-major, so they share them); the K-tile's base address is an SGPR pair and the
+  // LDS destination (M0) is <wave base> + immediate: a stage is 8 x {s_add_u32 m0; s_nop; global_load_lds_dwordx4}.
   const int srow = w * 32 + (lane >> 3);
-  const int c0 = (lane & 7) ^ ((srow >> 1) & 7);
-  const unsigned offE = (unsigned)((srow * K + (c0 << 3)) * 2);
-  const unsigned offO = (unsigned)((srow * K + ((c0 ^ 4) << 3)) * 2);
-  const size_t jstep = (size_t)8 * K * 2;
-  typedef unsigned dbg_u32x4 __attribute__((ext_vector_type(4)));
-  dbg_u32x4 dbg_sink = {0u, 0u, 0u, 0u};
-  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
-  auto stage = [&](const char* baseM, const char* baseN, int buf) {
-    if (DBG == 1 || DBG == 3) return;
+  unsigned soff[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned off = (j & 1) ? offO : offE;
-      if (DBG == 11) {  // as DBG 10 but SGPR base + 32-bit VGPR offset (saddr form): is the cost the 64-bit address transfer?
-        const char* bm = baseM + j * jstep;
-        const char* bn = baseN + j * jstep;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dbg_sink) : "v"(off), "s"(bm) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dbg_sink) : "v"(off), "s"(bn) : "memory");
-        continue;
-      }
-      if (DBG == 10) {  // the same loads into a (dummy) register instead of the LDS: is the per-instruction cost TA- or LDS-side?
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dbg_sink) : "v"(baseM + j * jstep + off) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dbg_sink) : "v"(baseN + j * jstep + off) : "memory");
-        continue;
-      }
-      if (DBG == 9) {  // same instruction count, a quarter of the bytes
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off),
-                                         (lds_ptr_t)(smem + buf * S_OPB + (w * 4 + j) * 1024), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off),
-                                         (lds_ptr_t)(smem + S_NBASE + buf * S_OPB + (w * 4 + j) * 1024), 4, 0, 0);
-        continue;
-      }
-      if (!(flags & 8)) {
-        // SGPR base + 32-bit VGPR offset ("saddr") form: half the per-lane address bits to move per DMA instruction
-        // (ablation DBG 11: -18 % of the per-instruction cost).  M0 (LDS destination) is written in the same statement.
-        const char* bm = baseM + j * jstep;
-        const char* bn = baseN + j * jstep;
-        const unsigned dm = lds_base + buf * S_OPB + (w * 4 + j) * 1024;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(bm), "s"(dm) : "memory");
-        if (DBG == 8) continue;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(bn), "s"(dm + S_NBASE) : "memory");
-        continue;
-      }
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseM + j * jstep + off),
-                                       (lds_ptr_t)(smem + buf * S_OPB + (w * 4 + j) * 1024), 16, 0, 0);
-      if (DBG == 8) continue;  // half the bytes and half the instructions: M operand only
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(baseN + j * jstep + off),
-                                       (lds_ptr_t)(smem + S_NBASE + buf * S_OPB + (w * 4 + j) * 1024), 16, 0, 0);
-    }
-  };
+  for (int j = 0; j < 4; ++j) {
+    const int row = srow + 8 * j;
+    soff[j] = (unsigned)((row * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2);
+  }
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+  const unsigned dmw = lds_base + w * 4096;  // this wave's first piece inside an operand tile
+#define S_DMA(off, base, cimm)                                                                              \
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dmw), "n"(cimm) \
+               : "memory", "scc")
+#define S_STAGE(pM, pN, buf)                                      \
+  if (DBG != 1 && DBG != 3) {                                     \
+    S_DMA(soff[0], pM, (buf) * S_OPB);                            \
+    S_DMA(soff[0], pN, (buf) * S_OPB + S_NBASE);                  \
+    S_DMA(soff[1], pM, (buf) * S_OPB + 1024);                     \
+    S_DMA(soff[1], pN, (buf) * S_OPB + S_NBASE + 1024);           \
+    S_DMA(soff[2], pM, (buf) * S_OPB + 2048);                     \
+    S_DMA(soff[2], pN, (buf) * S_OPB + S_NBASE + 2048);           \
+    S_DMA(soff[3], pM, (buf) * S_OPB + 3072);                     \
+    S_DMA(soff[3], pN, (buf) * S_OPB + S_NBASE + 3072);           \
+  }                                                               \
+  S_FENCE();
 
   // ---- fragment read addresses (LDS byte addresses): one per (operand, k-step); buffer and fragment index are
   // immediates.  The reads are inline asm so that THIS file places the lgkmcnt waits (hipcc's own placement waits
@@ -189,25 +152,41 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   S_FENCE();
 // the fragment set read one step earlier has landed when at most the 6 reads issued since are outstanding
 #define S_WAIT_PREV() asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); S_FENCE();
-#define S_WAIT_ALL() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); S_FENCE();
 #define S_MFMA(F)                                                                                                  \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] =  \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F[4 + ni]), __builtin_bit_cast(bf16x8, F[mi]), acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F[4 + ni]), __builtin_bit_cast(bf16x8, F[mi]), acc[mi][ni], 0, 0, 0); \
+  S_FENCE();
 
+  // One K-tile = S_KT_HEAD (k-steps 0..2 and the LDS drain), a vmcnt wait + barrier, the stage of a later K-tile into
+  // the buffer just released, then S_KT_TAIL (pre-read of the next K-tile's first fragments + k-step 3's MFMAs).
+#define S_KT_HEAD(buf)                                       \
+  S_READ(F1, buf, 1) S_WAIT_PREV() S_MFMA(F0)                \
+  S_READ(F0, buf, 2) S_WAIT_PREV() S_MFMA(F1)                \
+  S_READ(F1, buf, 3) S_WAIT_PREV() S_MFMA(F0)                \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+  S_FENCE();
+#define S_KT_SYNC(vm)                                        \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(vm) : "memory");  \
+  S_FENCE();                                                 \
+  __builtin_amdgcn_s_barrier();                              \
+  S_FENCE();
+#define S_KT_TAIL(buf, preread)                              \
+  if (preread) { S_READ(F0, (buf) ^ 1, 0) }                  \
+  S_MFMA(F1)
+
+  const int nk = K >> 6;  // K-tiles per output tile (even, >= 2)
   const char* curM = reinterpret_cast<const char*>(A) + (size_t)m0 * K * 2;
   const char* curN = reinterpret_cast<const char*>(W) + (size_t)n0 * K * 2;
-  const int nk = K >> 6;  // K-tiles per output tile (even, >= 2)
 
   // VMEM bookkeeping (vmcnt retires in order): "the stage of the next K-tile has landed" is vmcnt(0) in steady state.
-  // On the first K-tile after an epilogue the epilogue's own stores (S_EPI_ST per wave) are younger than that stage
-  // and may stay in flight: vmcnt(S_EPI_ST).  (An L2 prefetch of the K-tile 4 ahead was tried and measured neutral:
-  // the exposed staging time is LDS-DMA throughput, not HBM latency -- staging an L2-resident K-tile costs the same.)
+  // On the first K-tile after an epilogue the epilogue's own VMEM operations are younger than that stage and may stay in
+  // flight: vmcnt(S_EPI_VM).  bf16 outputs: 16 stores.  f32 residual: 32 loads + 32 stores, the loads consumed already.
   constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
-  constexpr int S_EPI_ST = (DBG == 5 || DBG == 6) ? 0 : (OUT_BF16 ? 16 : 32);  // f32: 32 loads + 32 stores follow; 32 youngest = stores
+  constexpr int S_EPI_VM = (DBG == 5 || DBG == 6) ? 0 : (OUT_BF16 ? 16 : (EPI == EPI_BIAS_RESID_F32 ? 40 : 32));
 
   // ---- prologue: K-tiles 0, 1 of the first tile; K-tile 0 landed + first fragment set read
-  stage(curM, curN, 0);
-  stage(curM + 128, curN + 128, 1);
+  S_STAGE(curM, curN, 0)
+  S_STAGE(curM + 128, curN + 128, 1)
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   S_FENCE();
   __builtin_amdgcn_s_barrier();
@@ -215,8 +194,8 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   S_READ(F0, 0, 0)
 
   // bias of the current tile: one LDS-DMA per wave at the tile's last K-tile drops the wave's 64 bias floats into
-  // its (then idle) epilogue scratch, AHEAD of the next tile's first operand DMA, so the epilogue neither queues
-  // behind those nor holds bias registers across the main loop.  (All four 16-lane groups fetch the same 256 B.)
+  // its (then idle) epilogue scratch, AHEAD of the next tile's K-tile-1 stage, so the epilogue neither queues
+  // behind that nor holds bias registers across the main loop.  (All four 16-lane groups fetch the same 256 B.)
   constexpr bool HAS_BIAS = EPI != EPI_TABLE_F32;
   const int rrow = lane >> 3, rch = lane & 7;  // epilogue read-back: row 8i + rrow, 16-B chunk rch
   auto load_bias = [&]() {
@@ -225,6 +204,18 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                                      (lds_ptr_t)(smem + S_SCRATCH + w * 4096), 16, 0, 0);
   };
 
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tstamp = DBG == 16 ? (long long)__builtin_readcyclecounter() : 0;
+  const long long tstart = tstamp;
+#define S_STAMP(slot)                                                  \
+  if (DBG == 16) {                                                     \
+    const long long now_ = (long long)__builtin_readcyclecounter();    \
+    ph[slot] += now_ - tstamp;                                         \
+    tstamp = now_;                                                     \
+  }
+
+  const char* sM = curM + 256;  // the next K-tile of this tile to stage (K-tile 2)
+  const char* sN = curN + 256;
   bool first = false;  // the K-tile about to run is the first one after an epilogue
   for (int j = 0;; ++j) {
     int nm0 = 0, nn0 = 0;
@@ -232,55 +223,71 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     const char* nxtM = reinterpret_cast<const char*>(A) + (size_t)nm0 * K * 2;
     const char* nxtN = reinterpret_cast<const char*>(W) + (size_t)nn0 * K * 2;
 
-    for (int t = 0; t < nk; t += 2) {
-      // K-tile t (buffer 0) and t+1 (buffer 1).  Stage targets: K-tile t+2 -> buffer 0, t+3 -> buffer 1.
-      const bool tail = t + 2 >= nk;
-      const bool more = !tail || have_next;  // a K-tile t+2 / t+3 exists in this block's stream
-      const char* sM = tail ? nxtM : curM + (size_t)(t + 2) * 128;
-      const char* sN = tail ? nxtN : curN + (size_t)(t + 2) * 128;
-
-#define S_KTILE(buf, is_first, bias_stmt, stage_stmt, next_ok) \
-  S_READ(F1, buf, 1)                                         \
-  S_WAIT_PREV()                                              \
-  S_MFMA(F0)                                                 \
-  S_FENCE();                                                 \
-  S_READ(F0, buf, 2)                                         \
-  S_WAIT_PREV()                                              \
-  S_MFMA(F1)                                                 \
-  S_FENCE();                                                 \
-  S_READ(F1, buf, 3)                                         \
-  S_WAIT_PREV()                                              \
-  S_MFMA(F0)                                                 \
-  S_FENCE();                                                 \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
-  if ((is_first) && !(flags & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(S_EPI_ST) : "memory"); \
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
-  S_FENCE();                                                 \
-  __builtin_amdgcn_s_barrier();                              \
-  S_FENCE();                                                 \
-  bias_stmt;                                                 \
-  stage_stmt;                                                \
-  if (next_ok) { S_READ(F0, (buf) ^ 1, 0) }                  \
-  S_FENCE();                                                 \
-  S_MFMA(F1)                                                 \
-  S_FENCE();
-
-      S_KTILE(0, first, (void)0, if (more) stage(sM, sN, 0), true)
-      first = false;
-      S_KTILE(1, false, if (tail) load_bias(), if (more) stage(sM + 128, sN + 128, 1), more)
+    if (nk > 2) {
+      // ---- first pair (K-tiles 0, 1): stage K-tiles 2, 3
+      S_KT_HEAD(0)
+      if (first) { S_KT_SYNC(S_EPI_VM) } else { S_KT_SYNC(0) }
+      S_STAGE(sM, sN, 0)
+      S_KT_TAIL(0, true)
+      S_STAMP(1)
+      S_KT_HEAD(1)
+      S_KT_SYNC(0)
+      S_STAGE(sM + 128, sN + 128, 1)
+      S_KT_TAIL(1, true)
+      S_STAMP(2)
+      sM += 256;
+      sN += 256;
+      // ---- steady state (K-tiles 2 .. nk-3): branch-free
+      for (int t = 2; t < nk - 2; t += 2) {
+        S_KT_HEAD(0)
+        S_KT_SYNC(0)
+        S_STAGE(sM, sN, 0)
+        S_KT_TAIL(0, true)
+        S_KT_HEAD(1)
+        S_KT_SYNC(0)
+        S_STAGE(sM + 128, sN + 128, 1)
+        S_KT_TAIL(1, true)
+        sM += 256;
+        sN += 256;
+        if (DBG == 16) { S_STAMP(3) ph[5] += 2; }
+      }
+      // ---- last pair (K-tiles nk-2, nk-1): stage the next tile's K-tiles 0, 1; fetch this tile's bias
+      S_KT_HEAD(0)
+      S_KT_SYNC(0)
+      if (have_next) { S_STAGE(nxtM, nxtN, 0) }
+      S_KT_TAIL(0, true)
+      S_KT_HEAD(1)
+      S_KT_SYNC(0)
+      load_bias();
+      if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) }
+      S_KT_TAIL(1, false)  // the next tile's first fragments are read after the epilogue (24 VGPRs it needs)
+      S_STAMP(4)
+    } else {
+      // ---- K = 128: the only pair is the first and the last one
+      S_KT_HEAD(0)
+      if (first) { S_KT_SYNC(S_EPI_VM) } else { S_KT_SYNC(0) }
+      if (have_next) { S_STAGE(nxtM, nxtN, 0) }
+      S_KT_TAIL(0, true)
+      S_KT_HEAD(1)
+      S_KT_SYNC(0)
+      load_bias();
+      if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) }
+      S_KT_TAIL(1, false)
+      S_STAMP(4)
     }
 
-    // ---- epilogue of this output tile, transposed through the wave's LDS scratch (the next tile's K-tiles 0/1 are
-    // already in flight / landed and its first fragment set is in F0)
-    S_WAIT_ALL()  // the next tile's first fragment set must have landed before hipcc may move/spill its registers
-    // bias landed in the scratch: only the next tile's stage (8 DMA) was issued after its DMA
-    if (have_next && !(flags & 2)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // ---- epilogue of this output tile, transposed through the wave's LDS scratch (the next tile's K-tile 0 has landed,
+    // its K-tile 1 is in flight).  The bias landed in the scratch: only the K-tile-1 stage (8 DMA) is younger than its DMA.
+    if (have_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // last tile: no stage was issued behind the bias DMA
     S_FENCE();
     if (DBG != 5) {
       unsigned char* scr = smem + S_SCRATCH + w * 4096;
-      if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16) {
-        bf16* yo = reinterpret_cast<bf16*>(outp) + (size_t)(m0 + wr * 128) * N + n0 + wc * 64;
+      if (OUT_BF16) {
+        // SGPR base + one 32-bit VGPR offset: no per-row address registers
+        const char* yb = reinterpret_cast<const char*>(outp) + ((size_t)(m0 + wr * 128) * N + n0 + wc * 64) * 2;
+        const unsigned voff = (unsigned)((rrow * N + rch * 8) * 2);
+        const size_t rstep = (size_t)8 * N * 2;  // 8 rows
         float4 b4[2][4];  // read before the first transposition pass overwrites the scratch (LDS ops stay in order)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -305,22 +312,75 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
               // row l31 = [8 chunks of 16 B]; chunk (4nt + g) holds columns 32nt + 8g .. +8, half hb
               *reinterpret_cast<bf16x4*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8) = o;
             }
+          u32x4 q[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int row = 8 * i + rrow;
-            const uint4 q = *reinterpret_cast<const uint4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4));
-            if (DBG != 6) store16_wt(yo + (size_t)(mt * 32 + row) * N + rch * 8, q, flags & 4);
-            else asm volatile("" ::"v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+            q[i] = *reinterpret_cast<const u32x4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const char* base = yb + (size_t)(mt * 4 + i) * rstep;
+            // s_nop: store-data hazard (hipcc cannot see that this is a store and may rewrite q right behind it)
+            if (DBG != 6) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(q[i]), "s"(base) : "memory");
+            else asm volatile("" ::"v"(q[i]));
           }
         }
-      } else {
-        // f32 output (in-place residual, or + table row): 32 x 32 sub-tile per pass, 128 B per row
-        float* xo = reinterpret_cast<float*>(outp) + (size_t)(m0 + wr * 128) * N + n0 + wc * 64;
+      } else if (EPI == EPI_BIAS_RESID_F32) {
+        // f32 in-place residual x += acc + bias: 8 passes of a 32 x 32 sub-tile (128 B per row).  The x rows of pass p+1 are
+        // requested before pass p stores.  Buffer loads / stores (SGPR descriptor of this wave's 128-row panel + SGPR
+        // offset of the 8-row group + one 32-bit lane offset): no address registers, and hipcc counts them itself -- with
+        // asm loads the register allocator may copy a result register before a hand-placed wait (seen: nondeterministic
+        // results), and with asm stores hipcc's own counts would wait for the stores.
+        char* xb = reinterpret_cast<char*>(outp) + ((size_t)(m0 + wr * 128) * N + n0 + wc * 64) * 4;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 0x7ffffffe, 0x00020000);
+        const int voff = (rrow * N + rch * 4) * 4;
+        const int rstep = 8 * N * 4;  // 8 rows
         float4 b4[2];
-        if (HAS_BIAS) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) b4[nt] = *reinterpret_cast<const float4*>(scr + (nt * 32 + rch * 4) * 4);
+        for (int nt = 0; nt < 2; ++nt) b4[nt] = *reinterpret_cast<const float4*>(scr + (nt * 32 + rch * 4) * 4);
+        S_FENCE();  // hipcc waits vmcnt(0) for the bias DMA before these LDS reads: keep the x loads behind that wait
+        u32x4 ext[2][4];
+#define S_LD_EXT(set, p)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+    ext[set][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (((p) >> 1) * 4 + i) * rstep + ((p) & 1) * 128, 0);
+        S_LD_EXT(0, 0)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int mt = p >> 1, nt = p & 1;
+          if (p < 7) { S_LD_EXT((p + 1) & 1, p + 1) }
+          S_FENCE();
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2],
+                                         acc[mt][nt][4 * g + 3]);
+            // columns 8g + 4hb .. +4 = 16-B chunk 2g + hb of row l31
+            *reinterpret_cast<float4*>(scr + l31 * 128 + (((2 * g + hb) ^ (l31 & 7)) << 4)) = v;
+          }
+          float4 q[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + rrow;
+            q[i] = *reinterpret_cast<const float4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 bq = b4[nt];
+            const u32x4 e = ext[p & 1][i];
+            // same association as the 128x128 kernel, x + (acc + bias), so a row's result does not depend on
+            // which kernel (i.e. which batch chunking) produced it
+            float4 o = q[i];
+            o.x += bq.x; o.y += bq.y; o.z += bq.z; o.w += bq.w;
+            o.x = __uint_as_float(e[0]) + o.x; o.y = __uint_as_float(e[1]) + o.y;
+            o.z = __uint_as_float(e[2]) + o.z; o.w = __uint_as_float(e[3]) + o.w;
+            const u32x4 ov = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(ov, xr, voff, (mt * 4 + i) * rstep + nt * 128, 0);
+          }
+          S_FENCE();
         }
+      } else {
+        // + table row (patch embedding: class token / positional rows), f32 out: once per forward, plain code
+        float* xo = reinterpret_cast<float*>(outp) + (size_t)(m0 + wr * 128) * N + n0 + wc * 64;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -329,31 +389,21 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int row = mt * 32 + 8 * i + rrow;
-              if (EPI == EPI_BIAS_RESID_F32)
-                ext[i] = *reinterpret_cast<const float4*>(xo + (size_t)row * N + nt * 32 + rch * 4);
-              else
-                ext[i] = *reinterpret_cast<const float4*>(table + (size_t)((m0 + wr * 128 + row) % T) * N + n0 + wc * 64 +
-                                                          nt * 32 + rch * 4);
+              ext[i] = *reinterpret_cast<const float4*>(table + (size_t)((m0 + wr * 128 + row) % T) * N + n0 + wc * 64 +
+                                                        nt * 32 + rch * 4);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2],
                                            acc[mt][nt][4 * g + 3]);
-              // columns 8g + 4hb .. +4 = 16-B chunk 2g + hb of row l31
               *reinterpret_cast<float4*>(scr + l31 * 128 + (((2 * g + hb) ^ (l31 & 7)) << 4)) = v;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int row = 8 * i + rrow;
               float4 q = *reinterpret_cast<const float4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4));
-              // same association as the 128x128 kernel, x + (acc + bias), so a row's result does not depend on
-              // which kernel (i.e. which batch chunking) produced it
-              if (EPI == EPI_BIAS_RESID_F32) {
-                const float4 bq = b4[nt];
-                q.x += bq.x; q.y += bq.y; q.z += bq.z; q.w += bq.w;
-              }
               q.x = ext[i].x + q.x; q.y = ext[i].y + q.y; q.z = ext[i].z + q.z; q.w = ext[i].w + q.w;
-              store16_wt(xo + (size_t)(mt * 32 + row) * N + nt * 32 + rch * 4, make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)), flags & 4);
+              *reinterpret_cast<float4*>(xo + (size_t)(mt * 32 + row) * N + nt * 32 + rch * 4) = q;
             }
           }
       }
@@ -369,26 +419,35 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    if (DBG == 16) { S_STAMP(0) ph[6] += 1; }
     if (!have_next) break;
+    S_READ(F0, 0, 0)  // first fragment set of the next tile (its K-tile 0 landed before the barrier of this tile's last K-tile)
     first = true;
     m0 = nm0;
     n0 = nn0;
-    curM = nxtM;
-    curN = nxtN;
+    sM = nxtM + 256;
+    sN = nxtN + 256;
   }
-  if (DBG == 10 || DBG == 11) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dbg_sink)::"memory");
+  if (DBG == 16 && tid == 0 && blockIdx.x < 2048) {
+    ph[7] = (long long)__builtin_readcyclecounter() - tstart;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_sp_phase[blockIdx.x * 8 + i] = ph[i];
+  }
+}
+
+// debug hook (not part of include/clipx.h): copies the DBG 16 phase counters of the last launch to the host
+extern "C" int clipx_dbg_phase_cycles(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sp_phase), (size_t)n * sizeof(long long));
 }
 
 template <int EPI, int DBG = 0>
 static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   const size_t smem = S_SCRATCH + 8 * 4096;  // 160 KiB: the whole LDS of the CU
   auto kern = gemm256sp_kernel<EPI, DBG>;
-  const char* fl = getenv("CLIPX_GEMM_FLAGS");  // A/B switches: bit 1 = drain vmcnt(0) at every wait, bit 2 = plain (L2-resident) output stores, bit 3 = builtin (64-bit VGPR address) LDS-DMA
-  const int flags = fl ? atoi(fl) : 0;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.N, g.K, g.M / 256,
-                     g.N / 256, flags);
+                     g.N / 256);
   return hipGetLastError();
 }
 
@@ -403,11 +462,7 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 3) return launch_sp_epi<EPI_BIAS_BF16, 3>(g, grid, st);
     if (d == 5) return launch_sp_epi<EPI_BIAS_BF16, 5>(g, grid, st);
     if (d == 6) return launch_sp_epi<EPI_BIAS_BF16, 6>(g, grid, st);
-    if (d == 7) return launch_sp_epi<EPI_BIAS_BF16, 7>(g, grid, st);
-    if (d == 8) return launch_sp_epi<EPI_BIAS_BF16, 8>(g, grid, st);
-    if (d == 9) return launch_sp_epi<EPI_BIAS_BF16, 9>(g, grid, st);
-    if (d == 10) return launch_sp_epi<EPI_BIAS_BF16, 10>(g, grid, st);
-    if (d == 11) return launch_sp_epi<EPI_BIAS_BF16, 11>(g, grid, st);
+    if (d == 16) return launch_sp_epi<EPI_BIAS_BF16, 16>(g, grid, st);
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);

@@ -29,13 +29,13 @@ def lib():
 
 
 # ------------------------------------------------------------------------------------------ per-kernel
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 @pytest.mark.parametrize("M,N,K", [(257, 128, 64), (514, 1024, 1024), (1000, 2304, 768), (130, 768, 3072), (65, 128, 640),
-                                   (33357, 512, 128), (65792, 1024, 1024), (2048, 4096, 1024), (19712, 768, 3072)])
+                                   (33357, 512, 128), (65792, 1024, 1024), (2048, 4096, 1024), (19712, 768, 3072), (16384, 256, 256)])
 def test_gemm_epilogues(lib, variant, M, N, K):
     """out = A W^T + b with bf16 operands: reference is the fp32 matmul of the SAME bf16-rounded operands,
     so only accumulation order differs (tol 2e-3 * |row| scale for bf16 outputs = 1 bf16 ulp + sum noise).
-    variant 2 = persistent 256x256 ping-pong kernel for the whole m-tiles + 128x128 kernel for the peeled rows;
+    variant 3 (default) = persistent 256x256 kernel for the whole m-tiles + 128x128 kernel for the peeled rows;
     (33357,512,128): 260 tiles -> two tiles per workgroup with K = one iteration; (65792,1024,1024): the ViT-L/14
     bs=256 out_proj shape (4 tiles per workgroup + 256 peeled rows)."""
     from clip_retrieval_amd._lib import check
