@@ -47,13 +47,21 @@ __device__ long long g_sp_phase[2048 * 8];
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // DBG (ablation, EPI_BIAS_BF16 only; garbage results): 1 = no staging, 3 = no staging and no ds_reads,
-// 5 = no epilogue at all, 6 = epilogue without its global stores, 16 = phase timer (correct results)
+// 5 = no epilogue at all, 6 = epilogue without its global stores, 16 = phase timer (correct results),
+// 17 / 18 = stage right behind the barrier (with / without timer), 19 / 20 = phase timer + ablations 1 / 3
 template <int EPI, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
                                                           int ntn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool DBG_TIMER = DBG == 16 || DBG == 17 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22 || DBG == 23;
+  constexpr bool DBG_L2HOT = DBG == 21;
+  // L2 prefetch distance in K-tiles (0 = off: DBG 22 with the phase timer, 24 without; 23 = distance 3 with timer)
+  constexpr int PFD = (DBG == 22 || DBG == 24) ? 0 : (DBG == 23 ? 3 : 4);
+  constexpr int NPF = PFD ? 1 : 0;  // prefetch instructions per wave per K-tile  // every CU stages the operand panels of tile (0, 0) (garbage results)
+  constexpr bool DBG_NO_STAGE = DBG == 1 || DBG == 3 || DBG == 19 || DBG == 20;
+  constexpr bool DBG_NO_READ = DBG == 3 || DBG == 20;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;  // waves w and w+4 share a SIMD (measured placement); rows differ, harmless here
@@ -63,7 +71,9 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   // ---- tile list of this block, XCD-aware: the 32 workgroups of an XCD (blockIdx % 8) walk 8 m-tiles x all n-tiles of a
   // group together, so the A panels and the W panels they share stay in that XCD's L2
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
-  auto tile_of = [&](int j, int& m0, int& n0) -> bool {
+  // shA / shW: which quarter of its A panel / eighth of its W panel this CU prefetches into the L2 (the panel is shared
+  // with the CUs of the XCD that work on the other n-tiles / m-tiles of the round)
+  auto tile_of = [&](int j, int& m0, int& n0, int& shA, int& shW) -> bool {
     const int logical = (j * 8 + xcd) * cpx + idx;
     if (logical >= ntiles) return false;
     const int per_group = 8 * ntn;
@@ -72,10 +82,12 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     const int gsz = (ntm - gm0) < 8 ? (ntm - gm0) : 8;
     m0 = (gm0 + within % gsz) * 256;
     n0 = (within / gsz) * 256;
+    shA = (within / gsz) & 3;
+    shW = (within % gsz) & 7;
     return true;
   };
-  int m0, n0;
-  if (!tile_of(0, m0, n0)) return;  // before any barrier
+  int m0, n0, shA0, shW0;
+  if (!tile_of(0, m0, n0, shA0, shW0)) return;  // before any barrier
 
   // ---- staging: wave w fills rows [32w, 32w+32) of both operands, 8 rows (1 KiB) per instruction (piece 4w + j =
   // rows 32w + 8j .. +8).  Source chunk = LDS chunk position ^ ((row>>1)&7).  One per-lane byte offset per piece
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dmw), "n"(cimm) \
                : "memory", "scc")
 #define S_STAGE(pM, pN, buf)                                      \
-  if (DBG != 1 && DBG != 3) {                                     \
+  if (!DBG_NO_STAGE) {                                            \
     S_DMA(soff[0], pM, (buf) * S_OPB);                            \
     S_DMA(soff[0], pN, (buf) * S_OPB + S_NBASE);                  \
     S_DMA(soff[1], pM, (buf) * S_OPB + 1024);                     \
@@ -104,6 +116,21 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     S_DMA(soff[3], pM, (buf) * S_OPB + 3072);                     \
     S_DMA(soff[3], pN, (buf) * S_OPB + S_NBASE + 3072);           \
   }                                                               \
+  S_FENCE();
+
+  // ---- L2 prefetch.  With operands that are already in the L2 a steady-state K-tile takes ~2340 cycles, with the real
+  // stream ~2760-3090 (phase timer, DBG 21 vs 16): the DMA of a K-tile has one K-tile of lead, less than an L2 miss takes.
+  // So every K-tile each wave also touches 12 lines of the K-tile PFD ahead (64 A rows + 32 W rows per CU: the CUs that
+  // share a panel split it) with one dword LDS-DMA whose 256 bytes land in an unused corner of the wave's idle epilogue
+  // scratch -- no destination register, and its miss latency is never waited for (vmcnt(NPF) at the K-tile's sync).
+  auto pf_addr = [&](int tm0, int tn0, int sA, int sW) -> const char* {
+    const int L = w * 12 + (lane % 12);
+    return L < 64 ? reinterpret_cast<const char*>(A) + (size_t)(tm0 + 64 * sA + L) * K * 2
+                  : reinterpret_cast<const char*>(W) + (size_t)(tn0 + 32 * sW + (L - 64)) * K * 2;
+  };
+  const unsigned pf_m0 = lds_base + S_SCRATCH + w * 4096 + 3584;
+#define S_PF(ptr)                                                                                             \
+  if (PFD) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(ptr), "s"(pf_m0) : "memory"); \
   S_FENCE();
 
   // ---- fragment read addresses (LDS byte addresses): one per (operand, k-step); buffer and fragment index are
@@ -131,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   // fragment one 128-bit register tuple across the loop back-edge (as 8 x bf16 it re-packs them with v_perm_b32)
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   i32x4 F0[6], F1[6];
-  if (DBG == 3) {
+  if (DBG_NO_READ) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       F0[i] = F1[i] = i32x4{0, 0, 0, 0};
@@ -141,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 
 #define S_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define S_READ(F, buf, kk)                                                                 \
-  if (DBG != 3) {                                                                          \
+  if (!DBG_NO_READ) {                                                                      \
     S_DSREAD(F[4], fN[kk], (buf) * S_OPB);                                                 \
     S_DSREAD(F[5], fN[kk], (buf) * S_OPB + 4096);                                          \
     S_DSREAD(F[0], fM[kk], (buf) * S_OPB);                                                 \
@@ -173,10 +200,16 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #define S_KT_TAIL(buf, preread)                              \
   if (preread) { S_READ(F0, (buf) ^ 1, 0) }                  \
   S_MFMA(F1)
+#define S_STAGE_LATE (DBG != 17 && DBG != 18)  // A/B: DBG 18 = stage right behind the barrier, 17 = that + phase timer
+// the stage of a K-tile goes behind k-step 3's MFMAs (S_STAGE_LATE) so that its 8 DMA issues overlap with their execution
+#define S_KT_END(buf, preread, stage_stmt)                   \
+  if (!S_STAGE_LATE) { stage_stmt }                          \
+  S_KT_TAIL(buf, preread)                                    \
+  if (S_STAGE_LATE) { stage_stmt }
 
   const int nk = K >> 6;  // K-tiles per output tile (even, >= 2)
-  const char* curM = reinterpret_cast<const char*>(A) + (size_t)m0 * K * 2;
-  const char* curN = reinterpret_cast<const char*>(W) + (size_t)n0 * K * 2;
+  const char* curM = reinterpret_cast<const char*>(A) + (DBG_L2HOT ? (size_t)0 : (size_t)m0 * K * 2);
+  const char* curN = reinterpret_cast<const char*>(W) + (DBG_L2HOT ? (size_t)0 : (size_t)n0 * K * 2);
 
   // VMEM bookkeeping (vmcnt retires in order): "the stage of the next K-tile has landed" is vmcnt(0) in steady state.
   // On the first K-tile after an epilogue the epilogue's own VMEM operations are younger than that stage and may stay in
@@ -196,19 +229,22 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   // bias of the current tile: one LDS-DMA per wave at the tile's last K-tile drops the wave's 64 bias floats into
   // its (then idle) epilogue scratch, AHEAD of the next tile's K-tile-1 stage, so the epilogue neither queues
   // behind that nor holds bias registers across the main loop.  (All four 16-lane groups fetch the same 256 B.)
+  // Inline asm: hipcc must not know about this DMA, or it waits vmcnt(0) before the epilogue's first LDS read.
   constexpr bool HAS_BIAS = EPI != EPI_TABLE_F32;
   const int rrow = lane >> 3, rch = lane & 7;  // epilogue read-back: row 8i + rrow, 16-B chunk rch
+  const unsigned bias_m0 = lds_base + S_SCRATCH + w * 4096;
+  const unsigned bias_off = (unsigned)((lane & 15) * 16);
   auto load_bias = [&]() {
     if (!HAS_BIAS) return;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(bias + n0 + wc * 64 + (lane & 15) * 4),
-                                     (lds_ptr_t)(smem + S_SCRATCH + w * 4096), 16, 0, 0);
+    const float* bp = bias + n0 + wc * 64;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(bias_off), "s"(bp), "s"(bias_m0) : "memory");
   };
 
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tstamp = DBG == 16 ? (long long)__builtin_readcyclecounter() : 0;
+  long long tstamp = DBG_TIMER ? (long long)__builtin_readcyclecounter() : 0;
   const long long tstart = tstamp;
 #define S_STAMP(slot)                                                  \
-  if (DBG == 16) {                                                     \
+  if (DBG_TIMER) {                                                     \
     const long long now_ = (long long)__builtin_readcyclecounter();    \
     ph[slot] += now_ - tstamp;                                         \
     tstamp = now_;                                                     \
@@ -216,63 +252,75 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 
   const char* sM = curM + 256;  // the next K-tile of this tile to stage (K-tile 2)
   const char* sN = curN + 256;
+  // prefetch stream: at K-tile t the prefetch targets K-tile t + PFD of the block's K-tile stream; it moves on to the next
+  // tile's panels after K-tile nk - PFD - 1.  Short K (< 8 K-tiles): the pointer stays on valid lines of K-tile 0.
+  // (operands of a few tens of MB mostly stay in the L2 / Infinity Cache anyway: there the extra requests cost ~3 %)
+  const bool pf_run = PFD && nk >= 8 && (size_t)ntm * 256 * K * 2 >= ((size_t)64 << 20);
+  const int pf_sw = pf_run ? nk - PFD - 1 : -1;
+  const int pf_step = pf_run ? 128 : 0;
+  const char* pfp = pf_addr(m0, n0, shA0, shW0) + (pf_run ? PFD * 128 : 0);
+#define S_PF_NEXT(t) pfp = ((t) == pf_sw) ? pf_nxt : pfp + pf_step;
   bool first = false;  // the K-tile about to run is the first one after an epilogue
   for (int j = 0;; ++j) {
-    int nm0 = 0, nn0 = 0;
-    const bool have_next = tile_of(j + 1, nm0, nn0);
-    const char* nxtM = reinterpret_cast<const char*>(A) + (size_t)nm0 * K * 2;
-    const char* nxtN = reinterpret_cast<const char*>(W) + (size_t)nn0 * K * 2;
+    int nm0 = 0, nn0 = 0, nshA = 0, nshW = 0;
+    const bool have_next = tile_of(j + 1, nm0, nn0, nshA, nshW);
+    const char* nxtM = reinterpret_cast<const char*>(A) + (DBG_L2HOT ? (size_t)0 : (size_t)nm0 * K * 2);
+    const char* nxtN = reinterpret_cast<const char*>(W) + (DBG_L2HOT ? (size_t)0 : (size_t)nn0 * K * 2);
+    const char* pf_nxt = have_next ? pf_addr(nm0, nn0, nshA, nshW) : pf_addr(m0, n0, 0, 0);
 
     if (nk > 2) {
       // ---- first pair (K-tiles 0, 1): stage K-tiles 2, 3
       S_KT_HEAD(0)
       if (first) { S_KT_SYNC(S_EPI_VM) } else { S_KT_SYNC(0) }
-      S_STAGE(sM, sN, 0)
-      S_KT_TAIL(0, true)
+      S_KT_END(0, true, S_STAGE(sM, sN, 0))
+      S_PF(pfp)
+      S_PF_NEXT(0)
       S_STAMP(1)
       S_KT_HEAD(1)
-      S_KT_SYNC(0)
-      S_STAGE(sM + 128, sN + 128, 1)
-      S_KT_TAIL(1, true)
+      S_KT_SYNC(NPF)
+      S_KT_END(1, true, S_STAGE(sM + 128, sN + 128, 1))
+      S_PF(pfp)
+      S_PF_NEXT(1)
       S_STAMP(2)
       sM += 256;
       sN += 256;
       // ---- steady state (K-tiles 2 .. nk-3): branch-free
       for (int t = 2; t < nk - 2; t += 2) {
         S_KT_HEAD(0)
-        S_KT_SYNC(0)
-        S_STAGE(sM, sN, 0)
-        S_KT_TAIL(0, true)
+        S_KT_SYNC(NPF)
+        S_KT_END(0, true, S_STAGE(sM, sN, 0))
+        S_PF(pfp)
+        S_PF_NEXT(t)
         S_KT_HEAD(1)
-        S_KT_SYNC(0)
-        S_STAGE(sM + 128, sN + 128, 1)
-        S_KT_TAIL(1, true)
+        S_KT_SYNC(NPF)
+        S_KT_END(1, true, S_STAGE(sM + 128, sN + 128, 1))
+        S_PF(pfp)
+        S_PF_NEXT(t + 1)
         sM += 256;
         sN += 256;
-        if (DBG == 16) { S_STAMP(3) ph[5] += 2; }
+        if (DBG_TIMER) { S_STAMP(3) ph[5] += 2; }
       }
-      // ---- last pair (K-tiles nk-2, nk-1): stage the next tile's K-tiles 0, 1; fetch this tile's bias
+      // ---- last pair (K-tiles nk-2, nk-1): stage the next tile's K-tiles 0, 1; fetch this tile's bias.  No prefetch (the
+      // epilogue's entry wait would have to sit out its miss); the stream pointer still advances.
       S_KT_HEAD(0)
-      S_KT_SYNC(0)
-      if (have_next) { S_STAGE(nxtM, nxtN, 0) }
-      S_KT_TAIL(0, true)
+      S_KT_SYNC(NPF)
+      S_KT_END(0, true, if (have_next) { S_STAGE(nxtM, nxtN, 0) })
       S_KT_HEAD(1)
       S_KT_SYNC(0)
       load_bias();
-      if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) }
-      S_KT_TAIL(1, false)  // the next tile's first fragments are read after the epilogue (24 VGPRs it needs)
+      S_KT_END(1, false, if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) })  // the next tile's first fragments are read after the epilogue (24 VGPRs it needs)
+      S_PF_NEXT(nk - 2)
+      S_PF_NEXT(nk - 1)
       S_STAMP(4)
     } else {
-      // ---- K = 128: the only pair is the first and the last one
+      // ---- K = 128: the only pair is the first and the last one (no prefetch)
       S_KT_HEAD(0)
       if (first) { S_KT_SYNC(S_EPI_VM) } else { S_KT_SYNC(0) }
-      if (have_next) { S_STAGE(nxtM, nxtN, 0) }
-      S_KT_TAIL(0, true)
+      S_KT_END(0, true, if (have_next) { S_STAGE(nxtM, nxtN, 0) })
       S_KT_HEAD(1)
       S_KT_SYNC(0)
       load_bias();
-      if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) }
-      S_KT_TAIL(1, false)
+      S_KT_END(1, false, if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) })
       S_STAMP(4)
     }
 
@@ -419,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    if (DBG == 16) { S_STAMP(0) ph[6] += 1; }
+    if (DBG_TIMER) { S_STAMP(0) ph[6] += 1; }
     if (!have_next) break;
     S_READ(F0, 0, 0)  // first fragment set of the next tile (its K-tile 0 landed before the barrier of this tile's last K-tile)
     first = true;
@@ -428,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     sM = nxtM + 256;
     sN = nxtN + 256;
   }
-  if (DBG == 16 && tid == 0 && blockIdx.x < 2048) {
+  if (DBG_TIMER && tid == 0 && blockIdx.x < 2048) {
     ph[7] = (long long)__builtin_readcyclecounter() - tstart;
 #pragma unroll
     for (int i = 0; i < 8; ++i) g_sp_phase[blockIdx.x * 8 + i] = ph[i];
@@ -463,6 +511,14 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 5) return launch_sp_epi<EPI_BIAS_BF16, 5>(g, grid, st);
     if (d == 6) return launch_sp_epi<EPI_BIAS_BF16, 6>(g, grid, st);
     if (d == 16) return launch_sp_epi<EPI_BIAS_BF16, 16>(g, grid, st);
+    if (d == 17) return launch_sp_epi<EPI_BIAS_BF16, 17>(g, grid, st);
+    if (d == 19) return launch_sp_epi<EPI_BIAS_BF16, 19>(g, grid, st);
+    if (d == 20) return launch_sp_epi<EPI_BIAS_BF16, 20>(g, grid, st);
+    if (d == 21) return launch_sp_epi<EPI_BIAS_BF16, 21>(g, grid, st);
+    if (d == 22) return launch_sp_epi<EPI_BIAS_BF16, 22>(g, grid, st);
+    if (d == 23) return launch_sp_epi<EPI_BIAS_BF16, 23>(g, grid, st);
+    if (d == 24) return launch_sp_epi<EPI_BIAS_BF16, 24>(g, grid, st);
+    if (d == 18) return launch_sp_epi<EPI_BIAS_BF16, 18>(g, grid, st);
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);

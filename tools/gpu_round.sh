@@ -1,7 +1,8 @@
 #!/bin/bash
 # One GPU visit: parity tests, microbench, the default bench line, a rocprofv3 kernel-trace of the same command and
 # the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) that bench.py's `traffic` fields
-# come from.   usage (on the GPU box, from the repo root): bash tools/gpu_round.sh <tag> [quick]
+# come from.   usage (on the GPU box, from the repo root): bash tools/gpu_round.sh <tag> [quick|lite]
+# quick = tests + microbench; lite = tests + bench line; default = everything
 set -u
 TAG=${1:-rX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -11,7 +12,11 @@ cd $ROOT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu_$TAG.log
 tail -3 $OUT/pytest_gpu_$TAG.log
-MB_VARIANTS=1,2,3 timeout 600 python tools/microbench.py > $OUT/microbench_$TAG.log 2>&1; cat $OUT/microbench_$TAG.log
+if [ "${2:-}" = "lite" ]; then
+  ( time timeout 900 python bench.py ) > $OUT/bench_$TAG.log 2>&1; tail -5 $OUT/bench_$TAG.log
+  exit 0
+fi
+MB_VARIANTS=1,3 timeout 600 python tools/microbench.py > $OUT/microbench_$TAG.log 2>&1; cat $OUT/microbench_$TAG.log
 if [ "${2:-}" != "quick" ]; then
   ( time timeout 900 python bench.py ) > $OUT/bench_$TAG.log 2>&1; tail -5 $OUT/bench_$TAG.log
   cd /tmp
