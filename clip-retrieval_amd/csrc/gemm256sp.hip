@@ -92,7 +92,10 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   // ---- staging: wave w fills rows [32w, 32w+32) of both operands, 8 rows (1 KiB) per instruction (piece 4w + j =
   // rows 32w + 8j .. +8).  Source chunk = LDS chunk position ^ ((row>>1)&7).  One per-lane byte offset per piece
   // (both operands are [rows, K] row-major, so they share them); the K-tile's base address is an SGPR pair and the
-  // LDS destination (M0) is <wave base> + immediate: a stage is 8 x {s_add_u32 m0; s_nop; global_load_lds_dwordx4}.
+  // LDS destination (M0) is <wave base> + immediate: a stage is 8 x {s_add_u32 m0; s_nop 3; global_load_lds_dwordx4}.
+  // (s_nop 3: M0 needs one wait state, and hipcc may have reloaded a spilled base SGPR with v_readlane right before this
+  // statement -- a VALU-written SGPR needs 5 wait states before a VMEM instruction reads it, and hipcc's hazard
+  // recognizer does not look inside inline asm.  tools/check_isa.py checks the generated code for both.)
   const int srow = w * 32 + (lane >> 3);
   unsigned soff[4];
 #pragma unroll
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
   const unsigned dmw = lds_base + w * 4096;  // this wave's first piece inside an operand tile
 #define S_DMA(off, base, cimm)                                                                              \
-  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dmw), "n"(cimm) \
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dmw), "n"(cimm) \
                : "memory", "scc")
 #define S_STAGE(pM, pN, buf)                                      \
   if (!DBG_NO_STAGE) {                                            \
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   auto load_bias = [&]() {
     if (!HAS_BIAS) return;
     const float* bp = bias + n0 + wc * 64;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(bias_off), "s"(bp), "s"(bias_m0) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(bias_off), "s"(bp), "s"(bias_m0) : "memory");
   };
 
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -369,8 +372,9 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const char* base = yb + (size_t)(mt * 4 + i) * rstep;
-            // s_nop: store-data hazard (hipcc cannot see that this is a store and may rewrite q right behind it)
-            if (DBG != 6) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(q[i]), "s"(base) : "memory");
+            // s_nop 4: the base SGPR may come straight from a v_readlane; s_nop 1: store-data hazard (hipcc cannot see that
+            // this is a store and may rewrite q right behind it)
+            if (DBG != 6) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(q[i]), "s"(base) : "memory");
             else asm volatile("" ::"v"(q[i]));
           }
         }

@@ -80,3 +80,20 @@ def test_host_merge_is_exact(lib):
     Dm, Im = merge_topk_host(D, I, k)
     Do, Io = merge_topk(D, I, k)
     assert np.array_equal(Im, Io) and np.array_equal(Dm, Do)
+
+
+def test_inline_asm_vmem_hazards():
+    """The persistent GEMM issues its LDS-DMA loads and epilogue stores from inline asm, which hipcc's hazard recognizer
+    does not see: lint the generated gfx950 code for VALU-written SGPRs read too early by a VMEM instruction and for VGPR
+    spills (a scratch reload waits vmcnt(0), i.e. for every store before it).  tools/check_isa.py."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py"),
+                        os.path.join(root, "clip-retrieval_amd", "csrc", "gemm256sp.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

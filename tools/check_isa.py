@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""ISA lint for the kernels that issue VMEM instructions from inline asm (gemm256sp.hip).
+
+hipcc's hazard recognizer does not look inside inline asm, so two gfx9 hazards have to be kept away by construction:
+  * an SGPR written by a VALU (v_readlane / v_readfirstlane, e.g. the reload of a spilled SGPR) must not be read by a
+    VMEM instruction within the next 5 wait states;
+  * no VGPR spills: a scratch reload carries `s_waitcnt vmcnt(0)`, which also waits for every store before it.
+Usage: check_isa.py file.hip [...]   (exit status 1 on a finding)
+"""
+import re
+import subprocess
+import sys
+import tempfile
+
+VMEM = ("global_", "buffer_", "scratch_", "flat_")
+
+
+def sgprs(tok):
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check(path):
+    with tempfile.NamedTemporaryFile(suffix=".s") as f:
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        "-o", f.name, path], check=True, stderr=subprocess.DEVNULL)
+        text = open(f.name).read()
+    findings = []
+    for m in re.finditer(r"\.name:\s+(\S+).*?\.vgpr_spill_count:\s+(\d+)", text, re.S):
+        if "gemm256sp_kernel" in m.group(1) and "ILi4E" not in m.group(1) and int(m.group(2)):
+            findings.append(f"{m.group(1)}: {m.group(2)} VGPR spills")
+    ins = [l.strip() for l in text.split("\n")]
+    ins = [l for l in ins if l and not l.startswith((";", ".")) and not l.endswith(":")]
+    for i, l in enumerate(ins):
+        if not l.startswith(("v_readlane_b32", "v_readfirstlane_b32")):
+            continue
+        dst = sgprs(l.split()[1].rstrip(","))
+        states = 0
+        for nxt in ins[i + 1:i + 8]:
+            if nxt.startswith(VMEM):
+                used = set()
+                for tok in re.findall(r"s\[\d+:\d+\]|\bs\d+\b", nxt):
+                    used |= sgprs(tok)
+                if dst & used and states < 5:
+                    findings.append(f"VALU-written SGPR read by VMEM after {states} wait states: {l}  ->  {nxt}")
+            states += (int(nxt.split()[1]) + 1) if nxt.startswith("s_nop") else 1
+            if states >= 5:
+                break
+    return findings
+
+
+if __name__ == "__main__":
+    bad = []
+    for p in sys.argv[1:]:
+        bad += [f"{p}: {x}" for x in check(p)]
+    print("\n".join(bad) if bad else "ISA lint: clean")
+    sys.exit(1 if bad else 0)
