@@ -36,9 +36,9 @@ constexpr int G_TM = 128, G_TN = 128, G_BK = 64;
 constexpr int G_STAGE_BYTES = (G_TM + G_TN) * G_BK * 2;  // 32 KiB
 constexpr int G_GROUP_M = 8;
 
-// DEEP (GLDS only): 4-deep LDS ring (128 KiB, one workgroup per CU) with the DMA of K-tile t+3 issued at K-tile t and ONE
-// barrier per K-tile.  For launches of few workgroups (the peeled 257th m-tile of ViT-L/14: 16..64 workgroups; B = 1
-// queries) nothing else runs on the CU to hide the DMA latency, and the 2-deep loop below then takes ~1.4 us per K-tile.
+// DEEP (GLDS only): 4-deep LDS ring (128 KiB, one workgroup per CU), the DMA of K-tile t+4 issued at K-tile t's barrier, ONE
+// barrier per K-tile, software-pipelined fragment reads.  The launches this kernel serves have few workgroups (the peeled
+// 257th m-tile of ViT-L/14: 16..64 workgroups; B = 1 queries), so nothing else runs on the CU to hide DMA or LDS latency.
 template <int EPI, bool GLDS, bool DEEP = false>
 __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
@@ -120,19 +120,104 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
       }
     };
     if (DEEP) {
-      // ring slot of K-tile t = t & 3; 8 DMA per thread per K-tile; K-tiles t+1, t+2 stay in flight across the barrier
-      issue(0, 0);
-      if (nk > 1) issue(1, 1);
-      if (nk > 2) issue(2, 2);
-      for (int t = 0; t < nk; ++t) {
-        const int rem = nk - 1 - t;  // K-tiles issued after K-tile t
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // K-tile t landed for every wave; every wave is done reading slot (t-1)&3
-        if (t + 3 < nk) issue(t + 3, (t + 3) & 3);
-        compute(t & 3);
+      // Software-pipelined loop (same scheme as gemm256sp.hip): 4-slot LDS ring, K-tile t+4 is staged right behind the
+      // barrier of K-tile t (the slot K-tile t just released), fragments of the next k-step are read (inline-asm
+      // ds_read_b128, counted lgkmcnt) while this k-step's 4 MFMAs run, and the one barrier of the K-tile sits before
+      // the last k-step's MFMAs with the next K-tile's first fragments read right behind it.  With one wave per SIMD
+      // nothing else covers LDS latency: the previous loop (4 reads; lgkmcnt(0); 4 MFMAs, four times per K-tile) took
+      // ~1 us per K-tile, this one ~0.35 us.  Needs M * K * 2 and N * K * 2 < 4 GiB (32-bit lane offsets).
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      const int wu = __builtin_amdgcn_readfirstlane(w);
+      const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+      const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds0);
+      unsigned offW[4], offA[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        offW[i] = (unsigned)(reinterpret_cast<const char*>(gW[i]) - reinterpret_cast<const char*>(W));
+        offA[i] = (unsigned)(reinterpret_cast<const char*>(gA[i]) - reinterpret_cast<const char*>(A));
       }
+      // fragment read addresses of ring slot 0 (+ 32 KiB per slot): W rows wn*64 + i*32 + l31, A rows wm*64 + j*32 + l31
+      unsigned fW[4], fA[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        fW[kk] = lds0 + (wn * 64) * 128 + foff[kk];
+        fA[kk] = lds0 + G_TN * G_BK * 2 + (wm * 64) * 128 + foff[kk];
+      }
+      i32x4 F0[4], F1[4];  // [0..1] W fragments (i), [2..3] A fragments (j)
+#define D_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define D_READ(F, so, kk)                          \
+  D_DSREAD(F[0], fW[kk] + (so), 0);                \
+  D_DSREAD(F[1], fW[kk] + (so), 4096);             \
+  D_DSREAD(F[2], fA[kk] + (so), 0);                \
+  D_DSREAD(F[3], fA[kk] + (so), 4096);             \
+  __builtin_amdgcn_sched_barrier(0);
+#define D_WAIT_PREV() asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#define D_MFMA(F)                                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =            \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F[i]), __builtin_bit_cast(bf16x8, F[2 + j]), acc[i][j], 0, 0, 0); \
+  __builtin_amdgcn_sched_barrier(0);
+      // one DMA: M0 = LDS address of the piece (SGPR), 32-bit lane offset, SGPR base of the K-tile
+#define D_DMA(off, base, dst)                                                                                         \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory")
+      auto stage = [&](int t, int slot) {
+        const char* bw = reinterpret_cast<const char*>(W) + (size_t)t * (G_BK * 2);
+        const char* ba = reinterpret_cast<const char*>(A) + (size_t)t * (G_BK * 2);
+        const unsigned d = lds_base + slot * G_STAGE_BYTES + wu * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          D_DMA(offW[i], bw, d + i * 1024);
+          D_DMA(offA[i], ba, d + G_TN * G_BK * 2 + i * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      const int npro = nk < 4 ? nk : 4;
+      for (int t = 0; t < npro; ++t) stage(t, t);
+      if (npro == 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (npro == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (npro == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      D_READ(F0, 0u, 0)
+      unsigned so = 0;  // byte offset of the current ring slot
+#define D_KT_HEAD()                                   \
+  D_READ(F1, so, 1) D_WAIT_PREV() D_MFMA(F0)           \
+  D_READ(F0, so, 2) D_WAIT_PREV() D_MFMA(F1)           \
+  D_READ(F1, so, 3) D_WAIT_PREV() D_MFMA(F0)           \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+  __builtin_amdgcn_sched_barrier(0);
+#define D_SYNC(vm)                                           \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(vm) : "memory");  \
+  __builtin_amdgcn_sched_barrier(0);                         \
+  __builtin_amdgcn_s_barrier();                              \
+  __builtin_amdgcn_sched_barrier(0);
+      int t = 0;
+      // steady state: K-tiles t+1 .. t+3 are in flight at the sync (K-tile t+1 is needed: 16 younger DMA), K-tile t+4 exists
+      for (; t + 4 < nk; ++t) {
+        D_KT_HEAD()
+        D_SYNC(16)
+        stage(t + 4, t & 3);
+        so = (so + G_STAGE_BYTES) & (4 * G_STAGE_BYTES - 1);
+        D_READ(F0, so, 0)
+        D_MFMA(F1)
+      }
+      // the last (up to) four K-tiles: nothing left to stage
+      for (; t < nk; ++t) {
+        const int rem = nk - 1 - t;  // K-tiles after this one (all issued)
+        D_KT_HEAD()
+        if (rem >= 3) { D_SYNC(16) } else if (rem == 2) { D_SYNC(8) } else { D_SYNC(0) }
+        so = (so + G_STAGE_BYTES) & (4 * G_STAGE_BYTES - 1);
+        if (rem > 0) { D_READ(F0, so, 0) }
+        D_MFMA(F1)
+      }
+#undef D_DSREAD
+#undef D_READ
+#undef D_WAIT_PREV
+#undef D_MFMA
+#undef D_DMA
+#undef D_KT_HEAD
+#undef D_SYNC
     } else {
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -207,7 +292,9 @@ static hipError_t launch_gemm_epi(const GemmArgs& g, hipStream_t st) {
   const dim3 grid(ntm * ntn), block(256);
   const size_t smem = 2 * G_STAGE_BYTES;
   const int cu = g.n_cu > 0 ? g.n_cu : 256;
-  if (g.variant == 1 && (int)grid.x <= cu && g.K >= 4 * G_BK) {
+  const bool small_off = (size_t)g.M * g.K * 2 < ((size_t)1 << 32) && (size_t)g.N * g.K * 2 < ((size_t)1 << 32);
+  (void)cu;
+  if (g.variant == 1 && g.K >= 2 * G_BK && small_off) {
     auto kern = gemm_bf16_kernel<EPI, true, true>;
     const size_t smem4 = 4 * G_STAGE_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
