@@ -307,11 +307,11 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
       // epilogue's entry wait would have to sit out its miss); the stream pointer still advances.
       S_KT_HEAD(0)
       S_KT_SYNC(NPF)
+      load_bias();  // lands before the next sync (vmcnt(0)): the epilogue does not have to wait for it
       S_KT_END(0, true, if (have_next) { S_STAGE(nxtM, nxtN, 0) })
       S_KT_HEAD(1)
       S_KT_SYNC(0)
-      load_bias();
-      S_KT_END(1, false, if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) })  // the next tile's first fragments are read after the epilogue (24 VGPRs it needs)
+      S_KT_END(1, false, if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) })  // the next tile's first fragments are read inside the epilogue (24 VGPRs it needs first)
       S_PF_NEXT(nk - 2)
       S_PF_NEXT(nk - 1)
       S_STAMP(4)
@@ -319,18 +319,17 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
       // ---- K = 128: the only pair is the first and the last one (no prefetch)
       S_KT_HEAD(0)
       if (first) { S_KT_SYNC(S_EPI_VM) } else { S_KT_SYNC(0) }
+      load_bias();
       S_KT_END(0, true, if (have_next) { S_STAGE(nxtM, nxtN, 0) })
       S_KT_HEAD(1)
       S_KT_SYNC(0)
-      load_bias();
       S_KT_END(1, false, if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) })
       S_STAMP(4)
     }
 
     // ---- epilogue of this output tile, transposed through the wave's LDS scratch (the next tile's K-tile 0 has landed,
-    // its K-tile 1 is in flight).  The bias landed in the scratch: only the K-tile-1 stage (8 DMA) is younger than its DMA.
-    if (have_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // last tile: no stage was issued behind the bias DMA
+    // its K-tile 1 is in flight; the bias landed in the scratch before the last K-tile's sync)
+#define S_NEXT_FRAGS() if (have_next) { S_READ(F0, 0, 0) }  // the next tile's first fragment set, read as soon as registers are free
     S_FENCE();
     if (DBG != 5) {
       unsigned char* scr = smem + S_SCRATCH + w * 4096;
@@ -346,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
           for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + (nt * 32 + 8 * g + 4 * hb) * 4);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+          if (mt == 3) { S_NEXT_FRAGS() }
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -358,10 +358,17 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                 if (EPI == EPI_BIAS_QGELU_BF16) v[e] = quick_gelu(v[e]);
                 if (EPI == EPI_BIAS_GELU_BF16) v[e] = gelu_erf(v[e]);
               }
-              bf16x4 o;
-              o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+              // two v_cvt_pk_bf16_f32 per quad (element-wise casts into a bf16x4 make hipcc convert one value at a time
+              // and assemble the pairs with v_perm / v_alignbit: 9 VALU per quad instead of 4)
+              typedef float f32x2_t __attribute__((ext_vector_type(2)));
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              const bf16x2_t o01 = __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t);
+              const bf16x2_t o23 = __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t);
+              uint2 o;
+              o.x = __builtin_bit_cast(unsigned, o01);
+              o.y = __builtin_bit_cast(unsigned, o23);
               // row l31 = [8 chunks of 16 B]; chunk (4nt + g) holds columns 32nt + 8g .. +8, half hb
-              *reinterpret_cast<bf16x4*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8) = o;
+              *reinterpret_cast<uint2*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8) = o;
             }
           u32x4 q[4];
 #pragma unroll
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           const int mt = p >> 1, nt = p & 1;
+          if (p == 6) { S_NEXT_FRAGS() }
           if (p < 7) { S_LD_EXT((p + 1) & 1, p + 1) }
           S_FENCE();
 #pragma unroll
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     if (DBG_TIMER) { S_STAMP(0) ph[6] += 1; }
     if (!have_next) break;
-    S_READ(F0, 0, 0)  // first fragment set of the next tile (its K-tile 0 landed before the barrier of this tile's last K-tile)
+    if (DBG == 5 || EPI == EPI_TABLE_F32) { S_READ(F0, 0, 0) }  // (the other epilogues read it inside: S_NEXT_FRAGS)
     first = true;
     m0 = nm0;
     n0 = nn0;
