@@ -531,7 +531,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
   bf16x8 qf_all[QPW][KS];
 #pragma unroll
   for (int qi = 0; qi < QPW; ++qi) {
-    const int qpos = (w * QPW + qi) * 32 + l31;
+    const int qpos = (qi * NW + w) * 32 + l31;  // query blocks are dealt round-robin to the waves
     const int qrow = qpos < T ? qpos : T - 1;  // padded query rows compute on a valid row and are never stored
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
   const int ksw = (l31 >> 1) & 7;
 #pragma unroll
   for (int qi = 0; qi < QPW; ++qi) {
-    const int qb = w * QPW + qi;
+    const int qb = qi * NW + w;
     if (qb >= NKB) break;
     const int qpos = qb * 32 + l31;
     bf16x8 qf[KS];
@@ -659,11 +659,22 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
       if (CAUSAL && kb > qb) continue;
       bf16x8 pf[2];
       const f32x16 sb = RECOMP ? s_block(kb) : sacc[RECOMP ? 0 : kb];
+      // pairs go through one v_cvt_pk_bf16_f32 (element-wise casts make hipcc convert singly and re-pack with v_perm)
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      unsigned pw[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[r], scale_log2e, nmx));
-        sum += p;
-        pf[r >> 3][r & 7] = (bf16)p;
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[r], scale_log2e, nmx));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[r + 1], scale_log2e, nmx));
+        sum += p0;
+        sum += p1;
+        pw[r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){p0, p1}, bf16x2_t));
+      }
+      {
+        const uint4 w0 = make_uint4(pw[0], pw[1], pw[2], pw[3]), w1 = make_uint4(pw[4], pw[5], pw[6], pw[7]);
+        pf[0] = *reinterpret_cast<const bf16x8*>(&w0);
+        pf[1] = *reinterpret_cast<const bf16x8*>(&w1);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
@@ -738,7 +749,11 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
     case 6: return launch_attention_cfg<64, 6, 3, 2>(qkv, out, B, T, H, causal, st);
     case 7: return launch_attention_cfg<64, 7, 4, 2>(qkv, out, B, T, H, causal, st);   // ViT-B/16 image (T=197)
     case 8: return launch_attention_cfg<64, 8, 4, 2>(qkv, out, B, T, H, causal, st);
-    case 9: return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st);   // ViT-L/14 image (T=257)
+    case 9: {  // ViT-L/14 image (T=257)
+      static const int cfg = getenv("CLIPX_ATTN_CFG") ? atoi(getenv("CLIPX_ATTN_CFG")) : 0;
+      if (cfg == 4) return launch_attention_cfg<64, 9, 4, 3>(qkv, out, B, T, H, causal, st);
+      return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st);
+    }
     default: return hipErrorInvalidValue;
   }
 }

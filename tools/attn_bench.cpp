@@ -1,0 +1,74 @@
+// attn_bench.cpp -- times the library's attention kernel (clipx_attention_dh_device, include/clipx.h) without Python and
+// checks a few (batch, head) pairs against an fp32 CPU softmax(QK^T/sqrt(dh))V of the same bf16 inputs.
+//   hipcc -O2 -o tools/attn_bench tools/attn_bench.cpp -ldl ;  tools/attn_bench [B T H dh causal]
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+typedef int (*attn_fn)(int, const void*, void*, int, int, int, int, int, void*);
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16); }
+int main(int argc, char** argv) {
+  std::string self = argv[0];
+  std::string dir = self.substr(0, self.find_last_of('/') == std::string::npos ? 0 : self.find_last_of('/'));
+  void* h = dlopen(((dir.empty() ? std::string(".") : dir) + "/../clip-retrieval_amd/lib/libclipx.so").c_str(), RTLD_NOW);
+  if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+  attn_fn attn = (attn_fn)dlsym(h, "clipx_attention_dh_device");
+  const int B = argc > 1 ? atoi(argv[1]) : 256, T = argc > 2 ? atoi(argv[2]) : 257, H = argc > 3 ? atoi(argv[3]) : 16;
+  const int dh = argc > 4 ? atoi(argv[4]) : 64, causal = argc > 5 ? atoi(argv[5]) : 0;
+  const size_t ld = (size_t)3 * H * dh, nq = (size_t)B * T * ld, no = (size_t)B * T * H * dh;
+  std::vector<uint16_t> hq(nq), ho(no);
+  unsigned r = 777u;
+  for (auto& v : hq) { r = r * 1664525u + 1013904223u; v = f2bf((((int)(r >> 9) & 0xffff) / 32768.f - 1.f) * 1.5f); }
+  void *dq, *dout;
+  CK(hipMalloc(&dq, nq * 2)); CK(hipMalloc(&dout, no * 2));
+  CK(hipMemcpy(dq, hq.data(), nq * 2, hipMemcpyHostToDevice));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  if (attn(0, dq, dout, B, T, H, dh, causal, st)) { fprintf(stderr, "attention call failed\n"); return 2; }
+  CK(hipStreamSynchronize(st));
+  CK(hipMemcpy(ho.data(), dout, no * 2, hipMemcpyDeviceToHost));
+  double maxerr = 0;
+  const int pairs[3][2] = {{0, 0}, {B / 2, H - 1}, {B - 1, H / 2}};
+  std::vector<float> s(T);
+  for (auto& ph : pairs) {
+    const int b = ph[0], hh = ph[1];
+    for (int q = 0; q < T; ++q) {
+      const uint16_t* qp = &hq[((size_t)b * T + q) * ld + hh * dh];
+      float mx = -1e30f;
+      const int kend = causal ? q + 1 : T;
+      for (int k = 0; k < kend; ++k) {
+        const uint16_t* kp = &hq[((size_t)b * T + k) * ld + H * dh + hh * dh];
+        float a = 0;
+        for (int d = 0; d < dh; ++d) a += bf2f(qp[d]) * bf2f(kp[d]);
+        s[k] = a / sqrtf((float)dh);
+        mx = std::max(mx, s[k]);
+      }
+      double sum = 0;
+      for (int k = 0; k < kend; ++k) { s[k] = expf(s[k] - mx); sum += s[k]; }
+      for (int d = 0; d < dh; ++d) {
+        double o = 0;
+        for (int k = 0; k < kend; ++k) o += s[k] * bf2f(hq[((size_t)b * T + k) * ld + 2 * H * dh + hh * dh + d]);
+        o /= sum;
+        maxerr = std::max(maxerr, fabs(o - bf2f(ho[((size_t)b * T + q) * (H * dh) + hh * dh + d])));
+      }
+    }
+  }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<float> ts;
+  for (int i = 0; i < 12; ++i) {
+    CK(hipEventRecord(e0, st)); attn(0, dq, dout, B, T, H, dh, causal, st); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+  }
+  std::sort(ts.begin(), ts.end());
+  const double fl = 4.0 * B * H * (double)T * T * dh * (causal ? 0.5 : 1.0);
+  printf("attention B=%d T=%d H=%d dh=%d causal=%d cfg=%s: median %.1f us (%.1f TFLOP/s), min %.1f us; max |err| vs fp32 CPU on 3 heads %.4g\n", B, T, H, dh,
+         causal, getenv("CLIPX_ATTN_CFG") ? getenv("CLIPX_ATTN_CFG") : "-", ts[ts.size() / 2] * 1e3, fl / (ts[ts.size() / 2] * 1e-3) / 1e12, ts[0] * 1e3, maxerr);
+  return maxerr < 0.02 ? 0 : 1;
+}
