@@ -12,7 +12,7 @@ taking the place of clip_back.py:589-596 for our index type.
 Same argument meaning and error behaviour as faiss: float32 C-contiguous [n, d] queries (anything else
 raises like faiss' SWIG wrapper does), int64 labels, -1 / -FLT_MAX padding, exceptions on misuse.
 Thread-safe: clip_back serves each request on its own werkzeug thread with n=1 (clip_back.py:1018);
-concurrent callers are coalesced into one HBM scan of up to 32 queries by a leader/follower batcher.
+concurrent callers are coalesced into one HBM scan of up to 64 queries (_SCAN_QUERIES) by a leader/follower batcher.
 """
 
 import ctypes as C
