@@ -507,7 +507,7 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 // =============================================================================================
 template <int DH, int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP>
 __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
-                                                              int H, float scale_log2e) {
+                                                              int H, float scale_log2e, int dbg) {
   constexpr int TP = NKB * 32;
   constexpr int CH = DH / 8;                      // 16-B chunks per key row
   constexpr int KS = DH / 16;                     // MFMA k-steps of the QK^T product
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
     }
   }
 
+  if (dbg != 2) {  // ablation 2: no staging (garbage results)
   // ---- stage K: CH lanes cover one key's row.  Loads are unconditional (row clamped, zeroed after) and issued as
   // one batch: a per-element `if (key < T) load` makes hipcc branch around every load and drain vmcnt(0) each time.
   {
@@ -599,7 +600,9 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
       }
     }
   }
+  }
   __syncthreads();
+  if (dbg == 1) return;  // ablation (CLIPX_ATTN_DBG=1): staging only
 
   const int ksw = (l31 >> 1) & 7;
 #pragma unroll
@@ -713,16 +716,17 @@ static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T,
   const size_t smem = (size_t)NKB * 32 * KROW + (size_t)DV * (NKB * 64 + 8);
   const float scale_log2e = (1.f / sqrtf((float)DH)) * 1.4426950408889634f;
   const dim3 grid(B * H), block(NW * 64);
+  static const int dbg = getenv("CLIPX_ATTN_DBG") ? atoi(getenv("CLIPX_ATTN_DBG")) : 0;  // ablations, see the kernel
   if (causal) {
     auto kern = attention_kernel<DH, NKB, NW, QPW, true, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg);
   } else {
     auto kern = attention_kernel<DH, NKB, NW, QPW, false, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg);
   }
   return hipGetLastError();
 }
