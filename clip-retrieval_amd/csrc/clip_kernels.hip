@@ -651,7 +651,10 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
     const float nmx = -mx * scale_log2e;
 
     // ---- per key block: P = exp2(S*c - m*c) -> bf16 (stays in registers as the B operand), then O^T += V^T P^T
-    float sum = 0.f;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t sum2 = {0.f, 0.f};
+    const int tail_keys = T - (NKB - 1) * 32;  // keys of the last key block that exist
     f32x16 oacc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -663,16 +666,21 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
       bf16x8 pf[2];
       const f32x16 sb = RECOMP ? s_block(kb) : sacc[RECOMP ? 0 : kb];
       // pairs go through one v_cvt_pk_bf16_f32 (element-wise casts make hipcc convert singly and re-pack with v_perm)
-      typedef float f32x2_t __attribute__((ext_vector_type(2)));
-      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
       unsigned pw[8];
+      // the scale-and-shift and the row sum run two values per instruction (v_pk_fma_f32 / v_pk_add_f32); in the last key
+      // block only the first `tail_keys` keys exist (ViT-L/14: 1 of 32): when they all sit in the first register quad
+      // the other 12 exponentials of the block are skipped (their P is exactly 0)
+      const bool short_tail = !CAUSAL && kb == NKB - 1 && tail_keys <= 4;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[r], scale_log2e, nmx));
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[r + 1], scale_log2e, nmx));
-        sum += p0;
-        sum += p1;
-        pw[r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){p0, p1}, bf16x2_t));
+        if (short_tail && r >= 4) {
+          pw[r >> 1] = 0u;
+          continue;
+        }
+        const f32x2_t e = (f32x2_t){sb[r], sb[r + 1]} * (f32x2_t){scale_log2e, scale_log2e} + (f32x2_t){nmx, nmx};
+        const f32x2_t pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        sum2 += pp;
+        pw[r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(pp, bf16x2_t));
       }
       {
         const uint4 w0 = make_uint4(pw[0], pw[1], pw[2], pw[3]), w1 = make_uint4(pw[4], pw[5], pw[6], pw[7]);
@@ -691,6 +699,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
           oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[s2], oacc[nb], 0, 0, 0);
         }
     }
+    float sum = sum2[0] + sum2[1];
     sum += __shfl_xor(sum, 32);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     // ---- store: lane owns query qpos, d = 32nb + 8g + 4hb + {0..3}
