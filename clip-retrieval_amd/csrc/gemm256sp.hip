@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
       // epilogue's entry wait would have to sit out its miss); the stream pointer still advances.
       S_KT_HEAD(0)
       S_KT_SYNC(NPF)
-      load_bias();  // lands before the next sync (vmcnt(0)): the epilogue does not have to wait for it
+      load_bias();  // lands before the next sync: the epilogue does not have to wait for it
       S_KT_END(0, true, if (have_next) { S_STAGE(nxtM, nxtN, 0) })
       S_KT_HEAD(1)
       S_KT_SYNC(0)
@@ -531,6 +531,11 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 23) return launch_sp_epi<EPI_BIAS_BF16, 23>(g, grid, st);
     if (d == 24) return launch_sp_epi<EPI_BIAS_BF16, 24>(g, grid, st);
     if (d == 18) return launch_sp_epi<EPI_BIAS_BF16, 18>(g, grid, st);
+  }
+  if (g.epi == EPI_BIAS_RESID_F32) {
+    const char* dbg = getenv("CLIPX_GEMM_DBG");
+    const int d = dbg ? atoi(dbg) : 0;
+    if (d == 16) return launch_sp_epi<EPI_BIAS_RESID_F32, 16>(g, grid, st);  // phase timer
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);
