@@ -55,10 +55,11 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
                                                           int ntn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool DBG_TIMER = DBG == 16 || DBG == 17 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22 || DBG == 23;
+  constexpr bool DBG_TIMER = DBG == 16 || DBG == 17 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22;
   constexpr bool DBG_L2HOT = DBG == 21;
-  // L2 prefetch distance in K-tiles (0 = off: DBG 22 with the phase timer, 24 without; 23 = distance 3 with timer)
-  constexpr int PFD = (DBG == 22 || DBG == 24) ? 0 : (DBG == 23 ? 3 : 4);
+  // L2 prefetch distance in K-tiles (0 = off: DBG 22 with the phase timer, 24 without).  Every CU prefetching all 512
+  // lines of its K-tile instead of its share of the panels is slower than no prefetch at all (3155 vs 3041 vs 2816 cycles).
+  constexpr int PFD = (DBG == 22 || DBG == 24) ? 0 : 4;
   constexpr int NPF = PFD ? 1 : 0;  // prefetch instructions per wave per K-tile  // every CU stages the operand panels of tile (0, 0) (garbage results)
   constexpr bool DBG_NO_STAGE = DBG == 1 || DBG == 3 || DBG == 19 || DBG == 20;
   constexpr bool DBG_NO_READ = DBG == 3 || DBG == 20;
@@ -528,7 +529,6 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 20) return launch_sp_epi<EPI_BIAS_BF16, 20>(g, grid, st);
     if (d == 21) return launch_sp_epi<EPI_BIAS_BF16, 21>(g, grid, st);
     if (d == 22) return launch_sp_epi<EPI_BIAS_BF16, 22>(g, grid, st);
-    if (d == 23) return launch_sp_epi<EPI_BIAS_BF16, 23>(g, grid, st);
     if (d == 24) return launch_sp_epi<EPI_BIAS_BF16, 24>(g, grid, st);
     if (d == 18) return launch_sp_epi<EPI_BIAS_BF16, 18>(g, grid, st);
   }
