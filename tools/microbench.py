@@ -56,7 +56,7 @@ def time_once(fn, reps):
 
 if "gemm" in what:
     # A/B of GEMM variants: shapes outer, variants interleaved inside each round (same clocks / thermal state),
-    # median over MB_ROUNDS rounds.  MB_VARIANTS = "1,3" or "3:flags" entries (CLIPX_GEMM_FLAGS).
+    # median over MB_ROUNDS rounds.  MB_VARIANTS = "1,3" or "3:dbg" entries (CLIPX_GEMM_DBG ablations of gemm256sp.hip).
     M = 256 * 257
     vspecs = os.environ.get("MB_VARIANTS", "1,3").split(",")
     rounds = int(os.environ.get("MB_ROUNDS", "5"))
@@ -77,9 +77,9 @@ if "gemm" in what:
         def setv(vspec):
             os.environ["CLIPX_GEMM_VARIANT"] = vspec.split(":")[0]
             if ":" in vspec:
-                os.environ["CLIPX_GEMM_FLAGS"] = vspec.split(":")[1]
+                os.environ["CLIPX_GEMM_DBG"] = vspec.split(":")[1]
             else:
-                os.environ.pop("CLIPX_GEMM_FLAGS", None)
+                os.environ.pop("CLIPX_GEMM_DBG", None)
 
         setv(vspecs[0])
         time_once(call, 30)  # clock ramp
