@@ -18,7 +18,19 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 __device__ __forceinline__ float quick_gelu(float v) {
   return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
 }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+// exact-erf GELU (open_clip LAION towers): erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below the bf16 step of
+// the output by four orders of magnitude) on v_rcp_f32 / v_exp_f32: ~14 VALU instructions instead of erff()'s ~30.
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float z = fabsf(v) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float erf_abs = __builtin_fmaf(-p * t, e, 1.f);  // erf(|v| / sqrt 2)
+  return 0.5f * v + 0.5f * fabsf(v) * erf_abs;           // 0.5 v (1 + sign(v) erf(|v|/sqrt 2))
+}
 
 // One accumulator quad of the transposed-product layout both kernels use (MFMA A operand = weight rows, B operand
 // = activation rows): the lane owns output row m and four consecutive columns n..n+3.
