@@ -314,14 +314,18 @@ def train_ivf_centroids(x_f16, nlist, niter=8, seed=0, device=0, max_points_per_
     sample = x_f16[np.sort(rng.choice(n, take, replace=False))] if take < n else x_f16
     cent = sample[rng.choice(sample.shape[0], nlist, replace=False)].astype(np.float32)
     s32 = sample.astype(np.float32)
+    s32t = np.ascontiguousarray(s32.T)
     for _ in range(niter):
         ci = Mi355xIndex(d, device=device, coalesce=False)
         ci.add(cent.astype(np.float16))
         a = _assign(ci, sample)
         ci.close()
-        sums = np.zeros((nlist, d), dtype=np.float64)
-        np.add.at(sums, a, s32)
+        # per-list sums, one weighted bincount per dimension over the transposed sample (float64 accumulation, deterministic;
+        # np.add.at takes ~14 s per iteration at 256 k x 768, this ~1 s)
         cnt = np.bincount(a, minlength=nlist)
+        sums = np.empty((nlist, d), dtype=np.float64)
+        for j in range(d):
+            sums[:, j] = np.bincount(a, weights=s32t[j], minlength=nlist)
         empty = cnt == 0
         cent = (sums / np.maximum(cnt, 1)[:, None]).astype(np.float32)
         if empty.any():  # re-seed empty clusters on random points (faiss splits big clusters; any re-seed is valid)
