@@ -31,7 +31,8 @@ def lib():
 # ------------------------------------------------------------------------------------------ per-kernel
 @pytest.mark.parametrize("variant", [0, 1, 3])
 @pytest.mark.parametrize("M,N,K", [(257, 128, 64), (514, 1024, 1024), (1000, 2304, 768), (130, 768, 3072), (65, 128, 640),
-                                   (33357, 512, 128), (65792, 1024, 1024), (2048, 4096, 1024), (19712, 768, 3072), (16384, 256, 256)])
+                                   (33357, 512, 128), (65792, 1024, 1024), (2048, 4096, 1024), (19712, 768, 3072), (16384, 256, 256),
+                                   (16640, 256, 384), (8192, 1024, 640), (65536, 512, 2048)])
 def test_gemm_epilogues(lib, variant, M, N, K):
     """out = A W^T + b with bf16 operands: reference is the fp32 matmul of the SAME bf16-rounded operands,
     so only accumulation order differs (tol 2e-3 * |row| scale for bf16 outputs = 1 bf16 ulp + sum noise).
