@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
       S_KT_END(0, true, if (have_next) { S_STAGE(nxtM, nxtN, 0) })
       S_KT_HEAD(1)
       S_KT_SYNC(0)
-      S_KT_END(1, false, if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) })  // the next tile's first fragments are read inside the epilogue (24 VGPRs it needs first)
+      S_KT_END(1, false, if (have_next) { S_STAGE(nxtM + 128, nxtN + 128, 1) })  // the next tile's first fragments are read after the epilogue (24 VGPRs it needs first)
       S_PF_NEXT(nk - 2)
       S_PF_NEXT(nk - 1)
       S_STAMP(4)
@@ -330,7 +330,6 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 
     // ---- epilogue of this output tile, transposed through the wave's LDS scratch (the next tile's K-tile 0 has landed,
     // its K-tile 1 is in flight; the bias landed in the scratch before the last K-tile's sync)
-#define S_NEXT_FRAGS() if (have_next) { S_READ(F0, 0, 0) }  // the next tile's first fragment set, read as soon as registers are free
     S_FENCE();
     if (DBG != 5) {
       unsigned char* scr = smem + S_SCRATCH + w * 4096;
@@ -346,7 +345,6 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
           for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + (nt * 32 + 8 * g + 4 * hb) * 4);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          if (mt == 3) { S_NEXT_FRAGS() }
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -408,7 +406,6 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           const int mt = p >> 1, nt = p & 1;
-          if (p == 6) { S_NEXT_FRAGS() }
           if (p < 7) { S_LD_EXT((p + 1) & 1, p + 1) }
           S_FENCE();
 #pragma unroll
@@ -482,7 +479,8 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     if (DBG_TIMER) { S_STAMP(0) ph[6] += 1; }
     if (!have_next) break;
-    if (DBG == 5 || EPI == EPI_TABLE_F32) { S_READ(F0, 0, 0) }  // (the other epilogues read it inside: S_NEXT_FRAGS)
+    S_READ(F0, 0, 0)  // first fragment set of the next tile (its K-tile 0 landed before the barrier of this tile's last K-tile);
+                      // asking for it earlier, inside the epilogue, does not help: hipcc sinks the block behind the last store
     first = true;
     m0 = nm0;
     n0 = nn0;

@@ -49,7 +49,74 @@ def check(path):
             states += (int(nxt.split()[1]) + 1) if nxt.startswith("s_nop") else 1
             if states >= 5:
                 break
+    findings += check_pending_lds_reads(text)
     return findings
+
+
+def vregs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check_pending_lds_reads(text):
+    """An inline-asm ds_read's destination counts as written at the end of the asm statement, so hipcc may touch it before
+    the data lands.  Replay every kernel linearly (no control-flow graph: restart after unconditional branches) with a FIFO
+    of outstanding LDS operations (LDS returns in order;
+    `s_waitcnt lgkmcnt(N)` leaves the N youngest) and flag any instruction OUTSIDE an asm statement that names a VGPR an
+    asm ds_read still has in flight (a v_mov / spill / early MFMA use of a fragment register)."""
+    findings = []
+    kernel, in_asm, fifo = None, False, []
+    for raw in text.split("\n"):
+        l = raw.strip()
+        m = re.match(r"(_Z\S+):", raw)
+        if m:
+            kernel, fifo = m.group(1), []
+            continue
+        if l.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if l.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not l or l.startswith((";", ".")) or l.endswith(":") or kernel is None or "gemm" not in kernel:
+            continue
+        op = l.split()[0]
+        if op == "s_endpgm":
+            kernel = None
+            continue
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", l)
+            if m:
+                n = int(m.group(1))
+                fifo = fifo[len(fifo) - n:] if n else []
+            continue
+        if op == "s_barrier":
+            continue
+        if op == "s_branch":  # what follows is reached from elsewhere: the replay is linear, so start over
+            fifo = []
+            continue
+        if op.startswith(("ds_", "s_load", "s_buffer_load", "s_memtime", "s_memrealtime")):
+            dst = set()
+            if in_asm and op.startswith("ds_read"):
+                dst = vregs(l.split()[1].rstrip(","))
+            fifo.append(dst)
+            if not in_asm:  # a compiler LDS op may of course name its own registers; only asm destinations are tracked
+                continue
+        if in_asm:
+            continue
+        pending = set().union(*fifo) if fifo else set()
+        if not pending:
+            continue
+        used = set()
+        for tok in re.findall(r"v\[\d+:\d+\]|\bv\d+\b", l):
+            used |= vregs(tok)
+        hit = used & pending
+        if hit:
+            findings.append(f"{kernel[:60]}: `{l}` touches v{sorted(hit)[0]}.. while an inline-asm ds_read into it is still in flight")
+    return findings[:20]
 
 
 if __name__ == "__main__":
