@@ -83,9 +83,10 @@ def test_host_merge_is_exact(lib):
 
 
 def test_inline_asm_vmem_hazards():
-    """The persistent GEMM issues its LDS-DMA loads and epilogue stores from inline asm, which hipcc's hazard recognizer
-    does not see: lint the generated gfx950 code for VALU-written SGPRs read too early by a VMEM instruction and for VGPR
-    spills (a scratch reload waits vmcnt(0), i.e. for every store before it).  tools/check_isa.py."""
+    """The GEMM kernels issue their LDS-DMA loads, fragment reads and epilogue stores from inline asm, which hipcc neither
+    counts nor guards: lint the generated gfx950 code for VALU-written SGPRs read too early by a VMEM instruction, for
+    fragment registers touched while their inline-asm ds_read is still in flight, and for VGPR spills in the persistent
+    kernel (a scratch reload waits vmcnt(0), i.e. for every store before it).  tools/check_isa.py."""
     import os
     import shutil
     import subprocess
@@ -94,6 +95,7 @@ def test_inline_asm_vmem_hazards():
     if not shutil.which("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py"),
-                        os.path.join(root, "clip-retrieval_amd", "csrc", "gemm256sp.hip")], capture_output=True, text=True)
+    csrc = os.path.join(root, "clip-retrieval_amd", "csrc")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py"), os.path.join(csrc, "gemm256sp.hip"),
+                        os.path.join(csrc, "clip_kernels.hip")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
