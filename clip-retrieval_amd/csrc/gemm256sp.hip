@@ -13,7 +13,7 @@
 //     register sets; the single s_barrier of the K-tile sits BEFORE the last step's MFMAs:
 //         step 3:  lgkmcnt(0); vmcnt(1)  [K-tile g+1 landed; the L2 prefetch may stay in flight]; s_barrier;
 //                  ds_read step 0 of K-tile g+1; 8 MFMA; stage K-tile g+2 into the buffer just released;
-//                  one dword LDS-DMA that pulls 12 lines of K-tile g+5 into the L2 (see "L2 prefetch" below)
+//                  one dword LDS-DMA that pulls 12 lines of K-tile g+4 into the L2 (see "L2 prefetch" below)
 //     Everything between the barrier and those MFMAs is on the critical path of all 8 waves at once, so the steady
 //     state is branch-free straight-line code: the first and last K-tile pair of a tile (epilogue bookkeeping, next
 //     tile's operands, bias) are separate copies of the K-tile body.
