@@ -18,7 +18,7 @@ static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)
 int main(int argc, char** argv) {
   std::string self = argv[0];
   std::string dir = self.substr(0, self.find_last_of('/') == std::string::npos ? 0 : self.find_last_of('/'));
-  void* h = dlopen(((dir.empty() ? std::string(".") : dir) + "/../clip-retrieval_amd/lib/libclipx.so").c_str(), RTLD_NOW);
+  void* h = dlopen(((dir.empty() ? std::string(".") : dir) + (getenv("CLIPX_LIB") ? std::string("/../clip-retrieval_amd/lib/") + getenv("CLIPX_LIB") : std::string("/../clip-retrieval_amd/lib/libclipx.so"))).c_str(), RTLD_NOW);
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   attn_fn attn = (attn_fn)dlsym(h, "clipx_attention_dh_device");
   const int B = argc > 1 ? atoi(argv[1]) : 256, T = argc > 2 ? atoi(argv[2]) : 257, H = argc > 3 ? atoi(argv[3]) : 16;
