@@ -41,7 +41,7 @@ static void set_cfg(const Cfg& c) {
 int main(int argc, char** argv) {
   std::string self = argv[0];
   std::string dir = self.substr(0, self.find_last_of('/') == std::string::npos ? 0 : self.find_last_of('/'));
-  std::string lib = (dir.empty() ? std::string(".") : dir) + "/../clip-retrieval_amd/lib/libclipx.so";
+  std::string lib = (dir.empty() ? std::string(".") : dir) + "/../clip-retrieval_amd/lib/" + (getenv("CLIPX_LIB") ? getenv("CLIPX_LIB") : "libclipx.so");  // CLIPX_LIB: A/B of two builds
   void* h = dlopen(lib.c_str(), RTLD_NOW);
   if (!h) {
     fprintf(stderr, "dlopen %s: %s\n", lib.c_str(), dlerror());
