@@ -49,14 +49,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // DBG (ablation, EPI_BIAS_BF16 only; garbage results): 1 = no staging, 3 = no staging and no ds_reads,
 // 5 = no epilogue at all, 6 = epilogue without its global stores, 16 = phase timer (correct results),
-// 17 / 18 = stage right behind the barrier (with / without timer), 19 / 20 = phase timer + ablations 1 / 3
+// 19 / 20 = phase timer + ablations 1 / 3, 21 = phase timer + L2-resident operands, 22 / 24 = no L2 prefetch (with / without timer)
 template <int EPI, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
                                                           int ntn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool DBG_TIMER = DBG == 16 || DBG == 17 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22;
+  constexpr bool DBG_TIMER = DBG == 16 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22;
   constexpr bool DBG_L2HOT = DBG == 21;
   // L2 prefetch distance in K-tiles (0 = off: DBG 22 with the phase timer, 24 without).  Every CU prefetching all 512
   // lines of its K-tile instead of its share of the panels is slower than no prefetch at all (3155 vs 3041 vs 2816 cycles).
@@ -205,12 +205,11 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #define S_KT_TAIL(buf, preread)                              \
   if (preread) { S_READ(F0, (buf) ^ 1, 0) }                  \
   S_MFMA(F1)
-#define S_STAGE_LATE (DBG != 17 && DBG != 18)  // A/B: DBG 18 = stage right behind the barrier, 17 = that + phase timer
-// the stage of a K-tile goes behind k-step 3's MFMAs (S_STAGE_LATE) so that its 8 DMA issues overlap with their execution
+// the stage of a K-tile goes behind k-step 3's MFMAs so that its 8 DMA issues overlap with their execution (measured:
+// the same as staging right behind the barrier, 2835 vs 2845 cycles per steady K-tile)
 #define S_KT_END(buf, preread, stage_stmt)                   \
-  if (!S_STAGE_LATE) { stage_stmt }                          \
   S_KT_TAIL(buf, preread)                                    \
-  if (S_STAGE_LATE) { stage_stmt }
+  stage_stmt
 
   const int nk = K >> 6;  // K-tiles per output tile (even, >= 2)
   const char* curM = reinterpret_cast<const char*>(A) + (DBG_L2HOT ? (size_t)0 : (size_t)m0 * K * 2);
@@ -523,13 +522,11 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 5) return launch_sp_epi<EPI_BIAS_BF16, 5>(g, grid, st);
     if (d == 6) return launch_sp_epi<EPI_BIAS_BF16, 6>(g, grid, st);
     if (d == 16) return launch_sp_epi<EPI_BIAS_BF16, 16>(g, grid, st);
-    if (d == 17) return launch_sp_epi<EPI_BIAS_BF16, 17>(g, grid, st);
     if (d == 19) return launch_sp_epi<EPI_BIAS_BF16, 19>(g, grid, st);
     if (d == 20) return launch_sp_epi<EPI_BIAS_BF16, 20>(g, grid, st);
     if (d == 21) return launch_sp_epi<EPI_BIAS_BF16, 21>(g, grid, st);
     if (d == 22) return launch_sp_epi<EPI_BIAS_BF16, 22>(g, grid, st);
     if (d == 24) return launch_sp_epi<EPI_BIAS_BF16, 24>(g, grid, st);
-    if (d == 18) return launch_sp_epi<EPI_BIAS_BF16, 18>(g, grid, st);
   }
   if (g.epi == EPI_BIAS_RESID_F32) {
     const char* dbg = getenv("CLIPX_GEMM_DBG");

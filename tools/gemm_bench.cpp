@@ -154,7 +154,7 @@ int main(int argc, char** argv) {
     typedef int (*dbg_fn)(long long*, int);
     dbg_fn dbgf = (dbg_fn)dlsym(h, "clipx_dbg_phase_cycles");
     for (size_t c = 0; c < cfgs.size() && dbgf; ++c) {
-      if (cfgs[c].d != "16" && cfgs[c].d != "17" && cfgs[c].d != "19" && cfgs[c].d != "20" && cfgs[c].d != "21" && cfgs[c].d != "22" && cfgs[c].d != "23" && cfgs[c].d != "25") continue;
+      if (cfgs[c].d != "16" && cfgs[c].d != "19" && cfgs[c].d != "20" && cfgs[c].d != "21" && cfgs[c].d != "22" && cfgs[c].d != "23" && cfgs[c].d != "25") continue;
       set_cfg(cfgs[c]);
       gemm(0, dA, dW, db, dO, M, N, K, epi, st);
       CK(hipStreamSynchronize(st));
