@@ -251,3 +251,30 @@ def test_reader_runner_writer_match_reference_run(tmp_path):
             # the reference stores absolute paths of its temporary folder: compare base names
             strip = lambda rows: [{k: (os.path.basename(v) if k == "image_path" else v) for k, v in row.items()} for row in rows]  # noqa: E731
             assert list(df.columns) == want["columns"] and strip(got_rows) == strip(want["rows"]), rel
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The newest bench line committed under profiles/ carries every field the driver's contract names (bench.py is only
+    runnable on the GPU box; this guards the JSON schema on the CPU)."""
+    import glob
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logs = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.log")))
+    assert logs, "no bench log committed under profiles/"
+    line = [l for l in open(logs[-1]) if l.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    k = d["knn"]["roofline"]
+    assert k["bound"] == "hbm" and abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-3
+    assert d["parity"]["ok"] is True
