@@ -505,7 +505,9 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 // RECOMP: S^T blocks are computed twice (pass 1: row max only, pass 2: exp + PV) instead of being kept in NKB*16
 // registers, for configurations where one query block per wave and many waves per workgroup pay.
 // =============================================================================================
-template <int DH, int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP>
+// TIMER (CLIPX_ATTN_DBG=9, tools/attn_bench): per-wave shader-cycle totals of staging / S + max / exp + PV / store
+__device__ long long g_attn_phase[8192 * 4];
+template <int DH, int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP, bool TIMER = false>
 __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
                                                               int H, float scale_log2e, int dbg) {
   constexpr int TP = NKB * 32;
@@ -519,6 +521,9 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
   unsigned char* sVt = smem + TP * KROW;    // [DV][VT_STRIDE]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int hb = lane >> 5, l31 = lane & 31;
+  long long tph[4] = {0, 0, 0, 0};
+  long long tst = TIMER ? (long long)__builtin_readcyclecounter() : 0;
+#define A_STAMP(i) if (TIMER) { const long long n_ = (long long)__builtin_readcyclecounter(); tph[i] += n_ - tst; tst = n_; }
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int ld = 3 * H * DH;  // qkv row stride (elements)
   const bf16* qbase = qkv + (size_t)b * T * ld + h * DH;
@@ -602,6 +607,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
   }
   }
   __syncthreads();
+  A_STAMP(0)
   if (dbg == 1) return;  // ablation (CLIPX_ATTN_DBG=1): staging only
 
   const int ksw = (l31 >> 1) & 7;
@@ -649,6 +655,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (mx == -INFINITY) mx = 0.f;  // padded query rows
     const float nmx = -mx * scale_log2e;
+    if (TIMER) { asm volatile("" : "+v"(mx)); A_STAMP(1) }
 
     // ---- per key block: P = exp2(S*c - m*c) -> bf16 (stays in registers as the B operand), then O^T += V^T P^T
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -702,6 +709,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
     float sum = sum2[0] + sum2[1];
     sum += __shfl_xor(sum, 32);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    if (TIMER) { asm volatile("" : "+v"(oacc[0]), "+v"(oacc[NB - 1])); A_STAMP(2) }
     // ---- store: lane owns query qpos, d = 32nb + 8g + 4hb + {0..3}
     if (qpos < T) {
       bf16* orow = out + ((size_t)b * T + qpos) * (H * DH) + h * DH;
@@ -716,7 +724,17 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
           *reinterpret_cast<bf16x4*>(orow + 32 * nb + 8 * g + 4 * hb) = o;
         }
     }
+    A_STAMP(3)
   }
+  if (TIMER && lane == 0 && blockIdx.x * NW + w < 8192) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g_attn_phase[(blockIdx.x * NW + w) * 4 + i] = tph[i];
+  }
+#undef A_STAMP
+}
+
+extern "C" int clipx_dbg_attn_phase(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_phase), (size_t)n * sizeof(long long));
 }
 
 template <int DH, int NKB, int NW, int QPW, bool RECOMP = false>
@@ -765,6 +783,15 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
     case 9: {  // ViT-L/14 image (T=257)
       static const int cfg = getenv("CLIPX_ATTN_CFG") ? atoi(getenv("CLIPX_ATTN_CFG")) : 0;
       if (cfg == 4) return launch_attention_cfg<64, 9, 4, 3>(qkv, out, B, T, H, causal, st);
+      if (cfg == 9 && !causal) {  // phase timer
+        constexpr int KROW = 128, DV = 64;
+        const size_t smem = (size_t)9 * 32 * KROW + (size_t)DV * (9 * 64 + 8);
+        auto kern = attention_kernel<64, 9, 3, 3, false, false, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(B * H), dim3(192), smem, st, qkv, out, T, H, (1.f / 8.f) * 1.4426950408889634f, 0);
+        return hipGetLastError();
+      }
       return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st);
     }
     default: return hipErrorInvalidValue;

@@ -70,5 +70,16 @@ int main(int argc, char** argv) {
   const double fl = 4.0 * B * H * (double)T * T * dh * (causal ? 0.5 : 1.0);
   printf("attention B=%d T=%d H=%d dh=%d causal=%d cfg=%s: median %.1f us (%.1f TFLOP/s), min %.1f us; max |err| vs fp32 CPU on 3 heads %.4g\n", B, T, H, dh,
          causal, getenv("CLIPX_ATTN_CFG") ? getenv("CLIPX_ATTN_CFG") : "-", ts[ts.size() / 2] * 1e3, fl / (ts[ts.size() / 2] * 1e-3) / 1e12, ts[0] * 1e3, maxerr);
+  typedef int (*dbg_fn)(long long*, int);
+  dbg_fn dbgf = (dbg_fn)dlsym(h, "clipx_dbg_attn_phase");
+  if (dbgf && getenv("CLIPX_ATTN_CFG") && atoi(getenv("CLIPX_ATTN_CFG")) == 9) {
+    const int nw = std::min(B * H, 2048) * 3;
+    std::vector<long long> ph((size_t)nw * 4);
+    if (!dbgf(ph.data(), nw * 4)) {
+      double s4[4] = {0, 0, 0, 0};
+      for (int i = 0; i < nw; ++i) for (int j = 0; j < 4; ++j) s4[j] += ph[(size_t)i * 4 + j] / (double)nw;
+      printf("  phases, shader cycles per wave (3 query blocks): staging %.0f | S + max %.0f | exp + PV %.0f | store %.0f\n", s4[0], s4[1], s4[2], s4[3]);
+    }
+  }
   return maxerr < 0.02 ? 0 : 1;
 }
