@@ -53,7 +53,20 @@ SIGNATURES = {
     "knnx_ivf_set_nprobe": (C.c_int, [_P, C.c_int]),
     "knnx_ivf_nlist": (C.c_int, [_P]),
     "knnx_merge_topk_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
-    "knnx_merge_topk_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "knnx_shards_create": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "knnx_shards_adopt": (C.c_int, [C.c_int, _P, _P, _P, C.POINTER(_P)]),
+    "knnx_shards_destroy": (None, [_P]),
+    "knnx_shards_reserve": (C.c_int, [_P, C.c_int64]),
+    "knnx_shards_add_f16": (C.c_int, [_P, _P, C.c_int64]),
+    "knnx_shards_add_f32": (C.c_int, [_P, _P, C.c_int64]),
+    "knnx_shards_synth_fill": (C.c_int, [_P, C.c_int64, C.c_uint64]),
+    "knnx_shards_ntotal": (C.c_int64, [_P]),
+    "knnx_shards_count": (C.c_int, [_P]),
+    "knnx_shards_get": (_P, [_P, C.c_int]),
+    "knnx_shards_search": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "knnx_shards_reconstruct": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "knnx_shards_range_search": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P, _P]),
+    "knnx_get_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "knnx_profile_enable": (C.c_int, [_P, C.c_int]),
     "knnx_profile_get": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "knnx_synth_fill": (C.c_int, [_P, C.c_int64, C.c_uint64]),

@@ -733,9 +733,11 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 #undef A_STAMP
 }
 
+#ifdef CLIPX_ABLATE
 extern "C" int clipx_dbg_attn_phase(long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_phase), (size_t)n * sizeof(long long));
 }
+#endif
 
 template <int DH, int NKB, int NW, int QPW, bool RECOMP = false>
 static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st) {
@@ -743,7 +745,11 @@ static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T,
   const size_t smem = (size_t)NKB * 32 * KROW + (size_t)DV * (NKB * 64 + 8);
   const float scale_log2e = (1.f / sqrtf((float)DH)) * 1.4426950408889634f;
   const dim3 grid(B * H), block(NW * 64);
-  static const int dbg = getenv("CLIPX_ATTN_DBG") ? atoi(getenv("CLIPX_ATTN_DBG")) : 0;  // ablations, see the kernel
+#ifdef CLIPX_ABLATE
+  static const int dbg = getenv("CLIPX_ATTN_DBG") ? atoi(getenv("CLIPX_ATTN_DBG")) : 0;  // ablations (tools build only), see the kernel
+#else
+  constexpr int dbg = 0;
+#endif
   if (causal) {
     auto kern = attention_kernel<DH, NKB, NW, QPW, true, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -781,7 +787,11 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
     case 7: return launch_attention_cfg<64, 7, 4, 2>(qkv, out, B, T, H, causal, st);   // ViT-B/16 image (T=197)
     case 8: return launch_attention_cfg<64, 8, 4, 2>(qkv, out, B, T, H, causal, st);
     case 9: {  // ViT-L/14 image (T=257)
+#ifdef CLIPX_ABLATE
       static const int cfg = getenv("CLIPX_ATTN_CFG") ? atoi(getenv("CLIPX_ATTN_CFG")) : 0;
+#else
+      constexpr int cfg = 0;
+#endif
       if (cfg == 4) return launch_attention_cfg<64, 9, 4, 3>(qkv, out, B, T, H, causal, st);
       if (cfg == 9 && !causal) {  // phase timer
         constexpr int KROW = 128, DV = 64;

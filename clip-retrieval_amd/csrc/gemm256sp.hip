@@ -496,10 +496,12 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   }
 }
 
-// debug hook (not part of include/clipx.h): copies the DBG 16 phase counters of the last launch to the host
+#ifdef CLIPX_ABLATE
+// debug hook (tools build only; not part of include/clipx.h): copies the DBG 16 phase counters of the last launch to the host
 extern "C" int clipx_dbg_phase_cycles(long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sp_phase), (size_t)n * sizeof(long long));
 }
+#endif
 
 template <int EPI, int DBG = 0>
 static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
@@ -516,6 +518,9 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
   if (g.M <= 0 || g.M % 256 != 0 || g.N % 256 != 0 || g.K % 128 != 0 || g.K <= 0) return hipErrorInvalidValue;
   int grid = (n_cu > 0 ? n_cu : 256) & ~7;  // one workgroup per CU; multiple of the 8 XCDs
   if (grid < 8) grid = 8;
+#ifdef CLIPX_ABLATE
+  // Ablation / phase-timer instantiations exist only in the tools build (make ablate -> lib/libclipx_ablate.so); the
+  // product library has no environment switch that changes what the hot path computes.
   if (g.epi == EPI_BIAS_BF16) {
     const char* dbg = getenv("CLIPX_GEMM_DBG");
     const int d = dbg ? atoi(dbg) : 0;
@@ -535,6 +540,7 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     const int d = dbg ? atoi(dbg) : 0;
     if (d == 16) return launch_sp_epi<EPI_BIAS_RESID_F32, 16>(g, grid, st);  // phase timer
   }
+#endif
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);
     case EPI_BIAS_QGELU_BF16: return launch_sp_epi<EPI_BIAS_QGELU_BF16>(g, grid, st);

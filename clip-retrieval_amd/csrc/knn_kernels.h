@@ -40,6 +40,7 @@ struct ScanArgs {
   const unsigned* nwork;
   int wide;              // 1: QB = 2 wide scan (64 queries, approximate scores; flat top-k only)
   const unsigned* gate;  // run only if *gate != 0 (null: always)
+  int tstride;           // flat scans: visit every tstride-th 32-row tile only (0 / 1 = all): the sample pass of the RQ scan
 };
 
 size_t scan_smem_bytes(int d, int cap, int nq_slots);
@@ -48,7 +49,7 @@ hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* 
 hipError_t launch_maxnorm(const _Float16* X, int64_t n, int d, int* maxnorm_enc, hipStream_t st);
 hipError_t launch_rescore(const _Float16* X, int d, const float* q, const int64_t* cand, const float* approx, int nq, int kw,
                           int k, int64_t id_base, const int* maxnorm_enc, float* D, int64_t* I, unsigned* need, unsigned* gate,
-                          hipStream_t st);
+                          unsigned long long* stats, hipStream_t st);
 hipError_t launch_select(const unsigned* need, int q0, int nq, int k, const float* Dfb, const int64_t* Ifb, float* D, int64_t* I,
                          hipStream_t st);
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st);
@@ -66,11 +67,30 @@ hipError_t launch_gather_inv(const _Float16* X, int d, int64_t id_lo, int64_t n_
                              int64_t n, float* out, hipStream_t st);
 hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
                             int64_t* I, hipStream_t st);
+hipError_t launch_merge_sorted(const float* Dp, const int64_t* Ip, int P, int n, int k, float* D, int64_t* I, hipStream_t st);
 hipError_t launch_gather(const _Float16* X, int64_t N, int d, int64_t id_base, const int64_t* ids, int64_t n,
                          float* out, hipStream_t st);
 hipError_t launch_f32_to_f16(const float* in, _Float16* out, int64_t n, hipStream_t st);
 hipError_t launch_range_sort(const float* rs, const uint32_t* ri, const unsigned* cnt, unsigned cap,
                              const int64_t* lims, int64_t id_base, int nq, float* D, int64_t* I, hipStream_t st);
 hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st);
+
+// ---- register-stationary-queries (RQ) scan, knn_rq_kernels.hip: up to rq_queries_per_pass(d) queries per pass over HBM
+constexpr int KNN_RQ_MAX = 256;        // queries of one RQ pass at d <= 768 (128 at d = 1024)
+constexpr int KNN_RQ_STRIDE = 128;     // the sample pass visits every 128th 32-row tile
+constexpr int KNN_RQ_MARGIN = 8;       // threshold = (k + 8)-th best sample score
+constexpr unsigned KNN_RQ_CAP = 16384; // hit list entries per query (expected (k + 8) * 128 ~ 6 k at k = 40)
+constexpr int64_t KNN_RQ_MIN_ROWS = (int64_t)1 << 21;  // below this the 64-query scan is used
+int rq_queries_per_pass(int d);  // 0: no RQ kernel for this d
+hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float* thr,
+                          unsigned* cnt, unsigned* lost, hipStream_t st);
+hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, const _Float16* qfrag, const float* thr, unsigned* cnt,
+                          unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
+                          hipStream_t st);
+hipError_t launch_rq_rescore(const _Float16* X, int d, const float* q, int nq, const unsigned* cnt, unsigned cap, float* hit_s,
+                             const uint32_t* hit_r, int* cntc, hipStream_t st);
+hipError_t launch_rq_proof(const float* q, int nq, int d, int k, const float* D, const float* thr, const unsigned* cnt,
+                           unsigned cap, const unsigned* lost, const int* maxnorm, unsigned* need, unsigned* gate,
+                           unsigned long long* stats, hipStream_t st);
 
 }  // namespace knnx

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     int* __restrict__ thr_g, float* __restrict__ part_s, uint32_t* __restrict__ part_i, int* __restrict__ part_n,
     float range_thr, unsigned* __restrict__ range_cnt, unsigned range_cap, float* __restrict__ range_s,
     uint32_t* __restrict__ range_i, const uint4* __restrict__ work, const unsigned* __restrict__ nwork_ptr,
-    const unsigned* __restrict__ gate) {
+    const unsigned* __restrict__ gate, int tstride) {
   constexpr int D = NCH * 128;
   constexpr int KS = D / 16;
   constexpr int NQ = 32 * QB;  // queries (= queues, thresholds) of this scan
@@ -175,7 +175,9 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
   }
   __syncthreads();
 
-  const int64_t ntile = IVF ? (int64_t)*nwork_ptr : (N + 31) >> 5;  // IVF: number of work items
+  // tstride > 1 (flat scans): only every tstride-th 32-row tile is visited -- the strided SAMPLE of the index from which
+  // the register-stationary scan (knn_rq_kernels.hip) takes its per-query thresholds
+  const int64_t ntile = IVF ? (int64_t)*nwork_ptr : (((N + 31) >> 5) + tstride - 1) / tstride;  // IVF: number of work items
   const int64_t ngroup = (ntile + KNN_WAVES - 1) / KNN_WAVES;
 
   half8 a0[8], a1[8];
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     if (IVF) {
       row = (int64_t)it_nxt.x * 32 + q;  // the arena is padded to whole tiles: always in range
     } else {
-      row = (grp * KNN_WAVES + w) * 32 + q;
+      row = (grp * KNN_WAVES + w) * (int64_t)tstride * 32 + q;
       row = row < N ? row : N - 1;
     }
     return reinterpret_cast<const half8*>(X + (size_t)row * D) + hb;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     xp = xnext;
 
     // ---- filter: lane (q, hb) owns rows row0 + (r&3) + 8*(r>>2) + 4*hb of query q
-    const int64_t row0 = (IVF ? (int64_t)it_cur.x : grp * KNN_WAVES + w) * 32 + 4 * hb;
+    const int64_t row0 = (IVF ? (int64_t)it_cur.x : (grp * KNN_WAVES + w) * (int64_t)tstride) * 32 + 4 * hb;
     // IVF: rows of this tile beyond the list's size are padding; the query must probe the tile's list
     const int64_t row_lim = IVF ? (int64_t)it_cur.x * 32 + (int64_t)it_cur.z : N;
     const bool q_ok = q < nq && (!IVF || ((it_cur.y >> q) & 1u));
@@ -563,18 +565,19 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const _Float16* __rest
                                                          unsigned* __restrict__ need) {
   __shared__ float s_sc[64];
   __shared__ long long s_id[64];
-  __shared__ float s_red[4];
+  __shared__ float s_red[4], s_qn[4];
   const int qq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* qv = q + (size_t)qq * d;
-  // |q - fp16(q)|^2
-  float e2 = 0.f;
+  // |q - fp16(q)|^2 and |q|^2
+  float e2 = 0.f, n2 = 0.f;
   for (int c = tid; c < d; c += 256) {
     const float v = qv[c];
     const float r = v - (float)(_Float16)v;
     e2 += r * r;
+    n2 += v * v;
   }
-  for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
-  if (lane == 0) s_red[w] = e2;
+  for (int o = 32; o > 0; o >>= 1) { e2 += __shfl_xor(e2, o); n2 += __shfl_xor(n2, o); }
+  if (lane == 0) { s_red[w] = e2; s_qn[w] = n2; }
   for (int j = w; j < kw; j += 4) {
     const int64_t row = cand[(size_t)qq * kw + j];
     float acc = 0.f;
@@ -607,7 +610,9 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const _Float16* __rest
     }
     if (r == (k < nvalid ? k : nvalid) - 1 || (nvalid == 0 && tid == 0)) {
       // this thread holds the k-th best exact score (or the last valid one)
-      const float eps = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]) * dec_f(*maxnorm);
+      // eps bounds |approx - exact| for every row: the fp16 rounding of the query (|q - fp16(q)| * |x|) plus the
+      // accumulation-order difference between the MFMA score and the FMA re-score (<= d * 2^-24 * |q| * |x| each)
+      const float eps = (sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]) + (float)d * 1.2e-7f * sqrtf(s_qn[0] + s_qn[1] + s_qn[2] + s_qn[3])) * dec_f(*maxnorm);
       const bool all_in = nvalid < kw;  // the index has fewer than kw rows for this query: nothing is outside
       const float a_last = approx[(size_t)qq * kw + kw - 1];
       const bool proven = all_in || (nvalid >= k && a_last + eps < se);
@@ -617,13 +622,19 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const _Float16* __rest
 }
 
 // gate[b] = any(need[32b .. 32b+31]) for the two 32-query halves of a wide scan
-__global__ void knn_gates_kernel(const unsigned* __restrict__ need, int nq, unsigned* __restrict__ gate) {
+// stats (may be null): [0] += queries served, [1] += proofs that failed (read by knnx_get_stats)
+__global__ void knn_gates_kernel(const unsigned* __restrict__ need, int nq, unsigned* __restrict__ gate,
+                                 unsigned long long* __restrict__ stats) {
   const int lane = threadIdx.x;  // 64 threads
   const unsigned v = lane < nq ? need[lane] : 0u;
   const unsigned long long m = __ballot(v != 0);
   if (lane == 0) {
     gate[0] = (unsigned)(m & 0xffffffffull) ? 1u : 0u;
     gate[1] = (unsigned)(m >> 32) ? 1u : 0u;
+    if (stats) {
+      atomicAdd(&stats[0], (unsigned long long)nq);
+      atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(m));
+    }
   }
 }
 
@@ -767,9 +778,9 @@ hipError_t launch_maxnorm(const _Float16* X, int64_t n, int d, int* maxnorm, hip
 }
 hipError_t launch_rescore(const _Float16* X, int d, const float* q, const int64_t* cand, const float* approx, int nq, int kw,
                           int k, int64_t id_base, const int* maxnorm, float* D, int64_t* I, unsigned* need, unsigned* gate,
-                          hipStream_t st) {
+                          unsigned long long* stats, hipStream_t st) {
   hipLaunchKernelGGL(knn_rescore_kernel, dim3(nq), dim3(256), 0, st, X, d, q, cand, approx, kw, k, id_base, maxnorm, D, I, need);
-  hipLaunchKernelGGL(knn_gates_kernel, dim3(1), dim3(64), 0, st, need, nq, gate);
+  hipLaunchKernelGGL(knn_gates_kernel, dim3(1), dim3(64), 0, st, need, nq, gate, stats);
   return hipGetLastError();
 }
 hipError_t launch_select(const unsigned* need, int q0, int nq, int k, const float* Dfb, const int64_t* Ifb, float* D, int64_t* I,
@@ -790,7 +801,7 @@ static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;                                                                              \
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(KNN_WG), smem, st, a.X, a.N, a.qfrag, a.nq, a.k, a.cap,         \
                        a.thr_g, a.part_s, a.part_i, a.part_n, a.range_thr, a.range_cnt, a.range_cap, a.range_s, \
-                       a.range_i, a.work, a.nwork, a.gate);                                                     \
+                       a.range_i, a.work, a.nwork, a.gate, a.tstride > 1 ? a.tstride : 1);                      \
     return hipGetLastError();                                                                                   \
   }
   switch (a.d) {
@@ -833,6 +844,44 @@ hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, i
                      (const int64_t*)nullptr, D, I, (const unsigned*)nullptr);
   return hipGetLastError();
 }
+// P-way merge of P sorted lists per query (score desc, id asc; id < 0 = padding at the tail of a list) -> the sorted top-k.
+// One thread per query, k * P steps: the large-k (k > 64) exchange of the in-process sharded index (rare: the front-end's
+// num_result_ids = 3000 requests), where a handful of queries carry a few thousand results each.
+__global__ void knn_merge_sorted_kernel(const float* __restrict__ Dp, const int64_t* __restrict__ Ip, int P, int n, int k,
+                                        float* __restrict__ D, int64_t* __restrict__ I) {
+  const int qq = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qq >= n) return;
+  int head[64];
+  for (int p = 0; p < P; ++p) head[p] = 0;
+  for (int j = 0; j < k; ++j) {
+    int best = -1;
+    float bs = 0.f;
+    int64_t bi = 0;
+    for (int p = 0; p < P; ++p) {
+      if (head[p] >= k) continue;
+      const size_t o = ((size_t)p * n + qq) * k + head[p];
+      const int64_t id = Ip[o];
+      if (id < 0) continue;
+      const float sc = Dp[o];
+      if (best < 0 || sc > bs || (sc == bs && id < bi)) { best = p; bs = sc; bi = id; }
+    }
+    if (best < 0) {
+      D[(size_t)qq * k + j] = -FLT_MAX;
+      I[(size_t)qq * k + j] = -1;
+    } else {
+      D[(size_t)qq * k + j] = bs;
+      I[(size_t)qq * k + j] = bi;
+      head[best]++;
+    }
+  }
+}
+hipError_t launch_merge_sorted(const float* Dp, const int64_t* Ip, int P, int n, int k, float* D, int64_t* I, hipStream_t st) {
+  if (P <= 0 || P > 64) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(knn_merge_sorted_kernel, dim3((n + 63) / 64), dim3(64), 0, st, Dp, Ip, P, n, k, D, I);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather(const _Float16* X, int64_t N, int d, int64_t id_base, const int64_t* ids, int64_t n,
                          float* out, hipStream_t st) {
   if (n == 0) return hipSuccess;

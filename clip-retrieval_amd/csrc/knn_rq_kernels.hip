@@ -1,0 +1,408 @@
+// knn_rq_kernels.hip -- the "register-stationary queries" (RQ) flat scan: up to 256 queries per pass over HBM.
+//
+// Stands in for the same faiss `IndexFlatIP.search` arithmetic as knn_kernels.hip (reference call sites
+// clip_retrieval/clip_back.py:362, clip_filter.py:55), for LARGE query batches (B > 64: SURVEY config 3 asks for B = 256).
+//
+// Why a second scan kernel.  The scan of knn_kernels.hip keeps the queries as the stationary MFMA operand in LDS and
+// streams index rows HBM -> VGPR.  128 queries x 768 x fp16 = 192 KiB do not fit the 160 KiB of LDS, so that design
+// stops at 64 queries per pass (2 470 QPS at 100 M rows, 0.19 of the B = 256 ceiling).  The only on-chip store large
+// enough for more queries is the register file (512 KiB per CU), and a register operand is private to its wave.  So the
+// roles are swapped:
+//   * every wave keeps ITS OWN 32 x QBW queries in registers for the whole kernel (fp16 "hi" parts as MFMA B fragments:
+//     QBW x d/16 x 4 VGPRs = 384 at d = 768, QBW = 2; one wave per SIMD, 512 registers each);
+//   * index rows go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4; no VGPRs, fragment-shaped so that the LDS image of a
+//     k-step is lane-linear: ds_read_b128 at <slot> + 1 KiB * kstep + 16 * lane is conflict-free) into a ring of 32-row
+//     tiles, and ALL waves of the workgroup read every tile: an X byte is fetched from HBM once and used by 4 waves x 64
+//     queries.  One s_barrier per tile; the DMA of tile t+2 is issued while tile t is being multiplied.
+//   * no LDS candidate queues (they were 80 B x 64 entries per query: another 160 KiB at 256 queries).  The scan is a
+//     RANGE scan with one threshold per query: a lane owns one query column of the 32 x 32 score tile and compares its 16
+//     scores with that query's threshold held in a register; hits (a few thousand per query per scan) are compacted by
+//     wave ballot into a small wave-private LDS staging list and flushed to per-query global hit lists.
+//   The thresholds come from a SAMPLE pass: the 64-query scan of knn_kernels.hip over every S-th tile (1/S of the bytes);
+//   the threshold of a query is the J-th best approximate score of the sample, J = k + 8.  Sample rows are index rows, so
+//   at least J >= k rows reach the threshold -- deterministically, whatever the data distribution -- and about J * S do.
+//   Afterwards the hits are re-scored exactly (fp32 FMA, the arithmetic of knn_rescore_kernel), the top-k selected by
+//   (score desc, id asc), and exactness is PROVEN per query: every row that is not a hit has approximate score < thr,
+//   hence exact score < thr + eps; if the k-th exact score among the hits is >= thr + eps no outsider belongs to the
+//   top-k.  A query whose proof fails (hit list overflow, or a k-th score within eps of the threshold) is re-run by the
+//   exact 32-query scan, gated on the device like the fallback of the 64-query wide scan.
+//
+// HBM-bound as long as the matrix pipe keeps up: per 32-row tile (48 KiB at d = 768) a SIMD issues 96
+// v_mfma_f32_32x32x16_f16 = 3 072 cycles; at ~6 TB/s a CU receives a tile every 2.05 us, i.e. the kernel stays on the
+// HBM roof while the shader clock is >= 1.5 GHz.  Algorithmic bytes per launch: N * d * 2 (the same as the 64-query scan).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <algorithm>
+#include "knn_kernels.h"
+
+namespace knnx {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int rq_enc_f(float f) {
+  int b = __float_as_int(f);
+  return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+__device__ __forceinline__ float rq_dec_f(int e) { return __int_as_float(e >= 0 ? e : (e ^ 0x7fffffff)); }
+
+// ---------------------------------------------------------------------------------------------
+// prep: f32 queries -> fp16-hi B fragments in wave-block order; thresholds from the sample pass; counters reset
+//   qfrag [nblk][KS][64 lanes][8 halves]: block b = queries 32b .. 32b+31; lane (n = l & 31, h = l >> 5) holds
+//   q_n[16 s + 8 h + j].  thr[q] = J-th best sample score (samp [nq, kw] descending, -FLT_MAX padded; fewer than J sample
+//   rows -> -inf: every row is a hit, which only happens on indexes far too small for this path); unused columns +inf.
+// ---------------------------------------------------------------------------------------------
+__global__ void knn_rq_prep_kernel(const float* __restrict__ q, int nq, int d, int nblk, _Float16* __restrict__ qfrag,
+                                   const float* __restrict__ samp, int kw, int J, float* __restrict__ thr,
+                                   unsigned* __restrict__ cnt, unsigned* __restrict__ lost) {
+  const int s = blockIdx.x, b = blockIdx.y;  // k-step, query block
+  const int lane = threadIdx.x;
+  const int n = 32 * b + (lane & 31), h = lane >> 5;
+  half8 hi;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) hi[j] = (n < nq) ? (_Float16)q[(size_t)n * d + 16 * s + 8 * h + j] : (_Float16)0.f;
+  reinterpret_cast<half8*>(qfrag)[((size_t)b * gridDim.x + s) * 64 + lane] = hi;
+  if (s == 0 && lane < 32) {
+    float t = INFINITY;
+    if (n < nq) {
+      const float v = samp[(size_t)n * kw + (J - 1)];
+      t = v > -FLT_MAX ? v : -INFINITY;
+    }
+    thr[n] = t;
+    cnt[n] = 0u;
+    lost[n] = 0u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the scan
+// ---------------------------------------------------------------------------------------------
+constexpr int RQ_STAGE = 256;   // entries of a wave's private staging list
+constexpr int RQ_FLUSH_AT = 96; // flush when at least this many are staged (a tile step adds a handful)
+
+// This wave's share of the LDS-DMA of tile `t` into ring slot `slot`.  Inline asm: hipcc must not know about the DMA, or
+// it drains vmcnt(0) before every LDS read; s_nop 0: M0 needs a wait state before the DMA reads it.  Past the end of the
+// index the last tile is re-loaded, which keeps the vmcnt arithmetic of the main loop uniform.
+template <int KS, int NW>
+__device__ __forceinline__ void rq_issue(const _Float16* __restrict__ X, int64_t t, int64_t ntile, int64_t last, unsigned voff,
+                                         unsigned voff_last, unsigned lds_base, int slot, int w) {
+  constexpr int TILE_BYTES = KS * 1024, GPW = KS / 4 / NW;
+  const int64_t tt = t < ntile ? t : last;
+  const unsigned vo = tt == last ? voff_last : voff;
+  // wave w takes the k-step groups w, w + NW, ...: its offsets inside the tile are <wave base> + a literal
+  const char* base = reinterpret_cast<const char*>(X) + (size_t)tt * TILE_BYTES + w * 128;
+  const unsigned m0b = lds_base + slot * TILE_BYTES + w * 4096;
+#pragma unroll
+  for (int g = 0; g < GPW; ++g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const char* p = base + (g * NW * 4 + j) * 32;  // k-step (g NW + w) 4 + j
+      asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(p), "s"(m0b),
+                   "n"((g * NW * 4 + j) * 1024)
+                   : "memory", "scc");
+    }
+  }
+}
+
+// KS = d / 16 k-steps; QBW = 32-query blocks per wave (1 or 2); NW = waves per workgroup (one per SIMD); NSLOT = ring slots
+template <int KS, int QBW, int NW, int NSLOT>
+__global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
+    const _Float16* __restrict__ X, int64_t N, const _Float16* __restrict__ qfrag, const float* __restrict__ thr,
+    unsigned* __restrict__ g_cnt, unsigned cap, float* __restrict__ hit_s, uint32_t* __restrict__ hit_r,
+    unsigned* __restrict__ g_lost, const unsigned* __restrict__ gate) {
+  constexpr int D = KS * 16;
+  constexpr int TILE_BYTES = KS * 1024;        // 32 rows x D x 2 B, stored as KS lane-linear 1 KiB k-step blocks
+  constexpr int GROUPS = KS / 4;               // DMA work unit: 4 consecutive k-steps = the same 128-B lines of 32 rows
+  constexpr int GPW = GROUPS / NW;             // groups per wave per tile
+  constexpr int DPW = GPW * 4;                 // DMA instructions per wave per tile
+  static_assert(GROUPS % NW == 0, "k-step groups must divide evenly among the waves");
+  if (gate && *gate == 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS map: NSLOT tiles, then per-wave staging lists {score, row, query}[RQ_STAGE]
+  unsigned char* stage = smem + NSLOT * TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qcol = lane & 31, hb = lane >> 5;
+  float* st_s = reinterpret_cast<float*>(stage + w * RQ_STAGE * 12);
+  uint32_t* st_r = reinterpret_cast<uint32_t*>(st_s + RQ_STAGE);
+  uint32_t* st_q = st_r + RQ_STAGE;
+
+  // ---- this wave's queries: B fragments for the whole kernel, and the thresholds of this lane's query columns
+  half8 Q[QBW][KS];
+  float tq[QBW];
+#pragma unroll
+  for (int b = 0; b < QBW; ++b) {
+    const int blk = w * QBW + b;
+    const half8* src = reinterpret_cast<const half8*>(qfrag) + (size_t)blk * KS * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) Q[b][s] = src[s * 64];
+    tq[b] = thr[blk * 32 + qcol];
+  }
+  // every fragment is "used" here once, so hipcc waits for these loads HERE: otherwise it counts them down at their first
+  // uses inside the tile loop, and the last of those waits (vmcnt(0)) would drain the DMA ring on every tile
+#pragma unroll
+  for (int b = 0; b < QBW; ++b) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      // the second block lives in accumulation registers for good (MFMA reads B operands from either file; without the
+      // constraint hipcc "spills" them to AGPRs and copies 4 registers back before every MFMA)
+      if (b == 0) asm volatile("" : "+v"(Q[b][s]));
+      else asm volatile("" : "+a"(Q[b][s]));
+    }
+    asm volatile("" : "+v"(tq[b]));
+  }
+
+  const int64_t ntile = (N + 31) >> 5;
+  const int64_t last = ntile - 1;
+  // lane offset of a fragment-shaped DMA: lane (row = l & 31, h = l >> 5) fetches 16 B of row `row` at column 8 h of the
+  // k-step; the k-step (32 B) and the tile are added to the SGPR base.  The last tile may be ragged: rows >= N re-read
+  // row N - 1 (never admitted by the filter).
+  const unsigned voff = (unsigned)(qcol * D * 2 + hb * 16);
+  const int lrow = (int)(N - 1 - last * 32);  // last valid row inside the last tile
+  const unsigned voff_last = (unsigned)((qcol < lrow ? qcol : lrow) * D * 2 + hb * 16);
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+
+  // issue this wave's share of tile `t` into ring slot `slot`: rq_issue() above (a lambda capturing by reference makes
+  // hipcc keep the closure in scratch memory)
+#define RQ_ISSUE(t_, slot_) rq_issue<KS, NW>(X, (t_), ntile, last, voff, voff_last, lds_base, (slot_), w)
+
+  int64_t t = blockIdx.x;
+  const int64_t gstride = gridDim.x;
+  // prologue: NSLOT - 1 tiles in flight
+#pragma unroll
+  for (int i = 0; i < NSLOT - 1; ++i) RQ_ISSUE(t + (int64_t)i * gstride, i);
+
+  int nst = 0;  // entries in this wave's staging list (wave-uniform)
+  int slot = 0;
+  for (; t < ntile; t += gstride) {
+    // tile t has landed (this wave's share: all but the DPW * (NSLOT - 2) youngest DMAs are done), then everyone's
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NSLOT - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {  // refill the slot that tile t - 1 (of this workgroup's sequence) occupied: every wave is past it
+      const int rs = slot == 0 ? NSLOT - 1 : slot - 1;
+      RQ_ISSUE(t + (int64_t)(NSLOT - 1) * gstride, rs);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float16v acc[QBW];
+#pragma unroll
+    for (int b = 0; b < QBW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    // A fragments (index rows) through a 4-deep register ring, three k-steps ahead of the MFMAs that use them.  The reads
+    // are inline asm so that THIS file places the lgkmcnt waits (hipcc waits lgkmcnt(0) right behind each read, which
+    // puts the LDS latency of every k-step in front of its MFMAs).
+    const unsigned xa = lds_base + slot * TILE_BYTES + lane * 16;
+    i32x4 A[4];
+#define RQ_DSREAD(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(xa), "n"(off))
+    RQ_DSREAD(A[0], 0);
+    RQ_DSREAD(A[1], 1024);
+    RQ_DSREAD(A[2], 2048);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 3 < KS) {
+        switch ((s + 3) & 3) {  // folds after unrolling; the offset must be a literal
+          case 0: RQ_DSREAD(A[0], ((s + 3) * 1024) & 0xffff); break;
+          case 1: RQ_DSREAD(A[1], ((s + 3) * 1024) & 0xffff); break;
+          case 2: RQ_DSREAD(A[2], ((s + 3) * 1024) & 0xffff); break;
+          default: RQ_DSREAD(A[3], ((s + 3) * 1024) & 0xffff); break;
+        }
+      }
+      const int ahead = KS - 1 - s < 3 ? KS - 1 - s : 3;  // reads issued after the one this step needs
+      if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+      else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < QBW; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A[s & 3]), Q[b][s], acc[b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef RQ_DSREAD
+
+    // ---- filter: lane (qcol, hb) owns rows row0 + (r & 3) + 8 (r >> 2) of its query column in each block
+    const int64_t row0 = t * 32 + 4 * hb;
+    bool any = false;
+#pragma unroll
+    for (int b = 0; b < QBW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) any |= acc[b][r] >= tq[b];
+    if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // a hit somewhere in the wave: ~1 tile step in 8
+#pragma unroll
+      for (int b = 0; b < QBW; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+          const bool hit = acc[b][r] >= tq[b] && row < N;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+          if (m != 0ull) {
+            const int pos = nst + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned qq = (unsigned)((w * QBW + b) * 32 + qcol);
+            if (hit) {
+              if (pos < RQ_STAGE) {
+                st_s[pos] = acc[b][r];
+                st_r[pos] = (uint32_t)row;
+                st_q[pos] = qq;
+              } else {
+                g_lost[qq] = 1u;  // staging overflow (flood of hits in one tile step): the query falls back
+              }
+            }
+            nst += __builtin_popcountll(m);
+          }
+        }
+      }
+      if (nst > RQ_STAGE) nst = RQ_STAGE;
+      if (nst >= RQ_FLUSH_AT) {
+        for (int i = lane; i < nst; i += 64) {
+          const unsigned qq = st_q[i];
+          const unsigned pos = atomicAdd(&g_cnt[qq], 1u);
+          if (pos < cap) {
+            hit_s[(size_t)qq * cap + pos] = st_s[i];
+            hit_r[(size_t)qq * cap + pos] = st_r[i];
+          }
+        }
+        nst = 0;
+      }
+      // the branch issued VMEM operations hipcc counts itself; drain so that the DMA arithmetic at the loop top holds
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+  }
+  // drain the DMAs still in flight (tail reloads) before the LDS is released, then the last staged hits
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int i = lane; i < nst; i += 64) {
+    const unsigned qq = st_q[i];
+    const unsigned pos = atomicAdd(&g_cnt[qq], 1u);
+    if (pos < cap) {
+      hit_s[(size_t)qq * cap + pos] = st_s[i];
+      hit_r[(size_t)qq * cap + pos] = st_r[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact re-scoring of the hits, in place: one wave per hit, fp32 FMA chain over the lane's columns then a butterfly --
+// the arithmetic of knn_rescore_kernel, so D does not depend on which path served the query.  grid = (chunks, nq).
+// Also writes cntc[q] = min(cnt[q], cap) for the selection kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_rq_rescore_kernel(const _Float16* __restrict__ X, int d, const float* __restrict__ q,
+                                                            const unsigned* __restrict__ cnt, unsigned cap,
+                                                            float* __restrict__ hit_s, const uint32_t* __restrict__ hit_r,
+                                                            int* __restrict__ cntc) {
+  const int qq = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned n = cnt[qq] < cap ? cnt[qq] : cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) cntc[qq] = (int)n;
+  const float* qv = q + (size_t)qq * d;
+  float qreg[16];  // d <= 1024: the lane's query columns
+#pragma unroll
+  for (int e = 0; e < 16; ++e) qreg[e] = (e * 64 + lane) < d ? qv[e * 64 + lane] : 0.f;
+  for (unsigned i = blockIdx.x * 4 + w; i < n; i += gridDim.x * 4) {
+    const _Float16* xr = X + (size_t)hit_r[(size_t)qq * cap + i] * d;
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (e * 64 + lane < d) acc = __builtin_fmaf((float)xr[e * 64 + lane], qreg[e], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) hit_s[(size_t)qq * cap + i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// proof: need[q] = 0 iff the top-k of query q is proven exact (see the file header); gate[g] = any need in queries
+// 32g .. 32g+31.  D [nq, k] is the exact top-k of the hits (knn_merge_kernel).  One 256-thread workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_rq_proof_kernel(const float* __restrict__ q, int nq, int d, int k,
+                                                          const float* __restrict__ D, const float* __restrict__ thr,
+                                                          const unsigned* __restrict__ cnt, unsigned cap,
+                                                          const unsigned* __restrict__ lost, const int* __restrict__ maxnorm,
+                                                          unsigned* __restrict__ need, unsigned* __restrict__ gate,
+                                                          unsigned long long* __restrict__ stats) {
+  __shared__ unsigned s_need[256];
+  const int qq = threadIdx.x;
+  unsigned nd = 0u;
+  if (qq < nq) {
+    const float* qv = q + (size_t)qq * d;
+    float e2 = 0.f, n2 = 0.f;
+    for (int c = 0; c < d; ++c) {
+      const float v = qv[c];
+      const float r = v - (float)(_Float16)v;
+      e2 += r * r;
+      n2 += v * v;
+    }
+    // |approx - exact| <= eps for every row: fp16 rounding of the query + accumulation-order slack (cf. knn_rescore_kernel)
+    const float eps = (sqrtf(e2) + (float)d * 1.2e-7f * sqrtf(n2)) * rq_dec_f(*maxnorm);
+    const float t = thr[qq];
+    const bool complete = cnt[qq] <= cap && lost[qq] == 0u;  // every row that reached the threshold was re-scored
+    const float dk = D[(size_t)qq * k + (k - 1)];            // k-th exact score among the hits (-FLT_MAX: fewer than k)
+    const bool all_rows = !(t > -INFINITY);                  // threshold -inf: the hits are the whole index
+    const bool proven = complete && (all_rows || (dk > -FLT_MAX && dk >= t + eps));
+    nd = proven ? 0u : 1u;
+    need[qq] = nd;
+  }
+  s_need[threadIdx.x] = nd;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    unsigned g = 0u;
+    for (int i = 0; i < 32; ++i) g += s_need[threadIdx.x * 32 + i];
+    gate[threadIdx.x] = g ? 1u : 0u;
+    if (stats && g) atomicAdd(&stats[1], (unsigned long long)g);
+  }
+  if (threadIdx.x == 0 && stats) atomicAdd(&stats[0], (unsigned long long)nq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int rq_queries_per_pass(int d) { return d == 1024 ? 128 : (d == 512 || d == 768 ? 256 : 0); }
+
+hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float* thr,
+                          unsigned* cnt, unsigned* lost, hipStream_t st) {
+  const int nblk = rq_queries_per_pass(d) / 32;
+  hipLaunchKernelGGL(knn_rq_prep_kernel, dim3(d / 16, nblk), dim3(64), 0, st, q_dev, nq, d, nblk, qfrag, samp, kw, J, thr, cnt, lost);
+  return hipGetLastError();
+}
+
+template <int KS, int QBW, int NW, int NSLOT>
+static hipError_t launch_rq_scan_cfg(const _Float16* X, int64_t N, const _Float16* qfrag, const float* thr, unsigned* cnt,
+                                     unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
+                                     hipStream_t st) {
+  const size_t smem = (size_t)NSLOT * KS * 1024 + (size_t)NW * RQ_STAGE * 12;
+  auto kern = knn_rq_scan_kernel<KS, QBW, NW, NSLOT>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate);
+  return hipGetLastError();
+}
+
+hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, const _Float16* qfrag, const float* thr, unsigned* cnt,
+                          unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
+                          hipStream_t st) {
+  switch (d) {
+    case 512: return launch_rq_scan_cfg<32, 2, 4, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+    case 768: return launch_rq_scan_cfg<48, 2, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+    case 1024: return launch_rq_scan_cfg<64, 1, 4, 2>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_rq_rescore(const _Float16* X, int d, const float* q, int nq, const unsigned* cnt, unsigned cap, float* hit_s,
+                             const uint32_t* hit_r, int* cntc, hipStream_t st) {
+  hipLaunchKernelGGL(knn_rq_rescore_kernel, dim3(32, nq), dim3(256), 0, st, X, d, q, cnt, cap, hit_s, hit_r, cntc);
+  return hipGetLastError();
+}
+
+hipError_t launch_rq_proof(const float* q, int nq, int d, int k, const float* D, const float* thr, const unsigned* cnt,
+                           unsigned cap, const unsigned* lost, const int* maxnorm, unsigned* need, unsigned* gate,
+                           unsigned long long* stats, hipStream_t st) {
+  hipLaunchKernelGGL(knn_rq_proof_kernel, dim3(1), dim3(256), 0, st, q, nq, d, k, D, thr, cnt, cap, lost, maxnorm, need, gate, stats);
+  return hipGetLastError();
+}
+
+}  // namespace knnx

@@ -84,6 +84,24 @@ struct knnx_index {
   float* wide_Dfb = nullptr;     // [32, 64]
   int64_t* wide_Ifb = nullptr;
 
+  // RQ scan (register-stationary queries, up to 256 per pass; knn_rq_kernels.hip): allocated on first use
+  int rq_ok = 1;               // KNNX_RQ=0 disables
+  int64_t rq_min_rows = KNN_RQ_MIN_ROWS;  // KNNX_RQ_MIN_ROWS overrides (tests run the RQ path on small indexes)
+  _Float16* rq_qfrag = nullptr;  // [8 blocks][d/16][64][8]
+  float* rq_thr = nullptr;       // [256]
+  unsigned *rq_cnt = nullptr, *rq_lost = nullptr, *rq_need = nullptr, *rq_gate = nullptr;  // [256] x3, [8]
+  int* rq_cntc = nullptr;        // [256]
+  float* rq_hit_s = nullptr;     // [256, KNN_RQ_CAP]
+  uint32_t* rq_hit_r = nullptr;
+  float* rq_samp = nullptr;      // [256, 64] sample scores
+  int64_t* rq_samp_i = nullptr;
+  unsigned long long* stats = nullptr;  // device counters: [0] queries served by a proof-based path, [1] proofs that failed
+
+  // scratch hand-over between streams: the per-handle scratch above is shared by every call, so each launch sequence
+  // first waits for the event the previous sequence recorded, whichever stream that ran on
+  hipEvent_t ev_scratch = nullptr;
+  bool ev_valid = false;
+
   int nt_loads = 0;
   bool prof = false;
   int64_t prof_launches = 0;
@@ -116,6 +134,8 @@ static int scan_cap(int d, int k) {
 }
 
 extern "C" const char* knnx_last_error(void) { return g_err.c_str(); }
+// used by knnx_sharded.hip (same library, other translation unit): set the thread-local message
+extern "C" int knnx_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
 extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
   if (!out) return fail(KNNX_E_ARG, "out is null");
@@ -140,18 +160,22 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
   ix->nt_loads = (nt && nt[0] == '1') ? 1 : 0;
   const char* wd = getenv("KNNX_WIDE");
   ix->wide_ok = (wd && wd[0] == '0') ? 0 : 1;
+  const char* rq = getenv("KNNX_RQ");
+  ix->rq_ok = (rq && rq[0] == '0') ? 0 : 1;
+  const char* rqm = getenv("KNNX_RQ_MIN_ROWS");
+  if (rqm && rqm[0]) ix->rq_min_rows = atoll(rqm);
   const char* gr = getenv("KNNX_GRID");
   if (gr && atoi(gr) > 0) ix->n_cu = atoi(gr);
   hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
   const size_t G = (size_t)ix->n_cu;
   if (e == hipSuccess) e = hipMalloc(&ix->qfrag, (size_t)d * 128);
-  if (e == hipSuccess) e = hipMalloc(&ix->q_dev, (size_t)KNN_NQ_MAX * d * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&ix->q_dev, (size_t)KNN_RQ_MAX * d * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&ix->thr_g, KNN_NQ_MAX * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&ix->part_s, G * KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&ix->part_i, G * KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&ix->part_n, G * KNN_NQ_MAX * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&ix->D_dev, (size_t)KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&ix->I_dev, (size_t)KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->D_dev, (size_t)KNN_RQ_MAX * KNNX_MAX_K_FAST * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&ix->I_dev, (size_t)KNN_RQ_MAX * KNNX_MAX_K_FAST * sizeof(int64_t));
   if (e == hipSuccess) e = hipMalloc(&ix->range_cnt, KNN_NQ * sizeof(unsigned));
   if (e == hipSuccess) e = hipMalloc(&ix->maxnorm, sizeof(int));
   if (e == hipSuccess) e = hipMemset(ix->maxnorm, 0, sizeof(int));  // order-encoded +0.0f
@@ -161,6 +185,9 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
   if (e == hipSuccess) e = hipMalloc(&ix->wide_gate, 2 * sizeof(unsigned));
   if (e == hipSuccess) e = hipMalloc(&ix->wide_Dfb, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&ix->wide_Ifb, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->stats, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(ix->stats, 0, 2 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_scratch, hipEventDisableTiming);
   if (e != hipSuccess) {
     std::string m = std::string("knnx_create: ") + hipGetErrorString(e);
     knnx_destroy(ix);
@@ -191,6 +218,19 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->wide_gate);
   hipFree(ix->wide_Dfb);
   hipFree(ix->wide_Ifb);
+  hipFree(ix->stats);
+  hipFree(ix->rq_qfrag);
+  hipFree(ix->rq_thr);
+  hipFree(ix->rq_cnt);
+  hipFree(ix->rq_lost);
+  hipFree(ix->rq_need);
+  hipFree(ix->rq_gate);
+  hipFree(ix->rq_cntc);
+  hipFree(ix->rq_hit_s);
+  hipFree(ix->rq_hit_r);
+  hipFree(ix->rq_samp);
+  hipFree(ix->rq_samp_i);
+  if (ix->ev_scratch) hipEventDestroy(ix->ev_scratch);
   if (ix->range_s) hipFree(ix->range_s);
   if (ix->range_i) hipFree(ix->range_i);
   if (ix->cent) knnx_destroy(ix->cent);
@@ -427,7 +467,7 @@ static int scan_topk_wide(knnx_index* ix, const float* q_dev, int nq, int k, flo
   HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ_MAX, KNN_WIDE_KW, nq, KNN_WIDE_KW, 0, nullptr,
                           ix->wide_approx, ix->wide_cand, nullptr, st));
   HIPCHK(launch_rescore(ix->rows, ix->d, q_dev, ix->wide_cand, ix->wide_approx, nq, KNN_WIDE_KW, k, ix->id_base, ix->maxnorm,
-                        D_out, I_out, ix->wide_need, ix->wide_gate, st));
+                        D_out, I_out, ix->wide_need, ix->wide_gate, ix->stats, st));
   for (int half = 0; half < 2; ++half) {
     const int q0 = half * KNN_NQ, n = std::min(KNN_NQ, nq - q0);
     if (n <= 0) break;
@@ -438,6 +478,116 @@ static int scan_topk_wide(knnx_index* ix, const float* q_dev, int nq, int k, flo
   return 0;
 }
 
+
+// ---- scratch guard: call at the start / end of every launch sequence that uses the handle's scratch (caller holds mu)
+static int scratch_acquire(knnx_index* ix, hipStream_t st) {
+  if (ix->ev_valid) HIPCHK(hipStreamWaitEvent(st, ix->ev_scratch, 0));
+  return 0;
+}
+static int scratch_release(knnx_index* ix, hipStream_t st) {
+  HIPCHK(hipEventRecord(ix->ev_scratch, st));
+  ix->ev_valid = true;
+  return 0;
+}
+
+// ---- RQ scan: up to rq_queries_per_pass(d) queries in ONE pass over HBM (see knn_rq_kernels.hip)
+static bool rq_usable(const knnx_index* ix, int nq, int k) {
+  return ix->rq_ok && ix->wide_ok && !ix->ivf_nlist && nq > KNN_NQ_MAX && k <= KNN_WIDE_MAX_K && rq_queries_per_pass(ix->d) > 0 &&
+         ix->ntotal >= ix->rq_min_rows && wide_cap(ix->d) > 0;
+}
+static int rq_alloc(knnx_index* ix) {
+  if (ix->rq_qfrag) return 0;
+  const size_t Q = KNN_RQ_MAX;
+  HIPCHK(hipMalloc(&ix->rq_qfrag, (size_t)(Q / 32) * (ix->d / 16) * 64 * 16));
+  HIPCHK(hipMalloc(&ix->rq_thr, Q * sizeof(float)));
+  HIPCHK(hipMalloc(&ix->rq_cnt, Q * sizeof(unsigned)));
+  HIPCHK(hipMalloc(&ix->rq_lost, Q * sizeof(unsigned)));
+  HIPCHK(hipMalloc(&ix->rq_need, Q * sizeof(unsigned)));
+  HIPCHK(hipMalloc(&ix->rq_gate, 8 * sizeof(unsigned)));
+  HIPCHK(hipMalloc(&ix->rq_cntc, Q * sizeof(int)));
+  HIPCHK(hipMalloc(&ix->rq_hit_s, Q * KNN_RQ_CAP * sizeof(float)));
+  HIPCHK(hipMalloc(&ix->rq_hit_r, Q * KNN_RQ_CAP * sizeof(uint32_t)));
+  HIPCHK(hipMalloc(&ix->rq_samp, Q * KNN_WIDE_KW * sizeof(float)));
+  HIPCHK(hipMalloc(&ix->rq_samp_i, Q * KNN_WIDE_KW * sizeof(int64_t)));
+  return 0;
+}
+static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st) {
+  int r = rq_alloc(ix);
+  if (r) return r;
+  const int d = ix->d;
+  // 1. thresholds: the 64-query scan over every KNN_RQ_STRIDE-th tile; threshold = (k + margin)-th best sample score
+  for (int g = 0; g * KNN_NQ_MAX < nq; ++g) {
+    const int q0 = g * KNN_NQ_MAX, n = std::min(KNN_NQ_MAX, nq - q0);
+    HIPCHK(launch_prep(q_dev + (size_t)q0 * d, n, d, ix->qfrag, ix->thr_g, nullptr, 1, nullptr, st));
+    ScanArgs a{};
+    a.X = ix->rows;
+    a.N = ix->ntotal;
+    a.d = d;
+    a.qfrag = ix->qfrag;
+    a.nq = n;
+    a.k = KNN_WIDE_KW;
+    a.cap = wide_cap(d);
+    a.grid = ix->n_cu;
+    a.mode = 0;
+    a.wide = 1;
+    a.tstride = KNN_RQ_STRIDE;
+    a.thr_g = ix->thr_g;
+    a.part_s = ix->part_s;
+    a.part_i = ix->part_i;
+    a.part_n = ix->part_n;
+    HIPCHK(launch_scan(a, st));
+    HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ_MAX, KNN_WIDE_KW, n, KNN_WIDE_KW, 0, nullptr,
+                            ix->rq_samp + (size_t)q0 * KNN_WIDE_KW, ix->rq_samp_i + (size_t)q0 * KNN_WIDE_KW, nullptr, st));
+  }
+  const int J = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
+  HIPCHK(launch_rq_prep(q_dev, nq, d, ix->rq_qfrag, ix->rq_samp, KNN_WIDE_KW, J, ix->rq_thr, ix->rq_cnt, ix->rq_lost, st));
+  // 2. the pass over the whole index
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ix->prof) {
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st));
+  }
+  HIPCHK(launch_rq_scan(ix->rows, ix->ntotal, d, ix->rq_qfrag, ix->rq_thr, ix->rq_cnt, KNN_RQ_CAP, ix->rq_hit_s, ix->rq_hit_r,
+                        ix->rq_lost, nullptr, ix->n_cu, st));
+  if (ix->prof) {
+    HIPCHK(hipEventRecord(e1, st));
+    ix->prof_events.emplace_back(e0, e1);
+  }
+  // 3. exact scores of the hits, exact top-k among them, proof
+  HIPCHK(launch_rq_rescore(ix->rows, d, q_dev, nq, ix->rq_cnt, KNN_RQ_CAP, ix->rq_hit_s, ix->rq_hit_r, ix->rq_cntc, st));
+  HIPCHK(launch_merge_u32(ix->rq_hit_s, ix->rq_hit_r, ix->rq_cntc, 1, nq, (int)KNN_RQ_CAP, nq, k, ix->id_base, nullptr, D_out, I_out,
+                          nullptr, st));
+  HIPCHK(launch_rq_proof(q_dev, nq, d, k, D_out, ix->rq_thr, ix->rq_cnt, KNN_RQ_CAP, ix->rq_lost, ix->maxnorm, ix->rq_need,
+                         ix->rq_gate, ix->stats, st));
+  // 4. unproven queries: the exact scan of their 32-query group, gated on the device
+  for (int g = 0; g * KNN_NQ < nq; ++g) {
+    const int q0 = g * KNN_NQ, n = std::min(KNN_NQ, nq - q0);
+    r = scan_topk(ix, q_dev + (size_t)q0 * d, n, k, ix->wide_Dfb, ix->wide_Ifb, st, ix->rq_gate + g);
+    if (r) return r;
+    HIPCHK(launch_select(ix->rq_need, q0, n, k, ix->wide_Dfb, ix->wide_Ifb, D_out, I_out, st));
+  }
+  return 0;
+}
+
+// one step of a search over device buffers: picks the widest scan that serves the remaining queries; returns the number taken
+static int scan_step(knnx_index* ix, const float* q_dev, int remaining, int k, float* D_out, int64_t* I_out, hipStream_t st,
+                     int* taken) {
+  int nq, r;
+  if (rq_usable(ix, remaining, k)) {
+    nq = std::min(rq_queries_per_pass(ix->d), remaining);
+    r = scan_topk_rq(ix, q_dev, nq, k, D_out, I_out, st);
+  } else if (wide_usable(ix, remaining, k)) {
+    nq = std::min(KNN_NQ_MAX, remaining);
+    r = scan_topk_wide(ix, q_dev, nq, k, D_out, I_out, st);
+  } else {
+    nq = std::min(KNN_NQ, remaining);
+    r = scan_topk(ix, q_dev, nq, k, D_out, I_out, st);
+  }
+  *taken = nq;
+  return r;
+}
+
 extern "C" int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int k, float* D_dev, int64_t* I_dev,
                                   void* stream) {
   if (!ix || !q_dev || !D_dev || !I_dev || n < 0 || k <= 0) return fail(KNNX_E_ARG, "bad search arguments");
@@ -445,32 +595,37 @@ extern "C" int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int
   std::lock_guard<std::mutex> lk(ix->mu);
   if (set_dev(ix)) return KNNX_E_HIP;
   hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+  if (scratch_acquire(ix, st)) return KNNX_E_HIP;
   for (int o = 0; o < n;) {
-    const bool wide = wide_usable(ix, n - o, k);
-    const int nq = std::min(wide ? KNN_NQ_MAX : KNN_NQ, n - o);
-    int r = wide ? scan_topk_wide(ix, q_dev + (size_t)o * ix->d, nq, k, D_dev + (size_t)o * k, I_dev + (size_t)o * k, st)
-                 : scan_topk(ix, q_dev + (size_t)o * ix->d, nq, k, D_dev + (size_t)o * k, I_dev + (size_t)o * k, st);
+    int nq = 0;
+    int r = scan_step(ix, q_dev + (size_t)o * ix->d, n - o, k, D_dev + (size_t)o * k, I_dev + (size_t)o * k, st, &nq);
     if (r) return r;
     o += nq;
   }
+  if (scratch_release(ix, st)) return KNNX_E_HIP;
   return KNNX_OK;
 }
 
 // k <= 64, host buffers; caller holds ix->mu
 static int search_fast_locked(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I) {
   hipStream_t st = ix->stream;
-  const size_t qb = (size_t)KNN_NQ_MAX * ix->d * sizeof(float);
-  const size_t db = (size_t)KNN_NQ_MAX * k * sizeof(float), ib = (size_t)KNN_NQ_MAX * k * sizeof(int64_t);
+  const size_t QM = KNN_RQ_MAX;  // the widest scan's query count: staging is sized for it
+  const size_t qb = QM * ix->d * sizeof(float);
+  const size_t db = QM * k * sizeof(float), ib = QM * k * sizeof(int64_t);
   int r = ensure_pin(ix, qb + db + ib);
   if (r) return r;
   char* pin = (char*)ix->pin;
+  if (scratch_acquire(ix, st)) return KNNX_E_HIP;
   for (int o = 0; o < n;) {
-    const bool wide = wide_usable(ix, n - o, k);
-    const int nq = std::min(wide ? KNN_NQ_MAX : KNN_NQ, n - o);
+    const int rem = n - o;
+    const int nq = rq_usable(ix, rem, k) ? std::min(rq_queries_per_pass(ix->d), rem)
+                                         : (wide_usable(ix, rem, k) ? std::min(KNN_NQ_MAX, rem) : std::min(KNN_NQ, rem));
     memcpy(pin, q + (size_t)o * ix->d, (size_t)nq * ix->d * sizeof(float));
     HIPCHK(hipMemcpyAsync(ix->q_dev, pin, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
-    r = wide ? scan_topk_wide(ix, ix->q_dev, nq, k, ix->D_dev, ix->I_dev, st) : scan_topk(ix, ix->q_dev, nq, k, ix->D_dev, ix->I_dev, st);
+    int took = 0;
+    r = scan_step(ix, ix->q_dev, nq, k, ix->D_dev, ix->I_dev, st, &took);
     if (r) return r;
+    if (took != nq) return fail(KNNX_E_STATE, "internal: scan step size mismatch");
     HIPCHK(hipMemcpyAsync(pin + qb, ix->D_dev, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(pin + qb + db, ix->I_dev, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -478,6 +633,7 @@ static int search_fast_locked(knnx_index* ix, const float* q, int n, int k, floa
     memcpy(I + (size_t)o * k, pin + qb + db, (size_t)nq * k * sizeof(int64_t));
     o += nq;
   }
+  if (scratch_release(ix, st)) return KNNX_E_HIP;
   return 0;
 }
 
@@ -537,6 +693,7 @@ static int range_scan(knnx_index* ix, const float* q_host, int nq, float thr, st
   hipStream_t st = ix->stream;
   int r = ensure_pin(ix, (size_t)KNN_NQ * ix->d * sizeof(float));
   if (r) return r;
+  if (scratch_acquire(ix, st)) return KNNX_E_HIP;
   memcpy(ix->pin, q_host, (size_t)nq * ix->d * sizeof(float));
   HIPCHK(hipMemcpyAsync(ix->q_dev, ix->pin, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
   for (;;) {
@@ -798,25 +955,15 @@ extern "C" int knnx_merge_topk_device(int device, const float* D_parts, const in
   return KNNX_OK;
 }
 
-extern "C" int knnx_merge_topk_host(const float* D_parts, const int64_t* I_parts, int P, int n, int k, float* D_out,
-                                    int64_t* I_out) {
-  if (!D_parts || !I_parts || !D_out || !I_out || P <= 0 || n < 0 || k <= 0) return fail(KNNX_E_ARG, "bad merge arguments");
-  std::vector<std::pair<float, int64_t>> v;
-  for (int qi = 0; qi < n; ++qi) {
-    v.clear();
-    for (int p = 0; p < P; ++p) {
-      const size_t b = ((size_t)p * n + qi) * k;
-      for (int j = 0; j < k; ++j)
-        if (I_parts[b + j] >= 0) v.emplace_back(D_parts[b + j], I_parts[b + j]);
-    }
-    std::sort(v.begin(), v.end(), [](const std::pair<float, int64_t>& a, const std::pair<float, int64_t>& b) {
-      return a.first > b.first || (a.first == b.first && a.second < b.second);
-    });
-    for (int j = 0; j < k; ++j) {
-      D_out[(size_t)qi * k + j] = j < (int)v.size() ? v[j].first : -FLT_MAX;
-      I_out[(size_t)qi * k + j] = j < (int)v.size() ? v[j].second : -1;
-    }
-  }
+extern "C" int knnx_get_stats(knnx_index* ix, int64_t* proof_queries, int64_t* proof_failures) {
+  if (!ix) return fail(KNNX_E_ARG, "index is null");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (set_dev(ix)) return KNNX_E_HIP;
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(hipStreamSynchronize(ix->stream));
+  HIPCHK(hipMemcpy(h, ix->stats, sizeof(h), hipMemcpyDeviceToHost));
+  if (proof_queries) *proof_queries = (int64_t)h[0];
+  if (proof_failures) *proof_failures = (int64_t)h[1];
   return KNNX_OK;
 }
 

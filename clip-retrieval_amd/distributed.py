@@ -6,7 +6,8 @@
     Every rank scans its shard for the same queries, the per-shard top-k (k x 12 B per query) are exchanged
     with ONE all-gather, and every rank merges P*k -> k with the (score desc, id asc) rule.  This is the
     only exchange step on the path; the reference itself has none (single-process faiss).
-The merge runs in lib/libclipx.so (device kernel for CUDA tensors, C++ for host tensors under gloo).
+The merge runs in lib/libclipx.so (device kernel) for CUDA tensors; host tensors (gloo, CPU tests) are merged with numpy.
+The ONE-process-many-GPUs variant of the same sharding (KnnService) is knn.ShardedMi355xIndex / knnx_shards_*.
 """
 
 import ctypes as C
@@ -14,8 +15,27 @@ import ctypes as C
 import numpy as np
 
 from ._lib import check, load_library
-from .knn import merge_topk_host
 from .runner import get_task_list  # noqa: F401  (re-export: encode-side task split)
+
+
+def merge_topk_host(D_parts, I_parts, k):
+    """[P, n, k] per-shard results with global ids -> [n, k] by (score desc, id asc), -1 / -FLT_MAX padded.
+    numpy, for HOST tensors only: the `gloo` backend of the CPU tests of the exchange logic.  On GPUs (backend "nccl" =
+    RCCL) the merge is the device kernel behind knnx_merge_topk_device; the library itself has no CPU arithmetic."""
+    D_parts = np.ascontiguousarray(D_parts, dtype=np.float32)
+    I_parts = np.ascontiguousarray(I_parts, dtype=np.int64)
+    P, n, kk = D_parts.shape
+    assert kk == k and I_parts.shape == D_parts.shape
+    Dc = np.transpose(D_parts, (1, 0, 2)).reshape(n, P * k)
+    Ic = np.transpose(I_parts, (1, 0, 2)).reshape(n, P * k)
+    D = np.full((n, k), -np.finfo(np.float32).max, dtype=np.float32)
+    I = np.full((n, k), -1, dtype=np.int64)
+    for i in range(n):
+        ok = Ic[i] >= 0
+        order = np.lexsort((Ic[i][ok], -Dc[i][ok].astype(np.float64)))[:k]
+        D[i, : order.size] = Dc[i][ok][order]
+        I[i, : order.size] = Ic[i][ok][order]
+    return D, I
 
 
 def shard_rows(total_rows, world_size, rank):

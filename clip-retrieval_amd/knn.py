@@ -12,7 +12,7 @@ taking the place of clip_back.py:589-596 for our index type.
 Same argument meaning and error behaviour as faiss: float32 C-contiguous [n, d] queries (anything else
 raises like faiss' SWIG wrapper does), int64 labels, -1 / -FLT_MAX padding, exceptions on misuse.
 Thread-safe: clip_back serves each request on its own werkzeug thread with n=1 (clip_back.py:1018);
-concurrent callers are coalesced into one HBM scan of up to 64 queries (_SCAN_QUERIES) by a leader/follower batcher.
+concurrent callers are coalesced into one HBM scan of up to 256 queries (_SCAN_QUERIES) by a leader/follower batcher.
 """
 
 import ctypes as C
@@ -25,7 +25,7 @@ import numpy as np
 from ._lib import HipLibraryError, check, load_library
 
 METRIC_INNER_PRODUCT = 0
-_SCAN_QUERIES = 64  # queries one HBM scan serves (KNN_NQ_MAX in csrc/knn_kernels.h: the wide scan)
+_SCAN_QUERIES = 256  # queries one HBM scan serves at most (KNN_RQ_MAX in csrc/knn_kernels.h: the RQ scan; 64: the wide scan)
 
 
 def _as_queries(x, d):
@@ -37,7 +37,87 @@ def _as_queries(x, d):
     return np.ascontiguousarray(x)
 
 
-class Mi355xIndex:
+class _FaissShaped:
+    """The part of the faiss Index surface clip_back / clip_filter exercise, on top of `_search_raw`,
+    `reconstruct_batch`, `range_search` and `ntotal` of the concrete index (one GPU or row-sharded)."""
+
+    def _init_queue(self, coalesce):
+        self._coalesce = coalesce
+        self._q_lock = threading.Lock()
+        self._pending = []  # [(k, want_r, query_row, slot)]
+        self._leader_active = False
+
+    def _search_coalesced(self, q, k, want_r):
+        """n == 1 callers from many threads: the first becomes the leader and serves every query queued
+        while the GPU was busy, up to one scan's worth, in a single pass over HBM."""
+        slot = {"ev": threading.Event(), "out": None, "err": None}
+        with self._q_lock:
+            self._pending.append((k, want_r, q[0], slot))
+            lead = not self._leader_active
+            if lead:
+                self._leader_active = True
+        if not lead:
+            slot["ev"].wait()
+        else:
+            while True:
+                with self._q_lock:
+                    if not self._pending:
+                        self._leader_active = False
+                        break
+                    k0, r0 = self._pending[0][0], self._pending[0][1]
+                    take = [p for p in self._pending if p[0] == k0 and p[1] == r0][:_SCAN_QUERIES]
+                    taken = set(id(p) for p in take)
+                    self._pending = [p for p in self._pending if id(p) not in taken]
+                try:
+                    qq = np.stack([p[2] for p in take]).astype(np.float32)
+                    D, I, R = self._search_raw(qq, k0, r0)
+                    for j, p in enumerate(take):
+                        p[3]["out"] = (D[j:j + 1], I[j:j + 1], R[j:j + 1] if R is not None else None)
+                except Exception as e:  # pylint: disable=broad-except
+                    for p in take:
+                        p[3]["err"] = e
+                for p in take:
+                    p[3]["ev"].set()
+        if slot["err"] is not None:
+            raise slot["err"]
+        return slot["out"]
+
+    def _do_search(self, x, k, want_r):
+        if k <= 0:
+            raise AssertionError("k must be positive")
+        q = _as_queries(x, self.d)
+        if q.shape[0] == 0:
+            return (np.empty((0, k), np.float32), np.empty((0, k), np.int64),
+                    np.empty((0, k, self.d), np.float32) if want_r else None)
+        if self._coalesce and q.shape[0] == 1:
+            return self._search_coalesced(q, int(k), want_r)
+        return self._search_raw(q, int(k), want_r)
+
+    def search(self, x, k):
+        D, I, _ = self._do_search(x, k, False)
+        return D, I
+
+    def search_and_reconstruct(self, x, k):
+        return self._do_search(x, k, True)
+
+    def reconstruct(self, key):
+        return self.reconstruct_batch(np.asarray([key], dtype=np.int64))[0]
+
+    def _pad(self, x):
+        if self._dpad == self.d:
+            return x
+        out = np.zeros((x.shape[0], self._dpad), dtype=x.dtype)
+        out[:, : self.d] = x
+        return out
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+class Mi355xIndex(_FaissShaped):
     """Flat inner-product index with fp16 rows resident in HBM (one GPU)."""
 
     def __init__(self, d, device=0, id_base=0, coalesce=True):
@@ -52,22 +132,13 @@ class Mi355xIndex:
         self.is_trained = True
         if id_base:
             check(self._lib, self._lib.knnx_set_id_base(self._h, int(id_base)), "knnx")
-        self._coalesce = coalesce
-        self._q_lock = threading.Lock()
-        self._pending = []  # [(k, query_row, slot)]
-        self._leader_active = False
+        self._init_queue(coalesce)
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
             self._lib.knnx_destroy(h)
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:  # pylint: disable=broad-except
-            pass
 
     @property
     def ntotal(self):
@@ -76,13 +147,6 @@ class Mi355xIndex:
     # ------------------------------------------------------------------ building
     def reserve(self, n_rows):
         check(self._lib, self._lib.knnx_reserve(self._h, int(n_rows)), "knnx")
-
-    def _pad(self, x):
-        if self._dpad == self.d:
-            return x
-        out = np.zeros((x.shape[0], self._dpad), dtype=x.dtype)
-        out[:, : self.d] = x
-        return out
 
     def add(self, x):
         """faiss Index.add: float32 (rounded to fp16 on the device) or float16 rows."""
@@ -148,62 +212,6 @@ class Mi355xIndex:
             R = np.ascontiguousarray(R[:, :, : self.d])
         return D, I, R
 
-    def _search_coalesced(self, q, k, want_r):
-        """n == 1 callers from many threads: the first becomes the leader and serves every query queued
-        while the GPU was busy, up to one scan's worth, in a single pass over HBM."""
-        slot = {"ev": threading.Event(), "out": None, "err": None}
-        with self._q_lock:
-            self._pending.append((k, want_r, q[0], slot))
-            lead = not self._leader_active
-            if lead:
-                self._leader_active = True
-        if not lead:
-            slot["ev"].wait()
-        else:
-            while True:
-                with self._q_lock:
-                    if not self._pending:
-                        self._leader_active = False
-                        break
-                    k0, r0 = self._pending[0][0], self._pending[0][1]
-                    take = [p for p in self._pending if p[0] == k0 and p[1] == r0][:_SCAN_QUERIES]
-                    taken = set(id(p) for p in take)
-                    self._pending = [p for p in self._pending if id(p) not in taken]
-                try:
-                    qq = np.stack([p[2] for p in take]).astype(np.float32)
-                    D, I, R = self._search_raw(qq, k0, r0)
-                    for j, p in enumerate(take):
-                        p[3]["out"] = (D[j:j + 1], I[j:j + 1], R[j:j + 1] if R is not None else None)
-                except Exception as e:  # pylint: disable=broad-except
-                    for p in take:
-                        p[3]["err"] = e
-                for p in take:
-                    p[3]["ev"].set()
-        if slot["err"] is not None:
-            raise slot["err"]
-        return slot["out"]
-
-    def _do_search(self, x, k, want_r):
-        if k <= 0:
-            raise AssertionError("k must be positive")
-        q = _as_queries(x, self.d)
-        if q.shape[0] == 0:
-            return (np.empty((0, k), np.float32), np.empty((0, k), np.int64),
-                    np.empty((0, k, self.d), np.float32) if want_r else None)
-        if self._coalesce and q.shape[0] == 1:
-            return self._search_coalesced(q, int(k), want_r)
-        return self._search_raw(q, int(k), want_r)
-
-    def search(self, x, k):
-        D, I, _ = self._do_search(x, k, False)
-        return D, I
-
-    def search_and_reconstruct(self, x, k):
-        return self._do_search(x, k, True)
-
-    def reconstruct(self, key):
-        return self.reconstruct_batch(np.asarray([key], dtype=np.int64))[0]
-
     def reconstruct_batch(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.int64)
         out = np.empty((keys.shape[0], self._dpad), dtype=np.float32)
@@ -231,23 +239,123 @@ class Mi355xIndex:
     def profile(self, on):
         check(self._lib, self._lib.knnx_profile_enable(self._h, 1 if on else 0), "knnx")
 
+    def stats(self):
+        """(queries served by a proof-based scan, queries whose exactness proof failed and were re-run exactly)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(self._lib, self._lib.knnx_get_stats(self._h, C.byref(a), C.byref(b)), "knnx")
+        return int(a.value), int(b.value)
+
     def profile_get(self):
         n, ms = C.c_int64(0), C.c_double(0.0)
         check(self._lib, self._lib.knnx_profile_get(self._h, C.byref(n), C.byref(ms)), "knnx")
         return int(n.value), float(ms.value)
 
 
-def merge_topk_host(D_parts, I_parts, k):
-    """[P, n, k] per-shard results with global ids -> [n, k]; host buffers (C++: knnx_merge_topk_host)."""
-    lib = load_library()
-    D_parts = np.ascontiguousarray(D_parts, dtype=np.float32)
-    I_parts = np.ascontiguousarray(I_parts, dtype=np.int64)
-    P, n, kk = D_parts.shape
-    assert kk == k and I_parts.shape == D_parts.shape
-    D = np.empty((n, k), dtype=np.float32)
-    I = np.empty((n, k), dtype=np.int64)
-    check(lib, lib.knnx_merge_topk_host(D_parts.ctypes.data, I_parts.ctypes.data, P, n, k, D.ctypes.data, I.ctypes.data), "knnx")
-    return D, I
+class ShardedMi355xIndex(_FaissShaped):
+    """Row-sharded index over several GPUs of ONE process behind the same faiss-shaped surface -- the object that goes
+    into `ClipResource.image_index` (clip_back.py:781-782) when the index needs more than one GPU (BASELINE config 5).
+    Shard g = rows [g*T/G, (g+1)*T/G) on devices[g]; ids = global row numbers.  C ABI: knnx_shards_* (include/knnx.h)."""
+
+    def __init__(self, d, devices, coalesce=True, _adopt=None):
+        self._lib = load_library()
+        self.d = int(d)
+        self._dpad = (self.d + 255) // 256 * 256
+        self.devices = [int(x) for x in devices]
+        h = C.c_void_p()
+        dv = (C.c_int * len(self.devices))(*self.devices)
+        if _adopt is None:
+            check(self._lib, self._lib.knnx_shards_create(len(self.devices), dv, self._dpad, METRIC_INNER_PRODUCT, C.byref(h)), "knnx")
+        else:
+            shards, row_lo = _adopt
+            hs = (C.c_void_p * len(shards))(*[sh._h for sh in shards])  # pylint: disable=protected-access
+            lo = (C.c_int64 * len(shards))(*[int(x) for x in row_lo])
+            check(self._lib, self._lib.knnx_shards_adopt(len(shards), hs, dv, lo, C.byref(h)), "knnx")
+            for sh in shards:
+                sh._h = None  # pylint: disable=protected-access  (owned by the sharded handle now)
+        self._h = h
+        self.metric_type = METRIC_INNER_PRODUCT
+        self.is_trained = True
+        self._init_queue(coalesce)
+
+    @classmethod
+    def from_shards(cls, shards, row_lo, coalesce=True):
+        """Adopt per-device `Mi355xIndex` objects (flat or IVF-Flat; shard g built with id_base = row_lo[g])."""
+        return cls(shards[0].d, [sh.device for sh in shards], coalesce=coalesce, _adopt=(shards, row_lo))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.knnx_shards_destroy(h)
+
+    @property
+    def ntotal(self):
+        return int(self._lib.knnx_shards_ntotal(self._h))
+
+    @property
+    def nshards(self):
+        return int(self._lib.knnx_shards_count(self._h))
+
+    def reserve(self, total_rows):
+        """Fix the row range of every shard; must precede add()."""
+        check(self._lib, self._lib.knnx_shards_reserve(self._h, int(total_rows)), "knnx")
+
+    def add(self, x):
+        x = np.asarray(x)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise AssertionError(f"add expects [n, {self.d}], got {x.shape}")
+        if x.dtype == np.float16:
+            x = np.ascontiguousarray(self._pad(x))
+            check(self._lib, self._lib.knnx_shards_add_f16(self._h, x.ctypes.data, x.shape[0]), "knnx")
+        elif x.dtype == np.float32:
+            x = np.ascontiguousarray(self._pad(x))
+            check(self._lib, self._lib.knnx_shards_add_f32(self._h, x.ctypes.data, x.shape[0]), "knnx")
+        else:
+            raise TypeError(f"add expects float32 or float16 rows, got {x.dtype}")
+
+    def synth_fill(self, rows_per_shard, seed):
+        if self._dpad != self.d:
+            raise HipLibraryError("synthetic fill needs d % 256 == 0")
+        check(self._lib, self._lib.knnx_shards_synth_fill(self._h, int(rows_per_shard), C.c_uint64(int(seed))), "knnx")
+
+    def _search_raw(self, q, k, want_r):
+        n = q.shape[0]
+        qp = np.ascontiguousarray(self._pad(q))
+        D = np.empty((n, k), dtype=np.float32)
+        I = np.empty((n, k), dtype=np.int64)
+        R = np.empty((n, k, self._dpad), dtype=np.float32) if want_r else None
+        check(self._lib, self._lib.knnx_shards_search(self._h, qp.ctypes.data, n, int(k), D.ctypes.data, I.ctypes.data,
+                                                      R.ctypes.data if want_r else None), "knnx")
+        if want_r and self._dpad != self.d:
+            R = np.ascontiguousarray(R[:, :, : self.d])
+        return D, I, R
+
+    def reconstruct_batch(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        out = np.empty((keys.shape[0], self._dpad), dtype=np.float32)
+        check(self._lib, self._lib.knnx_shards_reconstruct(self._h, keys.ctypes.data, keys.shape[0], out.ctypes.data), "knnx")
+        return np.ascontiguousarray(out[:, : self.d])
+
+    def range_search(self, x, thresh):
+        q = np.ascontiguousarray(self._pad(_as_queries(x, self.d)))
+        n = q.shape[0]
+        lims = np.zeros(n + 1, dtype=np.int64)
+        check(self._lib, self._lib.knnx_shards_range_search(self._h, q.ctypes.data, n, C.c_float(thresh), lims.ctypes.data, None, None), "knnx")
+        total = int(lims[n])
+        D = np.empty(total, dtype=np.float32)
+        I = np.empty(total, dtype=np.int64)
+        if total:
+            check(self._lib, self._lib.knnx_shards_range_search(self._h, q.ctypes.data, n, C.c_float(thresh), lims.ctypes.data,
+                                                                D.ctypes.data, I.ctypes.data), "knnx")
+        return lims, D, I
+
+    def shard_stats(self):
+        """Per-shard (proof-served queries, proof failures)."""
+        out = []
+        for g in range(self.nshards):
+            a, b = C.c_int64(0), C.c_int64(0)
+            check(self._lib, self._lib.knnx_get_stats(C.c_void_p(self._lib.knnx_shards_get(self._h, g)), C.byref(a), C.byref(b)), "knnx")
+            out.append((int(a.value), int(b.value)))
+        return out
 
 
 def embedding_files(folder):
@@ -259,12 +367,15 @@ def embedding_files(folder):
     return files
 
 
-def load_index(path, device=0, row_range=None, enable_faiss_memory_mapping=False):  # pylint: disable=unused-argument
+def load_index(path, device=0, row_range=None, enable_faiss_memory_mapping=False, devices=None):  # pylint: disable=unused-argument
     """Build an HBM-resident flat index from a folder of fp16 `.npy` partitions.
 
     Takes the place of clip_back.py:589-596 (`faiss.read_index`) for this index type; ids are the global
     row order of the concatenated partitions = the metadata row order (clip_back.py:401-417).
-    `row_range=(lo, hi)` loads one shard of a row-sharded index and sets its id base to `lo`.
+    `row_range=(lo, hi)` loads one shard of a row-sharded index and sets its id base to `lo` (one process per GPU);
+    `devices=[0, 1, ...]` builds ONE object that row-shards the whole folder over those GPUs of this process
+    (`ShardedMi355xIndex`, the KnnService case).  `enable_faiss_memory_mapping` is accepted for call compatibility:
+    rows are always resident in HBM; the files themselves are read through np.load(mmap_mode="r").
     """
     files = embedding_files(path)
     shapes = []
@@ -278,8 +389,14 @@ def load_index(path, device=0, row_range=None, enable_faiss_memory_mapping=False
         raise ValueError("embedding files disagree on the dimension")
     total = sum(s[0] for s in shapes)
     lo, hi = (0, total) if row_range is None else row_range
-    index = Mi355xIndex(d, device=device, id_base=lo)
-    index.reserve(max(hi - lo, 0))
+    if devices is not None:
+        if row_range is not None:
+            raise ValueError("row_range and devices are mutually exclusive")
+        index = ShardedMi355xIndex(d, devices)
+        index.reserve(total)
+    else:
+        index = Mi355xIndex(d, device=device, id_base=lo)
+        index.reserve(max(hi - lo, 0))
     start = 0
     for f, s in zip(files, shapes):
         a0, a1 = max(lo, start), min(hi, start + s[0])

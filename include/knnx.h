@@ -66,11 +66,14 @@ int knnx_dim(const knnx_index* ix);
 /* faiss Index.search(x, k) (clip_filter.py:55) and Index.search_and_reconstruct(x, k)
  * (clip_back.py:362).  q: host f32 [n, d] C-contiguous.  D: f32 [n, k], I: int64 [n, k],
  * R (may be NULL): f32 [n, k, d] (rows of id -1 are filled with 0xFF bytes like faiss).
- * Re-entrant; concurrent callers are serialised on the index's stream. */
+ * Re-entrant; concurrent callers are serialised on the index's stream.  One pass over HBM serves up to 32 queries
+ * (exact hi/lo scores), 64 (wide scan + proof) or, on flat indexes of >= 2 Mi rows with k <= 48, 256 queries (128 at
+ * d = 1024): the register-stationary scan of csrc/knn_rq_kernels.hip; every path returns the exact top-k. */
 int knnx_search(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I, float* R);
 
 /* Same with every buffer already in HBM (benchmark / all-gather path).  `stream` is a
- * hipStream_t (NULL = the index's own stream).  Asynchronous on that stream. */
+ * hipStream_t (NULL = the index's own stream).  Asynchronous on that stream; k <= 64.  The handle's scratch is shared
+ * by all calls: consecutive calls are ordered by an event even when they use different streams. */
 int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int k, float* D_dev,
                        int64_t* I_dev, void* stream);
 
@@ -99,9 +102,38 @@ int knnx_ivf_nlist(const knnx_index* ix);
  * the step after the RCCL all-gather of a row-sharded index.  Device buffers. */
 int knnx_merge_topk_device(int device, const float* D_parts, const int64_t* I_parts, int P, int n,
                            int k, float* D_out, int64_t* I_out, void* stream);
-/* Same merge on host buffers (single process owning several devices; gloo tests). */
-int knnx_merge_topk_host(const float* D_parts, const int64_t* I_parts, int P, int n, int k,
-                         float* D_out, int64_t* I_out);
+
+/* ---- one process, several GPUs: a row-sharded index behind ONE handle ----------------------------------------
+ * `KnnService` keeps one index object per modality in one process and calls it from its request threads
+ * (clip_back.py:343-362, 781-782, 1018); SURVEY 8(b) `knnx_create(n_devices, devices, ...)`, 8(e).  Shard g lives on
+ * devices[g] (a device may be listed more than once) and holds the contiguous global row range [lo_g, hi_g), ids =
+ * global row numbers.  A search sends the queries to every device, scans all shards concurrently (one stream per device),
+ * copies the per-shard top-k (n*k*12 bytes) peer-to-peer over xGMI to devices[0] and merges there with the kernel of
+ * knnx_merge_topk_device.  Same result contract as knnx_search.  Thread-safe (calls are serialised). */
+typedef struct knnx_shards knnx_shards;
+int knnx_shards_create(int n_shards, const int* devices, int d, int metric, knnx_shards** out);
+/* Take ownership of per-device indexes built elsewhere (flat or IVF-Flat with replicated centroids; shard g must have
+ * been given id_base = row_lo[g]).  On success the shards are destroyed with the handle. */
+int knnx_shards_adopt(int n_shards, knnx_index* const* shards, const int* devices, const int64_t* row_lo, knnx_shards** out);
+void knnx_shards_destroy(knnx_shards* s);
+/* Fix the row range of every shard (shard g = rows [g*T/G, (g+1)*T/G)) and size its arena; required before add. */
+int knnx_shards_reserve(knnx_shards* s, int64_t total_rows);
+/* faiss Index.add in global row order: fills shard 0, then shard 1, ... (streams to the owning shard). */
+int knnx_shards_add_f16(knnx_shards* s, const uint16_t* rows, int64_t n);
+int knnx_shards_add_f32(knnx_shards* s, const float* rows, int64_t n);
+/* Benchmark corpus: shard g = knnx_synth_fill(rows_per_shard, seed + g), id_base = g * rows_per_shard. */
+int knnx_shards_synth_fill(knnx_shards* s, int64_t rows_per_shard, uint64_t seed);
+int64_t knnx_shards_ntotal(const knnx_shards* s);
+int knnx_shards_count(const knnx_shards* s);
+knnx_index* knnx_shards_get(knnx_shards* s, int g); /* borrowed: profiling, nprobe */
+/* faiss Index.search / search_and_reconstruct / reconstruct_batch / range_search over all shards. */
+int knnx_shards_search(knnx_shards* s, const float* q, int n, int k, float* D, int64_t* I, float* R);
+int knnx_shards_reconstruct(knnx_shards* s, const int64_t* ids, int64_t n, float* out);
+int knnx_shards_range_search(knnx_shards* s, const float* q, int n, float thresh, int64_t* lims, float* D, int64_t* I);
+
+/* Counters of the proof-based scans (64-query wide scan, 256-query RQ scan): queries they served and queries whose
+ * exactness proof failed and were re-run by the exact 32-query scan (each failure costs one more pass over HBM). */
+int knnx_get_stats(knnx_index* ix, int64_t* proof_queries, int64_t* proof_failures);
 
 /* Live kernel timing for bench.py: when enabled, every scan launch is bracketed with
  * hipEvents on its own stream; get returns launches and summed milliseconds, then resets. */

@@ -67,7 +67,7 @@ def test_calls_fail_loudly_without_a_gpu(lib):
 
 def test_host_merge_is_exact(lib):
     import numpy as np
-    from clip_retrieval_amd.knn import merge_topk_host
+    from clip_retrieval_amd.distributed import merge_topk_host
     from oracle.knn_oracle import merge_topk
 
     rng = np.random.default_rng(0)

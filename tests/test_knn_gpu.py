@@ -330,3 +330,223 @@ def test_ivf_trained_recall():
     recall = np.mean([len(set(I[i]) & set(Io[i])) / 10 for i in range(64)])
     assert recall > 0.9, recall
     ix.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RQ scan: up to 256 queries per pass (csrc/knn_rq_kernels.hip).  KNNX_RQ_MIN_ROWS=0 makes small indexes take the path.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def rq_on_small_indexes(monkeypatch):
+    monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")  # read by knnx_create
+
+
+@pytest.mark.parametrize("d", [768, 512, 1024])
+def test_rq_scan_256_queries_parity(rq_on_small_indexes, d):
+    """65..256 queries share ONE pass over HBM: queries stationary in registers, thresholds from a strided sample,
+    hits re-scored exactly, exactness proven per query.  Must equal the oracle like every other path; the counters
+    show that the proof-based path (not the 32-query scan) served them."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    n = 60_000 + 13  # ragged last tile
+    x = _data(n, d, seed=21)
+    o, ix = FlatIPOracle(d), Mi355xIndex(d)
+    o.add(x)
+    ix.add(x)
+    served0 = ix.stats()[0]
+    for nq, k in [(256, 40), (200, 10), (65, 48), (129, 1), (300, 40)]:
+        q = _queries(nq, d, seed=nq + k, x=x)
+        D, I = ix.search(q, k)
+        Do, Io = o.search(q, k)
+        _check(D, I, Do, Io, f"rq d={d} nq={nq} k={k}")
+    served, failed = ix.stats()
+    assert served - served0 >= 256 + 200 + 65 + 129 + 300, "the proof-based scans did not serve these batches"
+    assert failed <= 8, f"{failed} proofs failed on ordinary data"
+    ix.close()
+
+
+def test_rq_scan_ties_floods_and_fallback(rq_on_small_indexes):
+    """Adversarial data for the RQ path.  (1) every row exists 100 times: the k-th exact score ties with rows at the
+    threshold, proofs fail, the gated exact scans must answer (ids in ascending order among ties).  (2) 40 000 copies of
+    ONE row: every copy reaches the threshold, the per-query hit list (16 384) overflows -> fallback.  Both must equal
+    the oracle exactly."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 768
+    base = _data(300, d, seed=12)
+    flood = np.concatenate([np.tile(base[:1], (40_000, 1)), _data(5_000, d, seed=13)])
+    for name, x in (("dups", np.tile(base, (100, 1))), ("flood", flood)):
+        o, ix = FlatIPOracle(d), Mi355xIndex(d)
+        o.add(x)
+        ix.add(x)
+        for nq, k in [(256, 40), (100, 5)]:
+            q = _queries(nq, d, seed=nq + k, x=x)
+            if name == "flood":
+                q[: nq // 2] = base[:1].astype(np.float32)  # half of the queries ARE the flooding row
+            D, I = ix.search(q, k)
+            Do, Io = o.search(q, k)
+            assert np.array_equal(I, Io), f"{name} nq={nq} k={k}: ids (ties in ascending id order)"
+            assert np.allclose(D, Do, atol=1e-5)
+        assert ix.stats()[1] > 0, f"{name}: expected failed proofs (fallback path untested otherwise)"
+        ix.close()
+
+
+def test_rq_full_scale_properties_256_planted_queries():
+    """8 M x 768 (12 GB; the RQ path's natural size class): 256 planted queries in one call -- every planted neighbour is
+    the top hit, scores agree with an fp32 recomputation from the CPU derivation of the corpus, and the answers are the
+    same as the 32-query exact scan's (batching independence across scan kernels)."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import planted_queries, synth_rows
+
+    d, n, seed = 768, 8_000_000, 3
+    ix = Mi355xIndex(d)
+    ix.synth_fill(n, seed)
+    rng = np.random.default_rng(1)
+    planted = np.sort(rng.choice(n, 256, replace=False))
+    planted[0], planted[-1] = 0, n - 1
+    q = planted_queries(planted, d, seed)
+    s0 = ix.stats()
+    D, I = ix.search(q, 40)
+    s1 = ix.stats()
+    assert s1[0] - s0[0] == 256, "256 queries must have gone through one RQ pass"
+    assert s1[1] - s0[1] == 0, "no proof may fail on this corpus"
+    assert np.array_equal(I[:, 0], planted)
+    assert (np.diff(D, axis=1) <= 0).all() and (I >= 0).all() and (I < n).all()
+    for i in (0, 100, 255):
+        rows = synth_rows(I[i], d, seed).astype(np.float32)
+        assert np.allclose(rows @ q[i], D[i], atol=1e-5)
+        assert len(set(I[i].tolist())) == 40
+    for lo in (0, 224):  # the same queries through the exact 32-query scan
+        D32, I32 = ix.search(q[lo:lo + 32], 40)
+        assert np.array_equal(I32, I[lo:lo + 32]) and np.allclose(D32, D[lo:lo + 32], atol=2e-6)
+    ix.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# merge kernel on its own, and the one-process row-sharded index (two shards on the one GPU of the test box)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P", [2, 8])
+def test_device_merge_kernel_vs_oracle(P):
+    """knnx_merge_topk_device (the step after the all-gather / peer copies): ties across shards, short lists, k = 1..64."""
+    import torch
+    from clip_retrieval_amd.distributed import ShardedIndex
+    from oracle.knn_oracle import merge_topk
+
+    rng = np.random.default_rng(P)
+    for n, k in [(5, 40), (1, 1), (64, 64), (3, 17)]:
+        D = np.sort(rng.standard_normal((P, n, k)).astype(np.float32), axis=-1)[..., ::-1].copy()
+        I = rng.permutation(P * n * k).reshape(P, n, k).astype(np.int64) + (1 << 33)  # ids beyond 32 bits
+        if P > 1 and k > 10:
+            D[1, :, 10:] = D[0, :, 10:]  # exact score ties across shards -> id order decides
+        if k > 30:
+            I[P - 1, 0, 30:] = -1  # a short list
+            D[P - 1, 0, 30:] = NEG
+            I[0, n - 1, :] = -1  # an empty list
+            D[0, n - 1, :] = NEG
+        Dg, Ig = torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda()
+        Dm, Im = ShardedIndex.merge_device(Dg, Ig, k)
+        torch.cuda.synchronize()
+        Do, Io = merge_topk(D, I, k)
+        assert np.array_equal(Im.cpu().numpy(), Io) and np.array_equal(Dm.cpu().numpy(), Do), f"P={P} n={n} k={k}"
+
+
+def test_sharded_index_two_shards_on_one_gpu_vs_flat_oracle():
+    """ShardedMi355xIndex(devices=[0, 0, 0]): three row shards, scans on per-shard streams, device-to-device gather,
+    device merge -- the in-process multi-GPU path of KnnService with every device being GPU 0.  search (k <= 64 and the
+    large-k path), search_and_reconstruct, reconstruct and range_search must equal the flat oracle over all rows."""
+    from clip_retrieval_amd.knn import ShardedMi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d, n = 768, 30_011
+    x = _data(n, d, seed=31)
+    x[20_000:20_050] = x[5:55]  # duplicates across shards: ties resolved by global id
+    o = FlatIPOracle(d)
+    o.add(x)
+    ix = ShardedMi355xIndex(d, [0, 0, 0])
+    ix.reserve(n)
+    for lo in range(0, n, 7_000):  # adds that straddle shard boundaries
+        ix.add(x[lo:lo + 7_000])
+    assert ix.ntotal == n and ix.nshards == 3
+    for nq, k in [(1, 40), (37, 40), (70, 5), (2, 64)]:
+        q = _queries(nq, d, seed=nq * 7 + k, x=x)
+        D, I, R = ix.search_and_reconstruct(q, k)
+        Do, Io = o.search(q, k)
+        _check(D, I, Do, Io, f"sharded nq={nq} k={k}")
+        assert np.array_equal(R, x[I].astype(np.float32))
+    q = _queries(3, d, seed=5, x=x)
+    D, I = ix.search(q, 200)  # k > 64: per-shard threshold descent + P-way merge of sorted lists on the device
+    Do, Io = o.search(q, 200)
+    _check(D, I, Do, Io, "sharded k=200")
+    ids = np.array([0, 10_003, 10_004, n - 1, -1], dtype=np.int64)
+    got = ix.reconstruct_batch(ids)
+    assert np.array_equal(got[:4], x[ids[:4]].astype(np.float32)) and np.isnan(got[4]).all()
+    lims, Dr, Ir = ix.range_search(q, 0.5)
+    lo_, Do_, Io_ = o.range_search(q, 0.5)
+    assert np.array_equal(lims, lo_) and np.array_equal(Ir, Io_) and np.allclose(Dr, Do_, atol=1e-5)
+    ix.close()
+
+
+def test_sharded_index_adopts_ivf_shards():
+    """Config-5 layout on one GPU: every shard is an IVF-Flat index over its row range with the SAME centroids
+    (replicated coarse quantiser) and global ids; the sharded handle must return what one IVF index over all rows returns."""
+    from clip_retrieval_amd.knn import Mi355xIndex, ShardedMi355xIndex, build_ivf_index
+    from oracle.knn_oracle import IVFFlatOracle
+
+    d, n, nlist, nprobe = 768, 12_000, 32, 6
+    x = _data(n, d, seed=41)
+    cent = x[np.random.default_rng(0).choice(n, nlist, replace=False)]
+    bounds = [0, 5_000, n]
+    shards = [build_ivf_index(x[bounds[g]:bounds[g + 1]], nlist, nprobe=nprobe, id_base=bounds[g], centroids=cent) for g in range(2)]
+    lists = np.concatenate([sh.ivf_lists for sh in shards])
+    ora = IVFFlatOracle(d, cent, lists, x)
+    ix = ShardedMi355xIndex.from_shards(shards, bounds[:2])
+    q = _queries(20, d, seed=3, x=x)
+    D, I = ix.search(q, 10)
+    Do, Io = ora.search(q, 10, nprobe)
+    _check(D, I, Do, Io, "sharded ivf")
+    ix.close()
+    assert all(sh._h is None for sh in shards)  # ownership moved
+
+
+def test_load_index_from_numpy_writer_output(tmp_path):
+    """`clip inference` output -> index (takes the place of clip_back.py:589-596): the img_emb_*.npy files NumpyWriter
+    writes (writer.py:67-75) are loaded in partition order, ids = global row order; row_range loads one shard with
+    id_base = lo; devices=[...] builds the in-process sharded object.  All three must answer like the oracle."""
+    from clip_retrieval_amd.knn import load_index
+    from clip_retrieval_amd.writer import NumpyWriter
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 512
+    parts = [_data(m, d, seed=50 + i) for i, m in enumerate((700, 1, 1300))]
+    for i, p in enumerate(parts):
+        w = NumpyWriter(partition_id=i, output_folder=str(tmp_path), enable_text=False, enable_image=True,
+                        enable_metadata=False, output_partition_count=3)
+        for lo in range(0, len(p), 512):  # batches as the Runner delivers them
+            w({"image_embs": p[lo:lo + 512], "text_embs": None, "image_filename": [f"{i}_{j}" for j in range(lo, min(lo + 512, len(p)))],
+               "text": None, "metadata": None})
+        w.flush()
+    x = np.concatenate(parts)
+    o = FlatIPOracle(d)
+    o.add(x)
+    q = _queries(9, d, seed=1, x=x)
+    Do, Io = o.search(q, 40)
+    folder = str(tmp_path / "img_emb")
+    ix = load_index(folder)
+    assert ix.ntotal == len(x) and ix.d == d
+    D, I = ix.search(q, 40)
+    _check(D, I, Do, Io, "load_index")
+    ix.close()
+    sh = load_index(folder, devices=[0, 0])
+    D, I, R = sh.search_and_reconstruct(q, 40)
+    _check(D, I, Do, Io, "load_index devices=[0,0]")
+    assert np.array_equal(R, x[I].astype(np.float32))
+    sh.close()
+    lo, hi = 650, 1500  # a shard that spans all three files
+    part = load_index(folder, row_range=(lo, hi))
+    op = FlatIPOracle(d)
+    op.add(x[lo:hi])
+    Dp, Ip = part.search(q, 40)
+    Dpo, Ipo = op.search(q, 40)
+    _check(Dp, Ip, Dpo, Ipo + lo, "load_index row_range")
+    part.close()
