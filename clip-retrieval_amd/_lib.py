@@ -77,6 +77,11 @@ SIGNATURES = {
     "clipx_destroy": (None, [_P]),
     "clipx_encode_image": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "clipx_encode_text": (C.c_int, [_P, _P, C.c_int, _P]),
+    "clipx_encode_image_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "clipx_encode_text_f32": (C.c_int, [_P, _P, C.c_int, _P]),
+    "clipx_encode_image_async": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "clipx_encode_text_async": (C.c_int, [_P, _P, C.c_int, _P, C.POINTER(_P)]),
+    "clipx_wait": (C.c_int, [_P]),
     "clipx_encode_image_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "clipx_encode_text_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "clipx_max_batch": (C.c_int, [_P]),

@@ -83,13 +83,23 @@ struct clipx_handle {
   float* x = nullptr;
   bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;
 
-  // host hand-over: two slots
-  void* pin_in[2] = {nullptr, nullptr};
-  void* pin_out[2] = {nullptr, nullptr};
-  void* dev_in[2] = {nullptr, nullptr};
-  uint16_t* dev_out[2] = {nullptr, nullptr};
+  // host hand-over: CLIPX_SLOTS staging slots (pinned in/out + device in/out); a slot carries one chunk from its upload to
+  // the moment its result has been copied to the caller (synchronous calls pipeline their chunks through them; every
+  // asynchronous ticket owns one)
+  static constexpr int NSLOT = 4;
+  void* pin_in[NSLOT] = {};
+  void* pin_out[NSLOT] = {};   // f16 [max_batch, E] then f32 [max_batch, E]
+  void* dev_in[NSLOT] = {};
+  uint16_t* dev_out[NSLOT] = {};
+  float* dev_out32[NSLOT] = {};
+  bool slot_busy[NSLOT] = {};
+  int slot_next = 0;
   size_t in_slot_bytes = 0, out_slot_bytes = 0;
-  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_copied[NSLOT] = {}, ev_done[NSLOT] = {};
+  // the activation workspace is shared by every call: a launch sequence first waits for the event the previous one
+  // recorded, whichever stream that ran on (callers of the *_device entry points may bring their own streams)
+  hipEvent_t ev_ws = nullptr;
+  bool ev_ws_valid = false;
 
   int prof = 0;  // bit k set: launches of kind k (0 gemm, 1 attention, 2 layernorm, 3 other) are bracketed by hipEvents
   std::vector<ProfEvent> prof_events;
@@ -230,14 +240,16 @@ static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
   // ---- host hand-over slots
   h->in_slot_bytes = std::max((size_t)Bm * 3 * d.image_size * d.image_size * sizeof(float), (size_t)Bm * d.ctx_len * sizeof(int32_t));
   h->out_slot_bytes = Bm * E * sizeof(uint16_t);
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < clipx_handle::NSLOT; ++s) {
     HIPCHK(hipHostMalloc(&h->pin_in[s], h->in_slot_bytes, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(&h->pin_out[s], h->out_slot_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&h->pin_out[s], h->out_slot_bytes * 3, hipHostMallocDefault));
     if ((r = dev_alloc(h, &h->dev_in[s], h->in_slot_bytes))) return r;
     if ((r = dev_alloc(h, (void**)&h->dev_out[s], h->out_slot_bytes))) return r;
+    if ((r = dev_alloc(h, (void**)&h->dev_out32[s], h->out_slot_bytes * 2))) return r;
     HIPCHK(hipEventCreateWithFlags(&h->ev_copied[s], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
   }
+  HIPCHK(hipEventCreateWithFlags(&h->ev_ws, hipEventDisableTiming));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -290,12 +302,13 @@ extern "C" void clipx_destroy(clipx_handle* h) {
   }
   for (void* p : h->owned) (void)hipFree(p);
   if (h->blob_dev) (void)hipFree(h->blob_dev);
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < clipx_handle::NSLOT; ++s) {
     if (h->pin_in[s]) (void)hipHostFree(h->pin_in[s]);
     if (h->pin_out[s]) (void)hipHostFree(h->pin_out[s]);
     if (h->ev_copied[s]) (void)hipEventDestroy(h->ev_copied[s]);
     if (h->ev_done[s]) (void)hipEventDestroy(h->ev_done[s]);
   }
+  if (h->ev_ws) (void)hipEventDestroy(h->ev_ws);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   delete h;
@@ -382,6 +395,16 @@ static int text_chunk(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, i
   return 0;
 }
 
+static int ws_acquire(clipx_handle* h, hipStream_t st) {
+  if (h->ev_ws_valid) HIPCHK(hipStreamWaitEvent(st, h->ev_ws, 0));
+  return 0;
+}
+static int ws_release(clipx_handle* h, hipStream_t st) {
+  HIPCHK(hipEventRecord(h->ev_ws, st));
+  h->ev_ws_valid = true;
+  return 0;
+}
+
 static size_t pix_bytes_per_image(const clipx_model_desc& d, int fmt) {
   const size_t px = (size_t)3 * d.image_size * d.image_size;
   return fmt == CLIPX_PIX_F32_NCHW ? px * sizeof(float) : px;
@@ -395,12 +418,14 @@ extern "C" int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   const size_t ib = pix_bytes_per_image(h->desc, pix_fmt), E = h->desc.embed_dim;
+  if (ws_acquire(h, st)) return CLIPX_E_HIP;
   for (int o = 0; o < B; o += h->max_batch) {
     const int nb = std::min(h->max_batch, B - o);
     int r = vision_chunk(h, st, (const char*)pixels_dev + (size_t)o * ib, nb, pix_fmt, out_f16_dev + (size_t)o * E,
                          out_f32_or_null ? out_f32_or_null + (size_t)o * E : nullptr);
     if (r) return r;
   }
+  if (ws_release(h, st)) return CLIPX_E_HIP;
   return CLIPX_OK;
 }
 
@@ -411,74 +436,167 @@ extern "C" int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev,
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   const size_t E = h->desc.embed_dim;
+  if (ws_acquire(h, st)) return CLIPX_E_HIP;
   for (int o = 0; o < B; o += h->max_batch) {
     const int nb = std::min(h->max_batch, B - o);
     int r = text_chunk(h, st, ids_dev + (size_t)o * h->desc.ctx_len, nb, out_f16_dev + (size_t)o * E,
                        out_f32_or_null ? out_f32_or_null + (size_t)o * E : nullptr);
     if (r) return r;
   }
+  if (ws_release(h, st)) return CLIPX_E_HIP;
   return CLIPX_OK;
 }
 
-// Host-buffer path: chunks of `host_chunk` (default max_batch) samples flow through two slots.  The copy stream uploads chunk c+1 while
-// the compute stream still runs the kernels of chunk c.  Caller memory that is already page-locked (the reference's
-// DataLoader collates with pin_memory: reader.py:198) is uploaded straight from where it lies; pageable memory is
-// first copied into the slot's pinned buffer by the CPU.  Chunking never changes a row's result (test: bitwise).
-template <typename ChunkFn>
-static int host_pipeline(clipx_handle* h, const char* in, size_t in_bytes_per_item, int B, uint16_t* out, ChunkFn fn) {
-  const size_t E = h->desc.embed_dim;
-  const int CH = h->host_chunk;
-  const int nchunk = (B + CH - 1) / CH;
+// Host-buffer path.  A chunk (<= host_chunk samples) travels through one staging slot: upload on the copy stream (straight
+// from caller memory when that is already page-locked -- the reference's DataLoader collates with pin_memory, reader.py:198
+// -- otherwise through the slot's pinned buffer), kernels + download on the compute stream, copy-out to the caller when
+// the slot is collected.  The upload of a later chunk runs while the kernels of an earlier one execute; the activation
+// workspace is shared, so the compute stream serialises the chunks.  Chunking never changes a row's result (test: bitwise).
+struct clipx_ticket {
+  clipx_handle* h;
+  int slot;
+  int nb;
+  uint16_t* out16;
+  float* out32;
+};
+
+enum { KIND_IMAGE = 0, KIND_TEXT = 1 };
+
+// caller holds h->mu.  Returns the slot index (>= 0) or a negative error code.
+static int slot_submit(clipx_handle* h, int kind, const char* src, size_t in_bytes_per_item, int nb, int pix_fmt, bool want32) {
+  int s = -1;
+  for (int i = 0; i < clipx_handle::NSLOT; ++i) {
+    const int c = (h->slot_next + i) % clipx_handle::NSLOT;
+    if (!h->slot_busy[c]) { s = c; break; }
+  }
+  if (s < 0) return fail(CLIPX_E_STATE, "all staging slots are in flight: clipx_wait() an earlier ticket first");
+  h->slot_next = (s + 1) % clipx_handle::NSLOT;
   hipPointerAttribute_t attr;
   bool pinned = false;
-  if (hipPointerGetAttributes(&attr, in) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
+  if (hipPointerGetAttributes(&attr, src) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
   else (void)hipGetLastError();  // plain malloc memory: the query fails, which is the answer
-  auto drain = [&](int c) -> int {  // copy chunk c's result out of its pinned slot
-    const int s = c & 1, o = c * CH, nb = std::min(CH, B - o);
-    HIPCHK(hipEventSynchronize(h->ev_done[s]));
-    memcpy(out + (size_t)o * E, h->pin_out[s], (size_t)nb * E * sizeof(uint16_t));
-    return 0;
-  };
-  for (int c = 0; c < nchunk; ++c) {
-    const int s = c & 1, o = c * CH, nb = std::min(CH, B - o);
-    int r;
-    if (c >= 2 && (r = drain(c - 2))) return r;  // slot s is free once chunk c-2 has been copied out
-    const char* src = in + (size_t)o * in_bytes_per_item;
-    if (!pinned) {
-      memcpy(h->pin_in[s], src, (size_t)nb * in_bytes_per_item);
-      src = (const char*)h->pin_in[s];
-    }
-    HIPCHK(hipMemcpyAsync(h->dev_in[s], src, (size_t)nb * in_bytes_per_item, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(hipEventRecord(h->ev_copied[s], h->copy_stream));
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copied[s], 0));
-    if ((r = fn(h->dev_in[s], nb, h->dev_out[s]))) return r;
-    HIPCHK(hipMemcpyAsync(h->pin_out[s], h->dev_out[s], (size_t)nb * E * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
+  if (!pinned) {
+    memcpy(h->pin_in[s], src, (size_t)nb * in_bytes_per_item);
+    src = (const char*)h->pin_in[s];
   }
-  for (int c = std::max(0, nchunk - 2); c < nchunk; ++c) {
-    int r = drain(c);
-    if (r) return r;
+  const size_t E = h->desc.embed_dim;
+  HIPCHK(hipMemcpyAsync(h->dev_in[s], src, (size_t)nb * in_bytes_per_item, hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(hipEventRecord(h->ev_copied[s], h->copy_stream));
+  HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copied[s], 0));
+  int r = ws_acquire(h, h->stream);
+  if (r) return r;
+  float* o32 = want32 ? h->dev_out32[s] : nullptr;
+  r = kind == KIND_IMAGE ? vision_chunk(h, h->stream, h->dev_in[s], nb, pix_fmt, h->dev_out[s], o32)
+                         : text_chunk(h, h->stream, (const int32_t*)h->dev_in[s], nb, h->dev_out[s], o32);
+  if (r) return r;
+  if ((r = ws_release(h, h->stream))) return r;
+  char* po = (char*)h->pin_out[s];
+  HIPCHK(hipMemcpyAsync(po, h->dev_out[s], (size_t)nb * E * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+  if (want32) HIPCHK(hipMemcpyAsync(po + h->out_slot_bytes, o32, (size_t)nb * E * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
+  h->slot_busy[s] = true;
+  return s;
+}
+
+// blocks until the slot's chunk is complete, copies it out, frees the slot.  Caller holds h->mu or owns the ticket.
+static int slot_collect(clipx_handle* h, int s, int nb, uint16_t* out16, float* out32) {
+  const size_t E = h->desc.embed_dim;
+  hipError_t e = hipEventSynchronize(h->ev_done[s]);
+  if (e == hipSuccess) {
+    const char* po = (const char*)h->pin_out[s];
+    if (out16) memcpy(out16, po, (size_t)nb * E * sizeof(uint16_t));
+    if (out32) memcpy(out32, po + h->out_slot_bytes, (size_t)nb * E * sizeof(float));
   }
+  h->slot_busy[s] = false;
+  if (e != hipSuccess) return fail(CLIPX_E_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
   return 0;
 }
 
-extern "C" int clipx_encode_image(clipx_handle* h, const void* pixels, int B, int pix_fmt, uint16_t* out_f16) {
-  if (!h || (B > 0 && (!pixels || !out_f16)) || B < 0) return fail(CLIPX_E_ARG, "bad encode_image arguments");
+// synchronous call: chunks pipelined two deep through the slots
+static int host_sync(clipx_handle* h, int kind, const char* in, size_t in_bytes_per_item, int B, int pix_fmt, uint16_t* out16,
+                     float* out32) {
+  const size_t E = h->desc.embed_dim;
+  const int CH = h->host_chunk;
+  const int nchunk = (B + CH - 1) / CH;
+  int prev_slot = -1, prev_o = 0, prev_nb = 0;
+  for (int c = 0; c < nchunk; ++c) {
+    const int o = c * CH, nb = std::min(CH, B - o);
+    const int s = slot_submit(h, kind, in + (size_t)o * in_bytes_per_item, in_bytes_per_item, nb, pix_fmt, out32 != nullptr);
+    if (s < 0) return s;
+    if (prev_slot >= 0) {
+      int r = slot_collect(h, prev_slot, prev_nb, out16 ? out16 + (size_t)prev_o * E : nullptr, out32 ? out32 + (size_t)prev_o * E : nullptr);
+      if (r) return r;
+    }
+    prev_slot = s; prev_o = o; prev_nb = nb;
+  }
+  if (prev_slot >= 0)
+    return slot_collect(h, prev_slot, prev_nb, out16 ? out16 + (size_t)prev_o * E : nullptr, out32 ? out32 + (size_t)prev_o * E : nullptr);
+  return 0;
+}
+
+static int encode_image_host(clipx_handle* h, const void* pixels, int B, int pix_fmt, uint16_t* out16, float* out32) {
+  if (!h || (B > 0 && (!pixels || (!out16 && !out32))) || B < 0) return fail(CLIPX_E_ARG, "bad encode_image arguments");
   if (pix_fmt != CLIPX_PIX_F32_NCHW && pix_fmt != CLIPX_PIX_U8_NHWC) return fail(CLIPX_E_ARG, "unknown pixel format");
   if (B == 0) return CLIPX_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHK(hipSetDevice(h->device));
-  return host_pipeline(h, (const char*)pixels, pix_bytes_per_image(h->desc, pix_fmt), B, out_f16,
-                       [&](void* din, int nb, uint16_t* dout) { return vision_chunk(h, h->stream, din, nb, pix_fmt, dout, nullptr); });
+  return host_sync(h, KIND_IMAGE, (const char*)pixels, pix_bytes_per_image(h->desc, pix_fmt), B, pix_fmt, out16, out32);
 }
-
-extern "C" int clipx_encode_text(clipx_handle* h, const int32_t* ids, int B, uint16_t* out_f16) {
-  if (!h || (B > 0 && (!ids || !out_f16)) || B < 0) return fail(CLIPX_E_ARG, "bad encode_text arguments");
+static int encode_text_host(clipx_handle* h, const int32_t* ids, int B, uint16_t* out16, float* out32) {
+  if (!h || (B > 0 && (!ids || (!out16 && !out32))) || B < 0) return fail(CLIPX_E_ARG, "bad encode_text arguments");
   if (B == 0) return CLIPX_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHK(hipSetDevice(h->device));
-  return host_pipeline(h, (const char*)ids, (size_t)h->desc.ctx_len * sizeof(int32_t), B, out_f16,
-                       [&](void* din, int nb, uint16_t* dout) { return text_chunk(h, h->stream, (const int32_t*)din, nb, dout, nullptr); });
+  return host_sync(h, KIND_TEXT, (const char*)ids, (size_t)h->desc.ctx_len * sizeof(int32_t), B, 0, out16, out32);
+}
+
+extern "C" int clipx_encode_image(clipx_handle* h, const void* pixels, int B, int pix_fmt, uint16_t* out_f16) {
+  return encode_image_host(h, pixels, B, pix_fmt, out_f16, nullptr);
+}
+extern "C" int clipx_encode_text(clipx_handle* h, const int32_t* ids, int B, uint16_t* out_f16) {
+  return encode_text_host(h, ids, B, out_f16, nullptr);
+}
+extern "C" int clipx_encode_image_f32(clipx_handle* h, const void* pixels, int B, int pix_fmt, float* out_f32) {
+  return encode_image_host(h, pixels, B, pix_fmt, nullptr, out_f32);
+}
+extern "C" int clipx_encode_text_f32(clipx_handle* h, const int32_t* ids, int B, float* out_f32) {
+  return encode_text_host(h, ids, B, nullptr, out_f32);
+}
+
+static int encode_async(clipx_handle* h, int kind, const void* in, size_t in_bytes_per_item, int B, int pix_fmt, uint16_t* out_f16,
+                        clipx_ticket** ticket) {
+  if (!h || !in || !out_f16 || !ticket || B <= 0) return fail(CLIPX_E_ARG, "bad encode_*_async arguments");
+  *ticket = nullptr;
+  if (B > h->max_batch) return fail(CLIPX_E_ARG, "an asynchronous call takes at most clipx_max_batch() samples");
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  const int s = slot_submit(h, kind, (const char*)in, in_bytes_per_item, B, pix_fmt, false);
+  if (s < 0) return s;
+  *ticket = new clipx_ticket{h, s, B, out_f16, nullptr};
+  return CLIPX_OK;
+}
+extern "C" int clipx_encode_image_async(clipx_handle* h, const void* pixels, int B, int pix_fmt, uint16_t* out_f16,
+                                        clipx_ticket** ticket) {
+  if (pix_fmt != CLIPX_PIX_F32_NCHW && pix_fmt != CLIPX_PIX_U8_NHWC) return fail(CLIPX_E_ARG, "unknown pixel format");
+  return encode_async(h, KIND_IMAGE, pixels, h ? pix_bytes_per_image(h->desc, pix_fmt) : 0, B, pix_fmt, out_f16, ticket);
+}
+extern "C" int clipx_encode_text_async(clipx_handle* h, const int32_t* ids, int B, uint16_t* out_f16, clipx_ticket** ticket) {
+  return encode_async(h, KIND_TEXT, ids, h ? (size_t)h->desc.ctx_len * sizeof(int32_t) : 0, B, 0, out_f16, ticket);
+}
+extern "C" int clipx_wait(clipx_ticket* t) {
+  if (!t) return fail(CLIPX_E_ARG, "ticket is null");
+  clipx_handle* h = t->h;
+  int r;
+  {
+    // the event wait runs outside the lock (other threads may submit meanwhile); the slot is this ticket's alone
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipEventSynchronize(h->ev_done[t->slot]);
+    std::lock_guard<std::mutex> lk(h->mu);
+    r = e == hipSuccess ? slot_collect(h, t->slot, t->nb, t->out16, t->out32)
+                        : (h->slot_busy[t->slot] = false, fail(CLIPX_E_HIP, std::string("clipx_wait: ") + hipGetErrorString(e)));
+  }
+  delete t;
+  return r;
 }
 
 extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out,

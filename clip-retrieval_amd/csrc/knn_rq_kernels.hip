@@ -83,27 +83,72 @@ __global__ void knn_rq_prep_kernel(const float* __restrict__ q, int nq, int d, i
 constexpr int RQ_STAGE = 256;   // entries of a wave's private staging list
 constexpr int RQ_FLUSH_AT = 96; // flush when at least this many are staged (a tile step adds a handful)
 
-// This wave's share of the LDS-DMA of tile `t` into ring slot `slot`.  Inline asm: hipcc must not know about the DMA, or
-// it drains vmcnt(0) before every LDS read; s_nop 0: M0 needs a wait state before the DMA reads it.  Past the end of the
-// index the last tile is re-loaded, which keeps the vmcnt arithmetic of the main loop uniform.
-template <int KS, int NW>
-__device__ __forceinline__ void rq_issue(const _Float16* __restrict__ X, int64_t t, int64_t ntile, int64_t last, unsigned voff,
-                                         unsigned voff_last, unsigned lds_base, int slot, int w) {
-  constexpr int TILE_BYTES = KS * 1024, GPW = KS / 4 / NW;
+// LDS-DMA of tile `t` into ring slot `slot`: this wave's piece IDX (of DPW = KS / NW) -- wave w takes the k-step groups
+// w, w + NW, ... (a group = 4 consecutive k-steps = the same 128-B lines of the 32 rows), piece IDX = k-step
+// ((IDX / 4) NW + w) 4 + IDX % 4.  Inline asm: hipcc must not know about the DMA, or it drains vmcnt(0) before every LDS
+// read; s_nop 0: M0 needs a wait state before the DMA reads it.  Past the end of the index the last tile is re-loaded,
+// which keeps the vmcnt arithmetic of the main loop uniform.
+struct RqTile {
+  const char* base;  // tile + this wave's offset
+  unsigned m0b;      // LDS address of the slot + this wave's offset
+  unsigned vo;       // per-lane byte offset (row, half)
+};
+template <int KS>
+__device__ __forceinline__ RqTile rq_tile(const _Float16* __restrict__ X, int64_t t, int64_t ntile, int64_t last, unsigned voff,
+                                          unsigned voff_last, unsigned lds_base, int slot, int w) {
+  constexpr int TILE_BYTES = KS * 1024;
   const int64_t tt = t < ntile ? t : last;
-  const unsigned vo = tt == last ? voff_last : voff;
-  // wave w takes the k-step groups w, w + NW, ...: its offsets inside the tile are <wave base> + a literal
-  const char* base = reinterpret_cast<const char*>(X) + (size_t)tt * TILE_BYTES + w * 128;
-  const unsigned m0b = lds_base + slot * TILE_BYTES + w * 4096;
+  RqTile r;
+  r.vo = tt == last ? voff_last : voff;
+  r.base = reinterpret_cast<const char*>(X) + (size_t)tt * TILE_BYTES + w * 128;
+  r.m0b = lds_base + slot * TILE_BYTES + w * 4096;
+  return r;
+}
+template <int NW, int IDX>
+__device__ __forceinline__ void rq_issue_one(const RqTile& r) {
+  constexpr int KOFF = (IDX / 4) * NW * 4 + (IDX % 4);  // k-step minus the wave's 4 w
+  const char* p = r.base + KOFF * 32;
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(r.vo), "s"(p), "s"(r.m0b), "n"(KOFF * 1024)
+               : "memory", "scc");
+}
+template <int NW, int DPW, int IDX = 0>
+__device__ __forceinline__ void rq_issue_all(const RqTile& r) {
+  if constexpr (IDX < DPW) {
+    rq_issue_one<NW, IDX>(r);
+    rq_issue_all<NW, DPW, IDX + 1>(r);
+  }
+}
+
+// ---- the k-loop of one tile, as a compile-time recursion over the k-step S (every LDS offset, wait count and DMA piece
+// index must be a literal of an inline-asm statement).  A fragments (index rows) go through a 4-deep register ring, three
+// k-steps ahead of the MFMAs that use them.  The reads are inline asm so that THIS file places the lgkmcnt waits (hipcc
+// waits lgkmcnt(0) right behind each read, which puts the LDS latency of every k-step in front of its MFMAs).
+template <int OFF>
+__device__ __forceinline__ void rq_dsread(i32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void rq_wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int KS, int QBW, int NW, int DPW, int S>
+__device__ __forceinline__ void rq_ksteps(unsigned xa, i32x4 (&A)[4], float16v (&acc)[QBW], const half8 (&Q)[QBW][KS],
+                                          const RqTile& refill) {
+  if constexpr (S < KS) {
+    if constexpr (S + 3 < KS) rq_dsread<(S + 3) * 1024>(A[(S + 3) & 3], xa);
+    rq_wait_lgkm<(KS - 1 - S < 3 ? KS - 1 - S : 3)>();  // reads issued after the one this step needs may stay in flight
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int g = 0; g < GPW; ++g) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const char* p = base + (g * NW * 4 + j) * 32;  // k-step (g NW + w) 4 + j
-      asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(p), "s"(m0b),
-                   "n"((g * NW * 4 + j) * 1024)
-                   : "memory", "scc");
+    for (int b = 0; b < QBW; ++b)
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A[S & 3]), Q[b][S], acc[b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // DMA piece S / (KS / DPW) of the refill behind this step's MFMAs: the DPW pieces are spread over the tile so that
+    // their issue time overlaps with MFMAs already queued instead of holding all waves at the top of the tile
+    if constexpr (S % (KS / DPW) == 1) {
+      rq_issue_one<NW, S / (KS / DPW)>(refill);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    rq_ksteps<KS, QBW, NW, DPW, S + 1>(xa, A, acc, Q, refill);
   }
 }
 
@@ -166,15 +211,14 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
   const unsigned voff_last = (unsigned)((qcol < lrow ? qcol : lrow) * D * 2 + hb * 16);
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
-  // issue this wave's share of tile `t` into ring slot `slot`: rq_issue() above (a lambda capturing by reference makes
-  // hipcc keep the closure in scratch memory)
-#define RQ_ISSUE(t_, slot_) rq_issue<KS, NW>(X, (t_), ntile, last, voff, voff_last, lds_base, (slot_), w)
+  // (helpers above instead of a lambda: a lambda capturing by reference makes hipcc keep the closure in scratch memory)
+#define RQ_TILE(t_, slot_) rq_tile<KS>(X, (t_), ntile, last, voff, voff_last, lds_base, (slot_), w)
 
   int64_t t = blockIdx.x;
   const int64_t gstride = gridDim.x;
   // prologue: NSLOT - 1 tiles in flight
 #pragma unroll
-  for (int i = 0; i < NSLOT - 1; ++i) RQ_ISSUE(t + (int64_t)i * gstride, i);
+  for (int i = 0; i < NSLOT - 1; ++i) rq_issue_all<NW, DPW>(RQ_TILE(t + (int64_t)i * gstride, i));
 
   int nst = 0;  // entries in this wave's staging list (wave-uniform)
   int slot = 0;
@@ -183,49 +227,24 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NSLOT - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    {  // refill the slot that tile t - 1 (of this workgroup's sequence) occupied: every wave is past it
-      const int rs = slot == 0 ? NSLOT - 1 : slot - 1;
-      RQ_ISSUE(t + (int64_t)(NSLOT - 1) * gstride, rs);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    // refill of the slot that tile t - 1 (of this workgroup's sequence) occupied -- every wave is past it.  The DPW DMA
+    // instructions are spread over the k-loop below, one every KS / DPW k-steps, so that their issue time (tens of
+    // cycles each) overlaps with MFMAs already queued instead of holding all waves at the top of the tile.
+    const RqTile refill = RQ_TILE(t + (int64_t)(NSLOT - 1) * gstride, slot == 0 ? NSLOT - 1 : slot - 1);
 
     float16v acc[QBW];
 #pragma unroll
     for (int b = 0; b < QBW; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    // A fragments (index rows) through a 4-deep register ring, three k-steps ahead of the MFMAs that use them.  The reads
-    // are inline asm so that THIS file places the lgkmcnt waits (hipcc waits lgkmcnt(0) right behind each read, which
-    // puts the LDS latency of every k-step in front of its MFMAs).
+    // the k-loop: rq_ksteps<...> above (A fragments through a 4-deep register ring, the refill DMAs spread over the steps)
     const unsigned xa = lds_base + slot * TILE_BYTES + lane * 16;
     i32x4 A[4];
-#define RQ_DSREAD(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(xa), "n"(off))
-    RQ_DSREAD(A[0], 0);
-    RQ_DSREAD(A[1], 1024);
-    RQ_DSREAD(A[2], 2048);
+    rq_dsread<0>(A[0], xa);
+    rq_dsread<1024>(A[1], xa);
+    rq_dsread<2048>(A[2], xa);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (s + 3 < KS) {
-        switch ((s + 3) & 3) {  // folds after unrolling; the offset must be a literal
-          case 0: RQ_DSREAD(A[0], ((s + 3) * 1024) & 0xffff); break;
-          case 1: RQ_DSREAD(A[1], ((s + 3) * 1024) & 0xffff); break;
-          case 2: RQ_DSREAD(A[2], ((s + 3) * 1024) & 0xffff); break;
-          default: RQ_DSREAD(A[3], ((s + 3) * 1024) & 0xffff); break;
-        }
-      }
-      const int ahead = KS - 1 - s < 3 ? KS - 1 - s : 3;  // reads issued after the one this step needs
-      if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-      else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < QBW; ++b)
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A[s & 3]), Q[b][s], acc[b], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#undef RQ_DSREAD
+    rq_ksteps<KS, QBW, NW, DPW, 0>(xa, A, acc, Q, refill);
 
     // ---- filter: lane (qcol, hb) owns rows row0 + (r & 3) + 8 (r >> 2) of its query column in each block
     const int64_t row0 = t * 32 + 4 * hb;
@@ -235,6 +254,7 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) any |= acc[b][r] >= tq[b];
     if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // a hit somewhere in the wave: ~1 tile step in 8
+      bool vmem = false;
 #pragma unroll
       for (int b = 0; b < QBW; ++b) {
 #pragma unroll
@@ -252,6 +272,7 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
                 st_q[pos] = qq;
               } else {
                 g_lost[qq] = 1u;  // staging overflow (flood of hits in one tile step): the query falls back
+                vmem = true;
               }
             }
             nst += __builtin_popcountll(m);
@@ -260,6 +281,7 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
       }
       if (nst > RQ_STAGE) nst = RQ_STAGE;
       if (nst >= RQ_FLUSH_AT) {
+        vmem = true;
         for (int i = lane; i < nst; i += 64) {
           const unsigned qq = st_q[i];
           const unsigned pos = atomicAdd(&g_cnt[qq], 1u);
@@ -270,8 +292,9 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
         }
         nst = 0;
       }
-      // the branch issued VMEM operations hipcc counts itself; drain so that the DMA arithmetic at the loop top holds
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // a flush (or a lost flag) issued VMEM operations that hipcc counts itself: drain, so that the DMA arithmetic at the
+      // loop top holds.  Rare (once per ~RQ_FLUSH_AT hits); a hit that is only staged in LDS touches no VMEM counter.
+      if (__builtin_amdgcn_ballot_w64(vmem) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
   }

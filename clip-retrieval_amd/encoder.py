@@ -206,6 +206,7 @@ def blob_from_checkpoint(path: str, arch: ClipArch) -> np.ndarray:
         except RuntimeError:
             sd = torch.load(path, map_location="cpu", weights_only=True)
             sd = sd.get("state_dict", sd)
+    sd = _strip_prefixes(dict(sd))
     if any(k.startswith("vision_model.") for k in sd):
         return blob_from_hf_state_dict(sd, arch)
     return blob_from_openai_state_dict(sd, arch)
@@ -244,7 +245,7 @@ class ClipEncoder:
             pass
 
     # ---- host buffers (the ClipMapper path)
-    def encode_image(self, pixels) -> np.ndarray:
+    def _image_array(self, pixels):
         a = pixels.numpy() if hasattr(pixels, "numpy") else np.asarray(pixels)
         S = self.arch.image_size
         if a.dtype == np.uint8:
@@ -256,19 +257,54 @@ class ClipEncoder:
                 raise ValueError(f"float images must be [B,3,{S},{S}] (NCHW), got {a.shape}")
             a = a.astype(np.float32, copy=False)
             fmt = PIX_F32_NCHW
-        a = np.ascontiguousarray(a)
-        out = np.empty((a.shape[0], self.embed_dim), dtype=np.float16)
-        check(self._lib, self._lib.clipx_encode_image(self._h, a.ctypes.data, a.shape[0], fmt, out.ctypes.data), "clipx")
-        return out
+        return np.ascontiguousarray(a), fmt
 
-    def encode_text(self, ids) -> np.ndarray:
+    def _token_array(self, ids):
         a = ids.numpy() if hasattr(ids, "numpy") else np.asarray(ids)
         if a.ndim != 2 or a.shape[1] != self.arch.ctx_len:
             raise ValueError(f"token ids must be [B,{self.arch.ctx_len}], got {a.shape}")
-        a = np.ascontiguousarray(a.astype(np.int32, copy=False))
-        out = np.empty((a.shape[0], self.embed_dim), dtype=np.float16)
-        check(self._lib, self._lib.clipx_encode_text(self._h, a.ctypes.data, a.shape[0], out.ctypes.data), "clipx")
+        if a.size and (a.min() < 0 or a.max() >= self.arch.vocab):
+            # the reference's nn.Embedding raises on an out-of-range id; the kernel would clamp it silently
+            raise IndexError(f"token id out of range [0, {self.arch.vocab}): min {a.min()}, max {a.max()}")
+        return np.ascontiguousarray(a.astype(np.int32, copy=False))
+
+    def encode_image(self, pixels, f32=False) -> np.ndarray:
+        """fp16 [B, E] unit-norm rows (mapper.py:57-59); f32=True: the fp32 rows before the fp16 rounding."""
+        a, fmt = self._image_array(pixels)
+        out = np.empty((a.shape[0], self.embed_dim), dtype=np.float32 if f32 else np.float16)
+        fn = self._lib.clipx_encode_image_f32 if f32 else self._lib.clipx_encode_image
+        check(self._lib, fn(self._h, a.ctypes.data, a.shape[0], fmt, out.ctypes.data), "clipx")
         return out
+
+    def encode_text(self, ids, f32=False) -> np.ndarray:
+        a = self._token_array(ids)
+        out = np.empty((a.shape[0], self.embed_dim), dtype=np.float32 if f32 else np.float16)
+        fn = self._lib.clipx_encode_text_f32 if f32 else self._lib.clipx_encode_text
+        check(self._lib, fn(self._h, a.ctypes.data, a.shape[0], out.ctypes.data), "clipx")
+        return out
+
+    # ---- asynchronous tickets (clipx_encode_*_async / clipx_wait): submit now, collect later
+    def submit_image(self, pixels):
+        a, fmt = self._image_array(pixels)
+        out = np.empty((a.shape[0], self.embed_dim), dtype=np.float16)
+        t = C.c_void_p()
+        check(self._lib, self._lib.clipx_encode_image_async(self._h, a.ctypes.data, a.shape[0], fmt, out.ctypes.data, C.byref(t)), "clipx")
+        return {"ticket": t, "out": out, "keep": (a, pixels)}  # inputs stay alive until the upload is done
+
+    def submit_text(self, ids):
+        a = self._token_array(ids)
+        out = np.empty((a.shape[0], self.embed_dim), dtype=np.float16)
+        t = C.c_void_p()
+        check(self._lib, self._lib.clipx_encode_text_async(self._h, a.ctypes.data, a.shape[0], out.ctypes.data, C.byref(t)), "clipx")
+        return {"ticket": t, "out": out, "keep": (a, ids)}
+
+    def collect(self, handle) -> np.ndarray:
+        t, handle["ticket"] = handle["ticket"], None
+        if t is None:
+            raise HipLibraryError("ticket was already collected")
+        check(self._lib, self._lib.clipx_wait(t), "clipx")
+        handle["keep"] = None
+        return handle["out"]
 
     # ---- device buffers (benchmark; callers that stage their own input)
     def encode_image_device(self, pix_ptr, B, fmt, out_f16_ptr, out_f32_ptr=None, stream=None):
@@ -301,12 +337,12 @@ class _TorchModelFacade:
     def encode_image(self, x):
         import torch  # pylint: disable=import-outside-toplevel
 
-        return torch.from_numpy(self._enc.encode_image(x.detach().cpu()).astype(np.float32))
+        return torch.from_numpy(self._enc.encode_image(x.detach().cpu(), f32=True))
 
     def encode_text(self, tok):
         import torch  # pylint: disable=import-outside-toplevel
 
-        return torch.from_numpy(self._enc.encode_text(tok.detach().cpu()).astype(np.float32))
+        return torch.from_numpy(self._enc.encode_text(tok.detach().cpu(), f32=True))
 
 
 _registry = {}
@@ -319,13 +355,46 @@ def register_encoder(name: str, encoder: ClipEncoder):
         _registry[("registered:" + name, encoder.device)] = encoder
 
 
+# `clip_model` strings of the reference (all_clip: "ViT-L/14", "open_clip:ViT-H-14/laion2b_s32b_b79k", "hf_clip:openai/clip-vit-large-patch14", ...)
+_HF_NAMES = {"openai/clip-vit-base-patch32": "ViT-B/32", "openai/clip-vit-base-patch16": "ViT-B/16",
+             "openai/clip-vit-large-patch14": "ViT-L/14"}
+
+
+def resolve_arch_name(clip_model: str) -> str:
+    """Map a reference model string onto a key of ARCHS (raises ValueError for unknown architectures)."""
+    if clip_model in ARCHS:
+        return clip_model
+    if clip_model.startswith("hf_clip:"):
+        name = _HF_NAMES.get(clip_model[len("hf_clip:"):])
+        if name:
+            return name
+    if clip_model.startswith("open_clip:"):
+        arch = clip_model[len("open_clip:"):].split("/")[0]  # "ViT-H-14/laion2b_s32b_b79k" -> "ViT-H-14"
+        pretrained = clip_model.split("/", 1)[1] if "/" in clip_model else ""
+        if pretrained == "openai" and "/".join(arch.rsplit("-", 1)) in ARCHS:
+            return "/".join(arch.rsplit("-", 1))  # open_clip:ViT-L-14/openai = the OpenAI (quick_gelu) weights
+        if "open_clip:" + arch in ARCHS:
+            return "open_clip:" + arch
+    raise ValueError(f"unknown clip_model {clip_model!r}; known architectures: {sorted(ARCHS)} "
+                     "(also hf_clip:openai/clip-vit-*, open_clip:<arch>/<pretrained>)")
+
+
+def _strip_prefixes(sd):
+    """Checkpoints saved from DataParallel / Lightning wrappers: drop a common 'module.' / 'model.' prefix."""
+    for pre in ("module.", "model."):
+        if sd and all(k.startswith(pre) for k in sd):
+            sd = {k[len(pre):]: v for k, v in sd.items()}
+    return sd
+
+
 def get_encoder(clip_model: str, clip_cache_path=None, device: int = 0) -> ClipEncoder:
     """Resolve a `clip_model` string to a resident encoder; cached per (model, device) because the
     reference constructs a ClipMapper per output partition (runner.py:31).
 
       registered:<name>        an encoder passed to register_encoder()
       random:<arch>[:seed]     random-init weights (benchmarks)
-      <arch>                   checkpoint `<clip_cache_path>/<arch with / -> ->.{pt,safetensors,bin,npy}`
+      <arch>                   checkpoint `<clip_cache_path>/<arch with / -> ->.{pt,safetensors,bin,npy}`; also the
+                               reference's `hf_clip:openai/clip-vit-*` and `open_clip:<arch>/<pretrained>` spellings
     """
     key = (clip_model, int(device))
     with _registry_lock:
@@ -340,10 +409,9 @@ def get_encoder(clip_model: str, clip_cache_path=None, device: int = 0) -> ClipE
         arch = ARCHS[name]
         enc = ClipEncoder(arch, random_blob(arch, seed), device)
     else:
-        if clip_model not in ARCHS:
-            raise ValueError(f"unknown clip_model {clip_model!r}; known: {sorted(ARCHS)}")
-        arch = ARCHS[clip_model]
-        stem = clip_model.replace("open_clip:", "").replace("/", "-")
+        name = resolve_arch_name(clip_model)
+        arch = ARCHS[name]
+        stem = name.replace("open_clip:", "").replace("/", "-")
         cands = []
         if clip_cache_path:
             if os.path.isfile(clip_cache_path):
@@ -360,13 +428,20 @@ def get_encoder(clip_model: str, clip_cache_path=None, device: int = 0) -> ClipE
     return enc
 
 
-def load_clip(clip_model="ViT-B/32", use_jit=True, warmup_batch_size=1, clip_cache_path=None, device=None):  # pylint: disable=unused-argument
-    """`all_clip.load_clip`-shaped factory -> (model, preprocess, tokenizer).
+def load_clip(clip_model="ViT-B/32", use_jit=True, warmup_batch_size=1, clip_cache_path=None, device=None, bpe_path=None):  # pylint: disable=unused-argument
+    """`all_clip.load_clip`-shaped factory -> (model, preprocess, tokenizer) (mapper.py:36-41, worker.py:52-57,
+    clip_back.py:865-868).
 
-    `preprocess` / `tokenizer` are the reference's CPU-side third-party callables (torchvision transform,
-    BPE tokenizer); they are not part of the accelerated path and are not re-implemented: both are None
-    here, and readers that need them take the ones from clip_retrieval_amd.reader.
+    model       `.encode_image(x)` / `.encode_text(tok)`: torch tensors in, torch fp32 unit-norm features out (the service
+                feeds fp32 features to the index, clip_back.py:231-232)
+    preprocess  PIL image -> f32 [3, S, S]: CLIP's transform restated (reader.clip_preprocess)
+    tokenizer   CLIP's BPE (tokenizer.SimpleTokenizer); needs the merges file (bpe_path / CLIP_BPE_PATH / next to the
+                checkpoint).  When the file is absent the returned tokenizer raises that FileNotFoundError on its first
+                call, so image-only pipelines still run and text pipelines fail loudly where the tokens are needed.
     """
+    from .reader import clip_preprocess  # pylint: disable=import-outside-toplevel
+    from .tokenizer import MissingTokenizer, SimpleTokenizer  # pylint: disable=import-outside-toplevel
+
     dev = 0
     if isinstance(device, int):
         dev = device
@@ -379,4 +454,15 @@ def load_clip(clip_model="ViT-B/32", use_jit=True, warmup_batch_size=1, clip_cac
         ids = np.zeros((warmup_batch_size, enc.arch.ctx_len), dtype=np.int32)
         ids[:, 0], ids[:, 1] = enc.arch.vocab - 2, enc.arch.vocab - 1
         enc.encode_text(ids)
-    return _TorchModelFacade(enc), None, None
+    size = enc.arch.image_size
+
+    def preprocess(image):
+        import torch  # pylint: disable=import-outside-toplevel
+
+        return torch.from_numpy(clip_preprocess(image, size))
+
+    try:
+        tokenizer = SimpleTokenizer(bpe_path=bpe_path, clip_cache_path=clip_cache_path, context_length=enc.arch.ctx_len)
+    except FileNotFoundError as e:
+        tokenizer = MissingTokenizer(e)
+    return _TorchModelFacade(enc), preprocess, tokenizer

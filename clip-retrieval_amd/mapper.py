@@ -60,6 +60,36 @@ class ClipMapper:
                 self._enc.encode_text(ids)
             self._enc._warm = True  # pylint: disable=protected-access
 
+    def submit(self, item):
+        """Stage the batch and enqueue its upload + kernels (clipx_encode_*_async); returns a handle for collect().
+        A caller that submits batch n+1 before collecting batch n overlaps n+1's upload with n's kernels (runner.Runner).
+        Batches larger than the library's max batch fall back to the synchronous call inside collect()."""
+        h = {"item": item, "img": None, "txt": None}
+        if self.enable_image and len(item["image_tensor"]) <= self._enc.max_batch:
+            h["img"] = self._enc.submit_image(item["image_tensor"])
+        if self.enable_text and len(item["text_tokens"]) <= self._enc.max_batch:
+            h["txt"] = self._enc.submit_text(item["text_tokens"])
+        return h
+
+    def collect(self, h):
+        item = h["item"]
+        image_embs = text_embs = image_filename = text = metadata = None
+        if self.enable_image:
+            image_embs = self._enc.collect(h["img"]) if h["img"] is not None else self._enc.encode_image(item["image_tensor"])
+            image_filename = item["image_filename"]
+        if self.enable_text:
+            text_embs = self._enc.collect(h["txt"]) if h["txt"] is not None else self._enc.encode_text(item["text_tokens"])
+            text = item["text"]
+        if self.enable_metadata:
+            metadata = item["metadata"]
+        return {
+            "image_embs": image_embs,
+            "text_embs": text_embs,
+            "image_filename": image_filename,
+            "text": text,
+            "metadata": metadata,
+        }
+
     def __call__(self, item):
         image_embs = text_embs = image_filename = text = metadata = None
         if self.enable_image:

@@ -65,7 +65,15 @@ class HashTokenizer:
 
 
 def folder_to_keys(folder, enable_text=True, enable_image=True, enable_metadata=False):
-    """Sorted keys present in every enabled modality (reference reader.py:10-51: text keys win, then image)."""
+    """Keys of a folder dataset, in the reference's order (reader.py:10-51).
+
+    One enabled modality (the reference's tested configuration, test_reader.py): exactly the reference's rule -- a key is
+    the file's path relative to the folder INCLUDING its extension, keys sorted as strings ('a-b.jpg' < 'a.png').
+    Several modalities: the reference intersects full paths of different extensions, i.e. it cannot pair `x.jpg` with
+    `x.txt` at all in this snapshot (KeyError at reader.py:97); here files are paired by the path without its suffix, the
+    order is that of the first enabled modality's full paths (text, then image, then metadata -- the reference's
+    priority), and two files of one modality that share a stem (a.jpg + a.png) are reported instead of silently dropped.
+    Returns (keys, text_files, image_files, metadata_files) with the three maps keyed by `keys`."""
     root = Path(folder)
 
     def index(exts):
@@ -73,17 +81,34 @@ def folder_to_keys(folder, enable_text=True, enable_image=True, enable_metadata=
         for ext in exts:
             for variant in (ext, ext.upper()):
                 for p in root.glob(f"**/*.{variant}"):
-                    found[p.relative_to(root).with_suffix("").as_posix()] = p
+                    found[p.relative_to(root).as_posix()] = p
         return found
 
     text_files = index(("txt",)) if enable_text else None
     image_files = index(IMAGE_EXTS) if enable_image else None
     metadata_files = index(("json",)) if enable_metadata else None
-    keys = None
-    for m in (text_files, image_files, metadata_files):
-        if m is not None:
-            keys = set(m) if keys is None else keys & set(m)
-    return sorted(keys or []), text_files, image_files, metadata_files
+    enabled = [m for m in (text_files, image_files, metadata_files) if m is not None]
+    if len(enabled) <= 1:
+        keys = sorted(enabled[0]) if enabled else []
+        return keys, text_files, image_files, metadata_files
+
+    def by_stem(m):
+        out = {}
+        for full in sorted(m):
+            stem = full.rsplit(".", 1)[0]
+            if stem in out:
+                print(f"folder_to_keys: {full} and {out[stem][0]} share a key; keeping {out[stem][0]}")
+                continue
+            out[stem] = (full, m[full])
+        return out
+
+    stems = [by_stem(m) for m in enabled]
+    common = set(stems[0])
+    for st in stems[1:]:
+        common &= set(st)
+    keys = [st for st in sorted(stems[0], key=lambda k: stems[0][k][0]) if st in common]
+    remap = lambda m: None if m is None else {k: v[1] for k, v in by_stem(m).items() if k in common}
+    return keys, remap(text_files), remap(image_files), remap(metadata_files)
 
 
 def _collate(samples, enable_image, enable_text, enable_metadata, pin):
@@ -147,20 +172,41 @@ class _BatchingReader:
     # webdataset pipeline (map(..., handler=warn_and_continue) before batching: reader.py:142-180).
     batch_before_filter = False
 
-    def __iter__(self):
+    def _decoded(self):
+        """Decoded samples in input order with a BOUNDED number of samples in flight (the reference's DataLoader holds at
+        most prefetch_factor * workers batches): raw bytes are only read when a slot is free, so a 10 k-member shard is
+        never resident at once (`Executor.map` would submit -- i.e. read and decode -- the whole partition up front)."""
+        from collections import deque  # pylint: disable=import-outside-toplevel
+
+        limit = max(2 * self.workers, 2) + self.batch_size
         with ThreadPoolExecutor(self.workers) as pool:
-            pending, taken = [], 0
-            for decoded in pool.map(self._decode, self._raw_samples()):
-                taken += 1
-                if decoded is not None:
-                    pending.append(decoded)
-                full = taken == self.batch_size if self.batch_before_filter else len(pending) == self.batch_size
-                if full:
-                    if pending:
-                        yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
-                    pending, taken = [], 0
-            if pending:
-                yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
+            inflight = deque()
+            raws = iter(self._raw_samples())
+            done = False
+            while True:
+                while not done and len(inflight) < limit:
+                    raw = next(raws, None)
+                    if raw is None:
+                        done = True
+                        break
+                    inflight.append(pool.submit(self._decode, raw))
+                if not inflight:
+                    return
+                yield inflight.popleft().result()
+
+    def __iter__(self):
+        pending, taken = [], 0
+        for decoded in self._decoded():
+            taken += 1
+            if decoded is not None:
+                pending.append(decoded)
+            full = taken == self.batch_size if self.batch_before_filter else len(pending) == self.batch_size
+            if full:
+                if pending:
+                    yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
+                pending, taken = [], 0
+        if pending:
+            yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
 
 
 class FilesReader(_BatchingReader):
@@ -194,8 +240,8 @@ class WebdatasetReader(_BatchingReader):
     def __init__(self, sampler, preprocess, tokenizer, input_dataset, batch_size, num_prepro_workers,
                  enable_text=True, enable_image=True, enable_metadata=False, wds_image_key="jpg",
                  wds_caption_key="txt", cache_path=None):
-        del cache_path  # shards are read in place
         super().__init__(preprocess, tokenizer, batch_size, num_prepro_workers, enable_text, enable_image, enable_metadata)
+        self.cache_path = cache_path  # webdataset's cache_dir (reader.py:138): remote shards are copied here once
         shards = [input_dataset] if isinstance(input_dataset, str) else list(input_dataset)
         self.shards = sampler(shards)
         self.image_key, self.caption_key = wds_image_key, wds_caption_key
@@ -211,10 +257,34 @@ class WebdatasetReader(_BatchingReader):
                 "text": fields[self.caption_key].decode("utf-8") if self.enable_text else None,
                 "metadata": fields["json"].decode("utf-8") if self.enable_metadata else None}
 
+    def _open_shard(self, shard):
+        """Local paths are streamed in place; URLs (s3://, gs://, https://, pipe-less) go through fsspec, copied to
+        `cache_path` once when it is set (the reference passes cache_dir to webdataset, reader.py:138)."""
+        if "://" not in shard:
+            return tarfile.open(shard, "r|*")
+        import fsspec  # pylint: disable=import-outside-toplevel
+
+        if self.cache_path:
+            import hashlib  # pylint: disable=import-outside-toplevel
+            import os  # pylint: disable=import-outside-toplevel
+
+            os.makedirs(self.cache_path, exist_ok=True)
+            local = os.path.join(self.cache_path, hashlib.sha1(shard.encode()).hexdigest()[:16] + "_" + shard.rsplit("/", 1)[-1])
+            if not os.path.exists(local):
+                with fsspec.open(shard, "rb") as src, open(local + ".part", "wb") as dst:
+                    while True:
+                        chunk = src.read(1 << 22)
+                        if not chunk:
+                            break
+                        dst.write(chunk)
+                os.replace(local + ".part", local)
+            return tarfile.open(local, "r|*")
+        return tarfile.open(fileobj=fsspec.open(shard, "rb").open(), mode="r|*")
+
     def _raw_samples(self):
         for shard in self.shards:
             try:
-                tf = tarfile.open(shard, "r|*")
+                tf = self._open_shard(shard)
             except (tarfile.TarError, OSError) as e:
                 print(f"warn_and_continue: {shard}: {e}")
                 continue

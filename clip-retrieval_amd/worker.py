@@ -1,0 +1,141 @@
+"""Per-GPU encode worker (encode half: "replicas only").
+
+Same call and the same builders as the reference worker (clip_retrieval/clip_inference/worker.py:22-127): a worker is
+handed a list of output-partition ids (`tasks`) and runs `Runner(task)` for each -- reader, mapper, writer and logger
+are built per partition exactly like there.  `gpu_worker()` is the counterpart of slurm_worker.py:40-61 for a
+single-node launch with one process per GPU (torch.distributed.run / any launcher that sets RANK, LOCAL_RANK,
+WORLD_SIZE): the partitions are dealt with `get_task_list`, the process binds to GPU `LOCAL_RANK`; there is no
+collective anywhere on this path and no rank ever waits for another.
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m clip_retrieval_amd.worker \
+        --input_dataset '/data/{000..999}.tar' --input_format webdataset --output_folder /out --output_partition_count 1000
+"""
+
+import json
+import os
+import re
+
+from .encoder import load_clip
+from .mapper import ClipMapper
+from .reader import FilesReader, WebdatasetReader
+from .runner import LoggerWriter, Runner, get_task_list
+from .writer import NumpyWriter
+
+
+def braceexpand(pattern):
+    """`{000..127}` numeric ranges and `{a,b}` lists of a shard pattern (the subset of the braceexpand package the
+    reference's datasets use, worker.py:47-48); nested and multiple groups expand as a cartesian product."""
+    m = re.search(r"\{([^{}]*)\}", pattern)
+    if not m:
+        return [pattern]
+    body, out = m.group(1), []
+    rng = re.fullmatch(r"(-?\d+)\.\.(-?\d+)", body)
+    if rng:
+        a, b = rng.group(1), rng.group(2)
+        width = max(len(a), len(b)) if (a.startswith("0") and len(a) > 1) or (b.startswith("0") and len(b) > 1) else 0
+        step = 1 if int(a) <= int(b) else -1
+        alts = [str(v).zfill(width) for v in range(int(a), int(b) + step, step)]
+    else:
+        alts = body.split(",")
+    for alt in alts:
+        out.extend(braceexpand(pattern[: m.start()] + alt + pattern[m.end():]))
+    return out
+
+
+def worker(
+    tasks,
+    input_dataset,
+    output_folder,
+    output_partition_count,
+    input_format="files",
+    cache_path=None,
+    batch_size=256,
+    num_prepro_workers=4,
+    enable_text=True,
+    enable_image=True,
+    enable_metadata=False,
+    wds_image_key="jpg",
+    wds_caption_key="txt",
+    clip_model="ViT-B/32",
+    mclip_model="sentence-transformers/clip-ViT-B-32-multilingual-v1",
+    use_mclip=False,
+    use_jit=True,
+    clip_cache_path=None,
+    device=0,
+):
+    """Start a worker"""
+    print("Starting the worker", flush=True)
+    if input_format == "webdataset" and not isinstance(input_dataset, list):
+        input_dataset = braceexpand(input_dataset)
+    print(f"dataset is {len(input_dataset)}", flush=True)
+
+    def reader_builder(sampler):
+        _, preprocess, tokenizer = load_clip(clip_model=clip_model, use_jit=use_jit, warmup_batch_size=0,
+                                             clip_cache_path=clip_cache_path, device=device)
+        if input_format == "files":
+            return FilesReader(sampler, preprocess, tokenizer, input_dataset, batch_size, num_prepro_workers,
+                               enable_text=enable_text, enable_image=enable_image, enable_metadata=enable_metadata)
+        if input_format == "webdataset":
+            return WebdatasetReader(sampler, preprocess, tokenizer, input_dataset, batch_size, num_prepro_workers,
+                                    enable_text=enable_text, enable_image=enable_image, enable_metadata=enable_metadata,
+                                    wds_image_key=wds_image_key, wds_caption_key=wds_caption_key, cache_path=cache_path)
+        raise ValueError(f"Unknown input_format: {input_format}")
+
+    def mapper_builder():
+        return ClipMapper(enable_image=enable_image, enable_text=enable_text, enable_metadata=enable_metadata,
+                          use_mclip=use_mclip, clip_model=clip_model, use_jit=use_jit, mclip_model=mclip_model,
+                          clip_cache_path=clip_cache_path, warmup_batch_size=batch_size, device=device)
+
+    def writer_builder(i):
+        return NumpyWriter(partition_id=i, output_folder=output_folder, enable_text=enable_text, enable_image=enable_image,
+                           enable_metadata=enable_metadata, output_partition_count=output_partition_count)
+
+    def logger_builder(i):
+        return LoggerWriter(partition_id=i, stats_folder=output_folder + "/stats")
+
+    runner = Runner(reader_builder=reader_builder, mapper_builder=mapper_builder, writer_builder=writer_builder,
+                    logger_builder=logger_builder, output_partition_count=output_partition_count)
+    for task in tasks:
+        print(f"Starting work on task {task}", flush=True)
+        runner(task)
+
+
+def gpu_worker(**worker_args):
+    """One process per GPU: this rank's share of the output partitions on GPU LOCAL_RANK (slurm_worker.py:40-61 with the
+    launcher's RANK / LOCAL_RANK / WORLD_SIZE in place of SLURM's variables).  WORKER_ARGS_PATH may hold the json of the
+    worker arguments like the reference's slurm distributor writes it."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", os.environ.get("SLURM_PROCID", "0")))
+    local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", "0")))
+    if os.environ.get("WORKER_ARGS_PATH"):
+        with open(os.environ["WORKER_ARGS_PATH"], "r", encoding="utf-8") as f:
+            worker_args = {**json.load(f), **worker_args}
+    num_tasks = int(os.environ.get("NUM_TASKS", worker_args["output_partition_count"]))
+    tasks = get_task_list(num_tasks, world, rank, local_rank)
+    print(f"worker global rank:{rank}\tlocal rank: {local_rank}\tprocessing tasks {tasks}", flush=True)
+    worker(tasks, device=local_rank, **worker_args)
+
+
+def _main(argv=None):
+    import argparse
+
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--input_dataset", required=True)
+    ap.add_argument("--output_folder", required=True)
+    ap.add_argument("--output_partition_count", type=int, required=True)
+    ap.add_argument("--input_format", default="files")
+    ap.add_argument("--cache_path")
+    ap.add_argument("--batch_size", type=int, default=256)
+    ap.add_argument("--num_prepro_workers", type=int, default=4)
+    ap.add_argument("--enable_text", type=lambda v: v.lower() in ("1", "true"), default=True)
+    ap.add_argument("--enable_image", type=lambda v: v.lower() in ("1", "true"), default=True)
+    ap.add_argument("--enable_metadata", type=lambda v: v.lower() in ("1", "true"), default=False)
+    ap.add_argument("--wds_image_key", default="jpg")
+    ap.add_argument("--wds_caption_key", default="txt")
+    ap.add_argument("--clip_model", default="ViT-B/32")
+    ap.add_argument("--clip_cache_path")
+    gpu_worker(**vars(ap.parse_args(argv)))
+
+
+if __name__ == "__main__":
+    _main()

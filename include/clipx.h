@@ -86,10 +86,27 @@ int clipx_encode_image(clipx_handle* h, const void* pixels, int B, int pix_fmt, 
  * (SOT ... EOT 0 0 ..; the pooled position is argmax(ids) like the reference model). */
 int clipx_encode_text(clipx_handle* h, const int32_t* ids, int B, uint16_t* out_f16);
 
+/* Same encoders with an f32 [B, embed_dim] result: the unit-norm embedding BEFORE the fp16 rounding.  The query side
+ * (`KnnService.compute_query`, clip_back.py:230-232, 244-246) hands fp32 features to the index. */
+int clipx_encode_image_f32(clipx_handle* h, const void* pixels, int B, int pix_fmt, float* out_f32);
+int clipx_encode_text_f32(clipx_handle* h, const int32_t* ids, int B, float* out_f32);
+
+/* Asynchronous tickets: the call stages the batch (B <= clipx_max_batch()), enqueues upload, kernels and
+ * download, and returns; clipx_wait() blocks until out_f16 is filled and releases the ticket.  The upload of ticket n+1
+ * overlaps the kernels of ticket n, so a caller that submits batch n+1 before it waits for batch n (the Runner in
+ * clip-retrieval_amd/runner.py) keeps the GPU busy across batches.  `pixels` / `ids` must stay valid until clipx_wait()
+ * when they are page-locked (they are uploaded in place); pageable memory is copied during the call.  At most 4 tickets
+ * can be outstanding per handle (CLIPX_E_STATE otherwise).  Every ticket must be waited for exactly once. */
+typedef struct clipx_ticket clipx_ticket;
+int clipx_encode_image_async(clipx_handle* h, const void* pixels, int B, int pix_fmt, uint16_t* out_f16, clipx_ticket** ticket);
+int clipx_encode_text_async(clipx_handle* h, const int32_t* ids, int B, uint16_t* out_f16, clipx_ticket** ticket);
+int clipx_wait(clipx_ticket* ticket);
+
 /* Same with every buffer already resident in HBM (benchmark path, and callers that do their own
  * hipMemcpyAsync double-buffering).  `stream` is a hipStream_t (NULL = the handle's stream);
  * asynchronous on that stream.  out_f32_or_null: optional f32 [B, embed_dim] copy of the
- * normalised embedding before the fp16 rounding (parity tests measure cosine on it). */
+ * normalised embedding before the fp16 rounding (parity tests measure cosine on it).  The handle's activation workspace
+ * is shared by all calls: consecutive calls are ordered by an event even when they use different streams. */
 int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, int pix_fmt, uint16_t* out_f16_dev,
                               float* out_f32_or_null, void* stream);
 int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,

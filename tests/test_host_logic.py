@@ -278,3 +278,160 @@ def test_committed_bench_line_follows_the_contract():
     k = d["knn"]["roofline"]
     assert k["bound"] == "hbm" and abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-3
     assert d["parity"]["ok"] is True
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: pipelined Runner, LoggerWriter, lazy reader, the reference's key rule, worker task split, preprocess
+# ---------------------------------------------------------------------------------------------------------------
+class _AsyncFakeMapper:
+    """submit/collect mapper (the shape of ours) over a deterministic "embedding": records the call order."""
+
+    def __init__(self, log):
+        self.log = log
+
+    def _emb(self, item):
+        x = item["image_tensor"].numpy()
+        return x.reshape(x.shape[0], -1)[:, :8].astype(np.float16)
+
+    def submit(self, item):
+        self.log.append(("submit", item["image_filename"][0]))
+        return {"item": item}
+
+    def collect(self, h):
+        item = h["item"]
+        self.log.append(("collect", item["image_filename"][0]))
+        return {"image_embs": self._emb(item), "text_embs": None, "image_filename": item["image_filename"], "text": None, "metadata": None}
+
+    def __call__(self, item):
+        return self.collect({"item": item})
+
+
+def test_pipelined_runner_equals_the_serial_loop_and_overlaps(tmp_path, image_folder):
+    """A mapper with submit/collect is driven one batch ahead (batch n+1 submitted before batch n is collected); files,
+    row order and the seven stat keys are those of the serial reference loop."""
+    from clip_retrieval_amd.reader import FilesReader, clip_preprocess
+    from clip_retrieval_amd.runner import LoggerWriter, NullLogger, Runner
+    from clip_retrieval_amd.writer import NumpyWriter
+
+    outs, logs = {}, {}
+    for mode in ("pipelined", "serial"):
+        log = []
+        mapper = _AsyncFakeMapper(log)
+        if mode == "serial":
+            mapper = mapper.__call__  # a plain callable: the reference's loop
+        out = tmp_path / mode
+        loggers = []
+
+        def logger_builder(i, out=out, loggers=loggers):
+            lg = LoggerWriter(i, str(out / "stats"))
+            loggers.append(lg)
+            return lg
+
+        r = Runner(lambda s: FilesReader(s, clip_preprocess, None, str(image_folder), 2, 2, enable_text=False),
+                   lambda mapper=mapper: mapper,
+                   lambda i, out=out: NumpyWriter(i, str(out), False, True, False, 1), logger_builder, 1)
+        r(0)
+        outs[mode] = np.load(out / "img_emb" / "img_emb_0.npy")
+        logs[mode] = log
+        stats = json.load(open(out / "stats" / "0.json"))
+        assert set(stats) == {"start_time", "end_time", "read_duration", "inference_duration", "write_duration", "total_duration", "sample_count"}
+        assert stats["sample_count"] == outs[mode].shape[0]
+        assert not (out / "stats" / "wip_0.json").exists()
+    assert np.array_equal(outs["pipelined"], outs["serial"]) and outs["serial"].shape[0] == 7
+    order = logs["pipelined"]
+    assert [k for k, _ in order[:3]] == ["submit", "submit", "collect"], order  # batch 1 submitted before batch 0 is collected
+    assert [n for k, n in order if k == "collect"] == [n for k, n in order if k == "submit"]  # collected in submission order
+
+
+def test_prefetcher_propagates_reader_errors():
+    from clip_retrieval_amd.runner import _Prefetcher
+
+    def gen():
+        yield 1
+        raise ValueError("decode exploded")
+
+    p = _Prefetcher(gen(), 2)
+    assert next(p) == 1
+    with pytest.raises(ValueError):
+        next(p)
+
+
+def test_reader_reads_lazily(image_folder):
+    """At most workers * 2 + batch_size samples are in flight: the bytes of later files are not read before the consumer
+    asks (ThreadPoolExecutor.map would have read and decoded the whole partition up front)."""
+    from clip_retrieval_amd.reader import FilesReader, clip_preprocess
+    from clip_retrieval_amd.runner import Sampler
+
+    r = FilesReader(Sampler(0, 1), clip_preprocess, None, str(image_folder), 1, 1, enable_text=False)
+    reads = []
+    inner = r._raw_samples
+
+    def counting():
+        for raw in inner():
+            reads.append(raw["key"])
+            yield raw
+
+    r._raw_samples = counting
+    it = iter(r)
+    next(it)
+    assert len(reads) <= 1 * 2 + 1 + 1, f"{len(reads)} of 7 files were read before the first batch was consumed"
+    assert sum(b["image_tensor"].shape[0] for b in it) == 6
+
+
+def test_folder_keys_follow_the_reference_rule(tmp_path):
+    """Single modality: full relative path INCLUDING the extension, string order (reference reader.py:10-51): a.jpg and
+    a.png are two samples and 'a-b.jpg' sorts before 'a.png'.  Several modalities are paired by stem, order of the first
+    modality, stem collisions reported."""
+    from clip_retrieval_amd.reader import folder_to_keys
+
+    for name in ("a.png", "a-b.jpg", "a.jpg", "sub/c.JPG", "a.txt", "a-b.txt", "zz.txt"):
+        p = tmp_path / name
+        p.parent.mkdir(exist_ok=True)
+        p.write_bytes(b"x")
+    keys, tf, imf, mf = folder_to_keys(str(tmp_path), enable_text=False, enable_image=True)
+    assert keys == ["a-b.jpg", "a.jpg", "a.png", "sub/c.JPG"] and tf is None and mf is None
+    assert all(k in imf for k in keys)
+    keys, tf, imf, _ = folder_to_keys(str(tmp_path), enable_text=True, enable_image=True)
+    assert keys == ["a-b", "a"]  # order of the text files 'a-b.txt' < 'a.txt'; zz has no image, sub/c no caption
+    assert tf["a"].name == "a.txt" and imf["a"].name == "a.jpg" and imf["a-b"].name == "a-b.jpg"
+
+
+def test_worker_deals_partitions_to_gpus(monkeypatch):
+    """gpu_worker = slurm_worker.py:40-61 with the launcher's variables: rank r of 8 gets get_task_list(NUM_TASKS, 8, r)
+    and binds to device LOCAL_RANK; brace patterns expand like the braceexpand package on the reference's shard specs."""
+    import clip_retrieval_amd.worker as W
+
+    assert W.braceexpand("/d/{000..002}.tar") == ["/d/000.tar", "/d/001.tar", "/d/002.tar"]
+    assert W.braceexpand("s3://b/{8..10}_{a,b}.tar") == ["s3://b/8_a.tar", "s3://b/8_b.tar", "s3://b/9_a.tar", "s3://b/9_b.tar", "s3://b/10_a.tar", "s3://b/10_b.tar"]
+    seen = {}
+    monkeypatch.setattr(W, "worker", lambda tasks, **kw: seen.update(tasks=tasks, **kw))
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "2")
+    monkeypatch.setenv("LOCAL_RANK", "2")
+    W.gpu_worker(input_dataset="x", output_folder="y", output_partition_count=21)
+    assert seen["tasks"] == W.get_task_list(21, 8, 2) == [6, 7, 8] and seen["device"] == 2
+    covered = sorted(t for r in range(8) for t in W.get_task_list(21, 8, r))
+    assert covered == list(range(21))
+
+
+def test_clip_preprocess_geometry_and_values():
+    """CLIP's transform restated: Resize(shorter side -> S, bicubic, torchvision's int(S * long / short) for the long side)
+    -> CenterCrop(S) (offsets int(round((dim - S) / 2))) -> RGB -> /255 -> (x - mean) / std, channel-first float32."""
+    from PIL import Image
+
+    from clip_retrieval_amd.reader import CLIP_MEAN, CLIP_STD, clip_preprocess
+
+    S = 224
+    for (w, h) in [(640, 480), (123, 456), (224, 224), (225, 224), (1001, 333)]:
+        img = Image.fromarray(np.random.default_rng(w).integers(0, 255, (h, w, 3), dtype=np.uint8))
+        out = clip_preprocess(img, S)
+        assert out.shape == (3, S, S) and out.dtype == np.float32
+        nw, nh = (S, int(S * h / w)) if w <= h else (int(S * w / h), S)
+        ref = img.resize((nw, nh), Image.BICUBIC)
+        left, top = int(round((nw - S) / 2.0)), int(round((nh - S) / 2.0))
+        ref = np.asarray(ref.crop((left, top, left + S, top + S)).convert("RGB"), dtype=np.float32) / np.float32(255)
+        ref = ((ref - CLIP_MEAN) / CLIP_STD).transpose(2, 0, 1)
+        assert np.allclose(out, ref, atol=1e-6)
+    # a constant grey image maps to (v/255 - mean)/std in every pixel; palette / greyscale inputs are converted to RGB
+    g = clip_preprocess(Image.new("L", (300, 200), 128), S)
+    assert np.allclose(g[:, 0, 0], (128 / 255 - CLIP_MEAN) / CLIP_STD, atol=1e-6) and np.allclose(g, g[:, :1, :1], atol=1e-6)

@@ -111,12 +111,19 @@ if "knn" in what:
     rows = int(os.environ.get("MB_KNN_ROWS", "20000000"))
     ix = Mi355xIndex(768)
     ix.synth_fill(rows, 3)
-    for nq in (1, 32, 64):
+    for nq in (1, 32, 64, 128, 256):
         q = torch.nn.functional.normalize(torch.randn(nq, 768, device="cuda"), dim=1)
         D = torch.empty(nq, 40, device="cuda")
         I = torch.empty(nq, 40, device="cuda", dtype=torch.int64)
-        timed(f"knn search_device rows={rows} nq={nq} k=40 (prep+scan+merge)",
+        s0 = ix.stats()
+        ix.profile(True)
+        timed(f"knn search_device rows={rows} nq={nq} k=40 (whole call)",
               lambda: ix.search_device(q.data_ptr(), nq, 40, D.data_ptr(), I.data_ptr(), st), nbytes=rows * 768 * 2.0)
+        ix.profile(False)
+        nl, ms = ix.profile_get()
+        s1 = ix.stats()
+        print(f"    main scan kernel alone: {ms / max(nl, 1) * 1e3:9.1f} us  {rows * 768 * 2.0 / (ms / max(nl, 1)) / 1e6:8.1f} GB/s   "
+              f"proof-served {s1[0] - s0[0]} failed {s1[1] - s0[1]}", flush=True)
 
 if "ivf" in what:
     # IVF-Flat search at moderate scale (built from host rows): bytes actually scanned = tiles of the probed lists
