@@ -29,6 +29,9 @@ struct GemmArgs {
                       // (variant 1) for the rest
   int n_cu;           // compute units of the device (variant 3 launches one workgroup per CU); 0 = 256
   int row0;           // EPI_TABLE_F32: table row = (row0 + m) % T (set by the launcher when it splits M)
+  const float* rowscale;  // bf16-output epilogues: out = act(acc * rowscale[m] + bias[n]); [M] f32, never null (the LayerNorm
+                          // 1/std of the row when the LayerNorm is folded into W, launch_rowstats; ones otherwise)
+  bf16* out16;            // EPI_BIAS_RESID_F32: also store the new x row as bf16 here (null: do not)
 };
 
 // number of 256-row m-tiles variant 3 hands to the 256x256 kernel for an [M, N] output
@@ -36,9 +39,20 @@ int gemm256_bulk_mtiles(int M, int N, int n_cu);
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 
-// x f32 [M, d] -> y (bf16 or f32) [M, d]; one wave per row; d % 256 == 0, d <= 2048
+// x f32 [M, d] -> y (bf16 or f32) [M, d]; one wave per row; d % 256 == 0, d <= 2048.  y16 (f32 output only, may be null):
+// also the bf16 rounding of y (ln_pre of the vision tower: the residual stream's bf16 shadow, see launch_rowstats)
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, int M,
-                            int d, float eps, hipStream_t st);
+                            int d, float eps, hipStream_t st, bf16* y16 = nullptr);
+
+// LayerNorm statistics of the bf16 shadow of the residual stream: rstd[m] = 1 / sqrt(var(x16[m, :]) + eps) (two-pass, fp32).
+// The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias absorbs beta:
+// clipx_api.hip fold_layernorm), whose epilogue multiplies by rstd[m].  One wave per row.
+hipError_t launch_rowstats(const bf16* x16, float* rstd, int M, int d, float eps, hipStream_t st);
+
+// LayerNorm-folded weights: Wf[n, k] = bf16(W[n,k] gamma[k] - mean_k(W[n,:] gamma)), cf[n] = bias[n] + sum_k beta[k] W[n,k]
+hipError_t launch_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, bf16* Wf, float* cf,
+                                 int N, int K, hipStream_t st);
+hipError_t launch_fill_f32(float* p, float v, int64_t n, hipStream_t st);
 
 // pixels -> bf16 patch matrix [B*T, Kp] (row b*T is the all-zero class-token row; k = c*P*P + iy*P + ix)
 // fmt 0: f32 NCHW already normalised (the reference's `image_tensor`); fmt 1: u8 NHWC, normalised here
@@ -48,9 +62,9 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 // qkv bf16 [B*T, 3*H*dh] -> out bf16 [B*T, H*dh]; softmax(q k^T / sqrt(dh) [+ causal]) v, head dim dh = 64 or 80
 hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st);
 
-// ids int32 [B, T] -> x f32 [B*T, d] = tok_emb[id] + pos_emb[t]
+// ids int32 [B, T] -> x f32 [B*T, d] = tok_emb[id] + pos_emb[t], and its bf16 shadow x16 (may be null)
 hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T,
-                             int d, int vocab, hipStream_t st);
+                             int d, int vocab, hipStream_t st, bf16* x16 = nullptr);
 
 // pooled row (CLS, or argmax(ids) for text) -> LayerNorm -> @ proj^T [E, d] -> / L2 norm -> fp16 [B, E]
 hipError_t launch_tail(const float* x, const int32_t* ids_or_null, const float* gamma, const float* beta,

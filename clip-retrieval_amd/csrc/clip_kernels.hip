@@ -43,7 +43,8 @@ template <int EPI, bool GLDS, bool DEEP = false>
 __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int M, int N,
-                                                          int K, int row0) {
+                                                          int K, int row0, const float* __restrict__ rowscale,
+                                                          bf16* __restrict__ out16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * hb;
         const float4 v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, row0);
+        gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, row0, rowscale, out16);
       }
     }
   }
@@ -299,17 +300,17 @@ static hipError_t launch_gemm_epi(const GemmArgs& g, hipStream_t st) {
     const size_t smem4 = 4 * G_STAGE_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem4, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0);
+    hipLaunchKernelGGL(kern, grid, block, smem4, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16);
   } else if (g.variant == 1) {
     auto kern = gemm_bf16_kernel<EPI, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16);
   } else {
     auto kern = gemm_bf16_kernel<EPI, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16);
   }
   return hipGetLastError();
 }
@@ -348,6 +349,7 @@ int gemm256_bulk_mtiles(int M, int N, int n_cu) {
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
+  if ((g.epi == EPI_BIAS_BF16 || g.epi == EPI_BIAS_QGELU_BF16 || g.epi == EPI_BIAS_GELU_BF16) && !g.rowscale) return hipErrorInvalidValue;
   if (g.variant >= 2 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
     const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
     // small problems (query-side B = 1: M = 257 or 77 rows) would put one 256x256 tile on each of a handful of CUs;
@@ -366,6 +368,8 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       const size_t esz = (g.epi == EPI_BIAS_RESID_F32 || g.epi == EPI_TABLE_F32) ? 4 : 2;
       r.out = reinterpret_cast<char*>(g.out) + (size_t)b.M * g.N * esz;
       r.row0 = g.row0 + b.M;
+      if (g.rowscale) r.rowscale = g.rowscale + b.M;
+      if (g.out16) r.out16 = g.out16 + (size_t)b.M * g.N;
       return launch_gemm128(r, st);
     }
   }
@@ -380,7 +384,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
 template <int NV, bool OUT_BF16>  // d = NV * 256
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, void* __restrict__ y, int M,
-                                                       float eps) {
+                                                       float eps, bf16* __restrict__ y16) {
   constexpr int d = NV * 256;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -419,18 +423,97 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(y) + (size_t)row * d)[c4] = ob;
     } else {
       reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (size_t)row * d)[c4] = o;
+      if (y16) {
+        bf16x4 ob;
+        ob[0] = (bf16)o.x; ob[1] = (bf16)o.y; ob[2] = (bf16)o.z; ob[3] = (bf16)o.w;
+        reinterpret_cast<bf16x4*>(y16 + (size_t)row * d)[c4] = ob;
+      }
     }
   }
 }
 
+// rstd of the bf16 shadow rows (see clip_kernels.h: launch_rowstats); d = NV * 512: a lane holds NV x 8 consecutive values
+template <int NV2>  // d = NV2 * 256 (NV2 x 4 values per lane)
+__global__ __launch_bounds__(256) void rowstats_kernel(const bf16* __restrict__ x16, float* __restrict__ rstd, int M, float eps) {
+  constexpr int d = NV2 * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16x4* xr = reinterpret_cast<const bf16x4*>(x16 + (size_t)row * d);
+  float v[NV2][4];
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < NV2; ++e) {
+    const bf16x4 h = xr[lane + 64 * e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[e][j] = (float)h[j];
+    s += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < NV2; ++e) {
+    const float a = v[e][0] - mean, b = v[e][1] - mean, c = v[e][2] - mean, dd = v[e][3] - mean;
+    q += (a * a + b * b) + (c * c + dd * dd);
+  }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if (lane == 0) rstd[row] = 1.f / sqrtf(q * (1.f / d) + eps);
+}
+
+hipError_t launch_rowstats(const bf16* x16, float* rstd, int M, int d, float eps, hipStream_t st) {
+  if (M <= 0) return hipSuccess;
+  const dim3 grid((M + 3) / 4), block(256);
+#define RS_CASE(NV) case NV * 256: hipLaunchKernelGGL((rowstats_kernel<NV>), grid, block, 0, st, x16, rstd, M, eps); break;
+  switch (d) {
+    RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef RS_CASE
+  return hipGetLastError();
+}
+
+// one workgroup per output row n of W [N, K]
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ bias,
+                                                            bf16* __restrict__ Wf, float* __restrict__ cf, int K) {
+  __shared__ float red[8];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* w = W + (size_t)n * K;
+  float sg = 0.f, sb = 0.f;
+  for (int k = tid; k < K; k += 256) {
+    sg += w[k] * gamma[k];
+    sb += w[k] * beta[k];
+  }
+  for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o); sb += __shfl_xor(sb, o); }
+  if ((tid & 63) == 0) { red[tid >> 6] = sg; red[4 + (tid >> 6)] = sb; }
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
+  for (int k = tid; k < K; k += 256) Wf[(size_t)n * K + k] = (bf16)(w[k] * gamma[k] - mean);
+  if (tid == 0) cf[n] = bias[n] + (red[4] + red[5] + red[6] + red[7]);
+}
+hipError_t launch_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, bf16* Wf, float* cf,
+                                 int N, int K, hipStream_t st) {
+  hipLaunchKernelGGL(fold_layernorm_kernel, dim3(N), dim3(256), 0, st, W, gamma, beta, bias, Wf, cf, K);
+  return hipGetLastError();
+}
+__global__ void fill_f32_kernel(float* __restrict__ p, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+hipError_t launch_fill_f32(float* p, float v, int64_t n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(256), dim3(256), 0, st, p, v, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, int M, int d,
-                            float eps, hipStream_t st) {
+                            float eps, hipStream_t st, bf16* y16) {
   if (M <= 0) return hipSuccess;
   const dim3 grid((M + 3) / 4), block(256);
 #define LN_CASE(NV)                                                                                           \
   case NV * 256:                                                                                              \
-    if (out_bf16) hipLaunchKernelGGL((layernorm_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, y, M, eps); \
-    else hipLaunchKernelGGL((layernorm_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, y, M, eps);    \
+    if (out_bf16) hipLaunchKernelGGL((layernorm_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, y, M, eps, (bf16*)nullptr); \
+    else hipLaunchKernelGGL((layernorm_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, y, M, eps, y16);    \
     break;
   switch (d) {
     LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
@@ -813,7 +896,7 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
 // =============================================================================================
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
                                                         const float* __restrict__ pos, float* __restrict__ x, int BT,
-                                                        int T, int d, int vocab) {
+                                                        int T, int d, int vocab, bf16* __restrict__ x16) {
   const int d4 = d / 4;
   const int64_t total = (int64_t)BT * d4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -823,16 +906,22 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const float4 a = reinterpret_cast<const float4*>(tok + (size_t)id * d)[c];
     const float4 p = reinterpret_cast<const float4*>(pos + (size_t)(row % T) * d)[c];
-    reinterpret_cast<float4*>(x + (size_t)row * d)[c] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    const float4 o = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+    reinterpret_cast<float4*>(x + (size_t)row * d)[c] = o;
+    if (x16) {
+      bf16x4 h;
+      h[0] = (bf16)o.x; h[1] = (bf16)o.y; h[2] = (bf16)o.z; h[3] = (bf16)o.w;
+      reinterpret_cast<bf16x4*>(x16 + (size_t)row * d)[c] = h;
+    }
   }
 }
 
 hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T, int d,
-                             int vocab, hipStream_t st) {
+                             int vocab, hipStream_t st, bf16* x16) {
   if (B <= 0) return hipSuccess;
   const int64_t total = (int64_t)B * T * (d / 4);
   const int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(text_embed_kernel, dim3(blocks), dim3(256), 0, st, ids, tok_emb, pos_emb, x, B * T, T, d, vocab);
+  hipLaunchKernelGGL(text_embed_kernel, dim3(blocks), dim3(256), 0, st, ids, tok_emb, pos_emb, x, B * T, T, d, vocab, x16);
   return hipGetLastError();
 }
 

@@ -40,6 +40,10 @@ namespace {
 struct LayerW {
   const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;  // into the f32 device blob
   bf16 *qkv_w, *out_w, *fc1_w, *fc2_w;                                          // bf16 copies
+  // ln_1 is folded into the QKV projection and ln_2 into fc1 (fold_layernorm): qkv_w / fc1_w hold
+  // bf16(W gamma - rowmean(W gamma)) and these are bias + W beta; the GEMM reads the bf16 shadow of the residual stream
+  // and its epilogue multiplies by the row's 1/std (launch_rowstats)
+  float *qkv_c, *fc1_c;
 };
 
 struct Tower {
@@ -80,8 +84,9 @@ struct clipx_handle {
   float *mean_dev = nullptr;
 
   // activation workspace (shared by both towers)
-  float* x = nullptr;
-  bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;
+  float* x = nullptr;      // residual stream, f32 [rows, width]
+  float* rstd = nullptr;   // [rows] LayerNorm 1/std of the current x16 rows
+  bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;  // xn = bf16 shadow of x
 
   // host hand-over: CLIPX_SLOTS staging slots (pinned in/out + device in/out); a slot carries one chunk from its upload to
   // the moment its result has been copied to the caller (synchronous calls pipeline their chunks through them; every
@@ -164,9 +169,11 @@ static int carve_layers(clipx_handle* h, Tower& t, float*& p) {
     if ((r = dev_alloc(h, (void**)&L.out_w, w * w * sizeof(bf16)))) return r;
     if ((r = dev_alloc(h, (void**)&L.fc1_w, mlp * w * sizeof(bf16)))) return r;
     if ((r = dev_alloc(h, (void**)&L.fc2_w, w * mlp * sizeof(bf16)))) return r;
-    HIPCHK(launch_f32_to_bf16(qkv_w32, L.qkv_w, (int64_t)(3 * w * w), h->stream));
+    if ((r = dev_alloc(h, (void**)&L.qkv_c, 3 * w * sizeof(float)))) return r;
+    if ((r = dev_alloc(h, (void**)&L.fc1_c, mlp * sizeof(float)))) return r;
+    HIPCHK(launch_fold_layernorm(qkv_w32, L.ln1_w, L.ln1_b, L.qkv_b, L.qkv_w, L.qkv_c, (int)(3 * w), (int)w, h->stream));
     HIPCHK(launch_f32_to_bf16(out_w32, L.out_w, (int64_t)(w * w), h->stream));
-    HIPCHK(launch_f32_to_bf16(fc1_w32, L.fc1_w, (int64_t)(mlp * w), h->stream));
+    HIPCHK(launch_fold_layernorm(fc1_w32, L.ln2_w, L.ln2_b, L.fc1_b, L.fc1_w, L.fc1_c, (int)mlp, (int)w, h->stream));
     HIPCHK(launch_f32_to_bf16(fc2_w32, L.fc2_w, (int64_t)(w * mlp), h->stream));
   }
   return 0;
@@ -232,6 +239,7 @@ static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
   const size_t nh = std::max(rowsV * V.mlp, rowsX * X.mlp);
   if ((r = dev_alloc(h, (void**)&h->x, nx * sizeof(float)))) return r;
   if ((r = dev_alloc(h, (void**)&h->xn, nx * sizeof(bf16)))) return r;
+  if ((r = dev_alloc(h, (void**)&h->rstd, std::max(rowsV, rowsX) * sizeof(float)))) return r;
   if ((r = dev_alloc(h, (void**)&h->qkv, nqkv * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->att, nx * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->hbuf, nh * sizeof(bf16)))) return r;
@@ -342,10 +350,11 @@ struct ProfScope {
 };
 
 static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* W, const float* bias, void* out,
-                    const float* table, int T, int M, int N, int K, int epi) {
+                    const float* table, int T, int M, int N, int K, int epi, const float* rowscale = nullptr, bf16* out16 = nullptr) {
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.table = table; g.T = T;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant; g.n_cu = h->n_cu; g.row0 = 0;
+  g.rowscale = rowscale; g.out16 = out16;
   ProfScope ps(h, st, 0, 2.0 * M * (double)N * K);
   HIPCHK(launch_gemm(g, st));
   return 0;
@@ -355,16 +364,21 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   const int M = B * t.T, w = t.width;
   const float eps = h->desc.ln_eps;
   const int act = h->desc.act == CLIPX_ACT_QUICK_GELU ? EPI_BIAS_QGELU_BF16 : EPI_BIAS_GELU_BF16;
+  // On entry h->xn holds the bf16 shadow of the residual stream h->x (written by ln_pre / the text embedding).  Per block:
+  //   rstd = rowstats(x16);  qkv = (x16 @ Wqkv'^T) * rstd + c_qkv      [= LN1(x16) @ Wqkv^T + b: LayerNorm folded]
+  //   att = attention(qkv);  x += att @ Wout^T + b_out, x16 = bf16(x)  [residual epilogue writes both]
+  //   rstd = rowstats(x16);  h = act((x16 @ Wfc1'^T) * rstd + c_fc1);  x += h @ Wfc2^T + b_fc2, x16 = bf16(x)
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& L = t.L[l];
+    const bool last = l + 1 == t.layers;  // the tail reads the f32 stream: no shadow needed after the last block
     int r;
-    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, L.ln1_w, L.ln1_b, h->xn, 1, M, w, eps, st)); }
-    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_b, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16))) return r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st)); }
+    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16, h->rstd))) return r;
     { ProfScope ps(h, st, 1, 4.0 * B * t.heads * (double)t.T * t.T * (w / t.heads)); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st)); }
-    if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->x, nullptr, 1, M, w, w, EPI_BIAS_RESID_F32))) return r;
-    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, L.ln2_w, L.ln2_b, h->xn, 1, M, w, eps, st)); }
-    if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_b, h->hbuf, nullptr, 1, M, t.mlp, w, act))) return r;
-    if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->x, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_F32))) return r;
+    if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->x, nullptr, 1, M, w, w, EPI_BIAS_RESID_F32, nullptr, h->xn))) return r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st)); }
+    if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, M, t.mlp, w, act, h->rstd))) return r;
+    if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->x, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_F32, nullptr, last ? nullptr : h->xn))) return r;
   }
   return 0;
 }
@@ -379,7 +393,7 @@ static int vision_chunk(clipx_handle* h, hipStream_t st, const void* pix_dev, in
   { ProfScope ps(h, st, 3, 0); HIPCHK(launch_im2col(pix_dev, fmt, B, d.image_size, d.patch_size, h->Kp, d.pix_mean, inv_std, h->patches, st)); }
   int r = run_gemm(h, st, h->patches, h->conv_w, nullptr, h->x, h->clspos, V.T, M, V.width, h->Kp, EPI_TABLE_F32);
   if (r) return r;
-  { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, h->ln_pre_w, h->ln_pre_b, h->x, 0, M, V.width, d.ln_eps, st)); }
+  { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, h->ln_pre_w, h->ln_pre_b, h->x, 0, M, V.width, d.ln_eps, st, h->xn)); }
   if ((r = run_layers(h, st, V, B, 0))) return r;
   { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, B, V.T, V.width, d.embed_dim, d.ln_eps, st)); }
   return 0;
@@ -388,7 +402,7 @@ static int vision_chunk(clipx_handle* h, hipStream_t st, const void* pix_dev, in
 static int text_chunk(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32) {
   const clipx_model_desc& d = h->desc;
   const Tower& X = h->txt;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, h->x, B, X.T, X.width, d.vocab, st)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, h->x, B, X.T, X.width, d.vocab, st, h->xn)); }
   int r = run_layers(h, st, X, B, 1);
   if (r) return r;
   { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, B, X.T, X.width, d.embed_dim, d.ln_eps, st)); }
@@ -608,6 +622,24 @@ extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void
   GemmArgs g{};
   g.A = (const bf16*)A_bf16; g.W = (const bf16*)W_bf16; g.bias = bias; g.out = out; g.table = nullptr; g.T = 1;
   g.M = M; g.N = N; g.K = K; g.epi = epi;
+  {  // bf16-output epilogues scale rows (LayerNorm-folded GEMMs of the encoder); the plain GEMM of this entry point uses ones
+    static std::mutex ones_mu;
+    static float* ones[64] = {};
+    static int ones_n[64] = {};
+    std::lock_guard<std::mutex> lk(ones_mu);
+    if (device < 0 || device >= 64) return fail(CLIPX_E_ARG, "bad device");
+    if (ones_n[device] < M) {
+      if (ones[device]) (void)hipFree(ones[device]);
+      ones[device] = nullptr;
+      ones_n[device] = 0;
+      HIPCHK(hipMalloc((void**)&ones[device], (size_t)M * sizeof(float)));
+      HIPCHK(launch_fill_f32(ones[device], 1.f, M, (hipStream_t)stream));
+      HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+      ones_n[device] = M;
+    }
+    g.rowscale = ones[device];
+    g.out16 = nullptr;
+  }
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   g.variant = gv ? std::min(3, std::max(0, atoi(gv))) : 3;
   int ncu = 0;

@@ -54,7 +54,7 @@ template <int EPI, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
-                                                          int ntn) {
+                                                          int ntn, const float* __restrict__ rowscale, bf16* __restrict__ out16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool DBG_TIMER = DBG == 16 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22;
   constexpr bool DBG_L2HOT = DBG == 21;
@@ -240,10 +240,19 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   const int rrow = lane >> 3, rch = lane & 7;  // epilogue read-back: row 8i + rrow, 16-B chunk rch
   const unsigned bias_m0 = lds_base + S_SCRATCH + w * 4096;
   const unsigned bias_off = (unsigned)((lane & 15) * 16);
+  // bf16-output epilogues also fetch the 128 row scales of the wave's panel (out = act(acc * rowscale[m] + bias[n]): the
+  // LayerNorm 1/std of a LayerNorm-folded GEMM) the same way, 1 KiB further into the scratch (both 32-lane halves fetch
+  // the same 512 B)
+  const unsigned rs_m0 = lds_base + S_SCRATCH + w * 4096 + 1024;
+  const unsigned rs_off = (unsigned)((lane & 31) * 16);
   auto load_bias = [&]() {
     if (!HAS_BIAS) return;
     const float* bp = bias + n0 + wc * 64;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(bias_off), "s"(bp), "s"(bias_m0) : "memory");
+    if (OUT_BF16) {
+      const float* rp = rowscale + m0 + wr * 128;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(rs_off), "s"(rp), "s"(rs_m0) : "memory");
+    }
   };
 
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -345,6 +354,9 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + (nt * 32 + 8 * g + 4 * hb) * 4);
+        float rr[4];  // row scales of the lane's rows 32 mt + l31
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) rr[mt] = *reinterpret_cast<const float*>(scr + 1024 + (mt * 32 + l31) * 4);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -352,8 +364,9 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const float4 bq = b4[nt][g];
-              float v[4] = {acc[mt][nt][4 * g + 0] + bq.x, acc[mt][nt][4 * g + 1] + bq.y,
-                            acc[mt][nt][4 * g + 2] + bq.z, acc[mt][nt][4 * g + 3] + bq.w};
+              // one fma per element, like gemm_store_quad (gemm_common.h): bit-identical rows from both kernels
+              float v[4] = {__builtin_fmaf(acc[mt][nt][4 * g + 0], rr[mt], bq.x), __builtin_fmaf(acc[mt][nt][4 * g + 1], rr[mt], bq.y),
+                            __builtin_fmaf(acc[mt][nt][4 * g + 2], rr[mt], bq.z), __builtin_fmaf(acc[mt][nt][4 * g + 3], rr[mt], bq.w)};
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 if (EPI == EPI_BIAS_QGELU_BF16) v[e] = quick_gelu(v[e]);
@@ -396,6 +409,13 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 0x7ffffffe, 0x00020000);
         const int voff = (rrow * N + rch * 4) * 4;
         const int rstep = 8 * N * 4;  // 8 rows
+        // bf16 shadow of the new x rows (read by the next LayerNorm-folded GEMM): 8 B per lane, same lane -> element map
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        bf16* xb16 = out16 ? out16 + ((size_t)(m0 + wr * 128) * N + n0 + wc * 64) : reinterpret_cast<bf16*>(xb);
+        const __amdgpu_buffer_rsrc_t xr16 = __builtin_amdgcn_make_buffer_rsrc(xb16, 0, 0x7ffffffe, 0x00020000);
+        const int voff16 = (rrow * N + rch * 4) * 2;
+        const int rstep16 = 8 * N * 2;
+        const bool shadow = out16 != nullptr;
         float4 b4[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) b4[nt] = *reinterpret_cast<const float4*>(scr + (nt * 32 + rch * 4) * 4);
@@ -435,6 +455,14 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
             o.z = __uint_as_float(e[2]) + o.z; o.w = __uint_as_float(e[3]) + o.w;
             const u32x4 ov = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
             __builtin_amdgcn_raw_buffer_store_b128(ov, xr, voff, (mt * 4 + i) * rstep + nt * 128, 0);
+            if (shadow) {
+              typedef float f32x2_t __attribute__((ext_vector_type(2)));
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              const bf16x2_t h01 = __builtin_convertvector((f32x2_t){o.x, o.y}, bf16x2_t);
+              const bf16x2_t h23 = __builtin_convertvector((f32x2_t){o.z, o.w}, bf16x2_t);
+              const u32x2 hv = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+              __builtin_amdgcn_raw_buffer_store_b64(hv, xr16, voff16, (mt * 4 + i) * rstep16 + nt * 64, 0);
+            }
           }
           S_FENCE();
         }
@@ -510,7 +538,7 @@ static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.N, g.K, g.M / 256,
-                     g.N / 256);
+                     g.N / 256, g.rowscale, g.out16);
   return hipGetLastError();
 }
 

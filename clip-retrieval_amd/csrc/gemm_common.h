@@ -34,17 +34,28 @@ __device__ __forceinline__ float gelu_erf(float v) {
 
 // One accumulator quad of the transposed-product layout both kernels use (MFMA A operand = weight rows, B operand
 // = activation rows): the lane owns output row m and four consecutive columns n..n+3.
+// bf16-output epilogues: out = act(acc * rowscale[m] + bias[n]) -- rowscale is the row's LayerNorm 1/std when the GEMM
+// consumes the raw residual stream with the LayerNorm folded into its weights (clipx_api.hip: fold_layernorm), 1 otherwise.
+// The multiply-add is ONE fma in both kernels, so a row's result does not depend on which kernel produced it.
+// f32 residual epilogue: x += acc + bias, and (out16 != null) the bf16 copy of the new x row that the next folded GEMM reads.
 template <int EPI>
 __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, const float* __restrict__ bias,
                                                 void* __restrict__ outp, const float* __restrict__ table, int T,
-                                                int row0 = 0) {
+                                                int row0, const float* __restrict__ rowscale, bf16* __restrict__ out16) {
+  constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
   if (EPI != EPI_TABLE_F32) {
     const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    if (OUT_BF16) {
+      const float r = rowscale[m];
+      v.x = __builtin_fmaf(v.x, r, b4.x); v.y = __builtin_fmaf(v.y, r, b4.y);
+      v.z = __builtin_fmaf(v.z, r, b4.z); v.w = __builtin_fmaf(v.w, r, b4.w);
+    } else {
+      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    }
   }
   if (EPI == EPI_BIAS_QGELU_BF16) { v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w); }
   if (EPI == EPI_BIAS_GELU_BF16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+  if (OUT_BF16) {
     bf16x4 o;
     o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp) + (size_t)m * N + n) = o;
@@ -53,6 +64,11 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
     float4 o = *p;
     o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
     *p = o;
+    if (out16) {
+      bf16x4 h;
+      h[0] = (bf16)o.x; h[1] = (bf16)o.y; h[2] = (bf16)o.z; h[3] = (bf16)o.w;
+      *reinterpret_cast<bf16x4*>(out16 + (size_t)m * N + n) = h;
+    }
   } else {  // EPI_TABLE_F32
     const float4 t4 = *reinterpret_cast<const float4*>(table + (size_t)((m + row0) % T) * N + n);
     v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;

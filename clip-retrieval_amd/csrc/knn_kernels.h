@@ -77,7 +77,7 @@ hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64
 
 // ---- register-stationary-queries (RQ) scan, knn_rq_kernels.hip: up to rq_queries_per_pass(d) queries per pass over HBM
 constexpr int KNN_RQ_MAX = 256;        // queries of one RQ pass at d <= 768 (128 at d = 1024)
-constexpr int KNN_RQ_STRIDE = 128;     // the sample pass visits every 128th 32-row tile
+constexpr int KNN_RQ_STRIDE = 128;     // the sample pass visits every 128th 32-row tile (fewer on small indexes: >= 4096 tiles sampled)
 constexpr int KNN_RQ_MARGIN = 8;       // threshold = (k + 8)-th best sample score
 constexpr unsigned KNN_RQ_CAP = 16384; // hit list entries per query (expected (k + 8) * 128 ~ 6 k at k = 40)
 constexpr int64_t KNN_RQ_MIN_ROWS = (int64_t)1 << 21;  // below this the 64-query scan is used

@@ -234,9 +234,10 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
 
     float16v acc[QBW];
 #pragma unroll
-    for (int b = 0; b < QBW; ++b)
+    for (int b = 0; b < QBW; ++b) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    }
     // the k-loop: rq_ksteps<...> above (A fragments through a 4-deep register ring, the refill DMAs spread over the steps)
     const unsigned xa = lds_base + slot * TILE_BYTES + lane * 16;
     i32x4 A[4];
@@ -248,11 +249,21 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
 
     // ---- filter: lane (qcol, hb) owns rows row0 + (r & 3) + 8 (r >> 2) of its query column in each block
     const int64_t row0 = t * 32 + 4 * hb;
+    // any hit in this wave?  One v_max3 tree per block and ONE compare instead of 16 compares + 16 mask ORs: this stretch
+    // runs with the matrix pipe idle.  (hipcc keeps the accumulators in AGPRs -- forcing them into VGPRs only adds copies --
+    // so every value still costs one v_accvgpr_read.)
     bool any = false;
 #pragma unroll
-    for (int b = 0; b < QBW; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) any |= acc[b][r] >= tq[b];
+    for (int b = 0; b < QBW; ++b) {
+      float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[b][0], acc[b][1]), acc[b][2]);
+      float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[b][3], acc[b][4]), acc[b][5]);
+      float m2 = __builtin_fmaxf(__builtin_fmaxf(acc[b][6], acc[b][7]), acc[b][8]);
+      float m3 = __builtin_fmaxf(__builtin_fmaxf(acc[b][9], acc[b][10]), acc[b][11]);
+      float m4 = __builtin_fmaxf(__builtin_fmaxf(acc[b][12], acc[b][13]), acc[b][14]);
+      m0 = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
+      m3 = __builtin_fmaxf(__builtin_fmaxf(m3, m4), acc[b][15]);
+      any |= __builtin_fmaxf(m0, m3) >= tq[b];
+    }
     if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // a hit somewhere in the wave: ~1 tile step in 8
       bool vmem = false;
 #pragma unroll

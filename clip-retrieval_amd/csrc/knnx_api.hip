@@ -515,7 +515,11 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
   int r = rq_alloc(ix);
   if (r) return r;
   const int d = ix->d;
-  // 1. thresholds: the 64-query scan over every KNN_RQ_STRIDE-th tile; threshold = (k + margin)-th best sample score
+  // 1. thresholds: the 64-query scan over every S-th tile; threshold = (k + margin)-th best sample score.  S = 128 on large
+  // indexes (1/128 of the bytes per sample pass, ~(k + 8) * 128 hits per query); smaller indexes sample at least 4096
+  // tiles (131 k rows) so that the threshold is not taken from a handful of rows (expected hits = (k + 8) * S)
+  const int64_t ntiles = (ix->ntotal + 31) / 32;
+  const int tstride = (int)std::max<int64_t>(1, std::min<int64_t>(KNN_RQ_STRIDE, ntiles / 4096));
   for (int g = 0; g * KNN_NQ_MAX < nq; ++g) {
     const int q0 = g * KNN_NQ_MAX, n = std::min(KNN_NQ_MAX, nq - q0);
     HIPCHK(launch_prep(q_dev + (size_t)q0 * d, n, d, ix->qfrag, ix->thr_g, nullptr, 1, nullptr, st));
@@ -530,7 +534,7 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
     a.grid = ix->n_cu;
     a.mode = 0;
     a.wide = 1;
-    a.tstride = KNN_RQ_STRIDE;
+    a.tstride = tstride;
     a.thr_g = ix->thr_g;
     a.part_s = ix->part_s;
     a.part_i = ix->part_i;

@@ -56,8 +56,15 @@ class FlatIPOracle:
         D = np.full((n, k), NEG, dtype=np.float32)
         I = np.full((n, k), -1, dtype=np.int64)
         for i in range(n):
-            # score descending, id ascending: lexsort's last key is the primary one
-            order = np.lexsort((np.arange(self.ntotal), -s[i].astype(np.float64)))[:k]
+            # score descending, id ascending (lexsort's last key is the primary one).  Only rows that can be in the top-k
+            # are sorted: everything scoring at least the k-th best value (ties included) -- the same result as sorting
+            # all rows, without an N log N sort per query on million-row checks.
+            if self.ntotal > 4 * k:
+                kth = np.partition(s[i], self.ntotal - k)[self.ntotal - k]
+                cand = np.nonzero(s[i] >= kth)[0]
+            else:
+                cand = np.arange(self.ntotal)
+            order = cand[np.lexsort((cand, -s[i][cand].astype(np.float64)))[:k]]
             D[i, :len(order)] = s[i, order]
             I[i, :len(order)] = order
         return D, I

@@ -267,3 +267,109 @@ def test_full_depth_vit_l14_parity():
     enc.close()
     assert ci.min() >= COS_BAR, f"ViT-L/14 image cos {ci}"
     assert ct.min() >= COS_BAR, f"ViT-L/14 text cos {ct}"
+
+
+def test_full_depth_vit_h14_parity():
+    """open_clip ViT-H/14 (BASELINE config 5's query encoder: erf GELU, 80-wide image heads, 32 + 24 layers) at FULL depth,
+    B = 2 -- round 1 only compared the 2-layer tiny-H/14."""
+    from clip_retrieval_amd.encoder import ClipEncoder
+    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    arch = ARCHS["ViT-H/14"]
+    oracle = HFClipOracle(arch, seed=0)
+    enc = ClipEncoder(_product_arch(arch), oracle.export_blob(), 0)
+    pix = normalise_u8_nhwc(synth_pixels_u8(2, seed=3))
+    ids = synth_tokens(2, seed=4)
+    _, wi = mapper_semantics(oracle.encode_image(torch.from_numpy(pix)))
+    _, wt = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
+    ci, ct = _cos(enc.encode_image(pix), wi), _cos(enc.encode_text(ids), wt)
+    enc.close()
+    assert ci.min() >= COS_BAR, f"ViT-H/14 image cos {ci}"
+    assert ct.min() >= COS_BAR, f"ViT-H/14 text cos {ct}"
+
+
+def test_load_clip_facade_query_path(tiny, tmp_path):
+    """`load_clip` -> (model, preprocess, tokenizer) as clip_back.py:865-868 / worker.py:52-57 use it: the B = 1 query
+    encodes of KnnService.compute_query (clip_back.py:227-246) return FP32 unit-norm torch features (not fp16-rounded),
+    equal to the oracle within the cosine bar; preprocess is a real callable; the tokenizer fails loudly without the
+    merges file and works when one is supplied."""
+    from PIL import Image
+
+    from clip_retrieval_amd.encoder import load_clip, register_encoder
+    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    register_encoder("facade-" + name, enc)
+    model, preprocess, tokenizer = load_clip("registered:facade-" + name, use_jit=False, warmup_batch_size=1, clip_cache_path=str(tmp_path))
+    pix = torch.from_numpy(normalise_u8_nhwc(synth_pixels_u8(1, seed=9)))
+    ids = torch.from_numpy(synth_tokens(1, seed=8)).long()
+    fi, ft = model.encode_image(pix), model.encode_text(ids)
+    assert fi.dtype == torch.float32 and ft.dtype == torch.float32 and tuple(fi.shape) == (1, arch.embed_dim)
+    assert torch.allclose(fi.norm(dim=-1), torch.ones(1), atol=1e-5)
+    assert not torch.equal(fi, fi.half().float()), "features must not be fp16-rounded (the service feeds fp32 to the index)"
+    assert torch.equal(fi.half(), torch.from_numpy(enc.encode_image(pix)))  # the fp16 path is the rounding of the same row
+    _, wi = mapper_semantics(oracle.encode_image(pix))
+    _, wt = mapper_semantics(oracle.encode_text(ids))
+    assert _cos(fi.numpy(), wi).min() >= COS_BAR and _cos(ft.numpy(), wt).min() >= COS_BAR
+    img = preprocess(Image.fromarray(synth_pixels_u8(1, seed=1)[0]))
+    assert tuple(img.shape) == (3, arch.image_size, arch.image_size) and img.dtype == torch.float32
+    with pytest.raises(FileNotFoundError):
+        tokenizer(["a photo"])
+    with pytest.raises(IndexError):
+        enc.encode_text(np.full((1, arch.ctx_len), arch.vocab, dtype=np.int64))  # the reference's embedding raises too
+
+
+def test_async_tickets_equal_the_synchronous_path(tiny):
+    """clipx_encode_*_async + clipx_wait: four tickets in flight (image, text, image, text of two batches -- what the
+    pipelined Runner submits) return bit-identical rows to the synchronous calls; a fifth ticket is refused; inputs may
+    be page-locked (uploaded in place) or pageable."""
+    from clip_retrieval_amd import HipLibraryError
+    from oracle.clip_oracle import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    pixs = [normalise_u8_nhwc(synth_pixels_u8(B, seed=40 + B)) for B in (3, 2)]
+    idss = [synth_tokens(B, seed=50 + B) for B in (3, 2)]
+    want = [(enc.encode_image(p), enc.encode_text(i)) for p, i in zip(pixs, idss)]
+    pinned = torch.from_numpy(pixs[0]).pin_memory()
+    hs = [enc.submit_image(pinned), enc.submit_text(idss[0]), enc.submit_image(pixs[1]), enc.submit_text(idss[1])]
+    with pytest.raises(HipLibraryError):
+        enc.submit_text(idss[1])
+    got = [enc.collect(h) for h in hs]
+    assert np.array_equal(got[0], want[0][0]) and np.array_equal(got[1], want[0][1])
+    assert np.array_equal(got[2], want[1][0]) and np.array_equal(got[3], want[1][1])
+    with pytest.raises(HipLibraryError):
+        enc.collect(hs[0])
+    h = enc.submit_text(idss[1])  # slots are free again
+    assert np.array_equal(enc.collect(h), want[1][1])
+
+
+def test_pipelined_runner_on_the_gpu(tiny, tmp_path):
+    """Runner + FilesReader + ClipMapper (submit/collect on real tickets) + NumpyWriter over an image folder: the files
+    equal those of the serial call path bit for bit."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from reader_fixture import make_folder
+
+    from clip_retrieval_amd.encoder import register_encoder
+    from clip_retrieval_amd.mapper import ClipMapper
+    from clip_retrieval_amd.reader import FilesReader, HashTokenizer, clip_preprocess
+    from clip_retrieval_amd.runner import NullLogger, Runner
+    from clip_retrieval_amd.writer import NumpyWriter
+
+    name, arch, oracle, enc = tiny
+    folder = make_folder(str(tmp_path / "data"))
+    register_encoder("runner-" + name, enc)
+    prep = lambda im: clip_preprocess(im, arch.image_size)
+    tok = HashTokenizer(arch.ctx_len, arch.vocab)
+    outs = {}
+    for mode in ("pipelined", "serial"):
+        def mapper_builder(mode=mode):
+            m = ClipMapper(True, True, False, False, "registered:runner-" + name, False, "", warmup_batch_size=1)
+            return m if mode == "pipelined" else m.__call__
+        out = tmp_path / mode
+        Runner(lambda s: FilesReader(s, prep, tok, folder, 4, 2, enable_text=True, enable_image=True),
+               mapper_builder, lambda i, out=out: NumpyWriter(i, str(out), True, True, False, 1), NullLogger, 1)(0)
+        outs[mode] = (np.load(out / "img_emb" / "img_emb_0.npy"), np.load(out / "text_emb" / "text_emb_0.npy"))
+    assert outs["serial"][0].shape[0] == 9
+    assert np.array_equal(outs["pipelined"][0], outs["serial"][0]) and np.array_equal(outs["pipelined"][1], outs["serial"][1])

@@ -22,9 +22,9 @@ if [ "${2:-}" != "quick" ]; then
   cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --cpu-seconds 0 --no-parity > $OUT/rocprof_$TAG.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${c}_$TAG -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --knn-scans 3 --cpu-seconds 0 --no-parity > $OUT/pmc_${c}_$TAG.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${c}_$TAG -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --knn-scans 2 --cpu-seconds 0 --no-parity > $OUT/pmc_${c}_$TAG.log 2>&1
   done
   cd $ROOT
-  python3 tools/traffic_summary.py $OUT/pmc_FETCH_SIZE_$TAG/p_counter_collection.csv $OUT/pmc_WRITE_SIZE_$TAG/p_counter_collection.csv > $OUT/traffic_$TAG.json; cat $OUT/traffic_$TAG.json
+  python3 tools/traffic_summary.py $OUT/pmc_FETCH_SIZE_$TAG/p_counter_collection.csv $OUT/pmc_WRITE_SIZE_$TAG/p_counter_collection.csv --steps 3 --warmup 1 > $OUT/traffic_$TAG.json; cat $OUT/traffic_$TAG.json
   ls -R $OUT/prof_$TAG | head
 fi
