@@ -413,9 +413,15 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         bf16* xb16 = out16 ? out16 + ((size_t)(m0 + wr * 128) * N + n0 + wc * 64) : reinterpret_cast<bf16*>(xb);
         const __amdgpu_buffer_rsrc_t xr16 = __builtin_amdgcn_make_buffer_rsrc(xb16, 0, 0x7ffffffe, 0x00020000);
-        const int voff16 = (rrow * N + rch * 4) * 2;
+        // Full 128-B lines: a row's 64 shadow columns of this wave are produced in two passes (nt = 0, 1), 4 columns per
+        // lane each; lane pairs (rch, rch ^ 1) swap one 8-B half so that the even lane owns columns 4 rch .. 4 rch + 7 of
+        // the nt = 0 half and the odd lane columns 32 + 4 (rch - 1) .. + 7 of the nt = 1 half: ONE 16-B store per row pair
+        // instead of two 8-B half-line stores (the store pipe is what this epilogue waits for).
+        const bool odd = (rch & 1) != 0;
+        const int voff16 = rrow * N * 2 + (odd ? 64 + (rch - 1) * 8 : rch * 8);
         const int rstep16 = 8 * N * 2;
         const bool shadow = out16 != nullptr;
+        u32x2 hkeep[4];
         float4 b4[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) b4[nt] = *reinterpret_cast<const float4*>(scr + (nt * 32 + rch * 4) * 4);
@@ -461,7 +467,15 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
               const bf16x2_t h01 = __builtin_convertvector((f32x2_t){o.x, o.y}, bf16x2_t);
               const bf16x2_t h23 = __builtin_convertvector((f32x2_t){o.z, o.w}, bf16x2_t);
               const u32x2 hv = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-              __builtin_amdgcn_raw_buffer_store_b64(hv, xr16, voff16, (mt * 4 + i) * rstep16 + nt * 64, 0);
+              if (nt == 0) {
+                hkeep[i] = hv;
+              } else {
+                const u32x2 send = odd ? hkeep[i] : hv;  // odd lanes give their nt = 0 half, even lanes their nt = 1 half
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, false);
+                const u32x4 full = odd ? u32x4{r0, r1, hv.x, hv.y} : u32x4{hkeep[i].x, hkeep[i].y, r0, r1};
+                __builtin_amdgcn_raw_buffer_store_b128(full, xr16, voff16, (mt * 4 + i) * rstep16, 0);
+              }
             }
           }
           S_FENCE();

@@ -82,8 +82,8 @@ constexpr int KNN_RQ_MARGIN = 8;       // threshold = (k + 8)-th best sample sco
 constexpr unsigned KNN_RQ_CAP = 16384; // hit list entries per query (expected (k + 8) * 128 ~ 6 k at k = 40)
 constexpr int64_t KNN_RQ_MIN_ROWS = (int64_t)1 << 21;  // below this the 64-query scan is used
 int rq_queries_per_pass(int d);  // 0: no RQ kernel for this d
-hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float* thr,
-                          unsigned* cnt, unsigned* lost, hipStream_t st);
+hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float slack,
+                          float* thr, unsigned* cnt, unsigned* lost, hipStream_t st);
 hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, const _Float16* qfrag, const float* thr, unsigned* cnt,
                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
                           hipStream_t st);

@@ -56,7 +56,7 @@ __device__ __forceinline__ float rq_dec_f(int e) { return __int_as_float(e >= 0 
 //   rows -> -inf: every row is a hit, which only happens on indexes far too small for this path); unused columns +inf.
 // ---------------------------------------------------------------------------------------------
 __global__ void knn_rq_prep_kernel(const float* __restrict__ q, int nq, int d, int nblk, _Float16* __restrict__ qfrag,
-                                   const float* __restrict__ samp, int kw, int J, float* __restrict__ thr,
+                                   const float* __restrict__ samp, int kw, int J, float slack, float* __restrict__ thr,
                                    unsigned* __restrict__ cnt, unsigned* __restrict__ lost) {
   const int s = blockIdx.x, b = blockIdx.y;  // k-step, query block
   const int lane = threadIdx.x;
@@ -69,7 +69,7 @@ __global__ void knn_rq_prep_kernel(const float* __restrict__ q, int nq, int d, i
     float t = INFINITY;
     if (n < nq) {
       const float v = samp[(size_t)n * kw + (J - 1)];
-      t = v > -FLT_MAX ? v : -INFINITY;
+      t = v > -FLT_MAX ? v - slack : -INFINITY;
     }
     thr[n] = t;
     cnt[n] = 0u;
@@ -396,10 +396,10 @@ __global__ __launch_bounds__(256) void knn_rq_proof_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 int rq_queries_per_pass(int d) { return d == 1024 ? 128 : (d == 512 || d == 768 ? 256 : 0); }
 
-hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float* thr,
-                          unsigned* cnt, unsigned* lost, hipStream_t st) {
+hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float slack,
+                          float* thr, unsigned* cnt, unsigned* lost, hipStream_t st) {
   const int nblk = rq_queries_per_pass(d) / 32;
-  hipLaunchKernelGGL(knn_rq_prep_kernel, dim3(d / 16, nblk), dim3(64), 0, st, q_dev, nq, d, nblk, qfrag, samp, kw, J, thr, cnt, lost);
+  hipLaunchKernelGGL(knn_rq_prep_kernel, dim3(d / 16, nblk), dim3(64), 0, st, q_dev, nq, d, nblk, qfrag, samp, kw, J, slack, thr, cnt, lost);
   return hipGetLastError();
 }
 

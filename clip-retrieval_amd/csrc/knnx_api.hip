@@ -493,7 +493,7 @@ static int scratch_release(knnx_index* ix, hipStream_t st) {
 // ---- RQ scan: up to rq_queries_per_pass(d) queries in ONE pass over HBM (see knn_rq_kernels.hip)
 static bool rq_usable(const knnx_index* ix, int nq, int k) {
   return ix->rq_ok && ix->wide_ok && !ix->ivf_nlist && nq > KNN_NQ_MAX && k <= KNN_WIDE_MAX_K && rq_queries_per_pass(ix->d) > 0 &&
-         ix->ntotal >= ix->rq_min_rows && wide_cap(ix->d) > 0;
+         ix->ntotal >= ix->rq_min_rows && scan_cap(ix->d, KNN_WIDE_KW) > 0;
 }
 static int rq_alloc(knnx_index* ix) {
   if (ix->rq_qfrag) return 0;
@@ -520,9 +520,13 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
   // tiles (131 k rows) so that the threshold is not taken from a handful of rows (expected hits = (k + 8) * S)
   const int64_t ntiles = (ix->ntotal + 31) / 32;
   const int tstride = (int)std::max<int64_t>(1, std::min<int64_t>(KNN_RQ_STRIDE, ntiles / 4096));
-  for (int g = 0; g * KNN_NQ_MAX < nq; ++g) {
-    const int q0 = g * KNN_NQ_MAX, n = std::min(KNN_NQ_MAX, nq - q0);
-    HIPCHK(launch_prep(q_dev + (size_t)q0 * d, n, d, ix->qfrag, ix->thr_g, nullptr, 1, nullptr, st));
+  // (the 64-query wide scan where its LDS queues fit, d <= 768; at d = 1024 the exact 32-query scan, whose scores are exact
+  // rather than fp16-hi: the threshold then gets a slack of a few eps so that the sample rows themselves still reach it)
+  const bool wide_samp = wide_cap(d) > 0;
+  const int gsz = wide_samp ? KNN_NQ_MAX : KNN_NQ;
+  for (int g = 0; g * gsz < nq; ++g) {
+    const int q0 = g * gsz, n = std::min(gsz, nq - q0);
+    HIPCHK(launch_prep(q_dev + (size_t)q0 * d, n, d, ix->qfrag, ix->thr_g, nullptr, wide_samp ? 1 : 0, nullptr, st));
     ScanArgs a{};
     a.X = ix->rows;
     a.N = ix->ntotal;
@@ -530,21 +534,22 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
     a.qfrag = ix->qfrag;
     a.nq = n;
     a.k = KNN_WIDE_KW;
-    a.cap = wide_cap(d);
+    a.cap = wide_samp ? wide_cap(d) : scan_cap(d, KNN_WIDE_KW);
     a.grid = ix->n_cu;
     a.mode = 0;
-    a.wide = 1;
+    a.wide = wide_samp ? 1 : 0;
     a.tstride = tstride;
     a.thr_g = ix->thr_g;
     a.part_s = ix->part_s;
     a.part_i = ix->part_i;
     a.part_n = ix->part_n;
     HIPCHK(launch_scan(a, st));
-    HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ_MAX, KNN_WIDE_KW, n, KNN_WIDE_KW, 0, nullptr,
+    HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, gsz, KNN_WIDE_KW, n, KNN_WIDE_KW, 0, nullptr,
                             ix->rq_samp + (size_t)q0 * KNN_WIDE_KW, ix->rq_samp_i + (size_t)q0 * KNN_WIDE_KW, nullptr, st));
   }
   const int J = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
-  HIPCHK(launch_rq_prep(q_dev, nq, d, ix->rq_qfrag, ix->rq_samp, KNN_WIDE_KW, J, ix->rq_thr, ix->rq_cnt, ix->rq_lost, st));
+  HIPCHK(launch_rq_prep(q_dev, nq, d, ix->rq_qfrag, ix->rq_samp, KNN_WIDE_KW, J, wide_samp ? 0.f : 1e-3f, ix->rq_thr, ix->rq_cnt,
+                        ix->rq_lost, st));
   // 2. the pass over the whole index
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->prof) {
