@@ -54,7 +54,8 @@ template <int EPI, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
-                                                          int ntn, const float* __restrict__ rowscale, bf16* __restrict__ out16) {
+                                                          int ntn, const float* __restrict__ rowscale, bf16* __restrict__ out16,
+                                                          int raster) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool DBG_TIMER = DBG == 16 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22;
   constexpr bool DBG_L2HOT = DBG == 21;
@@ -75,7 +76,27 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, cpx = gridDim.x >> 3;
   // shA / shW: which quarter of its A panel / eighth of its W panel this CU prefetches into the L2 (the panel is shared
   // with the CUs of the XCD that work on the other n-tiles / m-tiles of the round)
+  // Rasters (profiles/r02_gemm_raster.log, QKV 65536 x 3072 x 1024): every one reads 607-611 MB per launch past the L2
+  // (FETCH_SIZE x 2) = the output-stationary bound of an XCD round of 8 x 4 tiles ((8 + 4) x 0.5 MB per 32 tiles = 576 MB):
+  // a round streams 6 MB through a 4 MB L2, nothing of the previous round survives in it, the re-reads are served by the
+  // 256 MB Infinity Cache.  What the order changes is WHEN panels are re-read:
+  //   2 (the product's, when ntn % 4 == 0 and ntm % 64 == 0): an XCD owns the m-groups g = xcd (mod 8) and walks all
+  //     n-slices of a group in consecutive rounds (its 4 MB of A panels are re-read while still hot in the Infinity
+  //     Cache): steady K-tile 2681 cycles, QKV 1067 TF, fc1 1034 TF;
+  //   0 (fallback for other shapes): chunks in m-group-major order dealt round-robin to the XCDs: 2842 cycles, 1045 / 1006 TF;
+  //   1 (ablation only): the W slice is kept across rounds instead: 2798 cycles, 1024 / 991 TF.
   auto tile_of = [&](int j, int& m0, int& n0, int& shA, int& shW) -> bool {
+    if (raster != 0 && (ntn & 3) == 0 && (ntm & 63) == 0 && cpx == 32) {
+      const int nsl = ntn >> 2, ng = ntm >> 6;  // n-slices of 4 tiles; m-groups (of 8 tiles) per XCD
+      if (j >= nsl * ng) return false;
+      const int sl = raster == 1 ? j / ng : j % nsl, gi = raster == 1 ? j % ng : j / nsl;
+      const int gm0 = (gi * 8 + xcd) * 8;
+      m0 = (gm0 + (idx & 7)) * 256;
+      n0 = (sl * 4 + (idx >> 3)) * 256;
+      shA = (idx >> 3) & 3;
+      shW = idx & 7;
+      return true;
+    }
     const int logical = (j * 8 + xcd) * cpx + idx;
     if (logical >= ntiles) return false;
     const int per_group = 8 * ntn;
@@ -547,12 +568,16 @@ extern "C" int clipx_dbg_phase_cycles(long long* host, int n) {
 
 template <int EPI, int DBG = 0>
 static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
+  int raster = 2;
+#ifdef CLIPX_ABLATE
+  if (const char* fl = getenv("CLIPX_GEMM_FLAGS")) raster = atoi(fl) & 3;
+#endif
   const size_t smem = S_SCRATCH + 8 * 4096;  // 160 KiB: the whole LDS of the CU
   auto kern = gemm256sp_kernel<EPI, DBG>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.N, g.K, g.M / 256,
-                     g.N / 256, g.rowscale, g.out16);
+                     g.N / 256, g.rowscale, g.out16, raster);
   return hipGetLastError();
 }
 

@@ -80,12 +80,12 @@ __global__ void knn_rq_prep_kernel(const float* __restrict__ q, int nq, int d, i
 // ---------------------------------------------------------------------------------------------
 // the scan
 // ---------------------------------------------------------------------------------------------
-constexpr int RQ_STAGE = 256;   // entries of a wave's private staging list
-constexpr int RQ_FLUSH_AT = 96; // flush when at least this many are staged (a tile step adds a handful)
+constexpr int RQ_STAGE = 128;   // entries of a wave's private staging list
+constexpr int RQ_FLUSH_AT = 48; // flush when at least this many are staged (a tile step adds a handful)
 
-// LDS-DMA of tile `t` into ring slot `slot`: this wave's piece IDX (of DPW = KS / NW) -- wave w takes the k-step groups
-// w, w + NW, ... (a group = 4 consecutive k-steps = the same 128-B lines of the 32 rows), piece IDX = k-step
-// ((IDX / 4) NW + w) 4 + IDX % 4.  Inline asm: hipcc must not know about the DMA, or it drains vmcnt(0) before every LDS
+// LDS-DMA of tile `t` into ring slot `slot`: this wave's piece IDX (of DPW = KS / NW) -- wave w takes the DPW consecutive
+// k-steps w DPW .. w DPW + DPW - 1 (4 consecutive k-steps are the same 128-B lines of the 32 rows), piece IDX = k-step
+// w DPW + IDX.  Inline asm: hipcc must not know about the DMA, or it drains vmcnt(0) before every LDS
 // read; s_nop 0: M0 needs a wait state before the DMA reads it.  Past the end of the index the last tile is re-loaded,
 // which keeps the vmcnt arithmetic of the main loop uniform.
 struct RqTile {
@@ -93,20 +93,20 @@ struct RqTile {
   unsigned m0b;      // LDS address of the slot + this wave's offset
   unsigned vo;       // per-lane byte offset (row, half)
 };
-template <int KS>
+template <int KS, int NW>
 __device__ __forceinline__ RqTile rq_tile(const _Float16* __restrict__ X, int64_t t, int64_t ntile, int64_t last, unsigned voff,
                                           unsigned voff_last, unsigned lds_base, int slot, int w) {
-  constexpr int TILE_BYTES = KS * 1024;
+  constexpr int TILE_BYTES = KS * 1024, DPW = KS / NW;
   const int64_t tt = t < ntile ? t : last;
   RqTile r;
   r.vo = tt == last ? voff_last : voff;
-  r.base = reinterpret_cast<const char*>(X) + (size_t)tt * TILE_BYTES + w * 128;
-  r.m0b = lds_base + slot * TILE_BYTES + w * 4096;
+  r.base = reinterpret_cast<const char*>(X) + (size_t)tt * TILE_BYTES + w * (DPW * 32);
+  r.m0b = lds_base + slot * TILE_BYTES + w * (DPW * 1024);
   return r;
 }
 template <int NW, int IDX>
 __device__ __forceinline__ void rq_issue_one(const RqTile& r) {
-  constexpr int KOFF = (IDX / 4) * NW * 4 + (IDX % 4);  // k-step minus the wave's 4 w
+  constexpr int KOFF = IDX;  // k-step minus the wave's first one
   const char* p = r.base + KOFF * 32;
   asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(r.vo), "s"(p), "s"(r.m0b), "n"(KOFF * 1024)
                : "memory", "scc");
@@ -154,16 +154,14 @@ __device__ __forceinline__ void rq_ksteps(unsigned xa, i32x4 (&A)[4], float16v (
 
 // KS = d / 16 k-steps; QBW = 32-query blocks per wave (1 or 2); NW = waves per workgroup (one per SIMD); NSLOT = ring slots
 template <int KS, int QBW, int NW, int NSLOT>
-__global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
+__global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
     const _Float16* __restrict__ X, int64_t N, const _Float16* __restrict__ qfrag, const float* __restrict__ thr,
     unsigned* __restrict__ g_cnt, unsigned cap, float* __restrict__ hit_s, uint32_t* __restrict__ hit_r,
     unsigned* __restrict__ g_lost, const unsigned* __restrict__ gate) {
   constexpr int D = KS * 16;
   constexpr int TILE_BYTES = KS * 1024;        // 32 rows x D x 2 B, stored as KS lane-linear 1 KiB k-step blocks
-  constexpr int GROUPS = KS / 4;               // DMA work unit: 4 consecutive k-steps = the same 128-B lines of 32 rows
-  constexpr int GPW = GROUPS / NW;             // groups per wave per tile
-  constexpr int DPW = GPW * 4;                 // DMA instructions per wave per tile
-  static_assert(GROUPS % NW == 0, "k-step groups must divide evenly among the waves");
+  constexpr int DPW = KS / NW;                 // DMA instructions per wave per tile: NW waves x DPW consecutive k-steps
+  static_assert(KS % NW == 0, "k-steps must divide evenly among the waves");
   if (gate && *gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS map: NSLOT tiles, then per-wave staging lists {score, row, query}[RQ_STAGE]
@@ -212,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_rq_scan_kernel(
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
   // (helpers above instead of a lambda: a lambda capturing by reference makes hipcc keep the closure in scratch memory)
-#define RQ_TILE(t_, slot_) rq_tile<KS>(X, (t_), ntile, last, voff, voff_last, lds_base, (slot_), w)
+#define RQ_TILE(t_, slot_) rq_tile<KS, NW>(X, (t_), ntile, last, voff, voff_last, lds_base, (slot_), w)
 
   int64_t t = blockIdx.x;
   const int64_t gstride = gridDim.x;
@@ -419,8 +417,12 @@ hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, const _Float16* q
                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
                           hipStream_t st) {
   switch (d) {
-    case 512: return launch_rq_scan_cfg<32, 2, 4, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
-    case 768: return launch_rq_scan_cfg<48, 2, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+    case 512: return launch_rq_scan_cfg<32, 1, 8, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+    // d = 768: 8 waves x 32 queries, two waves per SIMD: a wave's LDS-DMA issue (~100 cycles per instruction during which it
+    // issues nothing else) is covered by its SIMD partner's MFMAs.  4 waves x 64 queries (one wave per SIMD, 501 registers)
+    // measured 59 % MFMA utilisation at 1.6 GHz: the 12 DMA issues per tile held the matrix pipe of their SIMD idle
+    // (profiles/r02_rq_pmc.txt).
+    case 768: return launch_rq_scan_cfg<48, 1, 8, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
     case 1024: return launch_rq_scan_cfg<64, 1, 4, 2>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
     default: return hipErrorInvalidValue;
   }
