@@ -52,6 +52,17 @@ SIGNATURES = {
     "knnx_ivf_set_lists": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "knnx_ivf_set_nprobe": (C.c_int, [_P, C.c_int]),
     "knnx_ivf_nlist": (C.c_int, [_P]),
+    "knnx_ivfb_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "knnx_ivfb_destroy": (None, [_P]),
+    "knnx_ivfb_set_centroids": (C.c_int, [_P, _P]),
+    "knnx_ivfb_get_centroids": (C.c_int, [_P, _P]),
+    "knnx_ivfb_set_sample": (C.c_int, [_P, _P, C.c_int64]),
+    "knnx_ivfb_assign_sample": (C.c_int, [_P, _P]),
+    "knnx_ivfb_update": (C.c_int, [_P, _P, _P]),
+    "knnx_ivfb_assign": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "knnx_ivf_begin": (C.c_int, [_P, C.c_int, _P, _P]),
+    "knnx_ivf_add_assigned": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
+    "knnx_ivf_end": (C.c_int, [_P]),
     "knnx_merge_topk_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "knnx_shards_create": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "knnx_shards_adopt": (C.c_int, [C.c_int, _P, _P, _P, C.POINTER(_P)]),

@@ -24,7 +24,7 @@ struct ScanArgs {
   int k;
   int cap;
   int grid;
-  int mode;  // 0 top-k, 1 range
+  int mode;  // 0 top-k, 1 range, 2 dump every score into range_s [nq, range_cap = N]
   int nt;    // 1 = nontemporal X loads (A/B switch, KNNX_NT=1)
   int* thr_g;
   float* part_s;
@@ -60,6 +60,9 @@ hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, 
 hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
                                const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
                                hipStream_t st);
+hipError_t launch_ivf_worklist_from_scores(const float* scores, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
+                                           const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
+                                           hipStream_t st);
 hipError_t launch_ivf_relayout(const _Float16* src, _Float16* dst, int d, int nlist, const int64_t* src0, const unsigned* tile0,
                                const unsigned* ntile, const unsigned* size, const int64_t* ids, int64_t id_lo, int64_t n_ids,
                                int64_t* idmap, uint32_t* inv, hipStream_t st);
@@ -87,6 +90,15 @@ hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, co
 hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, const _Float16* qfrag, const float* thr, unsigned* cnt,
                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
                           hipStream_t st);
+// IVF build (knn_rq_kernels.hip / knn_kernels.hip): out[i] = argmax_l <P[i], C[l]> (fp16 rows, exact fp32 scores, ties -> smaller l)
+hipError_t launch_assign(const _Float16* C, int64_t nlist, int d, const _Float16* P, int64_t n, int32_t* out, hipStream_t st);
+// one Lloyd update: cent[l] = fp16(mean of X[order[off[l] .. off[l+1])]) (lists with no member keep their row); one workgroup per list
+hipError_t launch_kmeans_update(const _Float16* X, int d, const int64_t* order, const int64_t* off, int nlist, _Float16* cent,
+                                hipStream_t st);
+// scatter n assigned rows into the tile-padded list-sorted arena: dst row = tile0[list] * 32 + pos; lays down idmap / inv
+hipError_t launch_ivf_scatter(const _Float16* src, int64_t n, int d, const int32_t* lists, const int32_t* pos, const int64_t* ids,
+                              const unsigned* tile0, int64_t id_lo, int64_t n_ids, _Float16* dst, int64_t* idmap, uint32_t* inv,
+                              hipStream_t st);
 hipError_t launch_rq_rescore(const _Float16* X, int d, const float* q, int nq, const unsigned* cnt, unsigned cap, float* hit_s,
                              const uint32_t* hit_r, int* cntc, hipStream_t st);
 hipError_t launch_rq_proof(const float* q, int nq, int d, int k, const float* D, const float* thr, const unsigned* cnt,

@@ -298,6 +298,14 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
         const int g = __hip_atomic_load(&thr_g[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicMax(&sm.thr[lane], g);
       }
+    } else if (MODE == 2) {
+      // every score goes to range_s [nq, N] (N = range_cap): the IVF coarse quantiser for nprobe > 64, where the
+      // top-nprobe centroids of a query no longer fit the LDS queues and are selected from the score matrix instead
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+        if (row < row_lim && q_ok) range_s[(size_t)q * range_cap + row] = acc_h[r] + acc_l[r] * KNN_LO_INV;
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -736,6 +744,104 @@ __global__ void knn_gather_rows_inv_kernel(const _Float16* __restrict__ X, int d
   for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)i * d + c] = ok ? (float)X[r * d + c] : __int_as_float(-1);
 }
 
+// Coarse quantiser for nprobe > 64: scores [nq, nlist] (dumped by the MODE 2 scan over the centroids) -> masks[l] |= 1 << q
+// for the nprobe best lists of query q, (score desc, list id asc) -- the selection rule of the top-k path.  One workgroup
+// per query: 32-step bisection on the order-encoded score for the nprobe-th value V, a second bisection over list ids
+// among the ties at V, then one marking pass.  The score row (<= 1 MiB) is re-read from the L2 in every step.
+__global__ __launch_bounds__(256) void ivf_select_mark_kernel(const float* __restrict__ scores, int nlist, int nprobe,
+                                                             unsigned* __restrict__ masks) {
+  __shared__ int red[8];
+  const int qq = blockIdx.x, tid = threadIdx.x;
+  const float* s = scores + (size_t)qq * nlist;
+  auto enc = [](float f) -> unsigned { return (unsigned)enc_f(f) ^ 0x80000000u; };  // unsigned order == float order
+  const int np = nprobe < nlist ? nprobe : nlist;
+  unsigned V = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned cand = V | (1u << bit);
+    int c = 0;
+    for (int l = tid; l < nlist; l += 256) c += enc(s[l]) >= cand ? 1 : 0;
+    if (block_count_256(c, red) >= np) V = cand;
+  }
+  int cg = 0, ce = 0;
+  for (int l = tid; l < nlist; l += 256) { const unsigned u = enc(s[l]); cg += u > V ? 1 : 0; ce += u == V ? 1 : 0; }
+  const int m1 = block_count_256(cg, red);
+  const int ceq = block_count_256(ce, red);
+  const int t = np - m1;  // lists to take among the ties at V, smallest ids first
+  int X = 0x7fffffff;
+  if (ceq > t) {
+    X = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+      const int hi = X | ((1 << bit) - 1);
+      int c = 0;
+      for (int l = tid; l < nlist; l += 256) c += (enc(s[l]) == V && l <= hi) ? 1 : 0;
+      if (block_count_256(c, red) < t) X |= (1 << bit);
+    }
+  }
+  for (int l = tid; l < nlist; l += 256) {
+    const unsigned u = enc(s[l]);
+    if (u > V || (u == V && l <= X)) atomicOr(&masks[l], 1u << qq);
+  }
+}
+
+// Lloyd update of the IVF k-means: one workgroup per list sums its member rows (order[] = the sample rows sorted by list,
+// ascending row id inside a list: a fixed summation order) in fp32 and writes the mean as the new fp16 centroid
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const _Float16* __restrict__ X, int d, const int64_t* __restrict__ order,
+                                                           const int64_t* __restrict__ off, _Float16* __restrict__ cent) {
+  const int l = blockIdx.x;
+  const int64_t a = off[l], b = off[l + 1];
+  if (b <= a) return;  // empty list: the caller re-seeds it
+  const float inv = 1.f / (float)(b - a);
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float s = 0.f;
+    for (int64_t i = a; i < b; ++i) s += (float)X[(size_t)order[i] * d + c];
+    cent[(size_t)l * d + c] = (_Float16)(s * inv);
+  }
+}
+hipError_t launch_kmeans_update(const _Float16* X, int d, const int64_t* order, const int64_t* off, int nlist, _Float16* cent,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(kmeans_update_kernel, dim3(nlist), dim3(256), 0, st, X, d, order, off, cent);
+  return hipGetLastError();
+}
+
+// one wave per row: copy into its slot of the list-sorted arena
+__global__ __launch_bounds__(256) void ivf_scatter_kernel(const _Float16* __restrict__ src, int64_t n, int d,
+                                                         const int32_t* __restrict__ lists, const int32_t* __restrict__ pos,
+                                                         const int64_t* __restrict__ ids, const unsigned* __restrict__ tile0,
+                                                         int64_t id_lo, int64_t n_ids, _Float16* __restrict__ dst,
+                                                         int64_t* __restrict__ idmap, uint32_t* __restrict__ inv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const size_t drow = (size_t)tile0[lists[r]] * 32 + (size_t)pos[r];
+  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)r * d);
+  uint4* o = reinterpret_cast<uint4*>(dst + drow * d);
+  for (int c = lane; c < d / 8; c += 64) o[c] = s[c];
+  if (lane == 0) {
+    const int64_t id = ids[r];
+    idmap[drow] = id;
+    if (id >= id_lo && id - id_lo < n_ids) inv[id - id_lo] = (uint32_t)drow;
+  }
+}
+hipError_t launch_ivf_scatter(const _Float16* src, int64_t n, int d, const int32_t* lists, const int32_t* pos, const int64_t* ids,
+                              const unsigned* tile0, int64_t id_lo, int64_t n_ids, _Float16* dst, int64_t* idmap, uint32_t* inv,
+                              hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src, n, d, lists, pos, ids, tile0, id_lo, n_ids,
+                     dst, idmap, inv);
+  return hipGetLastError();
+}
+
+hipError_t launch_ivf_worklist_from_scores(const float* scores, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
+                                           const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
+                                           hipStream_t st) {
+  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nlist * sizeof(unsigned), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ivf_select_mark_kernel, dim3(nq), dim3(256), 0, st, scores, nlist, nprobe, masks);
+  hipLaunchKernelGGL(ivf_offsets_kernel, dim3(1), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3(nlist), dim3(256), 0, st, masks, tile0, ntile, size, off, work);
+  return hipGetLastError();
+}
+
 hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
                                const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
                                hipStream_t st) {
@@ -818,6 +924,7 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
   if (a.wide) return (a.mode == 0 && !a.work) ? launch_scan_mode<0, false, false, 2>(a, st) : hipErrorInvalidValue;
   if (a.work) return a.mode == 0 ? launch_scan_mode<0, false, true>(a, st) : hipErrorInvalidValue;
   if (a.mode == 0) return a.nt ? launch_scan_mode<0, true>(a, st) : launch_scan_mode<0, false>(a, st);
+  if (a.mode == 2) return launch_scan_mode<2, false>(a, st);
   return launch_scan_mode<1, false>(a, st);
 }
 

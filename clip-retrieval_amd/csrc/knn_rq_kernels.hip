@@ -104,6 +104,7 @@ __device__ __forceinline__ RqTile rq_tile(const _Float16* __restrict__ X, int64_
   r.m0b = lds_base + slot * TILE_BYTES + w * (DPW * 1024);
   return r;
 }
+#define RQ_TILE(t_, slot_) rq_tile<KS, NW>(X, (t_), ntile, last, voff, voff_last, lds_base, (slot_), w)
 template <int NW, int IDX>
 __device__ __forceinline__ void rq_issue_one(const RqTile& r) {
   constexpr int KOFF = IDX;  // k-step minus the wave's first one
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
   const unsigned voff_last = (unsigned)((qcol < lrow ? qcol : lrow) * D * 2 + hb * 16);
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
-  // (helpers above instead of a lambda: a lambda capturing by reference makes hipcc keep the closure in scratch memory)
-#define RQ_TILE(t_, slot_) rq_tile<KS, NW>(X, (t_), ntile, last, voff, voff_last, lds_base, (slot_), w)
+  // (helpers above instead of a lambda: a lambda capturing by reference makes hipcc keep the closure in scratch memory;
+  // RQ_TILE is defined at file level, below rq_tile)
 
   int64_t t = blockIdx.x;
   const int64_t gstride = gridDim.x;
@@ -316,6 +317,113 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
       hit_s[(size_t)qq * cap + pos] = st_s[i];
       hit_r[(size_t)qq * cap + pos] = st_r[i];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// IVF build: list assignment = argmax over the centroids, for MANY points per launch (takes the place of
+// the autofaiss k-means / add of clip_index.py:12-66 for this index type).  The same register-stationary structure as the
+// scan with the roles of the build: a workgroup keeps ITS OWN NW x 32 points as the stationary operand (fp16 rows are
+// MFMA fragments as they lie in HBM) and streams ALL centroid tiles through the LDS ring; a lane owns one point and keeps
+// the running best (score, centroid) over its 16 rows of every tile.  Every workgroup reads the whole centroid matrix
+// (nlist x d x 2 B, L2 / Infinity-Cache resident: all workgroups walk it in step), so the kernel is MFMA-bound:
+// 2 n nlist d flops.  Scores are exact fp32 sums of fp16 x fp16 products; ties go to the smaller centroid id.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int NW, int NSLOT>
+__global__ __launch_bounds__(NW * 64, NW / 4) void knn_assign_kernel(const _Float16* __restrict__ C, int64_t nlist,
+                                                                     const _Float16* __restrict__ P, int64_t n,
+                                                                     int32_t* __restrict__ out) {
+  constexpr int D = KS * 16;
+  constexpr int TILE_BYTES = KS * 1024;
+  constexpr int DPW = KS / NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qcol = lane & 31, hb = lane >> 5;
+  const _Float16* X = C;  // the streamed operand (RQ_TILE below)
+  const int64_t N = nlist;
+
+  // this wave's 32 points as B fragments: lane (qcol, hb) holds point[16 s + 8 hb .. + 8] of every k-step s
+  const int64_t pidx = (int64_t)blockIdx.x * (NW * 32) + w * 32 + qcol;
+  const int64_t prow = pidx < n ? pidx : n - 1;
+  half8 Q[1][KS];
+  {
+    const half8* src = reinterpret_cast<const half8*>(P + (size_t)prow * D) + hb;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) Q[0][s] = src[2 * s];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(Q[0][s]));  // all landed before the DMA ring starts (see the scan)
+  }
+
+  const int64_t ntile = (N + 31) >> 5;
+  const int64_t last = ntile - 1;
+  const unsigned voff = (unsigned)(qcol * D * 2 + hb * 16);
+  const int lrow = (int)(N - 1 - last * 32);
+  const unsigned voff_last = (unsigned)((qcol < lrow ? qcol : lrow) * D * 2 + hb * 16);
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+
+#pragma unroll
+  for (int i = 0; i < NSLOT - 1; ++i) rq_issue_all<NW, DPW>(RQ_TILE((int64_t)i, i));
+
+  float best = -INFINITY;
+  int brow = 0;
+  int slot = 0;
+  for (int64_t t = 0; t < ntile; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NSLOT - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const RqTile refill = RQ_TILE(t + (NSLOT - 1), slot == 0 ? NSLOT - 1 : slot - 1);
+    float16v acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    const unsigned xa = lds_base + slot * TILE_BYTES + lane * 16;
+    i32x4 A[4];
+    rq_dsread<0>(A[0], xa);
+    rq_dsread<1024>(A[1], xa);
+    rq_dsread<2048>(A[2], xa);
+    __builtin_amdgcn_sched_barrier(0);
+    rq_ksteps<KS, 1, NW, DPW, 0>(xa, A, acc, Q, refill);
+    // running argmax of this lane's point over its 16 centroid rows of the tile (rows ascend with r: strict > keeps the
+    // smallest id among equal scores); the ragged last tile re-read centroid nlist - 1 into its padding rows
+    const int row0 = (int)(t * 32) + 4 * hb;
+    const bool ragged = t == last && (N & 31) != 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2);
+      const bool take = acc[0][r] > best && (!ragged || row < (int)N);
+      best = take ? acc[0][r] : best;
+      brow = take ? row : brow;
+    }
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail reloads still in flight
+  // the two half-waves of a point saw different rows of every tile
+  const float ob = __shfl_xor(best, 32);
+  const int orow = __shfl_xor(brow, 32);
+  if (ob > best || (ob == best && orow < brow)) brow = orow;
+  if (hb == 0 && pidx < n) out[pidx] = brow;
+}
+
+template <int KS, int NW, int NSLOT>
+static hipError_t launch_assign_cfg(const _Float16* C, int64_t nlist, const _Float16* P, int64_t n, int32_t* out, hipStream_t st) {
+  const size_t smem = (size_t)NSLOT * KS * 1024;
+  auto kern = knn_assign_kernel<KS, NW, NSLOT>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  const int64_t per = NW * 32;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n + per - 1) / per)), dim3(NW * 64), smem, st, C, nlist, P, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_assign(const _Float16* C, int64_t nlist, int d, const _Float16* P, int64_t n, int32_t* out, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (nlist <= 0) return hipErrorInvalidValue;
+  switch (d) {
+    case 256: return launch_assign_cfg<16, 8, 3>(C, nlist, P, n, out, st);
+    case 512: return launch_assign_cfg<32, 8, 3>(C, nlist, P, n, out, st);
+    case 768: return launch_assign_cfg<48, 8, 3>(C, nlist, P, n, out, st);
+    case 1024: return launch_assign_cfg<64, 4, 2>(C, nlist, P, n, out, st);
+    default: return hipErrorInvalidValue;
   }
 }
 

@@ -73,6 +73,12 @@ struct knnx_index {
   uint32_t* ivf_inv = nullptr;   // id - id_base -> padded arena row
   int64_t* ivf_Ic = nullptr;     // [KNN_NQ, KNNX_MAX_K_FAST] coarse result
   float* ivf_Dc = nullptr;
+  float* ivf_scores = nullptr;   // [KNN_NQ, nlist] coarse scores (nprobe > 64 only; allocated on first use)
+  // streaming build (knnx_ivf_begin .. knnx_ivf_end)
+  int ivfb_nlist = 0;
+  int64_t ivfb_total = 0, ivfb_added = 0;
+  std::vector<uint16_t> ivfb_cent;
+  void *ivfb_rows = nullptr, *ivfb_ids = nullptr, *ivfb_lists = nullptr, *ivfb_pos = nullptr;  // device staging of one chunk
 
   // wide scan (64 queries per pass): candidates, fallback results, proof flags; largest row norm (order-encoded)
   int wide_ok = 1;             // KNNX_WIDE=0 disables
@@ -246,6 +252,11 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->ivf_inv);
   hipFree(ix->ivf_Ic);
   hipFree(ix->ivf_Dc);
+  hipFree(ix->ivf_scores);
+  hipFree(ix->ivfb_rows);
+  hipFree(ix->ivfb_ids);
+  hipFree(ix->ivfb_lists);
+  hipFree(ix->ivfb_pos);
   if (ix->pin) hipHostFree(ix->pin);
   for (auto& ev : ix->prof_events) {
     hipEventDestroy(ev.first);
@@ -380,10 +391,35 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
     // coarse quantiser: top-nprobe centroids per query (the same flat scan over the [nlist, d] centroid rows), then
     // the work list = tiles of every list probed by at least one of the <= 32 queries, each with its query mask
     const int np = std::min(ix->ivf_nprobe, ix->ivf_nlist);
-    int r = scan_topk(ix->cent, q_dev, nq, np, ix->ivf_Dc, ix->ivf_Ic, st);
-    if (r) return r;
-    HIPCHK(launch_ivf_worklist(ix->ivf_Ic, nq, np, ix->ivf_nlist, ix->ivf_masks, ix->ivf_tile0, ix->ivf_ntile, ix->ivf_size,
-                               ix->ivf_off, ix->ivf_work, ix->ivf_nwork, st));
+    if (np <= KNNX_MAX_K_FAST) {
+      int r = scan_topk(ix->cent, q_dev, nq, np, ix->ivf_Dc, ix->ivf_Ic, st);
+      if (r) return r;
+      HIPCHK(launch_ivf_worklist(ix->ivf_Ic, nq, np, ix->ivf_nlist, ix->ivf_masks, ix->ivf_tile0, ix->ivf_ntile, ix->ivf_size,
+                                 ix->ivf_off, ix->ivf_work, ix->ivf_nwork, st));
+    } else {
+      // nprobe > 64 (BASELINE config 5 asks for 256): the centroid scan dumps every score, a selection kernel marks the
+      // nprobe best lists of each query
+      knnx_index* c = ix->cent;
+      if (!ix->ivf_scores) HIPCHK(hipMalloc(&ix->ivf_scores, (size_t)KNN_NQ * ix->ivf_nlist * sizeof(float)));
+      HIPCHK(launch_prep(q_dev, nq, c->d, c->qfrag, c->thr_g, nullptr, 0, gate, st));
+      ScanArgs ca{};
+      ca.gate = gate;
+      ca.X = c->rows;
+      ca.N = c->ntotal;
+      ca.d = c->d;
+      ca.qfrag = c->qfrag;
+      ca.nq = nq;
+      ca.k = 1;
+      ca.cap = 2;
+      ca.grid = c->n_cu;
+      ca.mode = 2;
+      ca.thr_g = c->thr_g;
+      ca.range_cap = (unsigned)ix->ivf_nlist;
+      ca.range_s = ix->ivf_scores;
+      HIPCHK(launch_scan(ca, st));
+      HIPCHK(launch_ivf_worklist_from_scores(ix->ivf_scores, nq, np, ix->ivf_nlist, ix->ivf_masks, ix->ivf_tile0, ix->ivf_ntile,
+                                             ix->ivf_size, ix->ivf_off, ix->ivf_work, ix->ivf_nwork, st));
+    }
   }
   HIPCHK(launch_prep(q_dev, nq, ix->d, ix->qfrag, ix->thr_g, nullptr, 0, gate, st));
   ScanArgs a{};
@@ -945,9 +981,283 @@ extern "C" int knnx_ivf_set_lists(knnx_index* ix, int nlist, const uint16_t* cen
   return KNNX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// IVF-Flat build on the device (stands in for the autofaiss call of clip_index.py:12-66 for this index
+// type).  Training: Lloyd iterations on a sample that stays resident in HBM -- assignment by knn_assign_kernel (MFMA-bound,
+// every workgroup streams the whole centroid matrix), update by one workgroup per list over the host-sorted member order.
+// Adding: two streaming passes over the embedding files, so that no second copy of a 256 GB shard is ever needed --
+// pass 1 knnx_ivfb_assign (rows -> list ids, 4 bytes per row kept by the caller), pass 2 knnx_ivf_begin /
+// knnx_ivf_add_assigned / knnx_ivf_end (rows scattered straight into the tile-padded list-sorted arena).  The host only
+// does integer bookkeeping (bincount, prefix sums, stable ranks inside a chunk).
+// ---------------------------------------------------------------------------------------------
+struct knnx_ivf_builder {
+  int device = 0, d = 0, nlist = 0;
+  hipStream_t stream = nullptr;
+  _Float16* cent = nullptr;    // [nlist, d]
+  _Float16* sample = nullptr;  // resident training sample
+  int64_t n_sample = 0;
+  _Float16* stage = nullptr;   // one chunk of streamed rows
+  int32_t* lists = nullptr;    // assignment of a chunk / of the sample
+  int64_t cap_rows = 0;
+  int64_t *order = nullptr, *off = nullptr;
+  void* pin = nullptr;
+  size_t pin_bytes = 0;
+};
+static const int64_t IVFB_CHUNK = (int64_t)1 << 20;  // rows per streamed chunk
+
+extern "C" void knnx_ivfb_destroy(knnx_ivf_builder* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  (void)hipFree(b->cent);
+  (void)hipFree(b->sample);
+  (void)hipFree(b->stage);
+  (void)hipFree(b->lists);
+  (void)hipFree(b->order);
+  (void)hipFree(b->off);
+  if (b->pin) (void)hipHostFree(b->pin);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+extern "C" int knnx_ivfb_create(int device, int d, int nlist, knnx_ivf_builder** out) {
+  if (!out || nlist <= 0) return fail(KNNX_E_ARG, "bad ivfb_create arguments");
+  *out = nullptr;
+  if (d <= 0 || d % 256 != 0 || d > 1024) return fail(KNNX_E_UNSUPPORTED, "d must be a multiple of 256 and <= 1024");
+  HIPCHK(hipSetDevice(device));
+  knnx_ivf_builder* b = new knnx_ivf_builder();
+  b->device = device;
+  b->d = d;
+  b->nlist = nlist;
+  hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&b->cent, (size_t)nlist * d * sizeof(_Float16));
+  if (e == hipSuccess) e = hipMalloc(&b->off, (size_t)(nlist + 1) * sizeof(int64_t));
+  if (e == hipSuccess) {
+    b->pin_bytes = (size_t)IVFB_CHUNK * d * sizeof(_Float16);
+    e = hipHostMalloc(&b->pin, b->pin_bytes, hipHostMallocDefault);
+  }
+  if (e != hipSuccess) {
+    knnx_ivfb_destroy(b);
+    return fail(e == hipErrorOutOfMemory ? KNNX_E_NOMEM : KNNX_E_HIP, std::string("ivfb_create: ") + hipGetErrorString(e));
+  }
+  *out = b;
+  return KNNX_OK;
+}
+
+extern "C" int knnx_ivfb_set_centroids(knnx_ivf_builder* b, const uint16_t* centroids_f16) {
+  if (!b || !centroids_f16) return fail(KNNX_E_ARG, "bad ivfb_set_centroids arguments");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemcpy(b->cent, centroids_f16, (size_t)b->nlist * b->d * sizeof(_Float16), hipMemcpyHostToDevice));
+  return KNNX_OK;
+}
+extern "C" int knnx_ivfb_get_centroids(knnx_ivf_builder* b, uint16_t* centroids_f16) {
+  if (!b || !centroids_f16) return fail(KNNX_E_ARG, "bad ivfb_get_centroids arguments");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(centroids_f16, b->cent, (size_t)b->nlist * b->d * sizeof(_Float16), hipMemcpyDeviceToHost));
+  return KNNX_OK;
+}
+
+static int ivfb_rows_cap(knnx_ivf_builder* b, int64_t rows) {
+  if (rows <= b->cap_rows) return 0;
+  (void)hipFree(b->stage);
+  (void)hipFree(b->lists);
+  b->stage = nullptr;
+  b->lists = nullptr;
+  b->cap_rows = 0;
+  HIPCHK(hipMalloc(&b->stage, (size_t)std::min<int64_t>(rows, IVFB_CHUNK) * b->d * sizeof(_Float16)));
+  HIPCHK(hipMalloc(&b->lists, (size_t)rows * sizeof(int32_t)));
+  b->cap_rows = rows;
+  return 0;
+}
+
+// upload host rows in chunks through the pinned buffer into dst (device)
+static int ivfb_upload(knnx_ivf_builder* b, const uint16_t* rows, int64_t n, _Float16* dst) {
+  const size_t rb = (size_t)b->d * sizeof(_Float16);
+  for (int64_t o = 0; o < n; o += IVFB_CHUNK) {
+    const int64_t m = std::min(IVFB_CHUNK, n - o);
+    memcpy(b->pin, rows + (size_t)o * b->d, (size_t)m * rb);
+    HIPCHK(hipMemcpyAsync(dst + (size_t)o * b->d, b->pin, (size_t)m * rb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
+  return 0;
+}
+
+extern "C" int knnx_ivfb_set_sample(knnx_ivf_builder* b, const uint16_t* rows_f16, int64_t n) {
+  if (!b || !rows_f16 || n <= 0) return fail(KNNX_E_ARG, "bad ivfb_set_sample arguments");
+  HIPCHK(hipSetDevice(b->device));
+  (void)hipFree(b->sample);
+  (void)hipFree(b->order);
+  b->sample = nullptr;
+  b->order = nullptr;
+  HIPCHK(hipMalloc(&b->sample, (size_t)n * b->d * sizeof(_Float16)));
+  HIPCHK(hipMalloc(&b->order, (size_t)n * sizeof(int64_t)));
+  b->n_sample = n;
+  int r = ivfb_rows_cap(b, n);
+  if (r) return r;
+  return ivfb_upload(b, rows_f16, n, b->sample);
+}
+
+extern "C" int knnx_ivfb_assign_sample(knnx_ivf_builder* b, int32_t* lists_out) {
+  if (!b || !lists_out || !b->sample) return fail(KNNX_E_ARG, "bad ivfb_assign_sample arguments (set a sample first)");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(launch_assign(b->cent, b->nlist, b->d, b->sample, b->n_sample, b->lists, b->stream));
+  HIPCHK(hipMemcpyAsync(lists_out, b->lists, (size_t)b->n_sample * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return KNNX_OK;
+}
+
+extern "C" int knnx_ivfb_update(knnx_ivf_builder* b, const int64_t* order, const int64_t* off) {
+  if (!b || !order || !off || !b->sample) return fail(KNNX_E_ARG, "bad ivfb_update arguments (set a sample first)");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipMemcpyAsync(b->order, order, (size_t)b->n_sample * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->off, off, (size_t)(b->nlist + 1) * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(launch_kmeans_update(b->sample, b->d, b->order, b->off, b->nlist, b->cent, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return KNNX_OK;
+}
+
+extern "C" int knnx_ivfb_assign(knnx_ivf_builder* b, const uint16_t* rows_f16, int64_t n, int32_t* lists_out) {
+  if (!b || (n > 0 && (!rows_f16 || !lists_out)) || n < 0) return fail(KNNX_E_ARG, "bad ivfb_assign arguments");
+  if (n == 0) return KNNX_OK;
+  HIPCHK(hipSetDevice(b->device));
+  int r = ivfb_rows_cap(b, std::min<int64_t>(n, IVFB_CHUNK));
+  if (r) return r;
+  const size_t rb = (size_t)b->d * sizeof(_Float16);
+  for (int64_t o = 0; o < n; o += IVFB_CHUNK) {
+    const int64_t m = std::min(IVFB_CHUNK, n - o);
+    memcpy(b->pin, rows_f16 + (size_t)o * b->d, (size_t)m * rb);
+    HIPCHK(hipMemcpyAsync(b->stage, b->pin, (size_t)m * rb, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(launch_assign(b->cent, b->nlist, b->d, b->stage, m, b->lists, b->stream));
+    HIPCHK(hipMemcpyAsync(lists_out + o, b->lists, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
+  return KNNX_OK;
+}
+
+extern "C" int knnx_ivf_begin(knnx_index* ix, int nlist, const uint16_t* centroids_f16, const int64_t* list_sizes) {
+  if (!ix || nlist <= 0 || !centroids_f16 || !list_sizes) return fail(KNNX_E_ARG, "bad ivf_begin arguments");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (set_dev(ix)) return KNNX_E_HIP;
+  if (ix->borrowed || ix->ntotal != 0 || ix->ivf_nlist || ix->ivfb_nlist) return fail(KNNX_E_STATE, "ivf_begin needs an empty index that owns its rows");
+  std::vector<unsigned> tile0(nlist), ntile(nlist), size(nlist);
+  int64_t run = 0, tiles = 0;
+  for (int l = 0; l < nlist; ++l) {
+    if (list_sizes[l] < 0) return fail(KNNX_E_ARG, "negative list size");
+    size[l] = (unsigned)list_sizes[l];
+    ntile[l] = (unsigned)((list_sizes[l] + 31) / 32);
+    tile0[l] = (unsigned)tiles;
+    run += list_sizes[l];
+    tiles += ntile[l];
+  }
+  if (tiles * 32 > (int64_t)0xffffffffll) return fail(KNNX_E_UNSUPPORTED, "more than 2^32 padded rows per device");
+  const int64_t prow = std::max<int64_t>(tiles * 32, 32);
+  if (ix->rows) hipFree(ix->rows);
+  ix->rows = nullptr;
+  ix->capacity = 0;
+  HIPCHK(hipMalloc(&ix->rows, (size_t)prow * ix->d * sizeof(_Float16)));
+  ix->capacity = prow;
+  hipError_t e = hipMemsetAsync(ix->rows, 0, (size_t)prow * ix->d * sizeof(_Float16), ix->stream);  // pad rows are zero
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_tile0, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_ntile, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_size, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_masks, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_off, nlist * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_nwork, sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_work, (size_t)std::max<int64_t>(tiles, 1) * sizeof(uint4));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_idmap, (size_t)prow * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_inv, (size_t)std::max<int64_t>(run, 1) * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_Ic, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivf_Dc, (size_t)KNN_NQ * KNNX_MAX_K_FAST * sizeof(float));
+  if (e == hipSuccess) e = hipMemsetAsync(ix->ivf_idmap, 0xFF, (size_t)prow * sizeof(int64_t), ix->stream);  // -1 on pad rows
+  if (e == hipSuccess) e = hipMemcpyAsync(ix->ivf_tile0, tile0.data(), nlist * sizeof(unsigned), hipMemcpyHostToDevice, ix->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ix->ivf_ntile, ntile.data(), nlist * sizeof(unsigned), hipMemcpyHostToDevice, ix->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ix->ivf_size, size.data(), nlist * sizeof(unsigned), hipMemcpyHostToDevice, ix->stream);
+  if (e == hipSuccess) e = hipMalloc(&ix->ivfb_rows, (size_t)IVFB_CHUNK * ix->d * sizeof(_Float16));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivfb_ids, (size_t)IVFB_CHUNK * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivfb_lists, (size_t)IVFB_CHUNK * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&ix->ivfb_pos, (size_t)IVFB_CHUNK * sizeof(int32_t));
+  if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KNNX_E_NOMEM : KNNX_E_HIP, std::string("ivf_begin: ") + hipGetErrorString(e));
+  ix->ivfb_cent.assign(centroids_f16, centroids_f16 + (size_t)nlist * ix->d);
+  ix->ivfb_nlist = nlist;
+  ix->ivfb_total = run;
+  ix->ivfb_added = 0;
+  return KNNX_OK;
+}
+
+extern "C" int knnx_ivf_add_assigned(knnx_index* ix, const uint16_t* rows_f16, int64_t n, const int64_t* ids, const int32_t* lists,
+                                     const int32_t* pos) {
+  if (!ix || (n > 0 && (!rows_f16 || !ids || !lists || !pos)) || n < 0) return fail(KNNX_E_ARG, "bad ivf_add_assigned arguments");
+  if (n == 0) return KNNX_OK;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (set_dev(ix)) return KNNX_E_HIP;
+  if (!ix->ivfb_nlist) return fail(KNNX_E_STATE, "call knnx_ivf_begin first");
+  if (ix->ivfb_added + n > ix->ivfb_total) return fail(KNNX_E_ARG, "more rows than the list sizes announced");
+  for (int64_t i = 0; i < n; ++i) {
+    if (lists[i] < 0 || lists[i] >= ix->ivfb_nlist || pos[i] < 0) return fail(KNNX_E_ARG, "list id / position out of range");
+    if (ids[i] < ix->id_base || ids[i] - ix->id_base >= ix->ivfb_total) return fail(KNNX_E_ARG, "ids must lie in [id_base, id_base + total rows)");
+  }
+  const size_t rb = (size_t)ix->d * sizeof(_Float16);
+  int r = ensure_pin(ix, (size_t)IVFB_CHUNK * (rb + 16));
+  if (r) return r;
+  char* pin = (char*)ix->pin;
+  for (int64_t o = 0; o < n; o += IVFB_CHUNK) {
+    const int64_t m = std::min(IVFB_CHUNK, n - o);
+    char* p_rows = pin;
+    char* p_ids = p_rows + (size_t)IVFB_CHUNK * rb;
+    char* p_lists = p_ids + (size_t)IVFB_CHUNK * 8;
+    char* p_pos = p_lists + (size_t)IVFB_CHUNK * 4;
+    memcpy(p_rows, rows_f16 + (size_t)o * ix->d, (size_t)m * rb);
+    memcpy(p_ids, ids + o, (size_t)m * 8);
+    memcpy(p_lists, lists + o, (size_t)m * 4);
+    memcpy(p_pos, pos + o, (size_t)m * 4);
+    HIPCHK(hipMemcpyAsync(ix->ivfb_rows, p_rows, (size_t)m * rb, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(ix->ivfb_ids, p_ids, (size_t)m * 8, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(ix->ivfb_lists, p_lists, (size_t)m * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(ix->ivfb_pos, p_pos, (size_t)m * 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(launch_ivf_scatter((const _Float16*)ix->ivfb_rows, m, ix->d, (const int32_t*)ix->ivfb_lists, (const int32_t*)ix->ivfb_pos,
+                              (const int64_t*)ix->ivfb_ids, ix->ivf_tile0, ix->id_base, ix->ivfb_total, ix->rows, ix->ivf_idmap,
+                              ix->ivf_inv, ix->stream));
+    HIPCHK(launch_maxnorm((const _Float16*)ix->ivfb_rows, m, ix->d, ix->maxnorm, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+  }
+  ix->ivfb_added += n;
+  return KNNX_OK;
+}
+
+extern "C" int knnx_ivf_end(knnx_index* ix) {
+  if (!ix) return fail(KNNX_E_ARG, "index is null");
+  int nlist;
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (set_dev(ix)) return KNNX_E_HIP;
+    if (!ix->ivfb_nlist) return fail(KNNX_E_STATE, "call knnx_ivf_begin first");
+    if (ix->ivfb_added != ix->ivfb_total) return fail(KNNX_E_STATE, "fewer rows were added than the list sizes announced");
+    nlist = ix->ivfb_nlist;
+    hipFree(ix->ivfb_rows); ix->ivfb_rows = nullptr;
+    hipFree(ix->ivfb_ids); ix->ivfb_ids = nullptr;
+    hipFree(ix->ivfb_lists); ix->ivfb_lists = nullptr;
+    hipFree(ix->ivfb_pos); ix->ivfb_pos = nullptr;
+  }
+  int r = knnx_create(ix->device, ix->d, KNNX_METRIC_INNER_PRODUCT, &ix->cent);
+  if (r) return r;
+  r = knnx_add_f16(ix->cent, ix->ivfb_cent.data(), nlist);
+  if (r) return r;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  ix->ntotal = ix->ivfb_total;
+  ix->ivf_nlist = nlist;
+  ix->ivf_nprobe = std::min(ix->ivf_nprobe, nlist);
+  ix->ivfb_nlist = 0;
+  ix->ivfb_cent.clear();
+  ix->ivfb_cent.shrink_to_fit();
+  return KNNX_OK;
+}
+
 extern "C" int knnx_ivf_set_nprobe(knnx_index* ix, int nprobe) {
   if (!ix) return fail(KNNX_E_ARG, "index is null");
-  if (nprobe < 1 || nprobe > KNNX_MAX_K_FAST) return fail(KNNX_E_UNSUPPORTED, "nprobe must be in 1..64");
+  if (nprobe < 1) return fail(KNNX_E_ARG, "nprobe must be >= 1");
   std::lock_guard<std::mutex> lk(ix->mu);
   ix->ivf_nprobe = nprobe;
   return KNNX_OK;

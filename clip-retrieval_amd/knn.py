@@ -409,19 +409,82 @@ def load_index(path, device=0, row_range=None, enable_faiss_memory_mapping=False
 
 # ------------------------------------------------------------------------------------------------------------
 # IVF-Flat index build (BASELINE config 5; takes the place of the autofaiss call of clip_index.py:12-66 for this
-# index type).  Build-time only: Lloyd iterations whose assignment step is the library's own flat scan over the
-# centroid rows (k = 1), centroid means on the host.
+# index type).  The arithmetic runs on the GPU through the builder entry points of include/knnx.h: list assignment is
+# the MFMA assignment kernel (csrc/knn_rq_kernels.hip: knn_assign_kernel), the Lloyd update one workgroup per list, the
+# final layout a scatter kernel; the host keeps integer bookkeeping only (bincount, prefix sums, stable ranks).
 # ------------------------------------------------------------------------------------------------------------
-def _assign(cent_index, x_f16, batch=8192):
-    out = np.empty(x_f16.shape[0], dtype=np.int64)
-    for o in range(0, x_f16.shape[0], batch):
-        _, I = cent_index.search(np.ascontiguousarray(x_f16[o:o + batch], dtype=np.float32), 1)
-        out[o:o + batch] = I[:, 0]
-    return out
+class IvfBuilder:
+    """Centroids (and optionally a training sample) resident on one GPU: knnx_ivfb_* of include/knnx.h."""
+
+    def __init__(self, d, nlist, device=0):
+        self._lib = load_library()
+        self.d, self.nlist, self.device = int(d), int(nlist), int(device)
+        self._dpad = (self.d + 255) // 256 * 256
+        h = C.c_void_p()
+        check(self._lib, self._lib.knnx_ivfb_create(self.device, self._dpad, self.nlist, C.byref(h)), "knnx")
+        self._h = h
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.knnx_ivfb_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+    def _rows(self, x):
+        x = np.asarray(x)
+        if x.dtype != np.float16:
+            x = x.astype(np.float16)
+        if self._dpad != self.d:
+            out = np.zeros((x.shape[0], self._dpad), dtype=np.float16)
+            out[:, : self.d] = x
+            x = out
+        return np.ascontiguousarray(x)
+
+    def set_centroids(self, c):
+        c = self._rows(c)
+        assert c.shape[0] == self.nlist
+        check(self._lib, self._lib.knnx_ivfb_set_centroids(self._h, c.ctypes.data), "knnx")
+
+    def centroids(self):
+        out = np.empty((self.nlist, self._dpad), dtype=np.float16)
+        check(self._lib, self._lib.knnx_ivfb_get_centroids(self._h, out.ctypes.data), "knnx")
+        return np.ascontiguousarray(out[:, : self.d])
+
+    def set_sample(self, x):
+        x = self._rows(x)
+        self._n_sample = x.shape[0]
+        check(self._lib, self._lib.knnx_ivfb_set_sample(self._h, x.ctypes.data, x.shape[0]), "knnx")
+
+    def assign_sample(self):
+        out = np.empty(self._n_sample, dtype=np.int32)
+        check(self._lib, self._lib.knnx_ivfb_assign_sample(self._h, out.ctypes.data), "knnx")
+        return out
+
+    def update(self, lists):
+        """One Lloyd update from the resident sample; returns the list sizes (empty lists keep their centroid)."""
+        order = np.ascontiguousarray(np.argsort(lists, kind="stable").astype(np.int64))
+        sizes = np.bincount(lists, minlength=self.nlist).astype(np.int64)
+        off = np.zeros(self.nlist + 1, dtype=np.int64)
+        np.cumsum(sizes, out=off[1:])
+        check(self._lib, self._lib.knnx_ivfb_update(self._h, order.ctypes.data, off.ctypes.data), "knnx")
+        return sizes
+
+    def assign(self, x):
+        """List id (argmax over the centroids, ties -> smaller id) of every row of x; rows are streamed in 1 Mi-row chunks."""
+        x = self._rows(x)
+        out = np.empty(x.shape[0], dtype=np.int32)
+        check(self._lib, self._lib.knnx_ivfb_assign(self._h, x.ctypes.data, x.shape[0], out.ctypes.data), "knnx")
+        return out
 
 
 def train_ivf_centroids(x_f16, nlist, niter=8, seed=0, device=0, max_points_per_centroid=256):
-    """k-means with inner-product assignment (faiss Clustering with an IndexFlatIP quantiser): returns fp16 [nlist, d]."""
+    """k-means with inner-product assignment (faiss Clustering with an IndexFlatIP quantiser): returns fp16 [nlist, d].
+    The sample (<= nlist * max_points_per_centroid rows, like faiss) stays resident in HBM across the iterations."""
     x_f16 = np.asarray(x_f16)
     rng = np.random.default_rng(seed)
     n, d = x_f16.shape
@@ -429,46 +492,60 @@ def train_ivf_centroids(x_f16, nlist, niter=8, seed=0, device=0, max_points_per_
         raise ValueError(f"need at least nlist={nlist} training rows, got {n}")
     take = min(n, nlist * max_points_per_centroid)
     sample = x_f16[np.sort(rng.choice(n, take, replace=False))] if take < n else x_f16
-    cent = sample[rng.choice(sample.shape[0], nlist, replace=False)].astype(np.float32)
-    s32 = sample.astype(np.float32)
-    s32t = np.ascontiguousarray(s32.T)
+    b = IvfBuilder(d, nlist, device)
+    b.set_sample(sample)
+    b.set_centroids(sample[rng.choice(sample.shape[0], nlist, replace=False)])
     for _ in range(niter):
-        ci = Mi355xIndex(d, device=device, coalesce=False)
-        ci.add(cent.astype(np.float16))
-        a = _assign(ci, sample)
-        ci.close()
-        # per-list sums, one weighted bincount per dimension over the transposed sample (float64 accumulation, deterministic;
-        # np.add.at takes ~14 s per iteration at 256 k x 768, this ~1 s)
-        cnt = np.bincount(a, minlength=nlist)
-        sums = np.empty((nlist, d), dtype=np.float64)
-        for j in range(d):
-            sums[:, j] = np.bincount(a, weights=s32t[j], minlength=nlist)
-        empty = cnt == 0
-        cent = (sums / np.maximum(cnt, 1)[:, None]).astype(np.float32)
-        if empty.any():  # re-seed empty clusters on random points (faiss splits big clusters; any re-seed is valid)
-            cent[empty] = s32[rng.choice(s32.shape[0], int(empty.sum()), replace=False)]
-    return cent.astype(np.float16)
+        sizes = b.update(b.assign_sample())
+        empty = np.flatnonzero(sizes == 0)
+        if empty.size:  # re-seed empty clusters on random points (faiss splits big clusters; any re-seed is valid)
+            cent = b.centroids()
+            cent[empty] = np.asarray(sample[rng.choice(sample.shape[0], empty.size, replace=False)], dtype=np.float16)
+            b.set_centroids(cent)
+    cent = b.centroids()
+    b.close()
+    return cent
 
 
-def build_ivf_index(x_f16, nlist, nprobe=16, niter=8, seed=0, device=0, id_base=0, centroids=None):
-    """fp16 rows [N, d] -> HBM-resident IVF-Flat index (ids = id_base + row number, like the flat index)."""
-    x_f16 = np.ascontiguousarray(np.asarray(x_f16).astype(np.float16))
+def _positions_in_lists(lists, cursor):
+    """Stable rank of every row inside its list, continuing from `cursor` (rows of earlier chunks); updates cursor."""
+    order = np.argsort(lists, kind="stable")
+    sl = lists[order]
+    start = np.flatnonzero(np.r_[True, sl[1:] != sl[:-1]])
+    run_len = np.diff(np.r_[start, sl.size])
+    rank_sorted = np.arange(sl.size) - np.repeat(start, run_len)
+    pos = np.empty(lists.size, dtype=np.int64)
+    pos[order] = rank_sorted + cursor[sl]
+    np.add.at(cursor, sl[start], run_len)
+    return pos.astype(np.int32)
+
+
+def build_ivf_index(x_f16, nlist, nprobe=16, niter=8, seed=0, device=0, id_base=0, centroids=None, chunk=1 << 20):
+    """fp16 rows [N, d] -> HBM-resident IVF-Flat index (ids = id_base + row number, like the flat index).  `x_f16` may be a
+    numpy memmap: rows are streamed twice in chunks (assignment, then scatter into the list-sorted arena)."""
     n, d = x_f16.shape
     if centroids is None:
         centroids = train_ivf_centroids(x_f16, nlist, niter=niter, seed=seed, device=device)
     centroids = np.asarray(centroids).astype(np.float16)
-    ci = Mi355xIndex(d, device=device, coalesce=False)
-    ci.add(centroids)
-    lists = _assign(ci, x_f16)
-    ci.close()
-    order = np.argsort(lists, kind="stable")
+    b = IvfBuilder(d, nlist, device)
+    b.set_centroids(centroids)
+    lists = np.empty(n, dtype=np.int32)
+    for o in range(0, n, chunk):
+        lists[o:o + chunk] = b.assign(x_f16[o:o + chunk])
+    b.close()
     sizes = np.bincount(lists, minlength=nlist).astype(np.int64)
     index = Mi355xIndex(d, device=device, id_base=id_base)
-    index.reserve(n)
-    step = 1 << 18
-    for o in range(0, n, step):
-        index.add(x_f16[order[o:o + step]])
-    index.set_ivf_lists(centroids, sizes, order.astype(np.int64) + id_base)
+    lib = index._lib  # pylint: disable=protected-access
+    cpad = np.ascontiguousarray(index._pad(centroids))  # pylint: disable=protected-access
+    check(lib, lib.knnx_ivf_begin(index._h, nlist, cpad.ctypes.data, sizes.ctypes.data), "knnx")  # pylint: disable=protected-access
+    cursor = np.zeros(nlist, dtype=np.int64)
+    for o in range(0, n, chunk):
+        rows = np.ascontiguousarray(index._pad(np.asarray(x_f16[o:o + chunk], dtype=np.float16)))  # pylint: disable=protected-access
+        ls = np.ascontiguousarray(lists[o:o + chunk])
+        pos = _positions_in_lists(ls, cursor)
+        ids = np.arange(o, o + rows.shape[0], dtype=np.int64) + id_base
+        check(lib, lib.knnx_ivf_add_assigned(index._h, rows.ctypes.data, rows.shape[0], ids.ctypes.data, ls.ctypes.data, pos.ctypes.data), "knnx")  # pylint: disable=protected-access
+    check(lib, lib.knnx_ivf_end(index._h), "knnx")  # pylint: disable=protected-access
     index.nprobe = min(nprobe, nlist)
     index.ivf_lists = lists  # kept for tests / recall measurement
     return index

@@ -91,12 +91,34 @@ int knnx_range_search(knnx_index* ix, const float* q, int n, float thresh, int64
  * (list 0 first), then call knnx_ivf_set_lists once: centroids fp16 [nlist, d] (the coarse quantiser is a flat scan
  * over them), list_sizes [nlist], ids [ntotal] = the id each added row carries (a permutation of
  * [id_base, id_base + ntotal)).  Afterwards knnx_search* probe the nprobe lists whose centroids score highest for the
- * query (faiss `nprobe`, clip_back.py:357-369) and return exactly the top-k of those lists' rows; k <= 64,
- * nprobe <= 64; range_search and add are refused on an IVF index. */
+ * query (faiss `nprobe`, clip_back.py:357-369) and return exactly the top-k of those lists' rows; k <= 64;
+ * range_search and add are refused on an IVF index. */
 int knnx_ivf_set_lists(knnx_index* ix, int nlist, const uint16_t* centroids_f16, const int64_t* list_sizes,
                        const int64_t* ids);
-int knnx_ivf_set_nprobe(knnx_index* ix, int nprobe);
+int knnx_ivf_set_nprobe(knnx_index* ix, int nprobe); /* 1 .. nlist (BASELINE config 5: 16 / 64 / 256) */
 int knnx_ivf_nlist(const knnx_index* ix);
+
+/* ---- IVF-Flat build on the device (stands in for the autofaiss call of clip_index.py:12-66) ----------
+ * Training: a builder keeps the centroids and a training sample resident in HBM.  One Lloyd iteration =
+ * knnx_ivfb_assign_sample (argmax over the centroids by the MFMA assignment kernel; ties -> smaller list id) + host
+ * bookkeeping (stable sort of the list ids -> order, prefix sums -> off) + knnx_ivfb_update (mean of each list's members,
+ * fixed summation order; empty lists keep their centroid for the caller to re-seed through knnx_ivfb_set_centroids).
+ * Adding without a second copy of the shard: pass 1 knnx_ivfb_assign streams the rows and returns their list ids;
+ * pass 2 knnx_ivf_begin(list sizes) / knnx_ivf_add_assigned(rows, ids, list, position inside the list) / knnx_ivf_end
+ * scatters the rows straight into the list-sorted, tile-padded arena of an empty index.  Host pointers throughout. */
+typedef struct knnx_ivf_builder knnx_ivf_builder;
+int knnx_ivfb_create(int device, int d, int nlist, knnx_ivf_builder** out);
+void knnx_ivfb_destroy(knnx_ivf_builder* b);
+int knnx_ivfb_set_centroids(knnx_ivf_builder* b, const uint16_t* centroids_f16);
+int knnx_ivfb_get_centroids(knnx_ivf_builder* b, uint16_t* centroids_f16);
+int knnx_ivfb_set_sample(knnx_ivf_builder* b, const uint16_t* rows_f16, int64_t n);
+int knnx_ivfb_assign_sample(knnx_ivf_builder* b, int32_t* lists_out);
+int knnx_ivfb_update(knnx_ivf_builder* b, const int64_t* order, const int64_t* off);
+int knnx_ivfb_assign(knnx_ivf_builder* b, const uint16_t* rows_f16, int64_t n, int32_t* lists_out);
+int knnx_ivf_begin(knnx_index* ix, int nlist, const uint16_t* centroids_f16, const int64_t* list_sizes);
+int knnx_ivf_add_assigned(knnx_index* ix, const uint16_t* rows_f16, int64_t n, const int64_t* ids, const int32_t* lists,
+                          const int32_t* pos);
+int knnx_ivf_end(knnx_index* ix);
 
 /* Merge P per-shard results ([P, n, k] each, already global ids) into the top-k [n, k];
  * the step after the RCCL all-gather of a row-sharded index.  Device buffers. */

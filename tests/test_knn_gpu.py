@@ -550,3 +550,81 @@ def test_load_index_from_numpy_writer_output(tmp_path):
     Dpo, Ipo = op.search(q, 40)
     _check(Dp, Ip, Dpo, Ipo + lo, "load_index row_range")
     part.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# IVF build on the device (assignment kernel, Lloyd update, streaming scatter) and nprobe > 64
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,nlist,n", [(768, 100, 5000), (512, 1000, 70_001), (1024, 33, 777), (256, 4096, 3000)])
+def test_ivf_assignment_kernel_vs_numpy_argmax(d, nlist, n):
+    """knn_assign_kernel (every workgroup streams all centroids, a lane keeps the running best of its point): list ids must
+    equal numpy's argmax of the fp32 scores of the same fp16 data, except where the two best scores are within 1e-5."""
+    from clip_retrieval_amd.knn import IvfBuilder
+
+    x = _data(n, d, seed=61)
+    cent = _data(nlist, d, seed=62)
+    cent[nlist // 2] = cent[nlist // 3]  # an exact duplicate centroid: ties go to the smaller id
+    b = IvfBuilder(d, nlist)
+    b.set_centroids(cent)
+    got = b.assign(x)
+    b.close()
+    s = x.astype(np.float32) @ cent.astype(np.float32).T
+    want = s.argmax(1)
+    bad = np.flatnonzero(got != want)
+    top2 = np.sort(s[bad], axis=1)[:, -2:]
+    assert got.min() >= 0 and got.max() < nlist
+    assert (np.abs(top2[:, 1] - s[bad, got[bad]]) < 1e-5).all(), f"{bad.size} assignments differ beyond near-ties"
+    assert bad.size <= n // 200
+    dup = got == nlist // 2
+    assert not dup.any(), "a tie between identical centroids must go to the smaller id"
+
+
+def test_ivf_device_kmeans_improves_and_build_is_consistent():
+    """Lloyd iterations on the device (assign + per-list mean): the k-means objective (mean best score) must not decrease,
+    every list of the built index holds exactly the rows assigned to it, and search over all lists equals the flat oracle."""
+    from clip_retrieval_amd.knn import IvfBuilder, build_ivf_index, train_ivf_centroids
+    from oracle.knn_oracle import FlatIPOracle
+
+    d, n, nlist = 768, 30_000, 64
+    rng = np.random.default_rng(7)
+    centers = rng.standard_normal((nlist, d)).astype(np.float32)
+    x = centers[rng.integers(0, nlist, n)] + 0.7 * rng.standard_normal((n, d)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
+    objs = []
+    for it in (1, 4):
+        c = train_ivf_centroids(x, nlist, niter=it, seed=0)
+        objs.append(float((x.astype(np.float32) @ c.astype(np.float32).T).max(1).mean()))
+    assert objs[1] >= objs[0] - 1e-4 and objs[1] > 0.5, objs
+    ix = build_ivf_index(x, nlist, nprobe=nlist, centroids=c)
+    assert ix.ntotal == n and ix.nlist == nlist
+    b = IvfBuilder(d, nlist)
+    b.set_centroids(c)
+    assert np.array_equal(b.assign(x), ix.ivf_lists)
+    b.close()
+    o = FlatIPOracle(d)
+    o.add(x)
+    q = _queries(20, d, seed=2, x=x)
+    D, I = ix.search(q, 10)  # nprobe = nlist: every list is scanned -> the flat answer
+    Do, Io = o.search(q, 10)
+    _check(D, I, Do, Io, "ivf all lists")
+    assert np.array_equal(ix.reconstruct_batch(np.array([0, 12_345, n - 1])), x[[0, 12_345, n - 1]].astype(np.float32))
+    ix.close()
+
+
+@pytest.mark.parametrize("nprobe", [65, 100, 256, 300])
+def test_ivf_nprobe_above_64(nprobe):
+    """BASELINE config 5 asks for nprobe up to 256: the coarse quantiser dumps all centroid scores and a selection kernel
+    marks the nprobe best lists (score desc, list id asc)."""
+    from clip_retrieval_amd.knn import build_ivf_index
+    from oracle.knn_oracle import IVFFlatOracle
+
+    d, n, nlist = 512, 20_000, 300
+    x = _data(n, d, seed=71)
+    cent = x[np.random.default_rng(1).choice(n, nlist, replace=False)]
+    ix = build_ivf_index(x, nlist, nprobe=min(nprobe, nlist), centroids=cent)
+    ora = IVFFlatOracle(d, cent, ix.ivf_lists, x)
+    q = _queries(37, d, seed=5, x=x)
+    D, I = ix.search(q, 40)
+    Do, Io = ora.search(q, 40, min(nprobe, nlist))
+    _check(D, I, Do, Io, f"ivf nprobe={nprobe}")
+    ix.close()

@@ -126,26 +126,49 @@ if "knn" in what:
               f"proof-served {s1[0] - s0[0]} failed {s1[1] - s0[1]}", flush=True)
 
 if "ivf" in what:
-    # IVF-Flat search at moderate scale (built from host rows): bytes actually scanned = tiles of the probed lists
+    # IVF-Flat at scale: device-side build (k-means on a resident sample, assignment kernel, streaming scatter) and search.
+    # The corpus is a mixture of Gaussians generated on the GPU and copied to host memory chunk by chunk (what a build from
+    # img_emb_*.npy files sees); bytes actually scanned by a search = tiles of the probed lists.
     import numpy as np
 
-    from clip_retrieval_amd.knn import build_ivf_index
+    from clip_retrieval_amd.knn import Mi355xIndex, build_ivf_index, train_ivf_centroids
 
-    rows, d, nlist = int(os.environ.get("MB_IVF_ROWS", "2000000")), 768, int(os.environ.get("MB_IVF_NLIST", "1024"))
-    rng = np.random.default_rng(0)
-    centers = rng.standard_normal((nlist, d)).astype(np.float32)
-    x = centers[rng.integers(0, nlist, rows)] + 0.5 * rng.standard_normal((rows, d)).astype(np.float32)
-    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
+    rows, d = int(os.environ.get("MB_IVF_ROWS", "2000000")), int(os.environ.get("MB_IVF_D", "768"))
+    nlist = int(os.environ.get("MB_IVF_NLIST", "1024"))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    centers = torch.randn(nlist, d, device="cuda", generator=g)
+    x = np.empty((rows, d), dtype=np.float16)
+    for o in range(0, rows, 1 << 20):
+        m = min(1 << 20, rows - o)
+        v = centers[torch.randint(0, nlist, (m,), device="cuda", generator=g)] + 0.5 * torch.randn(m, d, device="cuda", generator=g)
+        x[o:o + m] = torch.nn.functional.normalize(v, dim=1).half().cpu().numpy()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ix = build_ivf_index(x, nlist, nprobe=16, niter=4)
-    print(f"ivf build rows={rows} nlist={nlist}: {time.perf_counter() - t0:.1f} s (k-means 4 iters + assign + relayout)", flush=True)
-    for nq, nprobe in ((1, 16), (32, 16), (32, 64)):
-        ix.nprobe = nprobe
-        q = torch.from_numpy(x[rng.integers(0, rows, nq)].astype(np.float32)).cuda()
+    cent = train_ivf_centroids(x, nlist, niter=8)
+    t1 = time.perf_counter()
+    ix = build_ivf_index(x, nlist, nprobe=16, centroids=cent)
+    t2 = time.perf_counter()
+    print(f"ivf build rows={rows} d={d} nlist={nlist}: k-means (8 iterations on {min(rows, nlist * 256)} rows) {t1 - t0:.1f} s, "
+          f"assign + scatter of all rows {t2 - t1:.1f} s, total {t2 - t0:.1f} s", flush=True)
+    rng = np.random.default_rng(0)
+    nsub = min(rows, int(os.environ.get("MB_IVF_RECALL_ROWS", "1000000")))
+    qh = x[rng.integers(0, nsub, 32)].astype(np.float32) + 0.05 * rng.standard_normal((32, d)).astype(np.float32)
+    qh /= np.linalg.norm(qh, axis=1, keepdims=True)
+    flat = Mi355xIndex(d, coalesce=False)
+    flat.add(x)
+    _, If = flat.search(qh, 40)
+    flat.close()
+    for nq, nprobe in ((1, 16), (32, 16), (32, 64), (32, 256)):
+        ix.nprobe = min(nprobe, nlist)
+        q = torch.from_numpy(qh[:nq]).cuda()
         D = torch.empty(nq, 40, device="cuda")
         I = torch.empty(nq, 40, device="cuda", dtype=torch.int64)
         timed(f"ivf search rows={rows} nlist={nlist} nprobe={nprobe} nq={nq} k=40",
               lambda: ix.search_device(q.data_ptr(), nq, 40, D.data_ptr(), I.data_ptr(), st))
+        torch.cuda.synchronize()
+        Ii = I.cpu().numpy()
+        rec = np.mean([len(set(Ii[i]) & set(If[i])) / 40.0 for i in range(nq)])
+        print(f"    recall@40 vs the exact flat scan of the same {rows} rows: {rec:.4f}", flush=True)
 if "b1" in what:
     # query-side latency (KnnService.compute_query, clip_back.py:207-255): ONE text / ONE image through the towers
     from clip_retrieval_amd.encoder import ARCHS, ClipEncoder, random_blob
