@@ -43,6 +43,7 @@ SIGNATURES = {
     "knnx_add_f32": (C.c_int, [_P, _P, C.c_int64]),
     "knnx_attach_device_f16": (C.c_int, [_P, _P, C.c_int64]),
     "knnx_set_id_base": (C.c_int, [_P, C.c_int64]),
+    "knnx_reset": (C.c_int, [_P]),
     "knnx_ntotal": (C.c_int64, [_P]),
     "knnx_dim": (C.c_int, [_P]),
     "knnx_search": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),

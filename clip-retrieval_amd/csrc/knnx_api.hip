@@ -269,6 +269,19 @@ extern "C" void knnx_destroy(knnx_index* ix) {
 extern "C" int64_t knnx_ntotal(const knnx_index* ix) { return ix ? ix->ntotal : 0; }
 extern "C" int knnx_dim(const knnx_index* ix) { return ix ? ix->d : 0; }
 
+// faiss Index.reset(): forget the rows, keep the arena (the per-request dedup index of clip_back.py:290-294 is rebuilt from
+// the <= k result vectors of every query; allocating a fresh index per request would cost more than the search)
+extern "C" int knnx_reset(knnx_index* ix) {
+  if (!ix) return fail(KNNX_E_ARG, "index is null");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (ix->ivf_nlist || ix->ivfb_nlist) return fail(KNNX_E_STATE, "reset of an IVF index is not supported (destroy it instead)");
+  if (set_dev(ix)) return KNNX_E_HIP;
+  HIPCHK(hipStreamSynchronize(ix->stream));
+  ix->ntotal = 0;
+  HIPCHK(hipMemsetAsync(ix->maxnorm, 0, sizeof(int), ix->stream));
+  return KNNX_OK;
+}
+
 extern "C" int knnx_set_id_base(knnx_index* ix, int64_t id_base) {
   if (!ix) return fail(KNNX_E_ARG, "index is null");
   ix->id_base = id_base;

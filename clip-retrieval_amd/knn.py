@@ -162,6 +162,10 @@ class Mi355xIndex(_FaissShaped):
         else:
             raise TypeError(f"add expects float32 or float16 rows, got {x.dtype}")
 
+    def reset(self):
+        """faiss Index.reset(): drop the rows, keep the HBM arena."""
+        check(self._lib, self._lib.knnx_reset(self._h), "knnx")
+
     def attach_device_rows(self, dev_ptr, n_rows):
         """Borrow fp16 rows already in HBM (e.g. a torch tensor's data_ptr()); caller keeps them alive."""
         if self._dpad != self.d:

@@ -56,6 +56,9 @@ int knnx_add_f32(knnx_index* ix, const float* rows, int64_t n);
  * benchmark's on-device generator and by shard loaders that hipMemcpy themselves). */
 int knnx_attach_device_f16(knnx_index* ix, const void* dev_rows, int64_t n);
 
+/* faiss Index.reset(): drop all rows, keep the arena (flat indexes; the per-request dedup index of clip_back.py:290-294). */
+int knnx_reset(knnx_index* ix);
+
 /* Global id of local row 0 (row-sharded multi-GPU index: shard g has id_base = g*N/G). */
 int knnx_set_id_base(knnx_index* ix, int64_t id_base);
 

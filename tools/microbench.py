@@ -183,20 +183,79 @@ if "b1" in what:
     timed("encode_text  B=1 ViT-L/14 (device buffers)", lambda: enc.encode_text_device(ids.data_ptr(), 1, o16.data_ptr(), None, st))
 
 if "e2e" in what:
-    # host-buffer path of the C ABI (what ClipMapper.__call__ uses): f32 NCHW batch of 256 in host memory -> fp16 embeddings
+    # host-buffer path of the C ABI (what ClipMapper uses): f32 NCHW batches of 256 in host memory -> fp16 embeddings.
+    #   device-resident   the kernels alone (inputs already in HBM): the rate bench.py quotes
+    #   synchronous call  clipx_encode_image per batch: upload, kernels, download strictly one after the other
+    #   tickets           clipx_encode_image_async / clipx_wait, batch n+1 submitted before batch n is collected (what
+    #                     runner.Runner does with ClipMapper.submit / collect): the upload hides under the kernels
     import numpy as np
 
     from clip_retrieval_amd.encoder import ARCHS, ClipEncoder, random_blob
     from clip_retrieval_amd.synth import normalise_u8_nhwc, synth_pixels_u8
 
-    arch = ARCHS["ViT-L/14"]
+    arch = ARCHS[os.environ.get("MB_MODEL", "ViT-L/14")]
     enc = ClipEncoder(arch, random_blob(arch, seed=0), 0)
+    NB = int(os.environ.get("MB_E2E_BATCHES", "6"))
     pix = normalise_u8_nhwc(synth_pixels_u8(256, arch.image_size, seed=1))
-    pinned = torch.from_numpy(pix).pin_memory()
-    for name, arr in (("pageable numpy", pix), ("page-locked torch tensor", pinned)):
+    pinned = [torch.from_numpy(pix).pin_memory() for _ in range(2)]
+    dev = torch.from_numpy(pix).cuda()
+    o16 = torch.empty(256, arch.embed_dim, dtype=torch.float16, device="cuda")
+    enc.encode_image_device(dev.data_ptr(), 256, 0, o16.data_ptr(), None, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(NB):
+        enc.encode_image_device(dev.data_ptr(), 256, 0, o16.data_ptr(), None, st)
+    torch.cuda.synchronize()
+    t_dev = (time.perf_counter() - t0) / NB
+    print(f"encode_image B=256 device-resident: {t_dev * 1e3:.1f} ms/batch = {256 / t_dev:.0f} images/s", flush=True)
+    for name, arr in (("pageable numpy", pix), ("page-locked torch tensor", pinned[0])):
         enc.encode_image(arr)
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(NB):
             enc.encode_image(arr)
-        dt = (time.perf_counter() - t0) / 5
-        print(f"encode_image host path B=256 ({name}): {dt * 1e3:.1f} ms/batch = {256 / dt:.0f} images/s", flush=True)
+        dt = (time.perf_counter() - t0) / NB
+        print(f"encode_image B=256 synchronous host call ({name}): {dt * 1e3:.1f} ms/batch = {256 / dt:.0f} images/s "
+              f"({t_dev / dt:.3f} of device-resident)", flush=True)
+    for name, src in (("page-locked", pinned), ("pageable", [pix, pix])):
+        h = enc.submit_image(src[0])
+        t0 = time.perf_counter()
+        for i in range(1, NB + 1):
+            h2 = enc.submit_image(src[i & 1])
+            enc.collect(h)
+            h = h2
+        dt = (time.perf_counter() - t0) / NB
+        enc.collect(h)
+        print(f"encode_image B=256 tickets, one batch ahead ({name}): {dt * 1e3:.1f} ms/batch = {256 / dt:.0f} images/s "
+              f"({t_dev / dt:.3f} of device-resident)", flush=True)
+
+if "reader" in what:
+    # reader throughput: a webdataset-style tar of JPEGs -> decode + CLIP transform on a thread pool
+    import io
+    import tarfile
+    import tempfile
+
+    import numpy as np
+    from PIL import Image
+
+    from clip_retrieval_amd.reader import HashTokenizer, WebdatasetReader, clip_preprocess
+    from clip_retrieval_amd.runner import Sampler
+
+    n = int(os.environ.get("MB_READER_SAMPLES", "4000"))
+    rng = np.random.default_rng(0)
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "shard.tar")
+    with tarfile.open(path, "w") as tf:
+        base = rng.integers(0, 255, (256, 256, 3), dtype=np.uint8)
+        for i in range(n):
+            buf = io.BytesIO()
+            Image.fromarray(np.roll(base, i, axis=1)).save(buf, format="JPEG", quality=90)
+            for ext, data in (("jpg", buf.getvalue()), ("txt", f"caption number {i}".encode())):
+                ti = tarfile.TarInfo(f"{i:06d}.{ext}")
+                ti.size = len(data)
+                tf.addfile(ti, io.BytesIO(data))
+    for workers in (8, 32, 64):
+        r = WebdatasetReader(Sampler(0, 1), clip_preprocess, HashTokenizer(), [path], 256, workers)
+        t0 = time.perf_counter()
+        got = sum(b["image_tensor"].shape[0] for b in r)
+        dt = time.perf_counter() - t0
+        print(f"WebdatasetReader {got} JPEG 256x256 + captions, {workers} decode threads: {got / dt:.0f} samples/s", flush=True)
