@@ -876,6 +876,12 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
       constexpr int cfg = 0;
 #endif
       if (cfg == 4) return launch_attention_cfg<64, 9, 4, 3>(qkv, out, B, T, H, causal, st);
+#ifdef CLIPX_ABLATE
+      if (cfg == 5) return launch_attention_cfg<64, 9, 9, 1, true>(qkv, out, B, T, H, causal, st);   // 9 waves, S recomputed
+      if (cfg == 6) return launch_attention_cfg<64, 9, 5, 2>(qkv, out, B, T, H, causal, st);
+      if (cfg == 7) return launch_attention_cfg<64, 9, 9, 1>(qkv, out, B, T, H, causal, st);         // 9 waves, S kept (144 regs)
+      if (cfg == 8) return launch_attention_cfg<64, 9, 5, 2, true>(qkv, out, B, T, H, causal, st);
+#endif
       if (cfg == 9 && !causal) {  // phase timer
         constexpr int KROW = 128, DV = 64;
         const size_t smem = (size_t)9 * 32 * KROW + (size_t)DV * (9 * 64 + 8);
