@@ -99,6 +99,7 @@ SIGNATURES = {
     "clipx_max_batch": (C.c_int, [_P]),
     "clipx_embed_dim": (C.c_int, [_P]),
     "clipx_gemm_bf16_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "clipx_gemm_bf16_ex_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "clipx_attention_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_attention_dh_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_layernorm_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),

@@ -613,8 +613,8 @@ extern "C" int clipx_wait(clipx_ticket* t) {
   return r;
 }
 
-extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out,
-                                      int M, int N, int K, int epi, void* stream) {
+static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M, int N, int K, int epi,
+                     const float* rowscale, void* out16, void* stream) {
   if (!A_bf16 || !W_bf16 || !out || M <= 0 || N <= 0 || K <= 0) return fail(CLIPX_E_ARG, "bad gemm arguments");
   if (epi < 0 || epi > 3 || !bias) return fail(CLIPX_E_ARG, "epi must be 0..3 and bias non-null");
   if (N % 128 || K % 64) return fail(CLIPX_E_UNSUPPORTED, "N must be a multiple of 128 and K of 64");
@@ -622,7 +622,9 @@ extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void
   GemmArgs g{};
   g.A = (const bf16*)A_bf16; g.W = (const bf16*)W_bf16; g.bias = bias; g.out = out; g.table = nullptr; g.T = 1;
   g.M = M; g.N = N; g.K = K; g.epi = epi;
-  {  // bf16-output epilogues scale rows (LayerNorm-folded GEMMs of the encoder); the plain GEMM of this entry point uses ones
+  g.rowscale = rowscale;
+  g.out16 = epi == 3 ? (bf16*)out16 : nullptr;
+  if (!g.rowscale) {  // bf16-output epilogues scale rows (LayerNorm-folded GEMMs of the encoder); a plain GEMM uses ones
     static std::mutex ones_mu;
     static float* ones[64] = {};
     static int ones_n[64] = {};
@@ -638,7 +640,6 @@ extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void
       ones_n[device] = M;
     }
     g.rowscale = ones[device];
-    g.out16 = nullptr;
   }
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   g.variant = gv ? std::min(3, std::max(0, atoi(gv))) : 3;
@@ -648,6 +649,15 @@ extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void
   g.row0 = 0;
   HIPCHK(launch_gemm(g, (hipStream_t)stream));
   return CLIPX_OK;
+}
+
+extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out,
+                                      int M, int N, int K, int epi, void* stream) {
+  return gemm_hook(device, A_bf16, W_bf16, bias, out, M, N, K, epi, nullptr, nullptr, stream);
+}
+extern "C" int clipx_gemm_bf16_ex_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M,
+                                         int N, int K, int epi, const float* rowscale_or_null, void* out16_or_null, void* stream) {
+  return gemm_hook(device, A_bf16, W_bf16, bias, out, M, N, K, epi, rowscale_or_null, out16_or_null, stream);
 }
 
 extern "C" int clipx_attention_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int causal,

@@ -39,6 +39,18 @@ constexpr int S_NBASE = 65536;    // N operand tiles start here
 constexpr int S_SCRATCH = 131072; // per-wave 4 KiB epilogue scratch starts here
 
 #define S_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Store-data guard.  On gfx950 a buffer_store_dwordx4 reads its four data dwords over many cycles AFTER it has issued, and
+// hipcc assumes no hazard at all for the register-soffset form these epilogues use (GCNHazardRecognizer: the ">64-bit store
+// data" hazard is only modelled for stores WITHOUT a soffset register): when the register allocator reused a data register
+// 5-7 instructions behind the store, the store wrote the NEW contents (found by tests/test_clip_gpu.py::
+// test_gemm_layernorm_fold_hooks_both_kernels: z / w lanes of the f32 residual rows overwritten by the bf16 shadow
+// exchange).  The guard keeps the data registers live (an asm input) across 8 wait states behind the store (s_nop 3, 7 and 15 all pass; what matters is that the registers stay live).
+#ifndef CLIPX_STORE_GUARD_NOPS
+#define CLIPX_STORE_GUARD_NOPS 7
+#endif
+#define S_STR2(x) #x
+#define S_STR(x) S_STR2(x)
+#define S_STORE_GUARD(v) asm volatile("s_nop " S_STR(CLIPX_STORE_GUARD_NOPS) ::"v"(v))
 
 // DBG 16: per-phase shader-cycle totals of every block's wave 0 (8 counters per block): [0] epilogues, [1] / [2] first and
 // second K-tile after an epilogue, [3] steady-state K-tiles, [4] last K-tile pair of a tile, [5] number of steady K-tiles,
@@ -86,10 +98,10 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   //   0 (fallback for other shapes): chunks in m-group-major order dealt round-robin to the XCDs: 2842 cycles, 1045 / 1006 TF;
   //   1 (ablation only): the W slice is kept across rounds instead: 2798 cycles, 1024 / 991 TF.
   auto tile_of = [&](int j, int& m0, int& n0, int& shA, int& shW) -> bool {
-    if (raster != 0 && (ntn & 3) == 0 && (ntm & 63) == 0 && cpx == 32) {
+    if ((raster & 3) != 0 && (ntn & 3) == 0 && (ntm & 63) == 0 && cpx == 32) {
       const int nsl = ntn >> 2, ng = ntm >> 6;  // n-slices of 4 tiles; m-groups (of 8 tiles) per XCD
       if (j >= nsl * ng) return false;
-      const int sl = raster == 1 ? j / ng : j % nsl, gi = raster == 1 ? j % ng : j / nsl;
+      const int sl = (raster & 3) == 1 ? j / ng : j % nsl, gi = (raster & 3) == 1 ? j % ng : j / nsl;
       const int gm0 = (gi * 8 + xcd) * 8;
       m0 = (gm0 + (idx & 7)) * 256;
       n0 = (sl * 4 + (idx >> 3)) * 256;
@@ -482,12 +494,19 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
             o.z = __uint_as_float(e[2]) + o.z; o.w = __uint_as_float(e[3]) + o.w;
             const u32x4 ov = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
             __builtin_amdgcn_raw_buffer_store_b128(ov, xr, voff, (mt * 4 + i) * rstep + nt * 128, 0);
+            S_STORE_GUARD(ov);
             if (shadow) {
               typedef float f32x2_t __attribute__((ext_vector_type(2)));
               typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
               const bf16x2_t h01 = __builtin_convertvector((f32x2_t){o.x, o.y}, bf16x2_t);
               const bf16x2_t h23 = __builtin_convertvector((f32x2_t){o.z, o.w}, bf16x2_t);
               const u32x2 hv = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+#ifdef CLIPX_ABLATE
+              if (raster & 4) {  // A/B: two 8-B half-line stores per row instead of the paired 16-B store
+                __builtin_amdgcn_raw_buffer_store_b64(hv, xr16, (rrow * N + rch * 4) * 2, (mt * 4 + i) * rstep16 + nt * 64, 0);
+                S_STORE_GUARD(hv);
+              } else
+#endif
               if (nt == 0) {
                 hkeep[i] = hv;
               } else {
@@ -496,6 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                 const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, false);
                 const u32x4 full = odd ? u32x4{r0, r1, hv.x, hv.y} : u32x4{hkeep[i].x, hkeep[i].y, r0, r1};
                 __builtin_amdgcn_raw_buffer_store_b128(full, xr16, voff16, (mt * 4 + i) * rstep16, 0);
+                S_STORE_GUARD(full);
               }
             }
           }
@@ -570,7 +590,7 @@ template <int EPI, int DBG = 0>
 static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   int raster = 2;
 #ifdef CLIPX_ABLATE
-  if (const char* fl = getenv("CLIPX_GEMM_FLAGS")) raster = atoi(fl) & 3;
+  if (const char* fl = getenv("CLIPX_GEMM_FLAGS")) raster = atoi(fl) & 7;  // bits 0-1: raster, bit 2: 8-B shadow stores
 #endif
   const size_t smem = S_SCRATCH + 8 * 4096;  // 160 KiB: the whole LDS of the CU
   auto kern = gemm256sp_kernel<EPI, DBG>;

@@ -123,6 +123,12 @@ int clipx_embed_dim(const clipx_handle* h);
 int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M,
                            int N, int K, int epi, void* stream);
 
+/* The same with the two extras the encoder's LayerNorm-folded layers use: rowscale_or_null f32 [M] (epi 0..2:
+ * out = act(acc * rowscale[m] + bias[n]); null = ones) and out16_or_null bf16 [M, N] (epi 3: also the bf16 rounding of the
+ * new f32 rows -- the shadow of the residual stream the next folded GEMM reads). */
+int clipx_gemm_bf16_ex_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M, int N,
+                              int K, int epi, const float* rowscale_or_null, void* out16_or_null, void* stream);
+
 /* The attention and LayerNorm kernels in isolation (device pointers), for per-kernel parity tests:
  * qkv bf16 [B*T, 3*H*64] -> out bf16 [B*T, H*64];  x f32 [M, d] -> y (bf16 if out_bf16 else f32). */
 int clipx_attention_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int causal,

@@ -373,3 +373,66 @@ def test_pipelined_runner_on_the_gpu(tiny, tmp_path):
         outs[mode] = (np.load(out / "img_emb" / "img_emb_0.npy"), np.load(out / "text_emb" / "text_emb_0.npy"))
     assert outs["serial"][0].shape[0] == 9
     assert np.array_equal(outs["pipelined"][0], outs["serial"][0]) and np.array_equal(outs["pipelined"][1], outs["serial"][1])
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 1024), (65792, 1024, 4096), (19712, 768, 768), (1000, 1024, 1024)])
+def test_gemm_layernorm_fold_hooks_both_kernels(lib, M, N, K):
+    """The two extras of the LayerNorm-folded layers, on shapes that reach the persistent 256x256 kernel (the encoder parity
+    tests run batches whose GEMMs all fit the 128x128 kernel): (1) residual epilogue: the bf16 shadow must be EXACTLY the
+    bf16 rounding of the f32 rows it writes, and both kernels must agree bit for bit; (2) bf16 epilogues: out = act(acc *
+    rowscale[m] + bias[n]) against torch fp32, and bit-identical between the kernels."""
+    from clip_retrieval_amd._lib import check
+
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device="cuda")
+    x0 = torch.randn(M, N, generator=g, device="cuda")
+    rs = torch.rand(M, generator=g, device="cuda") + 0.5
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for variant in (3, 1):
+        os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
+        x = x0.clone()
+        x16 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        check(lib, lib.clipx_gemm_bf16_ex_device(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(x), M, N, K, 3, None, _ptr(x16), C.c_void_p(st)), "clipx")
+        y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        check(lib, lib.clipx_gemm_bf16_ex_device(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(y), M, N, K, 0, _ptr(rs), None, C.c_void_p(st)), "clipx")
+        torch.cuda.synchronize()
+        bad = (x16.view(torch.int16) != x.to(torch.bfloat16).view(torch.int16)).nonzero()
+        assert bad.numel() == 0, f"variant {variant}: shadow != bf16(x) at {bad[:5].tolist()} ({bad.shape[0]} elements)"
+        outs[variant] = (x, x16, y)
+    os.environ.pop("CLIPX_GEMM_VARIANT")
+    for a, b in zip(outs[3], outs[1]):
+        assert torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16), b.view(torch.int32 if b.dtype == torch.float32 else torch.int16))
+    ref = (A.float() @ W.float().T)
+    want = ref * rs[:, None] + bias
+    assert (outs[3][2].float() - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))
+    assert torch.allclose(outs[3][0], x0 + ref + bias, atol=2e-3 * float(ref.abs().max()))
+
+
+def test_large_batch_persistent_kernel_path_equals_128_path():
+    """A 2-layer ViT-L/14-width model at batch 64 and 256: here the GEMMs run on the persistent 256x256 kernel (LayerNorm
+    fold, shadow stores, raster 2) -- batch sizes the CPU oracle cannot follow in a test.  The same encoder forced onto the
+    128x128 kernel (CLIPX_GEMM_VARIANT=1), which the oracle tests above validate, must give bit-identical embeddings."""
+    from clip_retrieval_amd.encoder import ARCHS, ClipArch, ClipEncoder, random_blob
+    from clip_retrieval_amd.synth import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    base = ARCHS["ViT-L/14"]
+    arch = ClipArch(**{**{k: getattr(base, k) for k in ClipArch.__dataclass_fields__}, "v_layers": 2, "t_layers": 2})
+    blob = random_blob(arch, seed=0)
+    enc = ClipEncoder(arch, blob, 0)
+    os.environ["CLIPX_GEMM_VARIANT"] = "1"
+    try:
+        ref = ClipEncoder(arch, blob, 0)
+    finally:
+        os.environ.pop("CLIPX_GEMM_VARIANT")
+    for B in (64, 256):
+        pix = normalise_u8_nhwc(synth_pixels_u8(B, arch.image_size, seed=1))
+        ids = synth_tokens(B, arch.ctx_len, arch.vocab, seed=2)
+        a, b = enc.encode_image(pix), ref.encode_image(pix)
+        assert not np.isnan(a.astype(np.float32)).any() and np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"image B={B}"
+        a, b = enc.encode_text(ids), ref.encode_text(ids)
+        assert not np.isnan(a.astype(np.float32)).any() and np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"text B={B}"
+    enc.close()
+    ref.close()

@@ -17,6 +17,9 @@
 #include <vector>
 
 typedef int (*gemm_fn)(int, const void*, const void*, const float*, void*, int, int, int, int, void*);
+typedef int (*gemm_ex_fn)(int, const void*, const void*, const float*, void*, int, int, int, int, const float*, void*, void*);
+static gemm_ex_fn g_ex = nullptr;
+static void* g_shadow = nullptr;  // GEMM_BENCH_SHADOW=1: epi 3 also writes the bf16 shadow (clipx_gemm_bf16_ex_device)
 typedef const char* (*err_fn)(void);
 
 #define CK(x)                                                                 \
@@ -47,9 +50,15 @@ int main(int argc, char** argv) {
     fprintf(stderr, "dlopen %s: %s\n", lib.c_str(), dlerror());
     return 2;
   }
-  gemm_fn gemm = (gemm_fn)dlsym(h, "clipx_gemm_bf16_device");
+  gemm_fn gemm0 = (gemm_fn)dlsym(h, "clipx_gemm_bf16_device");
+  g_ex = (gemm_ex_fn)dlsym(h, "clipx_gemm_bf16_ex_device");
+  const bool want_shadow = getenv("GEMM_BENCH_SHADOW") && g_ex;
+  auto gemm = [&](int dev, const void* A, const void* W, const float* b, void* o, int M, int N, int K, int epi, void* st) -> int {
+    if (want_shadow && epi == 3 && g_shadow) return g_ex(dev, A, W, b, o, M, N, K, epi, nullptr, g_shadow, st);
+    return gemm0(dev, A, W, b, o, M, N, K, epi, st);
+  };
   err_fn lasterr = (err_fn)dlsym(h, "clipx_last_error");
-  if (!gemm) return 2;
+  if (!gemm0) return 2;
   int reps = 10;
   std::vector<std::vector<int>> shapes;
   std::vector<Cfg> cfgs;
@@ -99,6 +108,7 @@ int main(int argc, char** argv) {
     const size_t ob = nO * (f32out ? 4 : 2);
     CK(hipMalloc(&dA, nA * 2)); CK(hipMalloc(&dW, nW * 2)); CK(hipMalloc(&db, N * 4));
     CK(hipMalloc(&dO, ob)); CK(hipMalloc(&dRef, ob)); CK(hipMalloc(&dInit, ob));
+    if (want_shadow && f32out) CK(hipMalloc(&g_shadow, nO * 2));
     CK(hipMemcpy(dA, hA.data(), nA * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
@@ -173,6 +183,7 @@ int main(int argc, char** argv) {
              2.0 * M * N * K / (med * 1e-3) / 1e12, mn, 2.0 * M * N * K / (mn * 1e-3) / 1e12);
     }
     CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(db)); CK(hipFree(dO)); CK(hipFree(dRef)); CK(hipFree(dInit));
+    if (g_shadow) { CK(hipFree(g_shadow)); g_shadow = nullptr; }
   }
   return 0;
 }
