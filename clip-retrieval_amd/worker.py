@@ -17,7 +17,7 @@ import re
 
 from .encoder import load_clip
 from .mapper import ClipMapper
-from .reader import FilesReader, WebdatasetReader
+from .reader import FilesReader, WebdatasetReader, clip_preprocess_u8
 from .runner import LoggerWriter, Runner, get_task_list
 from .writer import NumpyWriter
 
@@ -62,16 +62,21 @@ def worker(
     use_jit=True,
     clip_cache_path=None,
     device=0,
+    gpu_normalise=True,
 ):
-    """Start a worker"""
+    """Start a worker.  gpu_normalise (not in the reference): the readers resize / crop on the host and hand uint8 pixels to
+    the mapper, which normalises on the GPU; False reproduces the reference's float32 `image_tensor` batches."""
     print("Starting the worker", flush=True)
     if input_format == "webdataset" and not isinstance(input_dataset, list):
         input_dataset = braceexpand(input_dataset)
     print(f"dataset is {len(input_dataset)}", flush=True)
 
     def reader_builder(sampler):
-        _, preprocess, tokenizer = load_clip(clip_model=clip_model, use_jit=use_jit, warmup_batch_size=0,
-                                             clip_cache_path=clip_cache_path, device=device)
+        model, preprocess, tokenizer = load_clip(clip_model=clip_model, use_jit=use_jit, warmup_batch_size=0,
+                                                 clip_cache_path=clip_cache_path, device=device)
+        if gpu_normalise:
+            size = model._enc.arch.image_size  # pylint: disable=protected-access
+            preprocess = lambda im: clip_preprocess_u8(im, size)  # noqa: E731
         if input_format == "files":
             return FilesReader(sampler, preprocess, tokenizer, input_dataset, batch_size, num_prepro_workers,
                                enable_text=enable_text, enable_image=enable_image, enable_metadata=enable_metadata)

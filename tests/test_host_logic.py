@@ -435,3 +435,21 @@ def test_clip_preprocess_geometry_and_values():
     # a constant grey image maps to (v/255 - mean)/std in every pixel; palette / greyscale inputs are converted to RGB
     g = clip_preprocess(Image.new("L", (300, 200), 128), S)
     assert np.allclose(g[:, 0, 0], (128 / 255 - CLIP_MEAN) / CLIP_STD, atol=1e-6) and np.allclose(g, g[:, :1, :1], atol=1e-6)
+
+
+def test_u8_preprocess_is_the_float_transform_before_normalisation(image_folder):
+    """clip_preprocess_u8 (resize + crop on the host, normalisation on the GPU) yields exactly the uint8 pixels the float
+    transform normalises, and a reader built with it collates uint8 [B, S, S, 3] batches."""
+    from PIL import Image
+
+    from clip_retrieval_amd.reader import CLIP_MEAN, CLIP_STD, FilesReader, clip_preprocess, clip_preprocess_u8
+    from clip_retrieval_amd.runner import Sampler
+
+    img = Image.fromarray(np.random.default_rng(5).integers(0, 255, (300, 411, 3), dtype=np.uint8))
+    u8 = clip_preprocess_u8(img, 224)
+    assert u8.shape == (224, 224, 3) and u8.dtype == np.uint8
+    want = ((u8.astype(np.float32) * np.float32(1 / 255.0) - CLIP_MEAN) / CLIP_STD).transpose(2, 0, 1)
+    assert np.allclose(clip_preprocess(img, 224), want, atol=1e-6)
+    r = FilesReader(Sampler(0, 1), clip_preprocess_u8, None, str(image_folder), 4, 2, enable_text=False)
+    b = next(iter(r))
+    assert b["image_tensor"].dtype.__str__() == "torch.uint8" and tuple(b["image_tensor"].shape) == (4, 224, 224, 3)

@@ -237,7 +237,7 @@ if "reader" in what:
     import numpy as np
     from PIL import Image
 
-    from clip_retrieval_amd.reader import HashTokenizer, WebdatasetReader, clip_preprocess
+    from clip_retrieval_amd.reader import HashTokenizer, WebdatasetReader, clip_preprocess, clip_preprocess_u8
     from clip_retrieval_amd.runner import Sampler
 
     n = int(os.environ.get("MB_READER_SAMPLES", "4000"))
@@ -253,9 +253,10 @@ if "reader" in what:
                 ti = tarfile.TarInfo(f"{i:06d}.{ext}")
                 ti.size = len(data)
                 tf.addfile(ti, io.BytesIO(data))
-    for workers in (8, 32, 64):
-        r = WebdatasetReader(Sampler(0, 1), clip_preprocess, HashTokenizer(), [path], 256, workers)
-        t0 = time.perf_counter()
-        got = sum(b["image_tensor"].shape[0] for b in r)
-        dt = time.perf_counter() - t0
-        print(f"WebdatasetReader {got} JPEG 256x256 + captions, {workers} decode threads: {got / dt:.0f} samples/s", flush=True)
+    for prep in (clip_preprocess, clip_preprocess_u8):
+        for workers in (8, 32):
+            r = WebdatasetReader(Sampler(0, 1), prep, HashTokenizer(), [path], 256, workers)
+            t0 = time.perf_counter()
+            got = sum(b["image_tensor"].shape[0] for b in r)
+            dt = time.perf_counter() - t0
+            print(f"WebdatasetReader {got} JPEG 256x256 + captions, {prep.__name__}, {workers} decode threads: {got / dt:.0f} samples/s", flush=True)
