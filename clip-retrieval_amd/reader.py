@@ -5,9 +5,11 @@ Same constructor arguments and batch dicts as the reference readers
   {"image_tensor": f32 [B,3,S,S], "image_filename": [str], "text_tokens": int [B,77], "text": [str],
    "metadata": [str]}  (only the enabled keys)
 with the reference's skip-bad-sample behaviour (reader.py:100-104,142,180,187-189).
-Differences, stated: no `webdataset` / `torchvision` / DataLoader worker processes are used -- tar members
-are grouped by the webdataset key rule (basename up to the first dot) with `tarfile`, decoded with PIL on a
-thread pool, and collated into (pinned when a GPU is present) torch tensors.  `preprocess` defaults to a
+Differences, stated: no `webdataset` / `torchvision` / DataLoader are used -- tar members are grouped by the
+webdataset key rule (basename up to the first dot) with `tarfile`, decoded with PIL in `num_prepro_workers` worker
+PROCESSES (what the reference's DataLoader workers are; chunks of raw samples go out, decoded arrays come back, input
+order is kept; a preprocess / tokenizer that cannot be pickled falls back to a thread pool, which the GIL bounds at
+~2 k samples/s) and collated into (pinned when a GPU is present) torch tensors.  `preprocess` defaults to a
 restatement of CLIP's transform (bicubic resize of the shorter side to S, centre crop, RGB, /255,
 mean/std); pass the real `preprocess`/`tokenizer` from the model package when they are available.
 """
@@ -65,10 +67,8 @@ class HashTokenizer:
     def __init__(self, ctx_len=77, vocab=49408):
         self.ctx_len, self.vocab = ctx_len, vocab
 
-    def __call__(self, texts):
-        import torch  # pylint: disable=import-outside-toplevel
-
-        out = torch.zeros(len(texts), self.ctx_len, dtype=torch.int64)
+    def tokenize_numpy(self, texts):
+        out = np.zeros((len(texts), self.ctx_len), dtype=np.int64)
         for i, t in enumerate(texts):
             ids = []
             for word in t.lower().split()[: self.ctx_len - 2]:
@@ -77,8 +77,13 @@ class HashTokenizer:
                     h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
                 ids.append(1 + h % (self.vocab - 3))
             seq = [self.vocab - 2] + ids + [self.vocab - 1]
-            out[i, : len(seq)] = torch.tensor(seq)
+            out[i, : len(seq)] = seq
         return out
+
+    def __call__(self, texts):
+        import torch  # pylint: disable=import-outside-toplevel
+
+        return torch.from_numpy(self.tokenize_numpy(texts))
 
 
 def folder_to_keys(folder, enable_text=True, enable_image=True, enable_metadata=False):
@@ -133,15 +138,155 @@ def _collate(samples, enable_image, enable_text, enable_metadata, pin):
 
     batch = {}
     if enable_image:
-        t = torch.from_numpy(np.stack([s["image_tensor"] for s in samples]))
-        batch["image_tensor"] = t.pin_memory() if pin else t
+        first = samples[0]["image_tensor"]
+        if pin:  # rows go straight into the page-locked batch (one copy instead of stack + pin_memory)
+            t = torch.empty((len(samples),) + first.shape, dtype=torch.from_numpy(np.empty(0, first.dtype)).dtype, pin_memory=True)
+            np.stack([s["image_tensor"] for s in samples], out=t.numpy())
+        else:
+            t = torch.from_numpy(np.stack([s["image_tensor"] for s in samples]))
+        batch["image_tensor"] = t
         batch["image_filename"] = [s["image_filename"] for s in samples]
     if enable_text:
-        batch["text_tokens"] = torch.stack([s["text_tokens"] for s in samples])
+        batch["text_tokens"] = torch.from_numpy(np.stack([s["text_tokens"] for s in samples]))
         batch["text"] = [s["text"] for s in samples]
     if enable_metadata:
         batch["metadata"] = [s["metadata"] for s in samples]
     return batch
+
+
+def _decode_sample(raw, preprocess, tokenizer, enable_image, enable_text, enable_metadata):
+    """raw: {"key", "image": bytes|None, "text": str|None, "metadata": str|None} -> sample dict of numpy arrays / strings, or
+    None for an undecodable image (reference reader.py:100-104: print and skip)."""
+    from PIL import Image, UnidentifiedImageError  # pylint: disable=import-outside-toplevel
+
+    out = {}
+    if enable_image:
+        try:
+            img = preprocess(Image.open(io.BytesIO(raw["image"])))
+        except (UnidentifiedImageError, OSError, ValueError) as e:
+            print(f"Failed to load image {raw['key']}. Error: {e}. Skipping.")
+            return None
+        img = img.numpy() if hasattr(img, "numpy") else np.asarray(img)
+        out["image_tensor"] = img if img.dtype == np.uint8 else img.astype(np.float32, copy=False)  # uint8 HWC: normalised on the GPU
+        out["image_filename"] = raw["key"]
+    if enable_text:
+        out["text"] = raw["text"]
+        tok = tokenizer.tokenize_numpy([raw["text"]])[0] if hasattr(tokenizer, "tokenize_numpy") else tokenizer([raw["text"]])[0]
+        out["text_tokens"] = tok.numpy() if hasattr(tok, "numpy") else np.asarray(tok)
+    if enable_metadata:
+        out["metadata"] = raw["metadata"]
+    return out
+
+
+class _DecodeWorker:
+    """One `_decode_worker` child and its two pipes."""
+
+    def __init__(self, blob):
+        import os  # pylint: disable=import-outside-toplevel
+        import subprocess  # pylint: disable=import-outside-toplevel
+        import sys  # pylint: disable=import-outside-toplevel
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # where the `clip_retrieval_amd` import shim lives
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.pathsep.join([root] + [p for p in sys.path if p] + [env.get("PYTHONPATH", "")])
+        self.proc = subprocess.Popen([sys.executable, "-m", "clip_retrieval_amd._decode_worker"], stdin=subprocess.PIPE,
+                                     stdout=subprocess.PIPE, env=env)
+        self._send_blob(blob)
+
+    def _send_blob(self, blob):
+        import struct  # pylint: disable=import-outside-toplevel
+
+        self.proc.stdin.write(struct.pack("<Q", len(blob)))
+        self.proc.stdin.write(blob)
+        self.proc.stdin.flush()
+
+    def recv(self):
+        import pickle  # pylint: disable=import-outside-toplevel
+        import struct  # pylint: disable=import-outside-toplevel
+
+        hdr = self.proc.stdout.read(8)
+        if len(hdr) < 8:
+            raise RuntimeError("decode worker died")
+        status, value = pickle.loads(self.proc.stdout.read(struct.unpack("<Q", hdr)[0]))
+        if status != "ok":
+            raise RuntimeError(f"decode worker: {value}")
+        return value
+
+    def roundtrip(self, raws):
+        import pickle  # pylint: disable=import-outside-toplevel
+
+        self._send_blob(pickle.dumps(raws, protocol=pickle.HIGHEST_PROTOCOL))
+        return self.recv()
+
+    def close(self):
+        try:
+            self.proc.stdin.close()
+            self.proc.wait(timeout=5)
+        except Exception:  # pylint: disable=broad-except
+            self.proc.kill()
+
+
+class _DecodePool:
+    """`num_prepro_workers` decode processes, started once per (preprocess, tokenizer, flags) and reused by every reader of
+    this process (Runner builds a new reader per partition, runner.py:30).  A thread per worker moves the chunks through the
+    pipes (pipe reads and writes release the GIL)."""
+
+    _pools = {}
+
+    def __init__(self, workers, blob):
+        import queue  # pylint: disable=import-outside-toplevel
+
+        self.workers = [_DecodeWorker(blob) for _ in range(workers)]
+        for w in self.workers:
+            w.recv()  # the worker unpickled the transform and the tokenizer
+        self.idle = queue.Queue()
+        for w in self.workers:
+            self.idle.put(w)
+        self.threads = ThreadPoolExecutor(workers)
+
+    def _run(self, raws):
+        w = self.idle.get()
+        try:
+            return w.roundtrip(raws)
+        finally:
+            self.idle.put(w)
+
+    def submit(self, raws):
+        return self.threads.submit(self._run, raws)
+
+    def close(self):
+        self.threads.shutdown(wait=False)
+        for w in self.workers:
+            w.close()
+
+    @classmethod
+    def get(cls, workers, args):
+        """The pool for these decode arguments, or None when they cannot travel to another process (a lambda, a transform
+        defined in the main script): the caller then decodes on threads."""
+        import atexit  # pylint: disable=import-outside-toplevel
+        import pickle  # pylint: disable=import-outside-toplevel
+
+        try:
+            blob = pickle.dumps(args, protocol=pickle.HIGHEST_PROTOCOL)
+        except Exception:  # pylint: disable=broad-except
+            return None
+        key = (workers, blob)
+        if key not in cls._pools:
+            if not cls._pools:
+                atexit.register(cls.shutdown)
+            try:
+                cls._pools[key] = cls(workers, blob)
+            except (RuntimeError, OSError) as e:
+                print(f"reader: decode processes unavailable ({e}); decoding on threads")
+                cls._pools[key] = None
+        return cls._pools[key]
+
+    @classmethod
+    def shutdown(cls):
+        for pool in cls._pools.values():
+            if pool is not None:
+                pool.close()
+        cls._pools.clear()
 
 
 class _BatchingReader:
@@ -151,6 +296,7 @@ class _BatchingReader:
         self.batch_size = batch_size
         self.workers = max(1, num_prepro_workers)
         self.enable_text, self.enable_image, self.enable_metadata = enable_text, enable_image, enable_metadata
+        self.use_processes = True  # False: decode on a thread pool inside this process
         if enable_text and tokenizer is None:
             raise ValueError("enable_text needs a tokenizer (pass the model package's, or HashTokenizer for synthetic data)")
         try:
@@ -160,26 +306,15 @@ class _BatchingReader:
         except ImportError:
             self.pin = False
 
-    def _decode(self, raw):
-        """raw: {"key", "image": bytes|None, "text": str|None, "metadata": str|None} -> sample dict or None"""
-        from PIL import Image, UnidentifiedImageError  # pylint: disable=import-outside-toplevel
+    # samples per task sent to a decode process: amortises the per-task pickling / wake-up cost (a task per sample caps the
+    # parent at a few thousand samples/s)
+    chunk = 16
 
-        out = {}
-        if self.enable_image:
-            try:
-                img = self.preprocess(Image.open(io.BytesIO(raw["image"])))
-            except (UnidentifiedImageError, OSError, ValueError) as e:
-                print(f"Failed to load image {raw['key']}. Error: {e}. Skipping.")
-                return None
-            img = img.numpy() if hasattr(img, "numpy") else np.asarray(img)
-            out["image_tensor"] = img if img.dtype == np.uint8 else img.astype(np.float32, copy=False)  # uint8 HWC: normalised on the GPU
-            out["image_filename"] = raw["key"]
-        if self.enable_text:
-            out["text"] = raw["text"]
-            out["text_tokens"] = self.tokenizer([raw["text"]])[0]
-        if self.enable_metadata:
-            out["metadata"] = raw["metadata"]
-        return out
+    def _decode_args(self):
+        return (self.preprocess, self.tokenizer, self.enable_image, self.enable_text, self.enable_metadata)
+
+    def _decode(self, raw):
+        return _decode_sample(raw, *self._decode_args())
 
     def _raw_samples(self):
         raise NotImplementedError
@@ -196,6 +331,24 @@ class _BatchingReader:
         never resident at once (`Executor.map` would submit -- i.e. read and decode -- the whole partition up front)."""
         from collections import deque  # pylint: disable=import-outside-toplevel
 
+        procs = _DecodePool.get(self.workers, self._decode_args()) if self.use_processes and self.workers > 1 else None
+        if procs is not None:
+            limit = 2 * self.workers + max(1, self.batch_size // self.chunk)  # chunks in flight
+            inflight, raws, done = deque(), iter(self._raw_samples()), False
+            while True:
+                while not done and len(inflight) < limit:
+                    part = []
+                    for raw in raws:
+                        part.append(raw)
+                        if len(part) == self.chunk:
+                            break
+                    if len(part) < self.chunk:
+                        done = True
+                    if part:
+                        inflight.append(procs.submit(part))
+                if not inflight:
+                    return
+                yield from inflight.popleft().result()
         limit = max(2 * self.workers, 2) + self.batch_size
         with ThreadPoolExecutor(self.workers) as pool:
             inflight = deque()

@@ -453,3 +453,37 @@ def test_u8_preprocess_is_the_float_transform_before_normalisation(image_folder)
     r = FilesReader(Sampler(0, 1), clip_preprocess_u8, None, str(image_folder), 4, 2, enable_text=False)
     b = next(iter(r))
     assert b["image_tensor"].dtype.__str__() == "torch.uint8" and tuple(b["image_tensor"].shape) == (4, 224, 224, 3)
+
+
+def test_decode_processes_equal_the_thread_pool(tmp_path, tar_shards):
+    """num_prepro_workers > 1 decodes in worker PROCESSES (the reference's DataLoader workers, reader.py:184-205): same
+    batches, bit for bit and in the same order, as decoding inside this process; a corrupt member is skipped the same way;
+    a transform that cannot be pickled falls back to threads."""
+    import torch
+
+    from clip_retrieval_amd.reader import HashTokenizer, WebdatasetReader, _DecodePool, clip_preprocess, clip_preprocess_u8
+    from clip_retrieval_amd.runner import Sampler
+
+    bad = tmp_path / "bad.tar"
+    with tarfile.open(bad, "w") as tf:
+        for name, data in (("x0.jpg", b"not a jpeg"), ("x0.txt", b"broken"), ("x1.jpg", _jpeg(120, 90, 5)), ("x1.txt", b"fine")):
+            ti = tarfile.TarInfo(name)
+            ti.size = len(data)
+            tf.addfile(ti, io.BytesIO(data))
+    shards = tar_shards + [str(bad)]
+    for prep in (clip_preprocess, clip_preprocess_u8):
+        out = {}
+        for procs in (False, True):
+            r = WebdatasetReader(Sampler(0, 1), prep, HashTokenizer(), shards, 5, 3)
+            r.use_processes, r.chunk = procs, 2
+            out[procs] = list(r)
+        assert [b["image_tensor"].shape[0] for b in out[True]] == [5, 5, 2]
+        for a, b in zip(out[False], out[True]):
+            assert torch.equal(a["image_tensor"], b["image_tensor"]) and a["image_tensor"].dtype == b["image_tensor"].dtype
+            assert torch.equal(a["text_tokens"], b["text_tokens"]) and a["text"] == b["text"]
+            assert a["image_filename"] == b["image_filename"]
+    assert any(p is not None for p in _DecodePool._pools.values()), "the process path did not start any worker"
+    n_pools = len(_DecodePool._pools)
+    r = WebdatasetReader(Sampler(0, 1), lambda im: clip_preprocess(im), HashTokenizer(), tar_shards, 4, 3)  # noqa: E731
+    assert sum(b["image_tensor"].shape[0] for b in r) == 11 and len(_DecodePool._pools) == n_pools
+    _DecodePool.shutdown()

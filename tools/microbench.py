@@ -135,6 +135,10 @@ if "ivf" in what:
 
     rows, d = int(os.environ.get("MB_IVF_ROWS", "2000000")), int(os.environ.get("MB_IVF_D", "768"))
     nlist = int(os.environ.get("MB_IVF_NLIST", "1024"))
+    avail = int(next(l.split()[1] for l in open("/proc/meminfo") if l.startswith("MemAvailable"))) * 1024
+    if rows * d * 2 * 1.4 > avail:  # the corpus is held in host memory like a folder of .npy files would be; never drive the box out of memory
+        rows = int(avail / (d * 2 * 1.4)) // (1 << 20) * (1 << 20)
+        print(f"ivf: host memory allows {rows} rows", flush=True)
     g = torch.Generator(device="cuda").manual_seed(0)
     centers = torch.randn(nlist, d, device="cuda", generator=g)
     x = np.empty((rows, d), dtype=np.float16)
@@ -253,10 +257,18 @@ if "reader" in what:
                 ti = tarfile.TarInfo(f"{i:06d}.{ext}")
                 ti.size = len(data)
                 tf.addfile(ti, io.BytesIO(data))
+    print(f"host cores: {os.cpu_count()}", flush=True)
     for prep in (clip_preprocess, clip_preprocess_u8):
-        for workers in (8, 32):
-            r = WebdatasetReader(Sampler(0, 1), prep, HashTokenizer(), [path], 256, workers)
-            t0 = time.perf_counter()
-            got = sum(b["image_tensor"].shape[0] for b in r)
-            dt = time.perf_counter() - t0
-            print(f"WebdatasetReader {got} JPEG 256x256 + captions, {prep.__name__}, {workers} decode threads: {got / dt:.0f} samples/s", flush=True)
+        for procs in (False, True):
+            for workers in (8, 32):
+                for rep in range(2):  # the second pass reuses the started worker processes (as consecutive partitions do)
+                    r = WebdatasetReader(Sampler(0, 1), prep, HashTokenizer(), [path], 256, workers)
+                    r.use_processes = procs
+                    t0 = time.perf_counter()
+                    got = sum(b["image_tensor"].shape[0] for b in r)
+                    dt = time.perf_counter() - t0
+                print(f"WebdatasetReader {got} JPEG 256x256 + captions, {prep.__name__}, {workers} decode "
+                      f"{'processes' if procs else 'threads'}: {got / dt:.0f} samples/s", flush=True)
+    t0 = time.perf_counter()
+    k = sum(1 for _ in WebdatasetReader(Sampler(0, 1), clip_preprocess_u8, HashTokenizer(), [path], 256, 8)._raw_samples())
+    print(f"tar iteration alone (parent process): {k / (time.perf_counter() - t0):.0f} samples/s", flush=True)
