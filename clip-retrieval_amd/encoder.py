@@ -439,7 +439,7 @@ def load_clip(clip_model="ViT-B/32", use_jit=True, warmup_batch_size=1, clip_cac
                 checkpoint).  When the file is absent the returned tokenizer raises that FileNotFoundError on its first
                 call, so image-only pipelines still run and text pipelines fail loudly where the tokens are needed.
     """
-    from .reader import clip_preprocess  # pylint: disable=import-outside-toplevel
+    from .reader import ClipTransform  # pylint: disable=import-outside-toplevel
     from .tokenizer import MissingTokenizer, SimpleTokenizer  # pylint: disable=import-outside-toplevel
 
     dev = 0
@@ -456,10 +456,7 @@ def load_clip(clip_model="ViT-B/32", use_jit=True, warmup_batch_size=1, clip_cac
         enc.encode_text(ids)
     size = enc.arch.image_size
 
-    def preprocess(image):
-        import torch  # pylint: disable=import-outside-toplevel
-
-        return torch.from_numpy(clip_preprocess(image, size))
+    preprocess = ClipTransform(size)  # a picklable callable (the readers send it to their decode processes)
 
     try:
         tokenizer = SimpleTokenizer(bpe_path=bpe_path, clip_cache_path=clip_cache_path, context_length=enc.arch.ctx_len)

@@ -60,6 +60,19 @@ def clip_preprocess_u8(image, size=224):
     return np.asarray(image.crop((left, top, left + size, top + size)).convert("RGB"), dtype=np.uint8)
 
 
+class ClipTransform:
+    """`preprocess` as `load_clip` returns it (all_clip's second result; the reference uses it at reader.py:83,144 and
+    clip_back.py:241): PIL image -> torch f32 [3, size, size].  A class, not a closure, so that it can be pickled."""
+
+    def __init__(self, size=224):
+        self.size = size
+
+    def __call__(self, image):
+        import torch  # pylint: disable=import-outside-toplevel
+
+        return torch.from_numpy(clip_preprocess(image, self.size))
+
+
 class HashTokenizer:
     """Deterministic stand-in for CLIP's BPE tokenizer, FOR SYNTHETIC DATA ONLY (the BPE merges file ships
     inside the `clip` wheel, which is not available offline): words -> ids by FNV hash, SOT ... EOT, zero pad."""

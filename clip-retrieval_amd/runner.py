@@ -117,6 +117,7 @@ class Runner:
         batches = iter(source if source is not None else reader)
         pending = None  # (handle, batch sample count, wall0, read_duration, submit_duration)
         exhausted = False
+        last_end = None
         try:
             while True:
                 wall0 = time.time()
@@ -145,9 +146,13 @@ class Runner:
                     writer(embeddings)
                     t5 = time.perf_counter()
                     wall1 = time.time()
-                    logger({"start_time": w0, "end_time": wall1, "read_duration": read_d,
+                    # batches overlap in the pipelined loop: a batch is charged the wall time since the previous batch
+                    # finished, so that the summed total_duration is the partition's wall time like in the serial loop
+                    start = w0 if last_end is None else max(w0, last_end)
+                    last_end = wall1
+                    logger({"start_time": start, "end_time": wall1, "read_duration": read_d,
                             "inference_duration": sub_d + (t4 - t3), "write_duration": t5 - t4,
-                            "total_duration": wall1 - w0, "sample_count": count})
+                            "total_duration": wall1 - start, "sample_count": count})
                 else:
                     if batch is None:
                         break

@@ -11,6 +11,7 @@ collective anywhere on this path and no rank ever waits for another.
         --input_dataset '/data/{000..999}.tar' --input_format webdataset --output_folder /out --output_partition_count 1000
 """
 
+import functools
 import json
 import os
 import re
@@ -76,7 +77,7 @@ def worker(
                                                  clip_cache_path=clip_cache_path, device=device)
         if gpu_normalise:
             size = model._enc.arch.image_size  # pylint: disable=protected-access
-            preprocess = lambda im: clip_preprocess_u8(im, size)  # noqa: E731
+            preprocess = functools.partial(clip_preprocess_u8, size=size)  # picklable: travels to the decode processes
         if input_format == "files":
             return FilesReader(sampler, preprocess, tokenizer, input_dataset, batch_size, num_prepro_workers,
                                enable_text=enable_text, enable_image=enable_image, enable_metadata=enable_metadata)

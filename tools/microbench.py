@@ -13,7 +13,7 @@ import clip_retrieval_amd  # noqa: E402
 from clip_retrieval_amd._lib import check  # noqa: E402
 
 lib = clip_retrieval_amd.load_library()
-what = set(sys.argv[1:]) or {"gemm", "attn", "knn", "ln"}  # extra targets: ivf, b1
+what = set(sys.argv[1:]) or {"gemm", "attn", "knn", "ln"}  # extra targets: ivf, b1, e2e, reader, pipeline
 REPS = int(os.environ.get("MB_REPS", "5"))
 P = lambda t: C.c_void_p(t.data_ptr())
 
@@ -272,3 +272,55 @@ if "reader" in what:
     t0 = time.perf_counter()
     k = sum(1 for _ in WebdatasetReader(Sampler(0, 1), clip_preprocess_u8, HashTokenizer(), [path], 256, 8)._raw_samples())
     print(f"tar iteration alone (parent process): {k / (time.perf_counter() - t0):.0f} samples/s", flush=True)
+
+if "pipeline" in what:
+    # The whole drop-in (BASELINE config 4 on one GPU): worker() = tar shards -> WebdatasetReader (decode processes, uint8
+    # pixels) -> pipelined Runner -> ClipMapper (async tickets) -> NumpyWriter, ViT-L/14 image + text, random weights.
+    import glob
+    import gzip
+    import io
+    import tarfile
+    import tempfile
+
+    import numpy as np
+    from PIL import Image
+
+    from clip_retrieval_amd.worker import worker
+
+    shards_n, per = int(os.environ.get("MB_PIPE_SHARDS", "8")), int(os.environ.get("MB_PIPE_PER_SHARD", "2048"))
+    tmp = tempfile.mkdtemp()
+    rng = np.random.default_rng(0)
+    jpegs = []
+    for i in range(64):
+        buf = io.BytesIO()
+        Image.fromarray(rng.integers(0, 255, (256, 256, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=90)
+        jpegs.append(buf.getvalue())
+    shards = []
+    for sh in range(shards_n):
+        path = os.path.join(tmp, f"{sh:03d}.tar")
+        with tarfile.open(path, "w") as tf:
+            for i in range(per):
+                for ext, data in (("jpg", jpegs[(sh * per + i) % 64]), ("txt", f"a photo number {sh * per + i} of something".encode())):
+                    ti = tarfile.TarInfo(f"{sh:03d}{i:06d}.{ext}")
+                    ti.size = len(data)
+                    tf.addfile(ti, io.BytesIO(data))
+        shards.append(path)
+    bpe = os.path.join(tmp, "bpe_simple_vocab_16e6.txt.gz")  # a stand-in merges file (the real one is not available offline)
+    with gzip.open(bpe, "wt", encoding="utf-8") as f:
+        f.write("#version: 0.2\nt h\nth e</w>\no f</w>\np h\n")
+    os.environ["CLIP_BPE_PATH"] = bpe
+    for workers in (8, 32):
+        out = os.path.join(tmp, f"out{workers}")
+        args = dict(input_dataset=shards, output_folder=out, output_partition_count=2, input_format="webdataset", batch_size=256,
+                    num_prepro_workers=workers, enable_text=True, enable_image=True, clip_model="random:ViT-L/14")
+        t0 = time.perf_counter()
+        worker([0], **args)  # first partition: model build, worker start-up, warm-up
+        t1 = time.perf_counter()
+        worker([1], **args)
+        t2 = time.perf_counter()
+        n = shards_n * per // 2
+        rows = sum(np.load(f, mmap_mode="r").shape[0] for f in glob.glob(out + "/img_emb/*.npy"))
+        print(f"pipeline worker() ViT-L/14 image+text, {workers} decode processes: first partition {n / (t1 - t0):.0f} samples/s "
+              f"(with start-up), second partition {n / (t2 - t1):.0f} samples/s; {rows} embeddings written", flush=True)
+        for f in sorted(glob.glob(out + "/stats/*.json"))[-1:]:
+            print("    stats of the last partition:", open(f).read()[:400], flush=True)
