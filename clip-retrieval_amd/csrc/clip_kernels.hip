@@ -358,7 +358,12 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (bulk > 0 && (int64_t)bulk * (g.N / 256) >= cu / 2) {
       GemmArgs b = g;
       b.M = bulk * 256;
+#ifdef CLIPX_ABLATE
+      // variant 5 (tools build only): the two-workgroups-per-CU experiment of gemm2wg.hip (bitwise equal, 25-35 % slower)
+      hipError_t e = g.variant == 5 ? launch_gemm2wg(b, g.n_cu, st) : launch_gemm256sp(b, g.n_cu, st);
+#else
       hipError_t e = launch_gemm256sp(b, g.n_cu, st);
+#endif
       if (e != hipSuccess) return e;
       if (b.M == g.M) return hipSuccess;
       GemmArgs r = g;  // remaining rows [bulk*256, M)

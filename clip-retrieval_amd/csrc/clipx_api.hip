@@ -286,7 +286,7 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   if (hc && atoi(hc) > 0) h->host_chunk = atoi(hc);
   h->host_chunk = std::min(h->host_chunk, h->max_batch);
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
-  if (gv) h->gemm_variant = std::min(3, std::max(0, atoi(gv)));
+  if (gv) h->gemm_variant = std::min(5, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r = create_impl(h, blob, blob_floats);
   if (r) {
@@ -642,7 +642,7 @@ static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const f
     g.rowscale = ones[device];
   }
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
-  g.variant = gv ? std::min(3, std::max(0, atoi(gv))) : 3;
+  g.variant = gv ? std::min(5, std::max(0, atoi(gv))) : 3;
   int ncu = 0;
   HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
   g.n_cu = ncu;

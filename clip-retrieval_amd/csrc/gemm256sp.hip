@@ -459,15 +459,21 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) b4[nt] = *reinterpret_cast<const float4*>(scr + (nt * 32 + rch * 4) * 4);
         S_FENCE();  // hipcc waits vmcnt(0) for the bias DMA before these LDS reads: keep the x loads behind that wait
-        u32x4 ext[2][4];
+        // x rows are requested RESID_LA passes ahead of their use (the fragment registers are dead here: room for it)
+#ifndef CLIPX_RESID_LA
+#define CLIPX_RESID_LA 1
+#endif
+        constexpr int LA = (DBG >= 41 && DBG <= 43) ? DBG - 40 : CLIPX_RESID_LA;  // DBG 41..43: A/B of the lookahead
+        u32x4 ext[LA + 1][4];
 #define S_LD_EXT(set, p)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
     ext[set][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, (((p) >> 1) * 4 + i) * rstep + ((p) & 1) * 128, 0);
-        S_LD_EXT(0, 0)
+#pragma unroll
+        for (int p = 0; p < LA; ++p) { S_LD_EXT(p, p) }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           const int mt = p >> 1, nt = p & 1;
-          if (p < 7) { S_LD_EXT((p + 1) & 1, p + 1) }
+          if (p + LA < 8) { S_LD_EXT((p + LA) % (LA + 1), p + LA) }
           S_FENCE();
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float4 bq = b4[nt];
-            const u32x4 e = ext[p & 1][i];
+            const u32x4 e = ext[p % (LA + 1)][i];
             // same association as the 128x128 kernel, x + (acc + bias), so a row's result does not depend on
             // which kernel (i.e. which batch chunking) produced it
             float4 o = q[i];
@@ -626,6 +632,9 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     const char* dbg = getenv("CLIPX_GEMM_DBG");
     const int d = dbg ? atoi(dbg) : 0;
     if (d == 16) return launch_sp_epi<EPI_BIAS_RESID_F32, 16>(g, grid, st);  // phase timer
+    if (d == 41) return launch_sp_epi<EPI_BIAS_RESID_F32, 41>(g, grid, st);  // x-load lookahead 1 / 2 / 3 passes
+    if (d == 42) return launch_sp_epi<EPI_BIAS_RESID_F32, 42>(g, grid, st);
+    if (d == 43) return launch_sp_epi<EPI_BIAS_RESID_F32, 43>(g, grid, st);
   }
 #endif
   switch (g.epi) {
