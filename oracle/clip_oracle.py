@@ -114,6 +114,30 @@ class HFClipOracle:
                     p.add_(torch.randn(p.shape, generator=g) * 0.05)
 
     @torch.no_grad()
+    def make_trained_like(self, seed: int = 0) -> None:
+        """Push the seeded random weights towards the statistics of TRAINED CLIP towers, which random init does not have and
+        which stress a bf16 operand path (missing #3): LayerNorm gains spread over two orders of magnitude with a
+        few large ones, LayerNorm biases of order 1, two 'massive activation' channels per tower (a constant of +-30..40 in the
+        residual stream from the first block on: 50-100 x the other channels), sharper attention (q, k scaled up) and a
+        negative fc1 bias.  No real checkpoint is available offline; this is the closest stand-in.  Call before export_blob()."""
+        g = torch.Generator().manual_seed(1000 + seed)
+        for name, p in self.model.named_parameters():
+            if ("layer_norm" in name or "layernorm" in name or "layrnorm" in name) and name.endswith("weight"):
+                p.mul_(torch.exp(torch.randn(p.shape, generator=g) * 0.5))
+                idx = torch.randperm(p.numel(), generator=g)[: max(1, p.numel() // 100)]
+                p.view(-1)[idx] *= 8.0
+            elif ("layer_norm" in name or "layernorm" in name or "layrnorm" in name) and name.endswith("bias"):
+                p.add_(torch.randn(p.shape, generator=g) * 0.5)
+            elif name.endswith("q_proj.weight") or name.endswith("k_proj.weight"):
+                p.mul_(2.5)
+            elif name.endswith("mlp.fc1.bias"):
+                p.sub_(0.5)
+            elif name.endswith("encoder.layers.0.mlp.fc2.bias"):
+                c = torch.randperm(p.numel(), generator=g)[:2]
+                p[c[0]] += 40.0
+                p[c[1]] -= 30.0
+
+    @torch.no_grad()
     def encode_image(self, pixel_values: torch.Tensor) -> torch.Tensor:
         out = self.model.get_image_features(pixel_values=pixel_values.float())
         return out if isinstance(out, torch.Tensor) else out.pooler_output

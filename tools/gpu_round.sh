@@ -16,7 +16,7 @@ if [ "${2:-}" = "lite" ]; then
   ( time timeout 900 python bench.py ) > $OUT/bench_$TAG.log 2>&1; tail -5 $OUT/bench_$TAG.log
   exit 0
 fi
-MB_VARIANTS=1,3 MB_KNN_ROWS=100000000 timeout 900 python tools/microbench.py gemm attn ln knn b1 ivf e2e reader > $OUT/microbench_$TAG.log 2>&1; cat $OUT/microbench_$TAG.log
+MB_VARIANTS=1,3 MB_KNN_ROWS=100000000 timeout 900 python tools/microbench.py gemm attn ln knn b1 ivf e2e reader pipeline > $OUT/microbench_$TAG.log 2>&1; cat $OUT/microbench_$TAG.log
 if [ "${2:-}" != "quick" ]; then
   ( time timeout 900 python bench.py ) > $OUT/bench_$TAG.log 2>&1; tail -5 $OUT/bench_$TAG.log
   cd /tmp
