@@ -97,6 +97,7 @@ SIGNATURES = {
     "clipx_encode_image_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "clipx_encode_text_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "clipx_max_batch": (C.c_int, [_P]),
+    "clipx_graphs_cached": (C.c_int, [_P]),
     "clipx_embed_dim": (C.c_int, [_P]),
     "clipx_gemm_bf16_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_gemm_bf16_ex_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),

@@ -12,7 +12,8 @@ enum GemmEpilogue {
   EPI_BIAS_QGELU_BF16 = 1,  // out bf16 = quick_gelu(acc + bias)                 (fc1, OpenAI CLIP)
   EPI_BIAS_GELU_BF16 = 2,   // out bf16 = gelu_erf(acc + bias)                   (fc1, open_clip LAION)
   EPI_BIAS_RESID_F32 = 3,   // out f32 [M,N] += acc + bias   (in place residual) (out_proj, fc2)
-  EPI_TABLE_F32 = 4         // out f32 = acc + table[m % T][n]                   (patch embed + cls/pos)
+  EPI_TABLE_F32 = 4,        // out f32 = acc + table[m % T][n]                   (patch embed + cls/pos)
+  EPI_RAW_F32 = 5           // internal (split-K): out f32 [M,N] = acc, no bias; the reduction kernel applies the epilogue
 };
 
 struct GemmArgs {
@@ -32,6 +33,8 @@ struct GemmArgs {
   const float* rowscale;  // bf16-output epilogues: out = act(acc * rowscale[m] + bias[n]); [M] f32, never null (the LayerNorm
                           // 1/std of the row when the LayerNorm is folded into W, launch_rowstats; ones otherwise)
   bf16* out16;            // EPI_BIAS_RESID_F32: also store the new x row as bf16 here (null: do not)
+  float* splitk_ws;       // device scratch for split-K partial products (null: never split), splitk_ws_bytes of it
+  size_t splitk_ws_bytes;
 };
 
 // number of 256-row m-tiles variant 3 hands to the 256x256 kernel for an [M, N] output
@@ -67,9 +70,10 @@ hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const flo
                              int d, int vocab, hipStream_t st, bf16* x16 = nullptr);
 
 // pooled row (CLS, or argmax(ids) for text) -> LayerNorm -> @ proj^T [E, d] -> / L2 norm -> fp16 [B, E]
+// scratch: B * E floats of device memory (the un-normalised projection between the two kernels)
 hipError_t launch_tail(const float* x, const int32_t* ids_or_null, const float* gamma, const float* beta,
-                       const bf16* proj, uint16_t* out_f16, float* out_f32_or_null, int B, int T, int d, int E,
-                       float eps, hipStream_t st);
+                       const bf16* proj, uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d,
+                       int E, float eps, hipStream_t st);
 
 hipError_t launch_f32_to_bf16(const float* in, bf16* out, int64_t n, hipStream_t st);
 // conv weight [width, 3*P*P] f32 -> bf16 [width, Kp] zero padded

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int M, int N,
                                                           int K, int row0, const float* __restrict__ rowscale,
-                                                          bf16* __restrict__ out16) {
+                                                          bf16* __restrict__ out16, int kz) {
+  // kz > 0 (EPI_RAW_F32, DEEP only): split-K -- workgroup column blockIdx.y multiplies K-tiles [y * kz, (y + 1) * kz) and
+  // writes its raw accumulators to outp + y * M * N
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = K / G_BK;
+  const int nk = kz > 0 ? kz : K / G_BK;
+  const int t0 = kz > 0 ? (int)blockIdx.y * kz : 0;  // first K-tile of this workgroup
+  if (EPI == EPI_RAW_F32) outp = reinterpret_cast<float*>(outp) + (size_t)blockIdx.y * M * N;
 
   auto compute = [&](int buf) {
     const unsigned char* sW = smem + buf * G_STAGE_BYTES + (wn * 64) * 128;
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
 #define D_DMA(off, base, dst)                                                                                         \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory")
       auto stage = [&](int t, int slot) {
-        const char* bw = reinterpret_cast<const char*>(W) + (size_t)t * (G_BK * 2);
-        const char* ba = reinterpret_cast<const char*>(A) + (size_t)t * (G_BK * 2);
+        const char* bw = reinterpret_cast<const char*>(W) + (size_t)(t0 + t) * (G_BK * 2);
+        const char* ba = reinterpret_cast<const char*>(A) + (size_t)(t0 + t) * (G_BK * 2);
         const unsigned d = lds_base + slot * G_STAGE_BYTES + wu * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -300,22 +304,93 @@ static hipError_t launch_gemm_epi(const GemmArgs& g, hipStream_t st) {
     const size_t smem4 = 4 * G_STAGE_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem4, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16);
+    hipLaunchKernelGGL(kern, grid, block, smem4, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
   } else if (g.variant == 1) {
     auto kern = gemm_bf16_kernel<EPI, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
   } else {
     auto kern = gemm_bf16_kernel<EPI, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
   }
   return hipGetLastError();
 }
 
+// ---- split-K for small M (the B = 1 .. 2 query encodes of KnnService.compute_query, clip_back.py:207-255).  M = 257 rows
+// give the 128x128 kernel 24 (N = 1024) .. 96 workgroups, each walking its whole K loop at ~0.5 us per K-tile with nothing
+// else on the CU: fc2 (K = 4096) 36 us, out-proj 13 us.  Splitting K over S workgroup columns fills the chip; the S partial
+// products (raw f32 accumulators) are summed in FIXED order 0 .. S-1 by a second kernel that applies the very epilogue code of
+// the unsplit kernels (gemm_store_quad).  The result is deterministic but not bitwise equal to
+// the unsplit sum, so the caller (clipx_api.hip) hands a scratch buffer only to the GEMMs of a single-sample API call: every
+// call with >= 2 samples keeps the invariant "a row does not depend on the batch (or chunk) it travels in".
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N,
+                                                           const float* __restrict__ bias, void* __restrict__ outp,
+                                                           const float* __restrict__ rowscale, bf16* __restrict__ out16) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // quad index
+  const int nq4 = N >> 2;
+  if (q >= (int64_t)M * nq4) return;
+  const int m = (int)(q / nq4), n = (int)(q - (int64_t)m * nq4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(part + (size_t)m * N + n);
+  for (int z = 1; z < S; ++z) {
+    const float4 p = *reinterpret_cast<const float4*>(part + ((size_t)z * M + m) * N + n);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  }
+  gemm_store_quad<EPI>(v, m, n, N, bias, outp, nullptr, 1, 0, rowscale, out16);
+}
+
+// number of K splits for an [M, N, K] problem on n_cu compute units (1 = do not split)
+static int splitk_factor(const GemmArgs& g) {
+  if (!g.splitk_ws || g.M > 1024 || g.epi == EPI_TABLE_F32 || g.epi == EPI_RAW_F32) return 1;
+  const int nk = g.K / G_BK;
+  // Measured at M = 257 (profiles/r02j_b1_kernels.txt): every launch has a floor of ~4.5 us, a split GEMM + its reduction
+  // cost 9.9 + 5.0 us whatever K is, the unsplit kernel 12 us at K = 1024 and 36 us at K = 4096: only long K loops pay.
+  // A single m-tile (the text query, M = 77: 6 .. 24 workgroups) gains from splitting shorter loops too (0.69 -> 0.62 ms).
+  if (nk < 8 || (nk < 32 && g.M > G_TM)) return 1;
+  const int cu = g.n_cu > 0 ? g.n_cu : 256;
+  const int tiles = ((g.M + G_TM - 1) / G_TM) * (g.N / G_TN);
+  int S = 1;
+  // the largest S <= 16 that divides the K loop, leaves each workgroup >= 4 K-tiles, does not go past one workgroup per CU
+  // more than needed and fits the scratch
+  for (int c = 2; c <= 16; ++c) {
+    if (nk % c != 0 || nk / c < 4) continue;
+    if ((size_t)c * g.M * g.N * sizeof(float) > g.splitk_ws_bytes) break;
+    if (tiles * (c - 1) >= cu) break;  // the previous split already filled the chip
+    S = c;
+  }
+  return S;
+}
+
+template <int EPI>
+static hipError_t launch_splitk_epi(const GemmArgs& g, int S, hipStream_t st) {
+  const int ntm = (g.M + G_TM - 1) / G_TM, ntn = g.N / G_TN;
+  auto kern = gemm_bf16_kernel<EPI_RAW_F32, true, true>;
+  const size_t smem4 = 4 * G_STAGE_BYTES;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(ntm * ntn, S), dim3(256), smem4, st, g.A, g.W, nullptr, g.splitk_ws, nullptr, 1, g.M, g.N, g.K, 0,
+                     nullptr, nullptr, (g.K / G_BK) / S);
+  const int64_t quads = (int64_t)g.M * (g.N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, g.splitk_ws, S, g.M, g.N,
+                     g.bias, g.out, g.rowscale, g.out16);
+  return hipGetLastError();
+}
+
 static hipError_t launch_gemm128(const GemmArgs& g, hipStream_t st) {
+  const bool small_off = (size_t)g.M * g.K * 2 < ((size_t)1 << 32) && (size_t)g.N * g.K * 2 < ((size_t)1 << 32);
+  const int S = (g.variant == 1 && small_off) ? splitk_factor(g) : 1;
+  if (S > 1) {
+    switch (g.epi) {
+      case EPI_BIAS_BF16: return launch_splitk_epi<EPI_BIAS_BF16>(g, S, st);
+      case EPI_BIAS_QGELU_BF16: return launch_splitk_epi<EPI_BIAS_QGELU_BF16>(g, S, st);
+      case EPI_BIAS_GELU_BF16: return launch_splitk_epi<EPI_BIAS_GELU_BF16>(g, S, st);
+      case EPI_BIAS_RESID_F32: return launch_splitk_epi<EPI_BIAS_RESID_F32>(g, S, st);
+      default: break;
+    }
+  }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_gemm_epi<EPI_BIAS_BF16>(g, st);
     case EPI_BIAS_QGELU_BF16: return launch_gemm_epi<EPI_BIAS_QGELU_BF16>(g, st);
@@ -368,6 +443,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       if (b.M == g.M) return hipSuccess;
       GemmArgs r = g;  // remaining rows [bulk*256, M)
       r.variant = 1;
+      r.splitk_ws = nullptr;  // rows of one large batch are computed the same way whichever kernel they land in
       r.A = g.A + (size_t)b.M * g.K;
       r.M = g.M - b.M;
       const size_t esz = (g.epi == EPI_BIAS_RESID_F32 || g.epi == EPI_TABLE_F32) ? 4 : 2;
@@ -947,16 +1023,18 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids,
-                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const bf16* __restrict__ proj, uint16_t* __restrict__ out_f16,
-                                                  float* __restrict__ out_f32, int T, int d, int E, float eps) {
+// Two launches: (E / 64, B) workgroups each LayerNorm the sample's pooled row (recomputed per workgroup: d floats) and
+// produce 64 projection outputs with 4 threads per output; a second kernel normalises.  (One workgroup per sample doing the
+// whole d x E projection took 79 us -- 3 % of a B = 1 image query, 8 % of a text query.)
+__global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const bf16* __restrict__ proj, float* __restrict__ o_raw, int T, int d,
+                                                       int E, float eps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* y = reinterpret_cast<float*>(smem);  // [d]
-  float* o = y + d;                           // [E]
-  float* red = o + E;                         // [4]   (all LDS in the one dynamic region: guide G17)
+  float* red = y + d;                         // [4]   (all LDS in the one dynamic region: guide G17)
   int* s_posp = reinterpret_cast<int*>(red + 4);
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x;
   if (tid == 0) {
     int best = 0;
     if (ids) {  // EOT token = highest id; first occurrence (torch.argmax semantics of the reference model)
@@ -978,21 +1056,32 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
   const float rstd = 1.f / sqrtf(block_sum_256(q, red) / d + eps);
   for (int c = tid; c < d; c += 256) y[c] = (y[c] - mean) * rstd * gamma[c] + beta[c];
   __syncthreads();
-  float ss = 0.f;
-  for (int e = tid; e < E; e += 256) {
-    const bf16x8* pr = reinterpret_cast<const bf16x8*>(proj + (size_t)e * d);
-    float acc = 0.f;
-    for (int c8 = 0; c8 < d / 8; ++c8) {
+  const int e = blockIdx.x * 64 + (tid >> 2), part = tid & 3;
+  const int seg = d >> 2;  // d % 32 == 0
+  float acc = 0.f;
+  if (e < E) {
+    const bf16x8* pr = reinterpret_cast<const bf16x8*>(proj + (size_t)e * d + part * seg);
+    const float* yp = y + part * seg;
+    for (int c8 = 0; c8 < seg / 8; ++c8) {
       const bf16x8 pw = pr[c8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc += y[c8 * 8 + j] * (float)pw[j];
+      for (int j = 0; j < 8; ++j) acc += yp[c8 * 8 + j] * (float)pw[j];
     }
-    o[e] = acc;
-    ss += acc * acc;
   }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  if (part == 0 && e < E) o_raw[(size_t)b * E + e] = acc;
+}
+
+__global__ __launch_bounds__(256) void tail_norm_kernel(const float* __restrict__ o_raw, uint16_t* __restrict__ out_f16,
+                                                       float* __restrict__ out_f32, int E) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float ss = 0.f;
+  for (int e = tid; e < E; e += 256) { const float v = o_raw[(size_t)b * E + e]; ss += v * v; }
   const float nrm = sqrtf(block_sum_256(ss, red));
   for (int e = tid; e < E; e += 256) {
-    const float v = o[e] / nrm;  // no epsilon: mapper.py:58 divides by the raw norm
+    const float v = o_raw[(size_t)b * E + e] / nrm;  // no epsilon: mapper.py:58 divides by the raw norm
     const _Float16 hv = (_Float16)v;
     out_f16[(size_t)b * E + e] = *reinterpret_cast<const uint16_t*>(&hv);
     if (out_f32) out_f32[(size_t)b * E + e] = v;
@@ -1000,11 +1089,14 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ x, 
 }
 
 hipError_t launch_tail(const float* x, const int32_t* ids_or_null, const float* gamma, const float* beta, const bf16* proj,
-                       uint16_t* out_f16, float* out_f32_or_null, int B, int T, int d, int E, float eps, hipStream_t st) {
+                       uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d, int E, float eps,
+                       hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  const size_t smem = (size_t)(d + E + 8) * sizeof(float);
-  hipLaunchKernelGGL(tail_kernel, dim3(B), dim3(256), smem, st, x, ids_or_null, gamma, beta, proj, out_f16,
-                     out_f32_or_null, T, d, E, eps);
+  if (d % 32 != 0 || !scratch) return hipErrorInvalidValue;
+  const size_t smem = (size_t)(d + 8) * sizeof(float);
+  hipLaunchKernelGGL(tail_proj_kernel, dim3((E + 63) / 64, B), dim3(256), smem, st, x, ids_or_null, gamma, beta, proj, scratch,
+                     T, d, E, eps);
+  hipLaunchKernelGGL(tail_norm_kernel, dim3(B), dim3(256), 0, st, scratch, out_f16, out_f32_or_null, E);
   return hipGetLastError();
 }
 

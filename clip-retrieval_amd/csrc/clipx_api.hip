@@ -11,7 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -87,6 +89,10 @@ struct clipx_handle {
   float* x = nullptr;      // residual stream, f32 [rows, width]
   float* rstd = nullptr;   // [rows] LayerNorm 1/std of the current x16 rows
   bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;  // xn = bf16 shadow of x
+  bool single_query = false;   // the API call being served is ONE sample (set by the entry points, not per chunk: the last
+                               // chunk of a 7-sample call is one sample too, and must equal its row of an unchunked call)
+  float* splitk_ws = nullptr;  // partial products of the small-M split-K GEMMs (clip_kernels.hip)
+  size_t splitk_ws_bytes = 0;
 
   // host hand-over: CLIPX_SLOTS staging slots (pinned in/out + device in/out); a slot carries one chunk from its upload to
   // the moment its result has been copied to the caller (synchronous calls pipeline their chunks through them; every
@@ -106,6 +112,11 @@ struct clipx_handle {
   hipEvent_t ev_ws = nullptr;
   bool ev_ws_valid = false;
 
+  // Small batches (the B = 1 query encode of KnnService.compute_query, clip_back.py:207-255) are ~170 dependent launches of
+  // 5-15 us kernels: their launch sequence is captured once per (tower, B, buffers, stream) into a hipGraph and replayed.
+  typedef std::tuple<int, int, int, const void*, const void*, const void*, hipStream_t> GraphKey;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  bool graphs_on = true;
   int prof = 0;  // bit k set: launches of kind k (0 gemm, 1 attention, 2 layernorm, 3 other) are bracketed by hipEvents
   std::vector<ProfEvent> prof_events;
 };
@@ -244,6 +255,8 @@ static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
   if ((r = dev_alloc(h, (void**)&h->att, nx * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->hbuf, nh * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->patches, rowsV * h->Kp * sizeof(bf16)))) return r;
+  h->splitk_ws_bytes = (size_t)32 << 20;
+  if ((r = dev_alloc(h, (void**)&h->splitk_ws, h->splitk_ws_bytes))) return r;
 
   // ---- host hand-over slots
   h->in_slot_bytes = std::max((size_t)Bm * 3 * d.image_size * d.image_size * sizeof(float), (size_t)Bm * d.ctx_len * sizeof(int32_t));
@@ -308,6 +321,7 @@ extern "C" void clipx_destroy(clipx_handle* h) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.second);
   for (void* p : h->owned) (void)hipFree(p);
   if (h->blob_dev) (void)hipFree(h->blob_dev);
   for (int s = 0; s < clipx_handle::NSLOT; ++s) {
@@ -323,6 +337,7 @@ extern "C" void clipx_destroy(clipx_handle* h) {
 }
 
 extern "C" int clipx_max_batch(const clipx_handle* h) { return h ? h->max_batch : 0; }
+extern "C" int clipx_graphs_cached(const clipx_handle* h) { return h ? (int)h->graphs.size() : 0; }
 extern "C" int clipx_embed_dim(const clipx_handle* h) { return h ? h->desc.embed_dim : 0; }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,6 +370,10 @@ static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* 
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.table = table; g.T = T;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant; g.n_cu = h->n_cu; g.row0 = 0;
   g.rowscale = rowscale; g.out16 = out16;
+  // split-K only on the single-query path (B == 1, KnnService.compute_query): every batch of two or more samples is computed
+  // by the unsplit kernels, whose rows do not depend on the batch they travel in (bitwise); a B = 1 row differs from the same
+  // sample inside a batch by f32 summation order only
+  if (h->single_query) { g.splitk_ws = h->splitk_ws; g.splitk_ws_bytes = h->splitk_ws_bytes; }
   ProfScope ps(h, st, 0, 2.0 * M * (double)N * K);
   HIPCHK(launch_gemm(g, st));
   return 0;
@@ -383,9 +402,60 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   return 0;
 }
 
+constexpr int GRAPH_MAX_B = 8;      // batches up to this size are replayed from a captured graph
+constexpr size_t GRAPH_MAX = 64;    // graphs kept per handle (distinct buffer sets of callers that bring their own)
+
+// Runs `body` (which only launches kernels on `st`) directly, or -- small batch, profiling off -- through a hipGraph captured
+// from exactly that launch sequence the first time this (tower, B, buffers, stream) combination is seen.  Any capture /
+// instantiate failure switches graphs off for the handle and runs the plain launches: same kernels, same results.
+template <class F>
+static int run_graphed(clipx_handle* h, hipStream_t st, const clipx_handle::GraphKey& key, int B, F&& body) {
+  if (!h->graphs_on || h->prof || B > GRAPH_MAX_B) return body();
+  auto it = h->graphs.find(key);
+  if (it != h->graphs.end()) {
+    HIPCHK(hipGraphLaunch(it->second, st));
+    return 0;
+  }
+  if (h->graphs.size() >= GRAPH_MAX) return body();
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    (void)hipGetLastError();
+    h->graphs_on = false;
+    return body();
+  }
+  const int r = body();
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(st, &g);
+  hipGraphExec_t ex = nullptr;
+  if (r == 0 && e == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+    (void)hipGraphDestroy(g);
+    h->graphs[key] = ex;
+    HIPCHK(hipGraphLaunch(ex, st));
+    return 0;
+  }
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  h->graphs_on = false;
+  return body();  // nothing ran during the capture
+}
+
+static int vision_chunk_body(clipx_handle* h, hipStream_t st, const void* pix_dev, int B, int fmt, uint16_t* out_f16,
+                             float* out_f32);
+static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32);
+
 // one chunk (B <= max_batch), everything on the device, asynchronous on `st`
 static int vision_chunk(clipx_handle* h, hipStream_t st, const void* pix_dev, int B, int fmt, uint16_t* out_f16,
                         float* out_f32) {
+  return run_graphed(h, st, clipx_handle::GraphKey(h->single_query ? 16 : 0, B, fmt, pix_dev, out_f16, out_f32, st), B,
+                     [&]() { return vision_chunk_body(h, st, pix_dev, B, fmt, out_f16, out_f32); });
+}
+
+static int text_chunk(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32) {
+  return run_graphed(h, st, clipx_handle::GraphKey(h->single_query ? 17 : 1, B, 0, ids_dev, out_f16, out_f32, st), B,
+                     [&]() { return text_chunk_body(h, st, ids_dev, B, out_f16, out_f32); });
+}
+
+static int vision_chunk_body(clipx_handle* h, hipStream_t st, const void* pix_dev, int B, int fmt, uint16_t* out_f16,
+                             float* out_f32) {
   const clipx_model_desc& d = h->desc;
   const Tower& V = h->vis;
   const int M = B * V.T;
@@ -395,17 +465,17 @@ static int vision_chunk(clipx_handle* h, hipStream_t st, const void* pix_dev, in
   if (r) return r;
   { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, h->ln_pre_w, h->ln_pre_b, h->x, 0, M, V.width, d.ln_eps, st, h->xn)); }
   if ((r = run_layers(h, st, V, B, 0))) return r;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, B, V.T, V.width, d.embed_dim, d.ln_eps, st)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, V.T, V.width, d.embed_dim, d.ln_eps, st)); }
   return 0;
 }
 
-static int text_chunk(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32) {
+static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32) {
   const clipx_model_desc& d = h->desc;
   const Tower& X = h->txt;
   { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, h->x, B, X.T, X.width, d.vocab, st, h->xn)); }
   int r = run_layers(h, st, X, B, 1);
   if (r) return r;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, B, X.T, X.width, d.embed_dim, d.ln_eps, st)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, X.T, X.width, d.embed_dim, d.ln_eps, st)); }
   return 0;
 }
 
@@ -432,6 +502,7 @@ extern "C" int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   const size_t ib = pix_bytes_per_image(h->desc, pix_fmt), E = h->desc.embed_dim;
+  h->single_query = B == 1;
   if (ws_acquire(h, st)) return CLIPX_E_HIP;
   for (int o = 0; o < B; o += h->max_batch) {
     const int nb = std::min(h->max_batch, B - o);
@@ -450,6 +521,7 @@ extern "C" int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev,
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   const size_t E = h->desc.embed_dim;
+  h->single_query = B == 1;
   if (ws_acquire(h, st)) return CLIPX_E_HIP;
   for (int o = 0; o < B; o += h->max_batch) {
     const int nb = std::min(h->max_batch, B - o);
@@ -532,6 +604,7 @@ static int host_sync(clipx_handle* h, int kind, const char* in, size_t in_bytes_
   const size_t E = h->desc.embed_dim;
   const int CH = h->host_chunk;
   const int nchunk = (B + CH - 1) / CH;
+  h->single_query = B == 1;
   int prev_slot = -1, prev_o = 0, prev_nb = 0;
   for (int c = 0; c < nchunk; ++c) {
     const int o = c * CH, nb = std::min(CH, B - o);
@@ -584,6 +657,7 @@ static int encode_async(clipx_handle* h, int kind, const void* in, size_t in_byt
   if (B > h->max_batch) return fail(CLIPX_E_ARG, "an asynchronous call takes at most clipx_max_batch() samples");
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHK(hipSetDevice(h->device));
+  h->single_query = B == 1;
   const int s = slot_submit(h, kind, (const char*)in, in_bytes_per_item, B, pix_fmt, false);
   if (s < 0) return s;
   *ticket = new clipx_ticket{h, s, B, out_f16, nullptr};

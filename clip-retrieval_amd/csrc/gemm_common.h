@@ -43,6 +43,10 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
                                                 void* __restrict__ outp, const float* __restrict__ table, int T,
                                                 int row0, const float* __restrict__ rowscale, bf16* __restrict__ out16) {
   constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
+  if (EPI == EPI_RAW_F32) {  // a split-K partial product: the accumulators as they are
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n) = v;
+    return;
+  }
   if (EPI != EPI_TABLE_F32) {
     const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
     if (OUT_BF16) {

@@ -317,6 +317,10 @@ class ClipEncoder:
             self._h, C.c_void_p(int(ids_ptr)), int(B), C.c_void_p(int(out_f16_ptr)),
             C.c_void_p(int(out_f32_ptr)) if out_f32_ptr else None, C.c_void_p(int(stream)) if stream else None), "clipx")
 
+    def graphs_cached(self):
+        """Small-batch launch sequences captured as hipGraphs so far (include/clipx.h: clipx_graphs_cached)."""
+        return int(self._lib.clipx_graphs_cached(self._h))
+
     def profile(self, on):
         """on: False/0 off, True/1 every kind, or a mask with bit (kind + 1): 2 gemm, 4 attention, 8 layernorm, 16 other."""
         check(self._lib, self._lib.clipx_profile_enable(self._h, int(on)), "clipx")

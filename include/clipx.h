@@ -115,6 +115,10 @@ int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uin
 /* Largest batch one launch sequence handles (workspace is sized for it at create time;
  * CLIPX_MAX_BATCH env var, default 256).  Bigger B is processed in chunks of this size. */
 int clipx_max_batch(const clipx_handle* h);
+/* Number of small-batch launch sequences this handle has captured as hipGraphs so far (batches of <= 8 samples -- the B = 1
+ * query encode of KnnService.compute_query, clip_back.py:207-255 -- are replayed from a graph per (tower, B, buffers, stream));
+ * introspection for tests and service dashboards. */
+int clipx_graphs_cached(const clipx_handle* h);
 int clipx_embed_dim(const clipx_handle* h);
 
 /* Raw bf16 GEMM of this library (out[m,n] = sum_k A[m,k] W[n,k] + bias[n]), device pointers;

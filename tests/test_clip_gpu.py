@@ -196,6 +196,50 @@ def test_chunked_batches_equal_unchunked(tiny):
     small.close()
 
 
+def test_small_batches_replayed_from_graphs_equal_the_plain_launches(tiny):
+    """Batches of <= 8 (the B = 1 query encode of clip_back.py:207-255) are captured into a hipGraph per (tower, B, buffers)
+    and replayed; a batch of 12 takes the plain launches.  Rows do not depend on the batch they travel in (bitwise), so
+    six calls of B = 2 -- first a capture per staging slot, then replays with NEW inputs in the same buffers -- must
+    reproduce the rows of the one plain call, and so must B = 1 calls through device buffers."""
+    name, arch, oracle, enc = tiny
+    from oracle.clip_oracle import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    pix, ids = normalise_u8_nhwc(synth_pixels_u8(12, seed=21)), synth_tokens(12, seed=22)
+    want_i, want_t = enc.encode_image(pix), enc.encode_text(ids)
+    for rep in range(2):
+        got_i = np.concatenate([enc.encode_image(pix[o:o + 2]) for o in range(0, 12, 2)])
+        got_t = np.concatenate([enc.encode_text(ids[o:o + 2]) for o in range(0, 12, 2)])
+        assert np.array_equal(got_i, want_i) and np.array_equal(got_t, want_t), f"{name} pass {rep}"
+    dpix = torch.from_numpy(pix).cuda()
+    dids = torch.from_numpy(ids).cuda()
+    out = torch.empty(1, arch.embed_dim, dtype=torch.float16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    # B = 1 API calls (the query path) additionally split the K loops of their GEMMs over more workgroups: the same arithmetic
+    # in another f32 summation order, so they are compared with the batch rows by cosine, and with THEMSELVES (first call =
+    # capture, later calls = replays that read new contents from the same buffers) bit for bit
+    first = {}
+    for i in (3, 7, 3):
+        one = dpix[i:i + 1].clone()
+        for _ in range(2):
+            one.copy_(dpix[i:i + 1])
+            torch.cuda.synchronize()
+            enc.encode_image_device(one.data_ptr(), 1, 0, out.data_ptr(), None, st)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()[0]
+            assert _cos(got[None], want_i[i][None]).min() > 1 - 1e-5
+            assert np.array_equal(first.setdefault(i, got.copy()), got)
+    assert enc.graphs_cached() >= 3, "small batches did not go through captured graphs"
+    tok = dids[0:1].clone()
+    for i in (5, 1, 5, 9):
+        tok.copy_(dids[i:i + 1])
+        torch.cuda.synchronize()
+        enc.encode_text_device(tok.data_ptr(), 1, out.data_ptr(), None, st)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()[0]
+        assert _cos(got[None], want_t[i][None]).min() > 1 - 1e-5
+        assert np.array_equal(first.setdefault(100 + i, got.copy()), got)
+
+
 def test_mapper_vs_reference_clipmapper_golden(tiny):
     """The HIP ClipMapper against fp16 embeddings produced by the reference's own ClipMapper code on the CPU
     (tests/golden/make_golden_mapper.py): per-sample cosine >= 1 - 1e-3 (north_star bar), same shapes and dtype."""
