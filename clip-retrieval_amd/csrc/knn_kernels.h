@@ -75,7 +75,8 @@ hipError_t launch_gather(const _Float16* X, int64_t N, int d, int64_t id_base, c
                          float* out, hipStream_t st);
 hipError_t launch_f32_to_f16(const float* in, _Float16* out, int64_t n, hipStream_t st);
 hipError_t launch_range_sort(const float* rs, const uint32_t* ri, const unsigned* cnt, unsigned cap,
-                             const int64_t* lims, int64_t id_base, int nq, float* D, int64_t* I, hipStream_t st);
+                             const int64_t* lims, int64_t id_base, const int64_t* idmap_or_null, int nq, float* D, int64_t* I,
+                             hipStream_t st);
 hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st);
 
 // ---- register-stationary-queries (RQ) scan, knn_rq_kernels.hip: up to rq_queries_per_pass(d) queries per pass over HBM

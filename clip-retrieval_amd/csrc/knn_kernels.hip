@@ -478,18 +478,20 @@ __global__ void knn_f32_to_f16_kernel(const float* __restrict__ in, _Float16* __
 __global__ __launch_bounds__(256) void knn_range_sort_kernel(const float* __restrict__ rs, const uint32_t* __restrict__ ri,
                                                             const unsigned* __restrict__ cnt, unsigned cap,
                                                             const int64_t* __restrict__ lims, int64_t id_base,
-                                                            float* __restrict__ D, int64_t* __restrict__ I) {
+                                                            const int64_t* __restrict__ idmap, float* __restrict__ D,
+                                                            int64_t* __restrict__ I) {
+  // idmap (IVF: arena row -> id) or id_base + row; the hits of a query leave in ascending id order
   const int qq = blockIdx.x;
   const unsigned n = cnt[qq] < cap ? cnt[qq] : cap;
   const float* s = rs + (size_t)qq * cap;
   const uint32_t* id = ri + (size_t)qq * cap;
   const int64_t o = lims[qq];
   for (unsigned e = threadIdx.x; e < n; e += 256) {
-    const uint32_t ie = id[e];
+    const int64_t ie = idmap ? idmap[id[e]] : (int64_t)id[e] + id_base;
     unsigned r = 0;
-    for (unsigned j = 0; j < n; ++j) r += id[j] < ie ? 1u : 0u;
+    for (unsigned j = 0; j < n; ++j) r += (idmap ? idmap[id[j]] : (int64_t)id[j] + id_base) < ie ? 1u : 0u;
     D[o + r] = s[e];
-    I[o + r] = (int64_t)ie + id_base;
+    I[o + r] = ie;
   }
 }
 
@@ -922,7 +924,10 @@ static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
 
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
   if (a.wide) return (a.mode == 0 && !a.work) ? launch_scan_mode<0, false, false, 2>(a, st) : hipErrorInvalidValue;
-  if (a.work) return a.mode == 0 ? launch_scan_mode<0, false, true>(a, st) : hipErrorInvalidValue;
+  if (a.work) {  // IVF work list: top-k (mode 0) or range (mode 1) over the rows of the probed lists
+    if (a.mode == 0) return launch_scan_mode<0, false, true>(a, st);
+    return a.mode == 1 ? launch_scan_mode<1, false, true>(a, st) : hipErrorInvalidValue;
+  }
   if (a.mode == 0) return a.nt ? launch_scan_mode<0, true>(a, st) : launch_scan_mode<0, false>(a, st);
   if (a.mode == 2) return launch_scan_mode<2, false>(a, st);
   return launch_scan_mode<1, false>(a, st);
@@ -1001,8 +1006,9 @@ hipError_t launch_f32_to_f16(const float* in, _Float16* out, int64_t n, hipStrea
   return hipGetLastError();
 }
 hipError_t launch_range_sort(const float* rs, const uint32_t* ri, const unsigned* cnt, unsigned cap,
-                             const int64_t* lims, int64_t id_base, int nq, float* D, int64_t* I, hipStream_t st) {
-  hipLaunchKernelGGL(knn_range_sort_kernel, dim3(nq), dim3(256), 0, st, rs, ri, cnt, cap, lims, id_base, D, I);
+                             const int64_t* lims, int64_t id_base, const int64_t* idmap, int nq, float* D, int64_t* I,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(knn_range_sort_kernel, dim3(nq), dim3(256), 0, st, rs, ri, cnt, cap, lims, id_base, idmap, D, I);
   return hipGetLastError();
 }
 hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st) {

@@ -395,12 +395,12 @@ extern "C" int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed) {
   return KNNX_OK;
 }
 
-// one scan of <= KNN_NQ queries already in HBM; results land in D_out/I_out (device, [nq, k])
 static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out,
-                     hipStream_t st, const unsigned* gate = nullptr) {
-  const int cap = scan_cap(ix->d, k);
-  if (cap < 0) return fail(KNNX_E_UNSUPPORTED, "k too large for the LDS queues at this d");
-  if (ix->ivf_nlist) {
+                     hipStream_t st, const unsigned* gate = nullptr);
+
+// IVF: the work list (ix->ivf_work / ivf_nwork) of <= KNN_NQ queries already in HBM
+static int ivf_build_worklist(knnx_index* ix, const float* q_dev, int nq, hipStream_t st, const unsigned* gate) {
+  {
     // coarse quantiser: top-nprobe centroids per query (the same flat scan over the [nlist, d] centroid rows), then
     // the work list = tiles of every list probed by at least one of the <= 32 queries, each with its query mask
     const int np = std::min(ix->ivf_nprobe, ix->ivf_nlist);
@@ -433,6 +433,18 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
       HIPCHK(launch_ivf_worklist_from_scores(ix->ivf_scores, nq, np, ix->ivf_nlist, ix->ivf_masks, ix->ivf_tile0, ix->ivf_ntile,
                                              ix->ivf_size, ix->ivf_off, ix->ivf_work, ix->ivf_nwork, st));
     }
+  }
+  return 0;
+}
+
+// one scan of <= KNN_NQ queries already in HBM; results land in D_out/I_out (device, [nq, k])
+static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out,
+                     hipStream_t st, const unsigned* gate) {
+  const int cap = scan_cap(ix->d, k);
+  if (cap < 0) return fail(KNNX_E_UNSUPPORTED, "k too large for the LDS queues at this d");
+  if (ix->ivf_nlist) {
+    int r = ivf_build_worklist(ix, q_dev, nq, st, gate);
+    if (r) return r;
   }
   HIPCHK(launch_prep(q_dev, nq, ix->d, ix->qfrag, ix->thr_g, nullptr, 0, gate, st));
   ScanArgs a{};
@@ -700,7 +712,6 @@ static int search_large_k_locked(knnx_index* ix, const float* q, int n, int k, f
 extern "C" int knnx_search(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I, float* R) {
   if (!ix || (n > 0 && (!q || !D || !I)) || n < 0 || k <= 0) return fail(KNNX_E_ARG, "bad search arguments");
   if (k > KNNX_MAX_K) return fail(KNNX_E_UNSUPPORTED, "k > 16384 is not implemented");
-  if (ix->ivf_nlist && k > KNNX_MAX_K_FAST) return fail(KNNX_E_UNSUPPORTED, "IVF search supports k <= 64");
   if (n == 0) return KNNX_OK;
   {
     std::lock_guard<std::mutex> lk(ix->mu);
@@ -761,10 +772,16 @@ static int range_scan(knnx_index* ix, const float* q_host, int nq, float thr, st
       HIPCHK(hipMalloc(&ix->range_i, ix->range_pool * sizeof(uint32_t)));
     }
     const unsigned cap = (unsigned)std::min<size_t>(ix->range_pool / (size_t)nq, 0xffffffffu);
+    if (ix->ivf_nlist) {  // IVF: the range is taken over the rows of the nprobe best lists of each query (faiss IndexIVF semantics)
+      r = ivf_build_worklist(ix, ix->q_dev, nq, st, nullptr);
+      if (r) return r;
+    }
     HIPCHK(launch_prep(ix->q_dev, nq, ix->d, ix->qfrag, ix->thr_g, ix->range_cnt, 0, nullptr, st));
     ScanArgs a{};
     a.X = ix->rows;
-    a.N = ix->ntotal;
+    a.N = ix->ivf_nlist ? ix->capacity : ix->ntotal;
+    a.work = ix->ivf_nlist ? ix->ivf_work : nullptr;
+    a.nwork = ix->ivf_nwork;
     a.d = ix->d;
     a.qfrag = ix->qfrag;
     a.nq = nq;
@@ -819,8 +836,8 @@ static int range_fetch(knnx_index* ix, int nq, const std::vector<unsigned>& coun
   if (e == hipSuccess)
     e = hipMemcpyAsync(lims_dev, loc.data(), (nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream);
   if (e == hipSuccess)
-    e = launch_range_sort(ix->range_s, ix->range_i, ix->range_cnt, cap, lims_dev, ix->id_base, nq, D_dev, I_dev,
-                          ix->stream);
+    e = launch_range_sort(ix->range_s, ix->range_i, ix->range_cnt, cap, lims_dev, ix->id_base,
+                          ix->ivf_nlist ? ix->ivf_idmap : nullptr, nq, D_dev, I_dev, ix->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(D, D_dev, (size_t)loc[nq] * sizeof(float), hipMemcpyDeviceToHost, ix->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(I, I_dev, (size_t)loc[nq] * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
@@ -835,7 +852,6 @@ extern "C" int knnx_range_search(knnx_index* ix, const float* q, int n, float th
                                  int64_t* I) {
   if (!ix || !lims || (n > 0 && !q) || n < 0) return fail(KNNX_E_ARG, "bad range_search arguments");
   if ((D == nullptr) != (I == nullptr)) return fail(KNNX_E_ARG, "D and I must both be null or both be set");
-  if (ix->ivf_nlist) return fail(KNNX_E_UNSUPPORTED, "range_search on an IVF index is not implemented");
   std::lock_guard<std::mutex> lk(ix->mu);
   if (set_dev(ix)) return KNNX_E_HIP;
   const bool fill = D != nullptr;
@@ -890,11 +906,20 @@ static int search_large_k_locked(knnx_index* ix, const float* q, int n, int k, f
       float step = std::max(top - s64, 1e-3f * std::max(1.f, fabsf(top)));
       float thr = s64 - step;
       std::vector<unsigned> counts;
+      int64_t prev_cnt = -1;
+      int stalled = 0;
       for (int it = 0;; ++it) {
         unsigned cap = 0;
         r = range_scan(ix, qq, 1, thr, counts, &cap);
         if (r) return r;
         const int64_t cnt = counts[0];
+        // an IVF index only reaches the rows of the probed lists: when three ever larger steps add nothing, take what there is
+        stalled = cnt == prev_cnt ? stalled + 1 : 0;
+        prev_cnt = cnt;
+        if (stalled >= 3 && thr > -FLT_MAX) {
+          thr = -FLT_MAX;
+          continue;
+        }
         if (cnt >= std::min<int64_t>(k, N) || !(thr > -FLT_MAX)) {
           std::vector<float> hd((size_t)cnt);
           std::vector<int64_t> hi((size_t)cnt);

@@ -94,8 +94,9 @@ int knnx_range_search(knnx_index* ix, const float* q, int n, float thresh, int64
  * (list 0 first), then call knnx_ivf_set_lists once: centroids fp16 [nlist, d] (the coarse quantiser is a flat scan
  * over them), list_sizes [nlist], ids [ntotal] = the id each added row carries (a permutation of
  * [id_base, id_base + ntotal)).  Afterwards knnx_search* probe the nprobe lists whose centroids score highest for the
- * query (faiss `nprobe`, clip_back.py:357-369) and return exactly the top-k of those lists' rows; k <= 64;
- * range_search and add are refused on an IVF index. */
+ * query (faiss `nprobe`, clip_back.py:357-369) and return exactly the top-k of those lists' rows (k up to KNNX_MAX_K;
+ * fewer rows than k in the probed lists: -1 / -FLT_MAX padding like faiss); knnx_range_search returns the rows of the probed
+ * lists above the threshold (faiss IndexIVF.range_search; clip_filter.py:52).  add is refused on an IVF index. */
 int knnx_ivf_set_lists(knnx_index* ix, int nlist, const uint16_t* centroids_f16, const int64_t* list_sizes,
                        const int64_t* ids);
 int knnx_ivf_set_nprobe(knnx_index* ix, int nprobe); /* 1 .. nlist (BASELINE config 5: 16 / 64 / 256) */

@@ -124,6 +124,24 @@ class IVFFlatOracle:
         return D, I
 
 
+    def range_search(self, q, thresh: float, nprobe: int):
+        """faiss IndexIVF.range_search: every row of the nprobe best lists with score > thresh (strict, like IndexFlat's
+        range search); returned per query in ascending id order (faiss leaves the order unspecified)."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        cs = q @ self.cent.astype(np.float32).T
+        lims, Ds, Is = [0], [], []
+        for i in range(q.shape[0]):
+            probes = np.lexsort((np.arange(cs.shape[1]), -cs[i].astype(np.float64)))[:nprobe]
+            cand = np.nonzero(np.isin(self.lists, probes))[0]
+            sc = self.rows[cand].astype(np.float32) @ q[i]
+            keep = sc > thresh
+            Ds.append(sc[keep])
+            Is.append(cand[keep])
+            lims.append(lims[-1] + int(keep.sum()))
+        return (np.asarray(lims, np.int64), np.concatenate(Ds) if Ds else np.zeros(0, np.float32),
+                np.concatenate(Is) if Is else np.zeros(0, np.int64))
+
+
 def merge_topk(D_parts, I_parts, k: int):
     """[P, n, k] per-shard results (global ids) -> top-k per query; the step after the all-gather."""
     D_parts = np.asarray(D_parts, dtype=np.float32)

@@ -311,6 +311,42 @@ def test_ivf_flat_parity(n, d, nlist, nprobe):
     ix.close()
 
 
+@pytest.mark.parametrize("nprobe", [3, 80])
+def test_ivf_range_search_and_large_k(nprobe):
+    """IVF indexes also serve `range_search` (clip_filter.py:52, the dedup of clip_back.py:290-309) and k > 64 (the
+    front end asks for 3000 results, clip_back.py:358): both over exactly the rows of the nprobe best lists.  A k larger than
+    what the probed lists hold is padded with -1 / -FLT_MAX like faiss does."""
+    from clip_retrieval_amd.knn import build_ivf_index
+    from oracle.knn_oracle import IVFFlatOracle
+
+    n, d, nlist = 30_011, 512, 96
+    x = _data(n, d, seed=77)
+    rng = np.random.default_rng(5)
+    cent = x[rng.choice(n, nlist, replace=False)]
+    ix = build_ivf_index(x, nlist, nprobe=nprobe, centroids=cent)
+    o = IVFFlatOracle(d, cent, ix.ivf_lists, x)
+    q = _queries(5, d, seed=9, x=x)
+    for thr in (0.3, 0.08, -2.0):  # -2: every row of the probed lists
+        lims, D, I = ix.range_search(q, thr)
+        lo, Do, Io = o.range_search(q, thr, nprobe)
+        assert np.array_equal(lims, lo), f"thr={thr}: {lims} vs {lo}"
+        for i in range(5):
+            a, b = slice(lims[i], lims[i + 1]), slice(lo[i], lo[i + 1])
+            oa, ob = np.argsort(I[a]), np.argsort(Io[b])
+            assert np.array_equal(I[a][oa], Io[b][ob]), f"thr={thr} query {i}: id sets differ"
+            assert np.abs(D[a][oa] - Do[b][ob]).max(initial=0.0) < 1e-5
+    for k in (200, 1000):
+        D, I = ix.search(q[:3], k)
+        Do, Io = o.search(q[:3], k, nprobe)
+        _check(D, I, Do, Io, f"ivf nprobe={nprobe} k={k}")
+    if nprobe == 3:  # three lists of ~300 rows hold fewer than 3000 rows: the tail is padding
+        D, I = ix.search(q[:2], 3000)
+        Do, Io = o.search(q[:2], 3000, nprobe)
+        assert (Io[:, -1] == -1).all()
+        _check(D, I, Do, Io, "ivf k = 3000 beyond the probed lists")
+    ix.close()
+
+
 def test_ivf_trained_recall():
     """k-means centroids from the library's own assignment scan: recall@10 vs exact flat on clustered data."""
     from clip_retrieval_amd.knn import build_ivf_index
