@@ -69,6 +69,31 @@ class ShardedIndex:
         dist.all_reduce(t, group=self.group)
         return int(t.item())
 
+    @staticmethod
+    def _record_buffer(n, k, device):
+        """One rank's results as ONE buffer of 12-byte records' worth of bytes (a single all-gather of
+        B x k x 12 bytes per rank): [n*k int64 ids | n*k float32 scores], padded to a multiple of 8 bytes.  Returns
+        (bytes, I view [n, k], D view [n, k])."""
+        import torch  # pylint: disable=import-outside-toplevel
+
+        nk = n * k
+        size = (nk * 12 + 7) // 8 * 8
+        rec = torch.empty(size, dtype=torch.uint8, device=device)
+        return rec, rec[: nk * 8].view(torch.int64).view(n, k), rec[nk * 8: nk * 12].view(torch.float32).view(n, k)
+
+    def _gather_records(self, rec, n, k):
+        """all-gather of the per-rank record buffers -> (Dg [world, n, k], Ig [world, n, k])."""
+        import torch  # pylint: disable=import-outside-toplevel
+        import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+
+        nk = n * k
+        out = torch.empty(self.world * rec.numel(), dtype=torch.uint8, device=rec.device)
+        dist.all_gather_into_tensor(out, rec, group=self.group)
+        out = out.view(self.world, rec.numel())
+        Ig = out[:, : nk * 8].contiguous().view(torch.int64).view(self.world, n, k)
+        Dg = out[:, nk * 8: nk * 12].contiguous().view(torch.float32).view(self.world, n, k)
+        return Dg, Ig
+
     def search(self, x, k):
         """Host queries in, host results out (the clip_back call shape)."""
         import torch  # pylint: disable=import-outside-toplevel
@@ -79,15 +104,11 @@ class ShardedIndex:
             return D, I
         on_gpu = dist.get_backend(self.group) == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-        Dt = torch.from_numpy(np.ascontiguousarray(D)).to(dev)
-        It = torch.from_numpy(np.ascontiguousarray(I)).to(dev)
-        n = Dt.shape[0]
-        # concatenated layout [world*n, k] (accepted by both gloo and RCCL), viewed as [world, n, k]
-        Dg = torch.empty((self.world * n, k), dtype=Dt.dtype, device=dev)
-        Ig = torch.empty((self.world * n, k), dtype=It.dtype, device=dev)
-        dist.all_gather_into_tensor(Dg, Dt, group=self.group)
-        dist.all_gather_into_tensor(Ig, It, group=self.group)
-        Dg, Ig = Dg.view(self.world, n, k), Ig.view(self.world, n, k)
+        n = D.shape[0]
+        rec, Iv, Dv = self._record_buffer(n, k, dev)
+        Iv.copy_(torch.from_numpy(np.ascontiguousarray(I)))
+        Dv.copy_(torch.from_numpy(np.ascontiguousarray(D)))
+        Dg, Ig = self._gather_records(rec, n, k)
         if on_gpu:
             Do, Io = self.merge_device(Dg, Ig, k)
             return Do.cpu().numpy(), Io.cpu().numpy()
@@ -103,8 +124,7 @@ class ShardedIndex:
         import torch.distributed as dist  # pylint: disable=import-outside-toplevel
 
         n = q_cuda.shape[0]
-        D = torch.empty((n, k), dtype=torch.float32, device=q_cuda.device)
-        I = torch.empty((n, k), dtype=torch.int64, device=q_cuda.device)
+        rec, I, D = self._record_buffer(n, k, q_cuda.device)  # the local scan writes straight into the record buffer
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=q_cuda.device)
         cur = torch.cuda.current_stream(q_cuda.device)
@@ -113,11 +133,8 @@ class ShardedIndex:
         cur.wait_stream(self._side)
         if self.world == 1:
             return D, I
-        Dg = torch.empty((self.world * n, k), dtype=torch.float32, device=q_cuda.device)
-        Ig = torch.empty((self.world * n, k), dtype=torch.int64, device=q_cuda.device)
-        dist.all_gather_into_tensor(Dg, D, group=self.group)
-        dist.all_gather_into_tensor(Ig, I, group=self.group)
-        return self.merge_device(Dg.view(self.world, n, k), Ig.view(self.world, n, k), k)
+        Dg, Ig = self._gather_records(rec, n, k)
+        return self.merge_device(Dg, Ig, k)
 
     @staticmethod
     def merge_device(Dg, Ig, k):
