@@ -81,9 +81,15 @@ hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64
 
 // ---- register-stationary-queries (RQ) scan, knn_rq_kernels.hip: up to rq_queries_per_pass(d) queries per pass over HBM
 constexpr int KNN_RQ_MAX = 256;        // queries of one RQ pass at d <= 768 (128 at d = 1024)
-constexpr int KNN_RQ_STRIDE = 128;     // the sample pass visits every 128th 32-row tile (fewer on small indexes: >= 4096 tiles sampled)
-constexpr int KNN_RQ_MARGIN = 8;       // threshold = (k + 8)-th best sample score
-constexpr unsigned KNN_RQ_CAP = 16384; // hit list entries per query (expected (k + 8) * 128 ~ 6 k at k = 40)
+// The sample pass visits every S-th 32-row tile, S = min(1024, tiles / 4096) (>= 4096 tiles = 131 k rows sampled); the
+// threshold is the J-th best sample score with J = k + 8 up to S = 128 and J = (k + 8) * 128 / S (>= 6) beyond, i.e. ~6 k
+// expected hits per query whatever the index size.  The number of index rows above the J-th best of a 1/S sample is
+// distribution-free (~ S * Gamma(J)): at J = 9, S = 763 (100 M rows) P(hits > 32768) < 1e-15 and P(hits < k) = 0.
+// (A 1/128 sample of 100 M rows cost 0.9 ms per 64-query pass -- cold LDS queues are pruned every round -- 3.6 ms of a
+// 45 ms search; the 1/763 sample 0.3 ms.)
+constexpr int KNN_RQ_STRIDE = 1024;
+constexpr int KNN_RQ_MARGIN = 8;
+constexpr unsigned KNN_RQ_CAP = 32768; // hit list entries per query
 constexpr int64_t KNN_RQ_MIN_ROWS = (int64_t)1 << 21;  // below this the 64-query scan is used
 int rq_queries_per_pass(int d);  // 0: no RQ kernel for this d
 hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float slack,

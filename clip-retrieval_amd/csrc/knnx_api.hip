@@ -576,9 +576,7 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
   int r = rq_alloc(ix);
   if (r) return r;
   const int d = ix->d;
-  // 1. thresholds: the 64-query scan over every S-th tile; threshold = (k + margin)-th best sample score.  S = 128 on large
-  // indexes (1/128 of the bytes per sample pass, ~(k + 8) * 128 hits per query); smaller indexes sample at least 4096
-  // tiles (131 k rows) so that the threshold is not taken from a handful of rows (expected hits = (k + 8) * S)
+  // 1. thresholds: the 64-query scan over every S-th tile; threshold = J-th best sample score (knn_kernels.h: KNN_RQ_STRIDE)
   const int64_t ntiles = (ix->ntotal + 31) / 32;
   const int tstride = (int)std::max<int64_t>(1, std::min<int64_t>(KNN_RQ_STRIDE, ntiles / 4096));
   // (the 64-query wide scan where its LDS queues fit, d <= 768; at d = 1024 the exact 32-query scan, whose scores are exact
@@ -608,7 +606,8 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
     HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, gsz, KNN_WIDE_KW, n, KNN_WIDE_KW, 0, nullptr,
                             ix->rq_samp + (size_t)q0 * KNN_WIDE_KW, ix->rq_samp_i + (size_t)q0 * KNN_WIDE_KW, nullptr, st));
   }
-  const int J = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
+  const int jfull = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
+  const int J = tstride <= 128 ? jfull : std::max(6, std::min(jfull, (jfull * 128 + tstride - 1) / tstride));
   HIPCHK(launch_rq_prep(q_dev, nq, d, ix->rq_qfrag, ix->rq_samp, KNN_WIDE_KW, J, wide_samp ? 0.f : 1e-3f, ix->rq_thr, ix->rq_cnt,
                         ix->rq_lost, st));
   // 2. the pass over the whole index
