@@ -94,7 +94,7 @@ constexpr int64_t KNN_RQ_MIN_ROWS = (int64_t)1 << 21;  // below this the 64-quer
 int rq_queries_per_pass(int d);  // 0: no RQ kernel for this d
 hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float slack,
                           float* thr, unsigned* cnt, unsigned* lost, hipStream_t st);
-hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, const _Float16* qfrag, const float* thr, unsigned* cnt,
+hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, int nq, const _Float16* qfrag, const float* thr, unsigned* cnt,
                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
                           hipStream_t st);
 // IVF build (knn_rq_kernels.hip / knn_kernels.hip): out[i] = argmax_l <P[i], C[l]> (fp16 rows, exact fp32 scores, ties -> smaller l)

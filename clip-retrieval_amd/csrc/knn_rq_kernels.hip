@@ -521,9 +521,13 @@ static hipError_t launch_rq_scan_cfg(const _Float16* X, int64_t N, const _Float1
   return hipGetLastError();
 }
 
-hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, const _Float16* qfrag, const float* thr, unsigned* cnt,
+hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, int nq, const _Float16* qfrag, const float* thr, unsigned* cnt,
                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
                           hipStream_t st) {
+  // up to 128 queries: four waves hold them all -- half the LDS reads of the X tiles and half the MFMAs of the 8-wave
+  // configuration, whose upper four waves would multiply padding
+  if (nq <= 128 && d == 768) return launch_rq_scan_cfg<48, 1, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+  if (nq <= 128 && d == 512) return launch_rq_scan_cfg<32, 1, 4, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
   switch (d) {
     case 512: return launch_rq_scan_cfg<32, 1, 8, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
     // d = 768: 8 waves x 32 queries, two waves per SIMD: a wave's LDS-DMA issue (~100 cycles per instruction during which it

@@ -617,7 +617,7 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, st));
   }
-  HIPCHK(launch_rq_scan(ix->rows, ix->ntotal, d, ix->rq_qfrag, ix->rq_thr, ix->rq_cnt, KNN_RQ_CAP, ix->rq_hit_s, ix->rq_hit_r,
+  HIPCHK(launch_rq_scan(ix->rows, ix->ntotal, d, nq, ix->rq_qfrag, ix->rq_thr, ix->rq_cnt, KNN_RQ_CAP, ix->rq_hit_s, ix->rq_hit_r,
                         ix->rq_lost, nullptr, ix->n_cu, st));
   if (ix->prof) {
     HIPCHK(hipEventRecord(e1, st));
