@@ -116,6 +116,8 @@ struct clipx_handle {
   // 5-15 us kernels: their launch sequence is captured once per (tower, B, buffers, stream) into a hipGraph and replayed.
   typedef std::tuple<int, int, int, const void*, const void*, const void*, hipStream_t> GraphKey;
   std::map<GraphKey, hipGraphExec_t> graphs;
+  std::map<GraphKey, int> graph_seen;  // a launch sequence is captured the SECOND time its key shows up: a caller that brings
+                                       // fresh buffers on every call (new addresses) never pays for captures it cannot reuse
   bool graphs_on = true;
   int prof = 0;  // bit k set: launches of kind k (0 gemm, 1 attention, 2 layernorm, 3 other) are bracketed by hipEvents
   std::vector<ProfEvent> prof_events;
@@ -417,6 +419,8 @@ static int run_graphed(clipx_handle* h, hipStream_t st, const clipx_handle::Grap
     return 0;
   }
   if (h->graphs.size() >= GRAPH_MAX) return body();
+  if (h->graph_seen.size() > 4 * GRAPH_MAX) h->graph_seen.clear();
+  if (++h->graph_seen[key] < 2) return body();
   if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) {
     (void)hipGetLastError();
     h->graphs_on = false;

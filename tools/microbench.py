@@ -19,7 +19,8 @@ P = lambda t: C.c_void_p(t.data_ptr())
 
 
 def timed(name, fn, flops=None, nbytes=None):
-    fn()
+    for _ in range(3):  # (small-batch encodes capture their hipGraph on the second call)
+        fn()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     st = torch.cuda.current_stream()
