@@ -325,3 +325,35 @@ if "pipeline" in what:
               f"(with start-up), second partition {n / (t2 - t1):.0f} samples/s; {rows} embeddings written", flush=True)
         for f in sorted(glob.glob(out + "/stats/*.json"))[-1:]:
             print("    stats of the last partition:", open(f).read()[:400], flush=True)
+
+if "sharded" in what:
+    # The one-process sharded index (knnx_shards_*, what KnnService holds on a multi-GPU node) against the single index over
+    # the same rows -- here with all shards on ONE GPU, so the scans serialise: what is measured is the price of the shard
+    # fan-out (query copies, per-shard top-k, peer gather, merge), not a scaling curve.
+    import numpy as np
+
+    from clip_retrieval_amd.knn import Mi355xIndex, ShardedMi355xIndex
+
+    total = int(os.environ.get("MB_SHARD_ROWS", "100000000"))
+    d, k = 768, 40
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((64, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+
+    def host_timed(name, fn, reps=5):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        dt = (time.perf_counter() - t0) / reps
+        print(f"{name:70s} {dt * 1e3:8.2f} ms per call  {64 / dt:8.0f} QPS", flush=True)
+
+    one = Mi355xIndex(d, coalesce=False)
+    one.synth_fill(total, 3)
+    host_timed(f"Mi355xIndex.search 64 queries, {total} rows, host buffers", lambda: one.search(q, k))
+    one.close()
+    for ns in (2, 4, 8):
+        sh = ShardedMi355xIndex(d, [0] * ns, coalesce=False)
+        sh.synth_fill(total // ns, 3)
+        host_timed(f"ShardedMi355xIndex.search 64 queries, {ns} shards x {total // ns} rows on one GPU", lambda: sh.search(q, k))
+        sh.close()
