@@ -18,7 +18,9 @@ The index stores rows as fp16 (the `img_emb_*.npy` files of clip_inference/write
 scores are fp32 accumulations of fp32(x_fp16) * q_fp32.
 
 PARITY UNPINNED: no reference test asserts anything about search results (tests/test_end2end.py:119
-checks only HTTP 200), and faiss itself cannot be run here.
+checks only HTTP 200), and faiss itself cannot be run here.  What stands in: tests/test_oracle.py checks this restatement
+against scikit-learn's brute-force NearestNeighbors (an independent exact search), and the GPU tests / bench.py additionally
+against torch matmul + topk over the full index and against planted neighbours.
 """
 
 import numpy as np

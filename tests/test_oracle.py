@@ -139,3 +139,42 @@ def test_oracle_matches_reference_clipmapper_golden(name):
     txt16, _ = mapper_semantics(o.encode_text(torch.from_numpy(ids)))
     assert img16.dtype == np.float16 and np.array_equal(img16, g["image_embs"])
     assert np.array_equal(txt16, g["text_embs"])
+
+
+def test_knn_oracle_against_an_independent_exact_search():
+    """faiss is not installable here and the reference asserts no search result, so the numpy restatement of IndexFlatIP is
+    pinned against an INDEPENDENT exact brute-force implementation instead: scikit-learn's NearestNeighbors (cosine distance on
+    unit-norm rows orders like the inner product).  Same neighbours in the same order, scores equal to 1e-5; plus the radius
+    query against range_search."""
+    from sklearn.neighbors import NearestNeighbors
+
+    from oracle.knn_oracle import FlatIPOracle, synth_rows
+
+    d, n, k = 256, 20000, 40
+    x = synth_rows(np.arange(n), d, seed=11)  # unit norm, fp16-stored
+    rng = np.random.default_rng(3)
+    q = x[rng.choice(n, 16, replace=False)].astype(np.float32) + 0.1 * rng.standard_normal((16, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    o = FlatIPOracle(d)
+    o.add(x)
+    D, I = o.search(q, k)
+    xf = x.astype(np.float64)
+    xf /= np.linalg.norm(xf, axis=1, keepdims=True)  # fp16 storage leaves norms at 1 +- 5e-4: cosine needs them exact
+    nn = NearestNeighbors(n_neighbors=k, algorithm="brute", metric="cosine").fit(xf)
+    dist, idx = nn.kneighbors(q.astype(np.float64))
+    # cosine re-normalises the rows, the inner product does not: compare the neighbour SETS of the well-separated part and the
+    # scores through the stored norms
+    norms = np.linalg.norm(x.astype(np.float64), axis=1)
+    for i in range(16):
+        ip_from_cos = (1.0 - dist[i]) * norms[idx[i]]
+        order = np.argsort(-ip_from_cos, kind="stable")
+        got = idx[i][order]
+        assert len(set(got[: k - 5]) - set(I[i])) == 0, f"query {i}: neighbour sets differ"
+        common = [j for j in range(k) if I[i][j] in set(idx[i])]
+        for j in common:
+            pos = int(np.where(idx[i] == I[i][j])[0][0])
+            assert abs(D[i][j] - ip_from_cos[pos]) < 1e-5
+    lims, Dr, Ir = o.range_search(q[:4], 0.3)
+    for i in range(4):
+        want = np.flatnonzero((x.astype(np.float32) @ q[i]) > 0.3)
+        assert np.array_equal(np.sort(Ir[lims[i]:lims[i + 1]]), want)
