@@ -1,5 +1,6 @@
 """Host-side mirrors of the reference interfaces vs golden vectors produced by the reference's own code
 (tests/golden/make_golden.py) and vs the expectations of the reference's tests."""
+import functools
 import hashlib
 import io
 import json
@@ -487,3 +488,71 @@ def test_decode_processes_equal_the_thread_pool(tmp_path, tar_shards):
     r = WebdatasetReader(Sampler(0, 1), lambda im: clip_preprocess(im), HashTokenizer(), tar_shards, 4, 3)  # noqa: E731
     assert sum(b["image_tensor"].shape[0] for b in r) == 11 and len(_DecodePool._pools) == n_pools
     _DecodePool.shutdown()
+
+
+def test_config1_plumbing_with_the_oracle_mapper(tmp_path):
+    """SURVEY config 1 (the reference's own CPU-runnable case, scaled down): synthetic JPEGs + captions in webdataset-style
+    tars -> WebdatasetReader (decode processes) -> Runner -> a mapper with ClipMapper's call shape whose model is the fp32
+    ORACLE (no GPU here) -> NumpyWriter + LoggerWriter.  Asserts the reference's output layout (writer.py:67-106): file names,
+    dtypes, shapes, row counts per partition, unit-norm fp16 rows, and that row i of the embeddings belongs to row i of the
+    metadata."""
+    import pandas as pd
+    from PIL import Image
+
+    from clip_retrieval_amd.reader import HashTokenizer, WebdatasetReader, clip_preprocess
+    from clip_retrieval_amd.runner import LoggerWriter, Runner
+    from clip_retrieval_amd.writer import NumpyWriter
+    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics
+
+    arch = ARCHS["tiny-B/32"]
+    oracle = HFClipOracle(arch, seed=0)
+    rng = np.random.default_rng(0)
+    shards, k = [], 0
+    for t in range(4):
+        p = tmp_path / f"{t:03d}.tar"
+        with tarfile.open(p, "w") as tf:
+            for _ in range(25):
+                g = np.linspace(0, 255, 256, dtype=np.float32)
+                img = (g[None, :, None] * 0.5 + g[:, None, None] * 0.5 + rng.normal(0, 8, (256, 256, 3))).clip(0, 255).astype(np.uint8)
+                buf = io.BytesIO()
+                Image.fromarray(img).save(buf, format="JPEG", quality=90)
+                for ext, data in (("jpg", buf.getvalue()), ("txt", f"caption {k}".encode())):
+                    ti = tarfile.TarInfo(f"{k:06d}.{ext}")
+                    ti.size = len(data)
+                    tf.addfile(ti, io.BytesIO(data))
+                k += 1
+        shards.append(str(p))
+
+    class OracleMapper:  # ClipMapper.__call__'s contract (mapper.py:49-78) on the CPU oracle
+        def __call__(self, item):
+            img16, _ = mapper_semantics(oracle.encode_image(item["image_tensor"]))
+            txt16, _ = mapper_semantics(oracle.encode_text(item["text_tokens"].clamp(max=arch.vocab - 1)))
+            return {"image_embs": img16, "text_embs": txt16, "image_filename": item["image_filename"], "text": item["text"],
+                    "metadata": None}
+
+    out = tmp_path / "out"
+    tok = HashTokenizer(arch.ctx_len, arch.vocab)
+    runner = Runner(
+        reader_builder=lambda s: WebdatasetReader(s, functools.partial(clip_preprocess, size=arch.image_size), tok, shards, 16, 2),
+        mapper_builder=OracleMapper,
+        writer_builder=lambda i: NumpyWriter(i, str(out), True, True, False, 2),
+        logger_builder=lambda i: LoggerWriter(i, str(out / "stats")),
+        output_partition_count=2,
+    )
+    runner(0)
+    runner(1)
+    total = 0
+    for i in range(2):
+        img = np.load(out / "img_emb" / f"img_emb_{i}.npy")
+        txt = np.load(out / "text_emb" / f"text_emb_{i}.npy")
+        meta = pd.read_parquet(out / "metadata" / f"metadata_{i}.parquet")
+        assert img.dtype == np.float16 and txt.dtype == np.float16 and img.shape == (50, arch.embed_dim) == txt.shape
+        assert len(meta) == 50 and list(meta.columns)[:2] == ["image_path", "caption"]
+        assert np.allclose(np.linalg.norm(img.astype(np.float32), axis=1), 1, atol=2e-3)
+        # partition i holds shards i, i + 2 (Sampler: every count-th shard) in order, 25 samples each
+        want = [f"caption {j}" for s in (i, i + 2) for j in range(25 * s, 25 * s + 25)]
+        assert list(meta["caption"]) == want
+        total += len(meta)
+        st = json.loads((out / "stats" / f"{i}.json").read_text())  # LoggerWriter: summed stats of the partition (logger.py:13-62)
+        assert st["sample_count"] == 50 and not (out / "stats" / f"wip_{i}.json").exists()
+    assert total == 100
