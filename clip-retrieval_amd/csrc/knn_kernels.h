@@ -77,7 +77,20 @@ hipError_t launch_f32_to_f16(const float* in, _Float16* out, int64_t n, hipStrea
 hipError_t launch_range_sort(const float* rs, const uint32_t* ri, const unsigned* cnt, unsigned cap,
                              const int64_t* lims, int64_t id_base, const int64_t* idmap_or_null, int nq, float* D, int64_t* I,
                              hipStream_t st);
+// hit lists longer than this are sorted by launch_range_sort_long (radix) instead of launch_range_sort (rank by counting)
+constexpr unsigned RANGE_SORT_SMALL = 4096;
+hipError_t launch_range_sort_long(const float* vs, const uint32_t* ri, unsigned n, int64_t id_base, const int64_t* idmap_or_null,
+                                  int key_bits, uint32_t* k0, uint32_t* k1, float* v0, float* v1, unsigned* hist, float* D, int64_t* I,
+                                  hipStream_t st);
 hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st);
+// the mixture corpus of BASELINE config 5 (knn_kernels.hip: knn_synth_mix_kernel): destination row i = corpus row
+// row_begin + i * row_stride; P_table = synth_mix_table_bytes(d) bytes of device scratch
+hipError_t launch_synth_mix(_Float16* X, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed, int64_t n_clusters,
+                            short* P_table, hipStream_t st);
+size_t synth_mix_table_bytes(int d);
+hipError_t launch_copy_rows(const _Float16* src, int d, const int64_t* src_rows, const int32_t* dst_rows, int64_t n, _Float16* dst,
+                            hipStream_t st);
+hipError_t launch_ivf_hist(const int32_t* lists, int64_t n, int nlist, unsigned long long* hist, hipStream_t st);
 
 // ---- register-stationary-queries (RQ) scan, knn_rq_kernels.hip: up to rq_queries_per_pass(d) queries per pass over HBM
 constexpr int KNN_RQ_MAX = 256;        // queries of one RQ pass at d <= 768 (128 at d = 1024)
@@ -103,9 +116,10 @@ hipError_t launch_assign(const _Float16* C, int64_t nlist, int d, const _Float16
 hipError_t launch_kmeans_update(const _Float16* X, int d, const int64_t* order, const int64_t* off, int nlist, _Float16* cent,
                                 hipStream_t st);
 // scatter n assigned rows into the tile-padded list-sorted arena: dst row = tile0[list] * 32 + pos; lays down idmap / inv
+// (ids == null: row i carries id id0 + i)
 hipError_t launch_ivf_scatter(const _Float16* src, int64_t n, int d, const int32_t* lists, const int32_t* pos, const int64_t* ids,
-                              const unsigned* tile0, int64_t id_lo, int64_t n_ids, _Float16* dst, int64_t* idmap, uint32_t* inv,
-                              hipStream_t st);
+                              int64_t id0, const unsigned* tile0, int64_t id_lo, int64_t n_ids, _Float16* dst, int64_t* idmap,
+                              uint32_t* inv, hipStream_t st);
 hipError_t launch_rq_rescore(const _Float16* X, int d, const float* q, int nq, const unsigned* cnt, unsigned cap, float* hit_s,
                              const uint32_t* hit_r, int* cntc, hipStream_t st);
 hipError_t launch_rq_proof(const float* q, int nq, int d, int k, const float* D, const float* thr, const unsigned* cnt,

@@ -479,10 +479,11 @@ __global__ __launch_bounds__(256) void knn_range_sort_kernel(const float* __rest
                                                             const unsigned* __restrict__ cnt, unsigned cap,
                                                             const int64_t* __restrict__ lims, int64_t id_base,
                                                             const int64_t* __restrict__ idmap, float* __restrict__ D,
-                                                            int64_t* __restrict__ I) {
+                                                            int64_t* __restrict__ I, unsigned max_n) {
   // idmap (IVF: arena row -> id) or id_base + row; the hits of a query leave in ascending id order
   const int qq = blockIdx.x;
   const unsigned n = cnt[qq] < cap ? cnt[qq] : cap;
+  if (n > max_n) return;  // long lists go through the radix sort below (rank-by-counting is O(n^2))
   const float* s = rs + (size_t)qq * cap;
   const uint32_t* id = ri + (size_t)qq * cap;
   const int64_t o = lims[qq];
@@ -493,6 +494,123 @@ __global__ __launch_bounds__(256) void knn_range_sort_kernel(const float* __rest
     D[o + r] = s[e];
     I[o + r] = ie;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// range_search post-pass for LONG hit lists (> RANGE_SORT_SMALL hits of one query: a large-k search that descended to a low
+// threshold, a range query over a dense neighbourhood): stable LSD radix sort by id, 4 bits per pass, one query at a time.
+// Per pass: digit histogram of every 2048-element block -> exclusive scan over [digit][block] -> stable scatter (ranks inside
+// a block by wave ballots: one ballot per digit value, waves ordered through an LDS table).  O(n) per pass instead of the
+// O(n^2) rank-by-counting above (1e12 comparisons at 1 M hits).
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_BLOCK = 2048;  // elements per 256-thread block
+__global__ __launch_bounds__(256) void rs_keys_kernel(const uint32_t* __restrict__ ri, const int64_t* __restrict__ idmap,
+                                                     int64_t id_base, unsigned n, uint32_t* __restrict__ keys) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keys[i] = idmap ? (uint32_t)(idmap[ri[i]] - id_base) : ri[i];
+}
+__global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict__ keys, unsigned n, int shift, unsigned nblk,
+                                                     unsigned* __restrict__ hist) {
+  __shared__ unsigned c[16];
+  if (threadIdx.x < 16) c[threadIdx.x] = 0u;
+  __syncthreads();
+  const unsigned base = blockIdx.x * RS_BLOCK;
+  for (int r = 0; r < RS_BLOCK / 256; ++r) {
+    const unsigned i = base + r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&c[(keys[i] >> shift) & 15u], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) hist[threadIdx.x * nblk + blockIdx.x] = c[threadIdx.x];
+}
+// single workgroup: in-place exclusive prefix sum over L entries
+__global__ __launch_bounds__(1024) void rs_scan_kernel(unsigned* __restrict__ h, unsigned L) {
+  __shared__ unsigned red[1024];
+  __shared__ unsigned carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < L; base += 1024) {
+    const unsigned l = base + tid;
+    const unsigned v = l < L ? h[l] : 0u;
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const unsigned t = tid >= o ? red[tid - o] : 0u;
+      __syncthreads();
+      red[tid] += t;
+      __syncthreads();
+    }
+    if (l < L) h[l] = carry + red[tid] - v;
+    __syncthreads();
+    if (tid == 1023) carry += red[1023];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restrict__ kin, const float* __restrict__ vin, unsigned n,
+                                                        int shift, unsigned nblk, const unsigned* __restrict__ offs,
+                                                        uint32_t* __restrict__ kout, float* __restrict__ vout) {
+  __shared__ unsigned run[16];    // next output slot of every digit for this block
+  __shared__ unsigned wc[4][16];  // this round's per-wave digit counts
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < 16) run[tid] = offs[tid * nblk + blockIdx.x];
+  __syncthreads();
+  const unsigned base = blockIdx.x * RS_BLOCK;
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  for (int r = 0; r < RS_BLOCK / 256; ++r) {
+    const unsigned i = base + r * 256 + tid;
+    const bool ok = i < n;
+    const uint32_t key = ok ? kin[i] : 0u;
+    const float val = ok ? vin[i] : 0.f;
+    const int dg = ok ? (int)((key >> shift) & 15u) : -1;
+    unsigned rank = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const unsigned long long m = __ballot(dg == v);
+      if (dg == v) rank = (unsigned)__builtin_popcountll(m & lt);
+      if (lane == 0) wc[w][v] = (unsigned)__builtin_popcountll(m);
+    }
+    __syncthreads();
+    if (ok) {
+      unsigned o = run[dg] + rank;
+      for (int ww = 0; ww < w; ++ww) o += wc[ww][dg];
+      kout[o] = key;
+      vout[o] = val;
+    }
+    __syncthreads();
+    if (tid < 16) run[tid] += wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void rs_emit_kernel(const uint32_t* __restrict__ keys, const float* __restrict__ vals, unsigned n,
+                                                     int64_t id_base, float* __restrict__ D, int64_t* __restrict__ I) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    D[i] = vals[i];
+    I[i] = (int64_t)keys[i] + id_base;
+  }
+}
+// one query's n hits (scores vs, arena rows / local ids ri) -> D, I sorted by ascending id.  Scratch: 2 key + 2 value buffers
+// of n entries and 16 * ceil(n / 2048) counters, owned by the caller.  key_bits = bits of the largest local id.
+hipError_t launch_range_sort_long(const float* vs, const uint32_t* ri, unsigned n, int64_t id_base, const int64_t* idmap, int key_bits,
+                                  uint32_t* k0, uint32_t* k1, float* v0, float* v1, unsigned* hist, float* D, int64_t* I,
+                                  hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const unsigned nb256 = (n + 255) / 256, nblk = (n + RS_BLOCK - 1) / RS_BLOCK;
+  hipLaunchKernelGGL(rs_keys_kernel, dim3(nb256), dim3(256), 0, st, ri, idmap, id_base, n, k0);
+  uint32_t* kbuf[2] = {k0, k1};
+  float* vbuf[2] = {v0, v1};
+  int cur = 0;
+  const float* vin = vs;  // the scores are only read: the first pass moves them into the ping-pong buffers
+  for (int shift = 0; shift < key_bits; shift += 4) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], n, shift, nblk, hist);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 16u * nblk);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(256), 0, st, kbuf[cur], vin, n, shift, nblk, hist, kbuf[cur ^ 1],
+                       vbuf[cur ^ 1]);
+    vin = vbuf[cur ^ 1];
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(rs_emit_kernel, dim3(nb256), dim3(256), 0, st, kbuf[cur], vin, n, id_base, D, I);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,6 +655,88 @@ __global__ __launch_bounds__(256) void knn_synth_kernel(_Float16* __restrict__ X
       float f = (float)((double)v[e] * scale);
       asm volatile("" : "+v"(f));  // keep the two roundings (f64->f32, f32->f16) separate: hipcc otherwise folds them
       X[(size_t)r * d + c] = (_Float16)f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// mixture corpus (BASELINE config 5: an index where IVF is meaningful), exactly re-derivable on the CPU
+// (oracle/knn_oracle.py: synth_mixture_rows).  A mixture of `n_clusters` Gaussians in a MIX_M-dimensional latent space,
+// embedded in R^d by a fixed random matrix, plus a little isotropic noise; integer arithmetic throughout:
+//   s8(salt, i)  = sum of the four low bytes of mix64((seed ^ salt) ^ (i * GOLD)) - 510         (~ N(0, 148^2))
+//   cluster(r)   = (((u1 * u2) >> 32) * n_clusters) >> 32,  u1 | u2 = the two halves of mix64((seed ^ SALT_C) ^ (r * GOLD)):
+//                  the product of two uniforms -- component weights are skewed (the first cluster is ~ 1 + ln(n_clusters)
+//                  times the average), like real embedding collections
+//   l_j          = s8(MU, cluster * M + j) + (1 + cluster % 3) * s8(Z, r * M + j)              j < M: centre + spread x noise
+//   v_c          = sum_j l_j * P[j][c] + 1024 * s8(N, r * d + c),  P[j][c] = s8(P, j * d + c)
+//   x(r, c)      = fp16(fp32(v_c / sqrt(sum_c v_c^2)))   (sqrt / divide in fp64, as in knn_synth_kernel)
+// The components overlap heavily (centre and within-component spread have the same scale), so the nearest neighbours of a
+// point straddle several k-means cells: recall@40 of an IVF index over it rises with nprobe instead of being 1 at once
+// (measured by tools/config5.py; a scaled-down numpy run of the same recipe gives 0.83 / 0.975 / 1.0 at nprobe 16 / 64 / 256
+// of 256 lists).  One wave per row; the lane owns column pairs (2 lane, 2 lane + 1) + 128 e.
+// ---------------------------------------------------------------------------------------------
+constexpr int MIX_M = 32;
+constexpr uint64_t MIX_SALT_P = 0x50u, MIX_SALT_C = 0xC1u, MIX_SALT_MU = 0x3Du, MIX_SALT_Z = 0x2Au, MIX_SALT_N = 0x4Eu;
+__device__ __forceinline__ int synth_s8(uint64_t seed, uint64_t idx) {
+  const uint64_t h = mix64(seed ^ (idx * 0x9e3779b97f4a7c15ull));
+  return (int)((h & 0xff) + ((h >> 8) & 0xff) + ((h >> 16) & 0xff) + ((h >> 24) & 0xff)) - 510;
+}
+__global__ __launch_bounds__(256) void knn_mix_table_kernel(short* __restrict__ P, int d, uint64_t seed) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < MIX_M * d) P[i] = (short)synth_s8(seed ^ MIX_SALT_P, (uint64_t)i);
+}
+__global__ __launch_bounds__(256) void knn_synth_mix_kernel(_Float16* __restrict__ X, int64_t row_begin, int64_t row_stride, int64_t n,
+                                                           int d, uint64_t seed, uint64_t n_clusters, const short* __restrict__ P) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // destination row
+  if (i >= n) return;
+  const uint64_t r = (uint64_t)(row_begin + i * row_stride);       // corpus row
+  const uint64_t hc = mix64((seed ^ MIX_SALT_C) ^ (r * 0x9e3779b97f4a7c15ull));
+  const uint64_t t = ((hc & 0xffffffffull) * (hc >> 32)) >> 32;
+  const uint64_t c = (t * n_clusters) >> 32;
+  const int spread = 1 + (int)(c % 3);
+  const int j = lane & (MIX_M - 1);
+  const int lj = synth_s8(seed ^ MIX_SALT_MU, c * MIX_M + j) + spread * synth_s8(seed ^ MIX_SALT_Z, r * MIX_M + j);
+  constexpr int MAXE = 8;  // d <= 1024: 8 column pairs per lane
+  int v0[MAXE], v1[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) { v0[e] = 0; v1[e] = 0; }
+  for (int jj = 0; jj < MIX_M; ++jj) {
+    const int l = __shfl(lj, jj);
+    const int* prow = reinterpret_cast<const int*>(P + (size_t)jj * d);
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int cp = e * 64 + lane;  // column pair index
+      if (2 * cp < d) {
+        const int pv = prow[cp];
+        v0[e] += l * (int)(short)(pv & 0xffff);
+        v1[e] += l * (pv >> 16);
+      }
+    }
+  }
+  long long ss = 0;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int col = 2 * (e * 64 + lane);
+    if (col < d) {
+      v0[e] += 1024 * synth_s8(seed ^ MIX_SALT_N, r * (uint64_t)d + (uint64_t)col);
+      v1[e] += 1024 * synth_s8(seed ^ MIX_SALT_N, r * (uint64_t)d + (uint64_t)col + 1);
+      ss += (long long)v0[e] * v0[e] + (long long)v1[e] * v1[e];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const double scale = 1.0 / sqrt((double)ss);
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int col = 2 * (e * 64 + lane);
+    if (col < d) {
+      float f0 = (float)((double)v0[e] * scale), f1 = (float)((double)v1[e] * scale);
+      asm volatile("" : "+v"(f0), "+v"(f1));  // keep the two roundings (f64->f32, f32->f16) separate
+      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+      half2v o;
+      o[0] = (_Float16)f0;
+      o[1] = (_Float16)f1;
+      *reinterpret_cast<half2v*>(X + (size_t)i * d + col) = o;
     }
   }
 }
@@ -808,8 +1008,9 @@ hipError_t launch_kmeans_update(const _Float16* X, int d, const int64_t* order, 
 // one wave per row: copy into its slot of the list-sorted arena
 __global__ __launch_bounds__(256) void ivf_scatter_kernel(const _Float16* __restrict__ src, int64_t n, int d,
                                                          const int32_t* __restrict__ lists, const int32_t* __restrict__ pos,
-                                                         const int64_t* __restrict__ ids, const unsigned* __restrict__ tile0,
-                                                         int64_t id_lo, int64_t n_ids, _Float16* __restrict__ dst,
+                                                         const int64_t* __restrict__ ids, int64_t id0,
+                                                         const unsigned* __restrict__ tile0, int64_t id_lo, int64_t n_ids,
+                                                         _Float16* __restrict__ dst,
                                                          int64_t* __restrict__ idmap, uint32_t* __restrict__ inv) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -819,17 +1020,48 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const _Float16* __rest
   uint4* o = reinterpret_cast<uint4*>(dst + drow * d);
   for (int c = lane; c < d / 8; c += 64) o[c] = s[c];
   if (lane == 0) {
-    const int64_t id = ids[r];
+    const int64_t id = ids ? ids[r] : id0 + r;  // ids == null: consecutive ids id0, id0 + 1, ... (a device-resident chunk of the corpus)
     idmap[drow] = id;
     if (id >= id_lo && id - id_lo < n_ids) inv[id - id_lo] = (uint32_t)drow;
   }
 }
 hipError_t launch_ivf_scatter(const _Float16* src, int64_t n, int d, const int32_t* lists, const int32_t* pos, const int64_t* ids,
-                              const unsigned* tile0, int64_t id_lo, int64_t n_ids, _Float16* dst, int64_t* idmap, uint32_t* inv,
-                              hipStream_t st) {
+                              int64_t id0, const unsigned* tile0, int64_t id_lo, int64_t n_ids, _Float16* dst, int64_t* idmap,
+                              uint32_t* inv, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src, n, d, lists, pos, ids, tile0, id_lo, n_ids,
-                     dst, idmap, inv);
+  hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src, n, d, lists, pos, ids, id0, tile0, id_lo,
+                     n_ids, dst, idmap, inv);
+  return hipGetLastError();
+}
+
+// dst[dst_rows[i], :] = src[src_rows[i], :] (k-means seeding: centroid <- sample row); one wave per pair
+__global__ __launch_bounds__(256) void copy_rows_kernel(const _Float16* __restrict__ src, int d, const int64_t* __restrict__ src_rows,
+                                                       const int32_t* __restrict__ dst_rows, int64_t n, _Float16* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)src_rows[i] * d);
+  uint4* o = reinterpret_cast<uint4*>(dst + (size_t)dst_rows[i] * d);
+  for (int c = lane; c < d / 8; c += 64) o[c] = s[c];
+}
+hipError_t launch_copy_rows(const _Float16* src, int d, const int64_t* src_rows, const int32_t* dst_rows, int64_t n, _Float16* dst,
+                            hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src, d, src_rows, dst_rows, n, dst);
+  return hipGetLastError();
+}
+
+// histogram of list ids (the list sizes knnx_ivf_begin needs), accumulated over the chunks of an assignment pass
+__global__ __launch_bounds__(256) void ivf_hist_kernel(const int32_t* __restrict__ lists, int64_t n, int nlist,
+                                                      unsigned long long* __restrict__ hist) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int l = lists[i];
+    if (l >= 0 && l < nlist) atomicAdd(&hist[l], 1ull);
+  }
+}
+hipError_t launch_ivf_hist(const int32_t* lists, int64_t n, int nlist, unsigned long long* hist, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ivf_hist_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, lists, n, nlist, hist);
   return hipGetLastError();
 }
 
@@ -1008,7 +1240,8 @@ hipError_t launch_f32_to_f16(const float* in, _Float16* out, int64_t n, hipStrea
 hipError_t launch_range_sort(const float* rs, const uint32_t* ri, const unsigned* cnt, unsigned cap,
                              const int64_t* lims, int64_t id_base, const int64_t* idmap, int nq, float* D, int64_t* I,
                              hipStream_t st) {
-  hipLaunchKernelGGL(knn_range_sort_kernel, dim3(nq), dim3(256), 0, st, rs, ri, cnt, cap, lims, id_base, idmap, D, I);
+  hipLaunchKernelGGL(knn_range_sort_kernel, dim3(nq), dim3(256), 0, st, rs, ri, cnt, cap, lims, id_base, idmap, D, I,
+                     (unsigned)RANGE_SORT_SMALL);
   return hipGetLastError();
 }
 hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st) {
@@ -1020,5 +1253,20 @@ hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64
   }
   return hipGetLastError();
 }
+
+hipError_t launch_synth_mix(_Float16* X, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed, int64_t n_clusters,
+                            short* P_table, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  if (d % 2 != 0 || d > 1024 || n_clusters <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(knn_mix_table_kernel, dim3((MIX_M * d + 255) / 256), dim3(256), 0, st, P_table, d, seed);
+  const int64_t chunk = 1 << 22;  // rows per launch (grid.x limit)
+  for (int64_t o = 0; o < n; o += chunk) {
+    const int64_t m = (n - o) < chunk ? (n - o) : chunk;
+    hipLaunchKernelGGL(knn_synth_mix_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, X + (size_t)o * d,
+                       row_begin + o * row_stride, row_stride, m, d, seed, (uint64_t)n_clusters, P_table);
+  }
+  return hipGetLastError();
+}
+size_t synth_mix_table_bytes(int d) { return (size_t)MIX_M * d * sizeof(short); }
 
 }  // namespace knnx

@@ -79,6 +79,10 @@ struct knnx_index {
   int64_t ivfb_total = 0, ivfb_added = 0;
   std::vector<uint16_t> ivfb_cent;
   void *ivfb_rows = nullptr, *ivfb_ids = nullptr, *ivfb_lists = nullptr, *ivfb_pos = nullptr;  // device staging of one chunk
+  // host mirror of the layout, so that every (list, position) a caller hands over is checked before it is scattered
+  // (a position past its list, or used twice, would silently overwrite a neighbouring list's rows)
+  std::vector<uint32_t> ivfb_size, ivfb_fill, ivfb_tile0;
+  std::vector<uint64_t> ivfb_taken;  // one bit per padded arena row
 
   // wide scan (64 queries per pass): candidates, fallback results, proof flags; largest row norm (order-encoded)
   int wide_ok = 1;             // KNNX_WIDE=0 disables
@@ -837,6 +841,28 @@ static int range_fetch(knnx_index* ix, int nq, const std::vector<unsigned>& coun
   if (e == hipSuccess)
     e = launch_range_sort(ix->range_s, ix->range_i, ix->range_cnt, cap, lims_dev, ix->id_base,
                           ix->ivf_nlist ? ix->ivf_idmap : nullptr, nq, D_dev, I_dev, ix->stream);
+  // hit lists too long for rank-by-counting: radix sort by id, one query at a time
+  unsigned longest = 0;
+  for (int i = 0; i < nq; ++i) longest = std::max(longest, counts[i] > RANGE_SORT_SMALL ? counts[i] : 0u);
+  if (e == hipSuccess && longest) {
+    uint32_t *k0 = nullptr, *k1 = nullptr;
+    float *v0 = nullptr, *v1 = nullptr;
+    unsigned* hist = nullptr;
+    e = hipMalloc(&k0, (size_t)longest * 4);
+    if (e == hipSuccess) e = hipMalloc(&k1, (size_t)longest * 4);
+    if (e == hipSuccess) e = hipMalloc(&v0, (size_t)longest * 4);
+    if (e == hipSuccess) e = hipMalloc(&v1, (size_t)longest * 4);
+    if (e == hipSuccess) e = hipMalloc(&hist, (size_t)16 * ((longest + 2047) / 2048) * sizeof(unsigned));
+    int key_bits = 1;
+    while (key_bits < 32 && ((int64_t)1 << key_bits) < std::max<int64_t>(ix->ntotal, 2)) ++key_bits;
+    for (int i = 0; i < nq && e == hipSuccess; ++i)
+      if (counts[i] > RANGE_SORT_SMALL)
+        e = launch_range_sort_long(ix->range_s + (size_t)i * cap, ix->range_i + (size_t)i * cap, counts[i], ix->id_base,
+                                   ix->ivf_nlist ? ix->ivf_idmap : nullptr, key_bits, k0, k1, v0, v1, hist, D_dev + loc[i],
+                                   I_dev + loc[i], ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    hipFree(k0); hipFree(k1); hipFree(v0); hipFree(v1); hipFree(hist);
+  }
   if (e == hipSuccess) e = hipMemcpyAsync(D, D_dev, (size_t)loc[nq] * sizeof(float), hipMemcpyDeviceToHost, ix->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(I, I_dev, (size_t)loc[nq] * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
@@ -912,8 +938,11 @@ static int search_large_k_locked(knnx_index* ix, const float* q, int n, int k, f
         r = range_scan(ix, qq, 1, thr, counts, &cap);
         if (r) return r;
         const int64_t cnt = counts[0];
-        // an IVF index only reaches the rows of the probed lists: when three ever larger steps add nothing, take what there is
-        stalled = cnt == prev_cnt ? stalled + 1 : 0;
+        // an IVF index only reaches the rows of the probed lists: when three ever larger steps add nothing, take what there is.
+        // Flat indexes never take this shortcut: a tight cluster of 64 <= C < k near-duplicates stalls the count
+        // while the next row is many steps away, and thr = -FLT_MAX there would fetch and sort all N rows; the step doubles
+        // every round, so cnt >= min(k, N) is reached after O(log(gap / spread)) scans.
+        stalled = (ix->ivf_nlist && cnt == prev_cnt) ? stalled + 1 : 0;
         prev_cnt = cnt;
         if (stalled >= 3 && thr > -FLT_MAX) {
           thr = -FLT_MAX;
@@ -1040,6 +1069,10 @@ struct knnx_ivf_builder {
   int64_t *order = nullptr, *off = nullptr;
   void* pin = nullptr;
   size_t pin_bytes = 0;
+  unsigned long long* hist = nullptr;  // [nlist] list sizes accumulated by knnx_ivfb_assign_device
+  bool sample_borrowed = false;        // sample points into caller memory (knnx_ivfb_set_sample_device)
+  std::vector<int32_t> h_lists;        // host scratch of knnx_ivfb_lloyd
+  std::vector<int64_t> h_order, h_off;
 };
 static const int64_t IVFB_CHUNK = (int64_t)1 << 20;  // rows per streamed chunk
 
@@ -1048,7 +1081,8 @@ extern "C" void knnx_ivfb_destroy(knnx_ivf_builder* b) {
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   (void)hipFree(b->cent);
-  (void)hipFree(b->sample);
+  if (!b->sample_borrowed) (void)hipFree(b->sample);
+  (void)hipFree(b->hist);
   (void)hipFree(b->stage);
   (void)hipFree(b->lists);
   (void)hipFree(b->order);
@@ -1070,6 +1104,8 @@ extern "C" int knnx_ivfb_create(int device, int d, int nlist, knnx_ivf_builder**
   hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&b->cent, (size_t)nlist * d * sizeof(_Float16));
   if (e == hipSuccess) e = hipMalloc(&b->off, (size_t)(nlist + 1) * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&b->hist, (size_t)nlist * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(b->hist, 0, (size_t)nlist * sizeof(unsigned long long));
   if (e == hipSuccess) {
     b->pin_bytes = (size_t)IVFB_CHUNK * d * sizeof(_Float16);
     e = hipHostMalloc(&b->pin, b->pin_bytes, hipHostMallocDefault);
@@ -1124,9 +1160,10 @@ static int ivfb_upload(knnx_ivf_builder* b, const uint16_t* rows, int64_t n, _Fl
 extern "C" int knnx_ivfb_set_sample(knnx_ivf_builder* b, const uint16_t* rows_f16, int64_t n) {
   if (!b || !rows_f16 || n <= 0) return fail(KNNX_E_ARG, "bad ivfb_set_sample arguments");
   HIPCHK(hipSetDevice(b->device));
-  (void)hipFree(b->sample);
+  if (!b->sample_borrowed) (void)hipFree(b->sample);
   (void)hipFree(b->order);
   b->sample = nullptr;
+  b->sample_borrowed = false;
   b->order = nullptr;
   HIPCHK(hipMalloc(&b->sample, (size_t)n * b->d * sizeof(_Float16)));
   HIPCHK(hipMalloc(&b->order, (size_t)n * sizeof(int64_t)));
@@ -1170,6 +1207,125 @@ extern "C" int knnx_ivfb_assign(knnx_ivf_builder* b, const uint16_t* rows_f16, i
     HIPCHK(hipMemcpyAsync(lists_out + o, b->lists, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
   }
+  return KNNX_OK;
+}
+
+
+// ---- the same builder for rows that are already in HBM (SURVEY 8 row f1 at BASELINE config 5's size: a 256 GB shard cannot
+// take a detour through host memory, and nothing of it needs to: the embeddings are produced on this GPU) ----------------
+extern "C" int knnx_ivfb_set_sample_device(knnx_ivf_builder* b, const void* rows_dev, int64_t n) {
+  if (!b || !rows_dev || n <= 0) return fail(KNNX_E_ARG, "bad ivfb_set_sample_device arguments");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (!b->sample_borrowed) (void)hipFree(b->sample);
+  (void)hipFree(b->order);
+  b->sample = (_Float16*)rows_dev;  // borrowed: the caller keeps it alive until the training is over
+  b->sample_borrowed = true;
+  b->order = nullptr;
+  HIPCHK(hipMalloc(&b->order, (size_t)n * sizeof(int64_t)));
+  b->n_sample = n;
+  return ivfb_rows_cap(b, n);
+}
+
+// centroid list_ids[i] := sample row sample_rows[i] (initial seeding, re-seeding of empty lists); host index arrays
+extern "C" int knnx_ivfb_seed_from_sample(knnx_ivf_builder* b, const int32_t* list_ids, const int64_t* sample_rows, int64_t n) {
+  if (!b || (n > 0 && (!list_ids || !sample_rows)) || n < 0 || !b->sample) return fail(KNNX_E_ARG, "bad ivfb_seed_from_sample arguments (set a sample first)");
+  if (n == 0) return KNNX_OK;
+  for (int64_t i = 0; i < n; ++i)
+    if (list_ids[i] < 0 || list_ids[i] >= b->nlist || sample_rows[i] < 0 || sample_rows[i] >= b->n_sample)
+      return fail(KNNX_E_ARG, "list id / sample row out of range");
+  HIPCHK(hipSetDevice(b->device));
+  int32_t* l_dev = nullptr;
+  int64_t* r_dev = nullptr;
+  HIPCHK(hipMalloc(&l_dev, (size_t)n * sizeof(int32_t)));
+  hipError_t e = hipMalloc(&r_dev, (size_t)n * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(l_dev, list_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(r_dev, sample_rows, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = launch_copy_rows(b->sample, b->d, r_dev, l_dev, n, b->cent, b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  (void)hipFree(l_dev);
+  (void)hipFree(r_dev);
+  if (e != hipSuccess) return fail(KNNX_E_HIP, std::string("ivfb_seed_from_sample: ") + hipGetErrorString(e));
+  return KNNX_OK;
+}
+
+// One Lloyd iteration over the resident sample, driven from here: assignment kernel -> list ids to the host -> counting sort
+// (member order = ascending sample row inside a list: the fixed summation order of knnx_ivfb_update) -> update kernel.
+// sizes_out [nlist] (host, may be null): members per list, so that the caller can re-seed the empty ones.
+extern "C" int knnx_ivfb_lloyd(knnx_ivf_builder* b, int64_t* sizes_out) {
+  if (!b || !b->sample) return fail(KNNX_E_ARG, "bad ivfb_lloyd arguments (set a sample first)");
+  HIPCHK(hipSetDevice(b->device));
+  const int64_t n = b->n_sample;
+  b->h_lists.resize((size_t)n);
+  b->h_order.resize((size_t)n);
+  b->h_off.assign((size_t)b->nlist + 1, 0);
+  HIPCHK(launch_assign(b->cent, b->nlist, b->d, b->sample, n, b->lists, b->stream));
+  HIPCHK(hipMemcpyAsync(b->h_lists.data(), b->lists, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (int64_t i = 0; i < n; ++i) b->h_off[(size_t)b->h_lists[i] + 1]++;
+  if (sizes_out) for (int l = 0; l < b->nlist; ++l) sizes_out[l] = b->h_off[(size_t)l + 1];
+  for (int l = 0; l < b->nlist; ++l) b->h_off[(size_t)l + 1] += b->h_off[l];
+  {
+    std::vector<int64_t> cur(b->h_off.begin(), b->h_off.end() - 1);
+    for (int64_t i = 0; i < n; ++i) b->h_order[(size_t)cur[b->h_lists[i]]++] = i;
+  }
+  HIPCHK(hipMemcpyAsync(b->order, b->h_order.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->off, b->h_off.data(), (size_t)(b->nlist + 1) * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(launch_kmeans_update(b->sample, b->d, b->order, b->off, b->nlist, b->cent, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return KNNX_OK;
+}
+
+// pass 1 over device-resident rows: lists_dev[i] = list of row i (device int32 [n]); the list sizes accumulate in the builder
+extern "C" int knnx_ivfb_assign_device(knnx_ivf_builder* b, const void* rows_dev, int64_t n, int32_t* lists_dev) {
+  if (!b || (n > 0 && (!rows_dev || !lists_dev)) || n < 0) return fail(KNNX_E_ARG, "bad ivfb_assign_device arguments");
+  if (n == 0) return KNNX_OK;
+  HIPCHK(hipSetDevice(b->device));
+  const int64_t step = (int64_t)1 << 22;  // rows per launch (grid size)
+  for (int64_t o = 0; o < n; o += step) {
+    const int64_t m = std::min(step, n - o);
+    HIPCHK(launch_assign(b->cent, b->nlist, b->d, (const _Float16*)rows_dev + (size_t)o * b->d, m, lists_dev + o, b->stream));
+  }
+  HIPCHK(launch_ivf_hist(lists_dev, n, b->nlist, b->hist, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return KNNX_OK;
+}
+
+// list sizes seen by knnx_ivfb_assign_device so far -> sizes_out [nlist] (host); reset != 0 clears the counters afterwards
+extern "C" int knnx_ivfb_list_sizes(knnx_ivf_builder* b, int64_t* sizes_out, int reset) {
+  if (!b || !sizes_out) return fail(KNNX_E_ARG, "bad ivfb_list_sizes arguments");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  static_assert(sizeof(unsigned long long) == sizeof(int64_t), "");
+  HIPCHK(hipMemcpy(sizes_out, b->hist, (size_t)b->nlist * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(b->hist, 0, (size_t)b->nlist * sizeof(unsigned long long)));
+  return KNNX_OK;
+}
+
+// Benchmark corpora generated straight into caller HBM: dst row i = corpus row row_begin + i * row_stride, fp16 [n, d].
+// kind 0: the isotropic corpus of knnx_synth_fill (row_stride must be 1); kind 1: the overlapping mixture of n_clusters
+// Gaussians of BASELINE config 5 (knn_kernels.hip: knn_synth_mix_kernel; oracle/knn_oracle.py: synth_mixture_rows).
+// Synchronous.
+extern "C" int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed,
+                                      int kind, int64_t n_clusters, void* stream) {
+  if (!dst_f16 || n < 0 || row_begin < 0 || row_stride < 1 || d <= 0 || d % 2 || d > 1024) return fail(KNNX_E_ARG, "bad synth_rows arguments");
+  if (n == 0) return KNNX_OK;
+  HIPCHK(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0) {
+    if (row_stride != 1) return fail(KNNX_E_UNSUPPORTED, "the isotropic corpus is generated with row_stride 1 only");
+    // the kernel addresses X[row * d]: shift the base so that corpus row row_begin lands on dst row 0
+    HIPCHK(launch_synth((_Float16*)dst_f16 - (size_t)row_begin * d, row_begin, n, d, seed, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return KNNX_OK;
+  }
+  if (kind != 1 || n_clusters <= 0) return fail(KNNX_E_ARG, "kind must be 0 or 1 (with n_clusters > 0)");
+  short* table = nullptr;
+  HIPCHK(hipMalloc(&table, synth_mix_table_bytes(d)));
+  hipError_t e = launch_synth_mix((_Float16*)dst_f16, row_begin, row_stride, n, d, seed, n_clusters, table, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(table);
+  if (e != hipSuccess) return fail(KNNX_E_HIP, std::string("synth_rows: ") + hipGetErrorString(e));
   return KNNX_OK;
 }
 
@@ -1218,10 +1374,27 @@ extern "C" int knnx_ivf_begin(knnx_index* ix, int nlist, const uint16_t* centroi
   if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KNNX_E_NOMEM : KNNX_E_HIP, std::string("ivf_begin: ") + hipGetErrorString(e));
   ix->ivfb_cent.assign(centroids_f16, centroids_f16 + (size_t)nlist * ix->d);
+  ix->ivfb_size.assign(size.begin(), size.end());
+  ix->ivfb_tile0.assign(tile0.begin(), tile0.end());
+  ix->ivfb_fill.assign(nlist, 0u);
+  ix->ivfb_taken.assign((size_t)(prow + 63) / 64, 0ull);
   ix->ivfb_nlist = nlist;
   ix->ivfb_total = run;
   ix->ivfb_added = 0;
   return KNNX_OK;
+}
+
+// claim arena slot (list, pos) for one row; caller holds ix->mu.  Returns false (message set) on a bad or reused slot.
+static bool ivfb_claim(knnx_index* ix, int32_t list, int64_t pos) {
+  if (list < 0 || list >= ix->ivfb_nlist) { fail(KNNX_E_ARG, "list id out of range"); return false; }
+  if (pos < 0 || pos >= (int64_t)ix->ivfb_size[list]) { fail(KNNX_E_ARG, "position is not inside its list (0 <= pos < list size)"); return false; }
+  const size_t slot = (size_t)ix->ivfb_tile0[list] * 32 + (size_t)pos;
+  uint64_t& word = ix->ivfb_taken[slot >> 6];
+  const uint64_t bit = 1ull << (slot & 63);
+  if (word & bit) { fail(KNNX_E_ARG, "two rows were given the same (list, position)"); return false; }
+  word |= bit;
+  ix->ivfb_fill[list]++;
+  return true;
 }
 
 extern "C" int knnx_ivf_add_assigned(knnx_index* ix, const uint16_t* rows_f16, int64_t n, const int64_t* ids, const int32_t* lists,
@@ -1232,10 +1405,18 @@ extern "C" int knnx_ivf_add_assigned(knnx_index* ix, const uint16_t* rows_f16, i
   if (set_dev(ix)) return KNNX_E_HIP;
   if (!ix->ivfb_nlist) return fail(KNNX_E_STATE, "call knnx_ivf_begin first");
   if (ix->ivfb_added + n > ix->ivfb_total) return fail(KNNX_E_ARG, "more rows than the list sizes announced");
-  for (int64_t i = 0; i < n; ++i) {
-    if (lists[i] < 0 || lists[i] >= ix->ivfb_nlist || pos[i] < 0) return fail(KNNX_E_ARG, "list id / position out of range");
+  for (int64_t i = 0; i < n; ++i)
     if (ids[i] < ix->id_base || ids[i] - ix->id_base >= ix->ivfb_total) return fail(KNNX_E_ARG, "ids must lie in [id_base, id_base + total rows)");
-  }
+  for (int64_t i = 0; i < n; ++i)
+    if (!ivfb_claim(ix, lists[i], pos[i])) {
+      // roll the claims of this call back: a refused call leaves the build as it was
+      for (int64_t j = 0; j < i; ++j) {
+        const size_t slot = (size_t)ix->ivfb_tile0[lists[j]] * 32 + (size_t)pos[j];
+        ix->ivfb_taken[slot >> 6] &= ~(1ull << (slot & 63));
+        ix->ivfb_fill[lists[j]]--;
+      }
+      return KNNX_E_ARG;
+    }
   const size_t rb = (size_t)ix->d * sizeof(_Float16);
   int r = ensure_pin(ix, (size_t)IVFB_CHUNK * (rb + 16));
   if (r) return r;
@@ -1255,9 +1436,47 @@ extern "C" int knnx_ivf_add_assigned(knnx_index* ix, const uint16_t* rows_f16, i
     HIPCHK(hipMemcpyAsync(ix->ivfb_lists, p_lists, (size_t)m * 4, hipMemcpyHostToDevice, ix->stream));
     HIPCHK(hipMemcpyAsync(ix->ivfb_pos, p_pos, (size_t)m * 4, hipMemcpyHostToDevice, ix->stream));
     HIPCHK(launch_ivf_scatter((const _Float16*)ix->ivfb_rows, m, ix->d, (const int32_t*)ix->ivfb_lists, (const int32_t*)ix->ivfb_pos,
-                              (const int64_t*)ix->ivfb_ids, ix->ivf_tile0, ix->id_base, ix->ivfb_total, ix->rows, ix->ivf_idmap,
+                              (const int64_t*)ix->ivfb_ids, 0, ix->ivf_tile0, ix->id_base, ix->ivfb_total, ix->rows, ix->ivf_idmap,
                               ix->ivf_inv, ix->stream));
     HIPCHK(launch_maxnorm((const _Float16*)ix->ivfb_rows, m, ix->d, ix->maxnorm, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+  }
+  ix->ivfb_added += n;
+  return KNNX_OK;
+}
+
+// The same pass for rows that are already in HBM (a shard generated or encoded on this GPU): row i carries id id0 + i and
+// goes to the next free position of lists_dev[i] -- positions inside a list follow the order of the calls and of the rows
+// inside a call, exactly what knn.build_ivf_index hands to knnx_ivf_add_assigned.  The list ids travel to the host once
+// (4 bytes per row) for the position bookkeeping; the rows never leave the device.
+extern "C" int knnx_ivf_add_assigned_device(knnx_index* ix, const void* rows_dev, int64_t n, int64_t id0, const int32_t* lists_dev) {
+  if (!ix || (n > 0 && (!rows_dev || !lists_dev)) || n < 0) return fail(KNNX_E_ARG, "bad ivf_add_assigned_device arguments");
+  if (n == 0) return KNNX_OK;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (set_dev(ix)) return KNNX_E_HIP;
+  if (!ix->ivfb_nlist) return fail(KNNX_E_STATE, "call knnx_ivf_begin first");
+  if (ix->ivfb_added + n > ix->ivfb_total) return fail(KNNX_E_ARG, "more rows than the list sizes announced");
+  if (id0 < ix->id_base || id0 - ix->id_base + n > ix->ivfb_total) return fail(KNNX_E_ARG, "ids must lie in [id_base, id_base + total rows)");
+  int r = ensure_pin(ix, (size_t)IVFB_CHUNK * 8);
+  if (r) return r;
+  int32_t* h_lists = (int32_t*)ix->pin;
+  int32_t* h_pos = h_lists + IVFB_CHUNK;
+  for (int64_t o = 0; o < n; o += IVFB_CHUNK) {
+    const int64_t m = std::min(IVFB_CHUNK, n - o);
+    HIPCHK(hipMemcpyAsync(h_lists, lists_dev + o, (size_t)m * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    for (int64_t i = 0; i < m; ++i) {
+      const int32_t l = h_lists[i];
+      if (l < 0 || l >= ix->ivfb_nlist) return fail(KNNX_E_ARG, "list id out of range");
+      const int64_t p = ix->ivfb_fill[l];
+      if (!ivfb_claim(ix, l, p)) return KNNX_E_ARG;  // (a list that is already full: more rows than its announced size)
+      h_pos[i] = (int32_t)p;
+    }
+    HIPCHK(hipMemcpyAsync(ix->ivfb_pos, h_pos, (size_t)m * 4, hipMemcpyHostToDevice, ix->stream));
+    const _Float16* src = (const _Float16*)rows_dev + (size_t)o * ix->d;
+    HIPCHK(launch_ivf_scatter(src, m, ix->d, lists_dev + o, (const int32_t*)ix->ivfb_pos, nullptr, id0 + o, ix->ivf_tile0, ix->id_base,
+                              ix->ivfb_total, ix->rows, ix->ivf_idmap, ix->ivf_inv, ix->stream));
+    HIPCHK(launch_maxnorm(src, m, ix->d, ix->maxnorm, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
   }
   ix->ivfb_added += n;
@@ -1273,6 +1492,12 @@ extern "C" int knnx_ivf_end(knnx_index* ix) {
     if (!ix->ivfb_nlist) return fail(KNNX_E_STATE, "call knnx_ivf_begin first");
     if (ix->ivfb_added != ix->ivfb_total) return fail(KNNX_E_STATE, "fewer rows were added than the list sizes announced");
     nlist = ix->ivfb_nlist;
+    for (int l = 0; l < nlist; ++l)
+      if (ix->ivfb_fill[l] != ix->ivfb_size[l]) return fail(KNNX_E_STATE, "a list received fewer rows than its announced size");
+    std::vector<uint32_t>().swap(ix->ivfb_size);
+    std::vector<uint32_t>().swap(ix->ivfb_fill);
+    std::vector<uint32_t>().swap(ix->ivfb_tile0);
+    std::vector<uint64_t>().swap(ix->ivfb_taken);
     hipFree(ix->ivfb_rows); ix->ivfb_rows = nullptr;
     hipFree(ix->ivfb_ids); ix->ivfb_ids = nullptr;
     hipFree(ix->ivfb_lists); ix->ivfb_lists = nullptr;

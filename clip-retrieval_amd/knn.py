@@ -486,6 +486,137 @@ class IvfBuilder:
         return out
 
 
+    # ---- rows that are already in HBM (device pointers; SURVEY 8 row f1 at BASELINE config 5's size) ----
+    def set_sample_device(self, dev_ptr, n):
+        """Borrow n fp16 rows [n, d_padded] of device memory as the training sample (the caller keeps them alive)."""
+        self._n_sample = int(n)
+        check(self._lib, self._lib.knnx_ivfb_set_sample_device(self._h, C.c_void_p(dev_ptr), int(n)), "knnx")
+
+    def seed_from_sample(self, list_ids, sample_rows):
+        """centroid list_ids[i] := sample row sample_rows[i] (initial seeding / re-seeding of empty lists)."""
+        li = np.ascontiguousarray(list_ids, dtype=np.int32)
+        sr = np.ascontiguousarray(sample_rows, dtype=np.int64)
+        assert li.shape == sr.shape
+        check(self._lib, self._lib.knnx_ivfb_seed_from_sample(self._h, li.ctypes.data, sr.ctypes.data, li.size), "knnx")
+
+    def lloyd(self):
+        """One Lloyd iteration over the resident sample, driven inside the library; returns the list sizes."""
+        sizes = np.empty(self.nlist, dtype=np.int64)
+        check(self._lib, self._lib.knnx_ivfb_lloyd(self._h, sizes.ctypes.data), "knnx")
+        return sizes
+
+    def assign_device(self, rows_ptr, n, lists_ptr):
+        """lists[i] = list of device row i (int32 device array); the list sizes accumulate in the builder."""
+        check(self._lib, self._lib.knnx_ivfb_assign_device(self._h, C.c_void_p(rows_ptr), int(n), C.c_void_p(lists_ptr)), "knnx")
+
+    def list_sizes(self, reset=False):
+        sizes = np.empty(self.nlist, dtype=np.int64)
+        check(self._lib, self._lib.knnx_ivfb_list_sizes(self._h, sizes.ctypes.data, int(bool(reset))), "knnx")
+        return sizes
+
+
+def synth_rows_device(dst_ptr, row_begin, n, d, seed, kind=0, n_clusters=0, row_stride=1, device=0, stream=None):
+    """Benchmark corpus rows generated into device memory (knnx_synth_rows_device): kind 0 isotropic, 1 config-5 mixture."""
+    lib = load_library()
+    check(lib, lib.knnx_synth_rows_device(int(device), C.c_void_p(dst_ptr), int(row_begin), int(row_stride), int(n), int(d),
+                                          C.c_uint64(seed), int(kind), int(n_clusters), C.c_void_p(stream) if stream else None), "knnx")
+
+
+def train_ivf_centroids_device(builder, sample_ptr, n_sample, niter=8, seed=0):
+    """k-means over a device-resident sample with `builder` (IvfBuilder): seeds from distinct random sample rows, runs
+    `niter` Lloyd iterations, re-seeds empty lists on random sample rows.  Returns the list sizes of the last iteration."""
+    rng = np.random.default_rng(seed)
+    builder.set_sample_device(sample_ptr, n_sample)
+    builder.seed_from_sample(np.arange(builder.nlist), np.sort(rng.choice(n_sample, builder.nlist, replace=False)))
+    sizes = None
+    for _ in range(niter):
+        sizes = builder.lloyd()
+        empty = np.flatnonzero(sizes == 0)
+        if empty.size:
+            builder.seed_from_sample(empty, rng.choice(n_sample, empty.size, replace=False))
+    return sizes
+
+
+def _download_i32(dev_ptr, n, device):  # pylint: disable=unused-argument
+    """n int32 from device memory to a numpy array (plain hipMemcpy through the HIP runtime libclipx.so already links)."""
+    out = np.empty(int(n), dtype=np.int32)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    rc = hip.hipMemcpy(out.ctypes.data, C.c_void_p(int(dev_ptr)), out.nbytes, 2)  # hipMemcpyDeviceToHost
+    if rc != 0:
+        raise HipLibraryError(f"hipMemcpy (device -> host) failed with code {rc}")
+    return out
+
+
+def _release_cached_device_memory():
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
+def build_ivf_index_device(fill_rows, n, d, nlist, nprobe=16, niter=8, seed=0, device=0, id_base=0, sample_rows=None,
+                           chunk=1 << 20, alloc=None, points_per_centroid=64, keep_lists=False):
+    """IVF-Flat index over n rows that are PRODUCED ON THE GPU (BASELINE config 5: one 125 M x 1024 shard = 256 GB of HBM).
+
+    `fill_rows(dst_ptr, row0, count, stride)` writes fp16 rows row0, row0 + stride, ... ([count, d], d a multiple of 256)
+    at device address dst_ptr; it is called for the training sample (stride > 1) and twice per chunk (assignment pass and
+    scatter pass) -- the corpus never exists twice.  `alloc(nbytes)` returns (device pointer, keep-alive object) for the
+    scratch buffers (sample, one chunk of rows, 4 bytes per row of list ids); default: torch uint8 tensors (torch is
+    this package's device-memory plumbing).  Returns (index, stats dict)."""
+    import time
+
+    assert d % 256 == 0, "device builds take padded rows (d % 256 == 0)"
+    lib = load_library()
+    if alloc is None:
+        def alloc(nbytes):
+            import torch
+
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=f"cuda:{device}")
+            return t.data_ptr(), t
+    t0 = time.perf_counter()
+    b = IvfBuilder(d, nlist, device)
+    n_sample = int(min(n, nlist * points_per_centroid)) if sample_rows is None else int(sample_rows)
+    stride = max(1, n // n_sample)
+    sample_ptr, sample_keep = alloc(n_sample * d * 2)
+    fill_rows(sample_ptr, 0, n_sample, stride)
+    train_ivf_centroids_device(b, sample_ptr, n_sample, niter=niter, seed=seed)
+    cent = np.ascontiguousarray(b.centroids())
+    del sample_keep
+    _release_cached_device_memory()  # the arena allocated below needs the bytes a caching allocator would sit on
+    t1 = time.perf_counter()
+    # pass 1: list of every row (4 bytes per row stay on the device), list sizes
+    lists_ptr, lists_keep = alloc(n * 4)
+    rows_ptr, rows_keep = alloc(min(chunk, n) * d * 2)
+    b.list_sizes(reset=True)
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        fill_rows(rows_ptr, o, m, 1)
+        b.assign_device(rows_ptr, m, lists_ptr + 4 * o)
+    sizes = b.list_sizes()
+    b.close()
+    _release_cached_device_memory()
+    t2 = time.perf_counter()
+    # pass 2: scatter into the list-sorted arena
+    index = Mi355xIndex(d, device=device, id_base=id_base)
+    check(lib, lib.knnx_ivf_begin(index._h, nlist, cent.ctypes.data, sizes.ctypes.data), "knnx")  # pylint: disable=protected-access
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        fill_rows(rows_ptr, o, m, 1)
+        check(lib, lib.knnx_ivf_add_assigned_device(index._h, C.c_void_p(rows_ptr), m, id_base + o, C.c_void_p(lists_ptr + 4 * o)), "knnx")  # pylint: disable=protected-access
+    check(lib, lib.knnx_ivf_end(index._h), "knnx")  # pylint: disable=protected-access
+    if keep_lists:  # tests / recall measurements: the list of every row (4 bytes per row to the host)
+        index.ivf_lists = _download_i32(lists_ptr, n, device)
+    del rows_keep, lists_keep
+    _release_cached_device_memory()
+    t3 = time.perf_counter()
+    index.nprobe = min(nprobe, nlist)
+    stats = {"train_s": t1 - t0, "assign_s": t2 - t1, "scatter_s": t3 - t2, "n_sample": n_sample, "list_sizes": sizes}
+    return index, stats
+
+
 def train_ivf_centroids(x_f16, nlist, niter=8, seed=0, device=0, max_points_per_centroid=256):
     """k-means with inner-product assignment (faiss Clustering with an IndexFlatIP quantiser): returns fp16 [nlist, d].
     The sample (<= nlist * max_points_per_centroid rows, like faiss) stays resident in HBM across the iterations."""

@@ -123,6 +123,23 @@ int knnx_ivf_begin(knnx_index* ix, int nlist, const uint16_t* centroids_f16, con
 int knnx_ivf_add_assigned(knnx_index* ix, const uint16_t* rows_f16, int64_t n, const int64_t* ids, const int32_t* lists,
                           const int32_t* pos);
 int knnx_ivf_end(knnx_index* ix);
+/* The same build for rows that are ALREADY IN HBM (BASELINE config 5: a 125 M x 1024 shard is 256 GB of the 288 GB -- it is
+ * produced on the GPU and can neither visit host memory nor exist twice).  Device pointers; every call is synchronous.
+ *   training   knnx_ivfb_set_sample_device (borrows the caller's sample rows), knnx_ivfb_seed_from_sample (initial centroids and
+ *              re-seeding of empty lists: centroid list_ids[i] := sample row sample_rows[i]; host index arrays),
+ *              knnx_ivfb_lloyd = one whole iteration (assign, counting sort on the host, update); sizes_out [nlist] or NULL
+ *   pass 1     knnx_ivfb_assign_device: lists_dev[i] = list of row i, list sizes accumulate in the builder ->
+ *              knnx_ivfb_list_sizes (host int64 [nlist]; reset != 0 clears the counters)
+ *   pass 2     knnx_ivf_begin(sizes) ... knnx_ivf_add_assigned_device (row i carries id id0 + i and takes the next free
+ *              position of its list) ... knnx_ivf_end
+ * knnx_ivf_add_assigned (host) and _device both refuse a list id out of range, a position outside its list and a (list,
+ * position) used twice; knnx_ivf_end refuses a list that did not receive its announced number of rows. */
+int knnx_ivfb_set_sample_device(knnx_ivf_builder* b, const void* rows_dev_f16, int64_t n);
+int knnx_ivfb_seed_from_sample(knnx_ivf_builder* b, const int32_t* list_ids, const int64_t* sample_rows, int64_t n);
+int knnx_ivfb_lloyd(knnx_ivf_builder* b, int64_t* sizes_out);
+int knnx_ivfb_assign_device(knnx_ivf_builder* b, const void* rows_dev_f16, int64_t n, int32_t* lists_dev);
+int knnx_ivfb_list_sizes(knnx_ivf_builder* b, int64_t* sizes_out, int reset);
+int knnx_ivf_add_assigned_device(knnx_index* ix, const void* rows_dev_f16, int64_t n, int64_t id0, const int32_t* lists_dev);
 
 /* Merge P per-shard results ([P, n, k] each, already global ids) into the top-k [n, k];
  * the step after the RCCL all-gather of a row-sharded index.  Device buffers. */
@@ -170,6 +187,13 @@ int knnx_profile_get(knnx_index* ix, int64_t* scan_launches, double* scan_ms);
  * row r = L2-normalised N(0,1)^d from a counter-based hash of (seed, r, col), rounded to
  * fp16.  Re-derivable on the CPU (oracle/knn_oracle.py:synth_rows). */
 int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed);
+
+/* Benchmark corpora generated straight into caller HBM (fp16 [n, d]; dst row i = corpus row row_begin + i * row_stride; any row
+ * is re-derivable on the CPU: oracle/knn_oracle.py).  kind 0: the isotropic corpus of knnx_synth_fill (row_stride 1 only);
+ * kind 1: BASELINE config 5's overlapping mixture of n_clusters Gaussians in a 32-dimensional latent space, where IVF recall
+ * is < 1 at small nprobe and rises with it.  `stream`: hipStream_t or NULL; synchronous. */
+int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed,
+                           int kind, int64_t n_clusters, void* stream);
 
 const char* knnx_last_error(void);
 

@@ -214,3 +214,47 @@ def planted_queries(row_ids, d: int, seed: int, noise: float = 0.1, qseed: int =
     q = x + noise * rng.standard_normal(x.shape).astype(np.float32) / np.sqrt(np.float32(d))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     return q.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE config 5's corpus (an overlapping mixture of Gaussians, so that IVF recall depends on nprobe), bit-identical
+# to knn_synth_mix_kernel (clip-retrieval_amd/csrc/knn_kernels.hip); see the recipe in that kernel's header comment
+# ----------------------------------------------------------------------------------------------
+MIX_M = 32
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_SALT_P, _SALT_C, _SALT_MU, _SALT_Z, _SALT_N = (np.uint64(v) for v in (0x50, 0xC1, 0x3D, 0x2A, 0x4E))
+
+
+def _s8(seed, idx):
+    with np.errstate(over="ignore"):
+        h = _mix64(np.uint64(seed) ^ (np.asarray(idx, dtype=np.uint64) * _GOLD))
+    b = np.uint64(0xFF)
+    return ((h & b) + ((h >> np.uint64(8)) & b) + ((h >> np.uint64(16)) & b) + ((h >> np.uint64(24)) & b)).astype(np.int64) - 510
+
+
+def mixture_cluster(rows, seed: int, n_clusters: int) -> np.ndarray:
+    """The mixture component of every corpus row (int64)."""
+    r = np.asarray(rows, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = _mix64((np.uint64(seed) ^ _SALT_C) ^ (r * _GOLD))
+        t = ((h & np.uint64(0xFFFFFFFF)) * (h >> np.uint64(32))) >> np.uint64(32)
+        c = (t * np.uint64(n_clusters)) >> np.uint64(32)
+    return c.astype(np.int64)
+
+
+def synth_mixture_rows(rows, d: int, seed: int, n_clusters: int) -> np.ndarray:
+    """fp16 [len(rows), d] of the config-5 corpus."""
+    rows = np.asarray(rows, dtype=np.uint64).reshape(-1)
+    seed = np.uint64(seed)
+    c = mixture_cluster(rows, int(seed), n_clusters).astype(np.uint64)
+    j = np.arange(MIX_M, dtype=np.uint64).reshape(1, -1)
+    cols = np.arange(d, dtype=np.uint64).reshape(1, -1)
+    with np.errstate(over="ignore"):
+        mu = _s8(seed ^ _SALT_MU, c.reshape(-1, 1) * np.uint64(MIX_M) + j)
+        z = _s8(seed ^ _SALT_Z, rows.reshape(-1, 1) * np.uint64(MIX_M) + j)
+        lat = mu + (1 + (c % np.uint64(3)).astype(np.int64)).reshape(-1, 1) * z          # [n, M]
+        P = _s8(seed ^ _SALT_P, (j.reshape(-1, 1) * np.uint64(d) + cols))                 # [M, d]
+        v = lat @ P + 1024 * _s8(seed ^ _SALT_N, rows.reshape(-1, 1) * np.uint64(d) + cols)
+    ss = (v * v).sum(axis=1, keepdims=True)
+    scale = 1.0 / np.sqrt(ss.astype(np.float64))
+    return (v.astype(np.float64) * scale).astype(np.float32).astype(np.float16)

@@ -664,3 +664,187 @@ def test_ivf_nprobe_above_64(nprobe):
     Do, Io = ora.search(q, 40, min(nprobe, nlist))
     _check(D, I, Do, Io, f"ivf nprobe={nprobe}")
     ix.close()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# round 3: device-resident IVF build (BASELINE config 5), the mixture corpus, long range lists, build validation
+# ------------------------------------------------------------------------------------------------------------
+def _torch_alloc(nbytes):
+    import torch
+
+    t = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda:0")
+    return t.data_ptr(), t
+
+
+@pytest.mark.parametrize("d,n_clusters", [(1024, 64), (256, 7), (768, 5000)])
+def test_mixture_corpus_is_bit_identical_to_the_cpu_derivation(d, n_clusters):
+    """knnx_synth_rows_device kind 1 (config 5's overlapping mixture) against oracle.knn_oracle.synth_mixture_rows, with a
+    row offset and a stride; kind 0 against synth_rows through the same entry point."""
+    import torch
+
+    from clip_retrieval_amd.knn import synth_rows_device
+    from oracle.knn_oracle import synth_mixture_rows, synth_rows
+
+    n, row0, stride, seed = 1500, 123_456_789, 977, 5
+    buf = torch.empty((n, d), dtype=torch.float16, device="cuda:0")
+    synth_rows_device(buf.data_ptr(), row0, n, d, seed, kind=1, n_clusters=n_clusters, row_stride=stride)
+    got = buf.cpu().numpy()
+    want = synth_mixture_rows(row0 + stride * np.arange(n), d, seed, n_clusters)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), f"{(got != want).sum()} halves differ"
+    nrm = np.linalg.norm(got.astype(np.float32), axis=1)
+    assert np.abs(nrm - 1).max() < 2e-3
+    synth_rows_device(buf.data_ptr(), 1000, n, d, 3, kind=0)
+    assert np.array_equal(buf.cpu().numpy().view(np.uint16), synth_rows(1000 + np.arange(n), d, 3).view(np.uint16))
+
+
+def test_ivf_build_from_device_rows_equals_the_host_build():
+    """build_ivf_index_device (rows produced on the GPU, two passes, positions assigned in row order) must lay out exactly
+    the index build_ivf_index makes from the same rows and centroids: same lists, same search results as the IVF oracle,
+    same reconstruct; k-means on the device-resident sample must not lose to its seeding."""
+    import torch
+
+    from clip_retrieval_amd.knn import IvfBuilder, build_ivf_index, build_ivf_index_device, synth_rows_device
+    from oracle.knn_oracle import IVFFlatOracle, synth_mixture_rows
+
+    d, n, nlist, seed, ncl = 1024, 40_000, 128, 5, 16
+
+    def fill(dst, row0, count, stride):
+        synth_rows_device(dst, row0, count, d, seed, kind=1, n_clusters=ncl, row_stride=stride)
+
+    ix, st = build_ivf_index_device(fill, n, d, nlist, nprobe=8, niter=4, seed=1, chunk=16_384, alloc=_torch_alloc, keep_lists=True,
+                                    points_per_centroid=64)
+    assert ix.ntotal == n and ix.nlist == nlist and st["n_sample"] == 8192
+    assert int(st["list_sizes"].sum()) == n and np.array_equal(np.bincount(ix.ivf_lists, minlength=nlist), st["list_sizes"])
+    x = synth_mixture_rows(np.arange(n), d, seed, ncl)
+    # the centroids the device training arrived at are not exposed by the index: train again (deterministic: same sample,
+    # same seed, fixed summation order) and assign through the host-pointer entry point of the same kernel
+    cent = None
+    b = IvfBuilder(d, nlist)
+    try:
+        from clip_retrieval_amd.knn import train_ivf_centroids_device
+
+        sample = torch.from_numpy(x[:: n // 8192][:8192].copy()).to("cuda:0")
+        train_ivf_centroids_device(b, sample.data_ptr(), 8192, niter=4, seed=1)
+        cent = b.centroids()
+        lists_host = b.assign(x)
+    finally:
+        b.close()
+    assert np.array_equal(lists_host, ix.ivf_lists), "device pass 1 and the host-pointer assignment disagree"
+    obj_seed = float((x.astype(np.float32) @ x[:: n // 8192][:nlist].astype(np.float32).T).max(1).mean())
+    obj = float((x.astype(np.float32) @ cent.astype(np.float32).T).max(1).mean())
+    assert obj > obj_seed, (obj, obj_seed)
+    ref = build_ivf_index(x, nlist, nprobe=8, centroids=cent)
+    ora = IVFFlatOracle(d, cent, ix.ivf_lists, x)
+    q = _queries(33, d, seed=9, x=x)
+    for npb in (1, 8, 128):
+        ix.nprobe = npb
+        ref.nprobe = npb
+        D, I = ix.search(q, 40)
+        Dr, Ir = ref.search(q, 40)
+        Do, Io = ora.search(q, 40, npb)
+        _check(D, I, Do, Io, f"device-built ivf nprobe={npb}")
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr), "device-built and host-built index answer differently"
+    ids = np.array([0, 1, 17_123, n - 1])
+    assert np.array_equal(ix.reconstruct_batch(ids), x[ids].astype(np.float32))
+    ix.close()
+    ref.close()
+
+
+def test_ivf_add_assigned_refuses_bad_slots():
+    """a position past its list or a (list, position) used twice must be refused, not scattered over a neighbour."""
+    from clip_retrieval_amd._lib import HipLibraryError, check
+    from clip_retrieval_amd.knn import Mi355xIndex
+
+    d, nlist = 256, 4
+    cent = _data(nlist, d, 1)
+    rows = _data(6, d, 2)
+    sizes = np.array([2, 1, 0, 3], dtype=np.int64)
+
+    def begin():
+        ix = Mi355xIndex(d)
+        check(ix._lib, ix._lib.knnx_ivf_begin(ix._h, nlist, cent.ctypes.data, sizes.ctypes.data), "knnx")
+        return ix
+
+    def add(ix, r, ids, lists, pos):
+        r = np.ascontiguousarray(r)
+        ids, lists, pos = np.asarray(ids, np.int64), np.asarray(lists, np.int32), np.asarray(pos, np.int32)
+        return ix._lib.knnx_ivf_add_assigned(ix._h, r.ctypes.data, len(ids), ids.ctypes.data, lists.ctypes.data, pos.ctypes.data)
+
+    ix = begin()
+    assert add(ix, rows[:1], [0], [1], [1]) == -1, "position 1 of a 1-row list"
+    assert add(ix, rows[:1], [0], [2], [0]) == -1, "a row for an empty list"
+    assert add(ix, rows[:2], [0, 1], [0, 0], [1, 1]) == -1, "the same slot twice in one call"
+    assert add(ix, rows[:2], [0, 1], [0, 0], [0, 1]) == 0
+    assert add(ix, rows[2:3], [2], [0], [1]) == -1, "a slot that an earlier call filled"
+    assert add(ix, rows[2:6], [2, 3, 4, 5], [1, 3, 3, 3], [0, 2, 0, 1]) == 0
+    check(ix._lib, ix._lib.knnx_ivf_end(ix._h), "knnx")
+    ix.nprobe = nlist
+    D, I = ix.search(rows.astype(np.float32), 1)
+    assert np.array_equal(I[:, 0], np.arange(6)), "every row finds itself after the refused calls"
+    ix.close()
+    ix = begin()
+    assert add(ix, rows[:2], [0, 1], [0, 0], [0, 1]) == 0
+    with pytest.raises(HipLibraryError):
+        check(ix._lib, ix._lib.knnx_ivf_end(ix._h), "knnx")  # fewer rows than announced
+    ix.close()
+
+
+def test_range_search_long_hit_lists_go_through_the_radix_sort():
+    """> 4096 hits per query: ids must still leave ascending and complete (flat and IVF), ADVICE r2."""
+    from clip_retrieval_amd.knn import Mi355xIndex, build_ivf_index
+    from oracle.knn_oracle import FlatIPOracle, IVFFlatOracle
+
+    d, n = 256, 70_000
+    x = _data(n, d, 5)
+    q = _queries(3, d, 6, x)
+    ix, o = Mi355xIndex(d, id_base=1_000_000), FlatIPOracle(d)
+    ix.add(x)
+    o.add(x)
+    for thr in (0.0, -0.05, 0.12):
+        lims, D, I = ix.range_search(q, thr)
+        lo, Do, Io = o.range_search(q, thr)
+        s = o.scores(q)
+        for i in range(q.shape[0]):
+            got, want = I[lims[i]:lims[i + 1]] - 1_000_000, Io[lo[i]:lo[i + 1]]
+            assert (np.diff(got) > 0).all(), "ids ascending"
+            for r in set(got.tolist()) ^ set(want.tolist()):
+                assert abs(s[i, r] - thr) < 2e-6
+            both = np.intersect1d(got, want)
+            assert np.allclose(D[lims[i]:lims[i + 1]][np.isin(got, both)], s[i, both], atol=1e-5), "scores travel with their ids"
+        assert max(np.diff(lims)) > 4096 or thr > 0.1
+    ix.close()
+    nlist = 16
+    cent = x[:nlist]
+    iv = build_ivf_index(x, nlist, nprobe=9, centroids=cent)
+    ora = IVFFlatOracle(d, cent, iv.ivf_lists, x)
+    lims, D, I = iv.range_search(q, -0.02)
+    lo, Do, Io = ora.range_search(q, -0.02, 9)
+    assert max(np.diff(lims)) > 4096
+    for i in range(q.shape[0]):
+        got, want = I[lims[i]:lims[i + 1]], Io[lo[i]:lo[i + 1]]
+        assert (np.diff(got) > 0).all()
+        assert len(set(got.tolist()) ^ set(want.tolist())) <= 2
+    iv.close()
+
+
+def test_large_k_with_a_tight_cluster_of_near_duplicates():
+    """100 near-duplicates of the query and nothing else close -- the threshold descent stalls at 100 < k hits for
+    several scans; a flat index must keep lowering the threshold (and answer exactly) instead of fetching the whole index."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d, n, k = 256, 50_000, 300
+    rng = np.random.default_rng(3)
+    x = _data(n, d, 8).astype(np.float32)
+    base = x[7].copy()
+    dup = rng.choice(n, 100, replace=False)
+    x[dup] = base + 1e-3 * rng.standard_normal((100, d)).astype(np.float32) / np.sqrt(d)
+    x = x.astype(np.float16)
+    ix, o = Mi355xIndex(d), FlatIPOracle(d)
+    ix.add(x)
+    o.add(x)
+    q = base.reshape(1, -1).astype(np.float32)
+    D, I = ix.search(q, k)
+    Do, Io = o.search(q, k)
+    _check(D, I, Do, Io, "tight cluster, k=300")
+    ix.close()
