@@ -53,6 +53,7 @@ SIGNATURES = {
     "knnx_ivf_set_lists": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "knnx_ivf_set_nprobe": (C.c_int, [_P, C.c_int]),
     "knnx_ivf_nlist": (C.c_int, [_P]),
+    "knnx_ivf_last_scan_tiles": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "knnx_ivfb_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "knnx_ivfb_destroy": (None, [_P]),
     "knnx_ivfb_set_centroids": (C.c_int, [_P, _P]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "clipx_embed_dim": (C.c_int, [_P]),
     "clipx_gemm_bf16_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_gemm_bf16_ex_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "clipx_gemm_f16_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "clipx_attention_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_attention_dh_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_layernorm_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),

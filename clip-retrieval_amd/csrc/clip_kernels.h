@@ -13,7 +13,9 @@ enum GemmEpilogue {
   EPI_BIAS_GELU_BF16 = 2,   // out bf16 = gelu_erf(acc + bias)                   (fc1, open_clip LAION)
   EPI_BIAS_RESID_F32 = 3,   // out f32 [M,N] += acc + bias   (in place residual) (out_proj, fc2)
   EPI_TABLE_F32 = 4,        // out f32 = acc + table[m % T][n]                   (patch embed + cls/pos)
-  EPI_RAW_F32 = 5           // internal (split-K): out f32 [M,N] = acc, no bias; the reduction kernel applies the epilogue
+  EPI_RAW_F32 = 5,          // internal (split-K): out f32 [M,N] = acc, no bias; the reduction kernel applies the epilogue
+  EPI_BIAS_RESID_H16 = 6    // out fp16 [M,N] = fp16(f32(out) + (acc + bias)): the encoder's residual stream lives in IEEE fp16
+                            // (out_proj, fc2): a third of the bytes of the f32 read-modify-write + bf16 shadow of EPI 3
 };
 
 struct GemmArgs {
@@ -35,6 +37,8 @@ struct GemmArgs {
   bf16* out16;            // EPI_BIAS_RESID_F32: also store the new x row as bf16 here (null: do not)
   float* splitk_ws;       // device scratch for split-K partial products (null: never split), splitk_ws_bytes of it
   size_t splitk_ws_bytes;
+  int f16;                // A and W hold IEEE fp16 instead of bf16 (v_mfma_f32_32x32x16_f16, same rate): the LayerNorm-folded
+                          // GEMMs, whose A operand is the fp16 residual stream itself.  bf16-output epilogues (0..2) and RAW only.
 };
 
 // number of 256-row m-tiles variant 3 hands to the 256x256 kernel for an [M, N] output
@@ -42,19 +46,20 @@ int gemm256_bulk_mtiles(int M, int N, int n_cu);
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 
-// x f32 [M, d] -> y (bf16 or f32) [M, d]; one wave per row; d % 256 == 0, d <= 2048.  y16 (f32 output only, may be null):
-// also the bf16 rounding of y (ln_pre of the vision tower: the residual stream's bf16 shadow, see launch_rowstats)
-hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, int M,
+// x f32 [M, d] -> y [M, d]; out_kind 0: f32, 1: bf16, 2: IEEE fp16 (ln_pre of the vision tower writes the fp16 residual
+// stream); one wave per row; d % 256 == 0, d <= 2048.  y16 (f32 output only, may be null): also the bf16 rounding of y
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_kind, int M,
                             int d, float eps, hipStream_t st, bf16* y16 = nullptr);
 
-// LayerNorm statistics of the bf16 shadow of the residual stream: rstd[m] = 1 / sqrt(var(x16[m, :]) + eps) (two-pass, fp32).
-// The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias absorbs beta:
-// clipx_api.hip fold_layernorm), whose epilogue multiplies by rstd[m].  One wave per row.
-hipError_t launch_rowstats(const bf16* x16, float* rstd, int M, int d, float eps, hipStream_t st);
+// LayerNorm statistics of the 16-bit residual stream rows (f16 != 0: IEEE fp16, else bf16): rstd[m] = 1 / sqrt(var(x16[m, :]) + eps)
+// (two-pass, fp32).  The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias
+// absorbs beta: clipx_api.hip fold_layernorm), whose epilogue multiplies by rstd[m].  One wave per row.
+hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16 = 0);
 
-// LayerNorm-folded weights: Wf[n, k] = bf16(W[n,k] gamma[k] - mean_k(W[n,:] gamma)), cf[n] = bias[n] + sum_k beta[k] W[n,k]
+// LayerNorm-folded weights: Wf[n, k] = r16(W[n,k] gamma[k] - mean_k(W[n,:] gamma)), cf[n] = bias[n] + sum_k beta[k] W[n,k];
+// r16 = bf16 rounding, or IEEE fp16 when f16 != 0
 hipError_t launch_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, bf16* Wf, float* cf,
-                                 int N, int K, hipStream_t st);
+                                 int N, int K, hipStream_t st, int f16 = 0);
 hipError_t launch_fill_f32(float* p, float v, int64_t n, hipStream_t st);
 
 // pixels -> bf16 patch matrix [B*T, Kp] (row b*T is the all-zero class-token row; k = c*P*P + iy*P + ix)
@@ -65,15 +70,17 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 // qkv bf16 [B*T, 3*H*dh] -> out bf16 [B*T, H*dh]; softmax(q k^T / sqrt(dh) [+ causal]) v, head dim dh = 64 or 80
 hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st);
 
-// ids int32 [B, T] -> x f32 [B*T, d] = tok_emb[id] + pos_emb[t], and its bf16 shadow x16 (may be null)
+// ids int32 [B, T] -> tok_emb[id] + pos_emb[t] as x f32 [B*T, d] (may be null) and / or x16 [B*T, d] (may be null; bf16, or
+// IEEE fp16 when x16_f16 != 0: the text tower's residual stream)
 hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T,
-                             int d, int vocab, hipStream_t st, bf16* x16 = nullptr);
+                             int d, int vocab, hipStream_t st, void* x16 = nullptr, int x16_f16 = 0);
 
 // pooled row (CLS, or argmax(ids) for text) -> LayerNorm -> @ proj^T [E, d] -> / L2 norm -> fp16 [B, E]
+// x: the residual stream, f32 [B*T, d] or (x_f16 != 0) IEEE fp16
 // scratch: B * E floats of device memory (the un-normalised projection between the two kernels)
-hipError_t launch_tail(const float* x, const int32_t* ids_or_null, const float* gamma, const float* beta,
+hipError_t launch_tail(const void* x, const int32_t* ids_or_null, const float* gamma, const float* beta,
                        const bf16* proj, uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d,
-                       int E, float eps, hipStream_t st);
+                       int E, float eps, hipStream_t st, int x_f16 = 0);
 
 hipError_t launch_f32_to_bf16(const float* in, bf16* out, int64_t n, hipStream_t st);
 // conv weight [width, 3*P*P] f32 -> bf16 [width, Kp] zero padded

@@ -39,7 +39,7 @@ constexpr int G_GROUP_M = 8;
 // DEEP (GLDS only): 4-deep LDS ring (128 KiB, one workgroup per CU), the DMA of K-tile t+4 issued at K-tile t's barrier, ONE
 // barrier per K-tile, software-pipelined fragment reads.  The launches this kernel serves have few workgroups (the peeled
 // 257th m-tile of ViT-L/14: 16..64 workgroups; B = 1 queries), so nothing else runs on the CU to hide DMA or LDS latency.
-template <int EPI, bool GLDS, bool DEEP = false>
+template <int EPI, bool GLDS, bool DEEP = false, bool F16 = false>  // F16: operands are IEEE fp16 (bits travel as "bf16" pointers)
 __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int M, int N,
@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = mfma_32x32x16<F16>(__builtin_bit_cast(frag_t, wf[i]), __builtin_bit_cast(frag_t, af[j]), acc[i][j]);
     }
   };
 
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
 #define D_WAIT_PREV() asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
 #define D_MFMA(F)                                                                                                   \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =            \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F[i]), __builtin_bit_cast(bf16x8, F[2 + j]), acc[i][j], 0, 0, 0); \
+      mfma_32x32x16<F16>(F[i], F[2 + j], acc[i][j]);                                                                   \
   __builtin_amdgcn_sched_barrier(0);
       // one DMA: M0 = LDS address of the piece (SGPR), 32-bit lane offset, SGPR base of the K-tile
 #define D_DMA(off, base, dst)                                                                                         \
@@ -291,27 +292,25 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
   }
 }
 
-template <int EPI>
+template <int EPI, bool F16 = false>
 static hipError_t launch_gemm_epi(const GemmArgs& g, hipStream_t st) {
   const int ntm = (g.M + G_TM - 1) / G_TM, ntn = g.N / G_TN;
   const dim3 grid(ntm * ntn), block(256);
   const size_t smem = 2 * G_STAGE_BYTES;
-  const int cu = g.n_cu > 0 ? g.n_cu : 256;
   const bool small_off = (size_t)g.M * g.K * 2 < ((size_t)1 << 32) && (size_t)g.N * g.K * 2 < ((size_t)1 << 32);
-  (void)cu;
   if (g.variant == 1 && g.K >= 2 * G_BK && small_off) {
-    auto kern = gemm_bf16_kernel<EPI, true, true>;
+    auto kern = gemm_bf16_kernel<EPI, true, true, F16>;
     const size_t smem4 = 4 * G_STAGE_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, smem4, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
   } else if (g.variant == 1) {
-    auto kern = gemm_bf16_kernel<EPI, true>;
+    auto kern = gemm_bf16_kernel<EPI, true, false, F16>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
   } else {
-    auto kern = gemm_bf16_kernel<EPI, false>;
+    auto kern = gemm_bf16_kernel<EPI, false, false, F16>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
@@ -367,7 +366,7 @@ static int splitk_factor(const GemmArgs& g) {
 template <int EPI>
 static hipError_t launch_splitk_epi(const GemmArgs& g, int S, hipStream_t st) {
   const int ntm = (g.M + G_TM - 1) / G_TM, ntn = g.N / G_TN;
-  auto kern = gemm_bf16_kernel<EPI_RAW_F32, true, true>;
+  auto kern = g.f16 ? gemm_bf16_kernel<EPI_RAW_F32, true, true, true> : gemm_bf16_kernel<EPI_RAW_F32, true, true, false>;
   const size_t smem4 = 4 * G_STAGE_BYTES;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
   if (e != hipSuccess) return e;
@@ -388,7 +387,16 @@ static hipError_t launch_gemm128(const GemmArgs& g, hipStream_t st) {
       case EPI_BIAS_QGELU_BF16: return launch_splitk_epi<EPI_BIAS_QGELU_BF16>(g, S, st);
       case EPI_BIAS_GELU_BF16: return launch_splitk_epi<EPI_BIAS_GELU_BF16>(g, S, st);
       case EPI_BIAS_RESID_F32: return launch_splitk_epi<EPI_BIAS_RESID_F32>(g, S, st);
+      case EPI_BIAS_RESID_H16: return launch_splitk_epi<EPI_BIAS_RESID_H16>(g, S, st);
       default: break;
+    }
+  }
+  if (g.f16) {  // fp16 operands exist for the bf16-output epilogues only (the LayerNorm-folded GEMMs)
+    switch (g.epi) {
+      case EPI_BIAS_BF16: return launch_gemm_epi<EPI_BIAS_BF16, true>(g, st);
+      case EPI_BIAS_QGELU_BF16: return launch_gemm_epi<EPI_BIAS_QGELU_BF16, true>(g, st);
+      case EPI_BIAS_GELU_BF16: return launch_gemm_epi<EPI_BIAS_GELU_BF16, true>(g, st);
+      default: return hipErrorInvalidValue;
     }
   }
   switch (g.epi) {
@@ -396,6 +404,7 @@ static hipError_t launch_gemm128(const GemmArgs& g, hipStream_t st) {
     case EPI_BIAS_QGELU_BF16: return launch_gemm_epi<EPI_BIAS_QGELU_BF16>(g, st);
     case EPI_BIAS_GELU_BF16: return launch_gemm_epi<EPI_BIAS_GELU_BF16>(g, st);
     case EPI_BIAS_RESID_F32: return launch_gemm_epi<EPI_BIAS_RESID_F32>(g, st);
+    case EPI_BIAS_RESID_H16: return launch_gemm_epi<EPI_BIAS_RESID_H16>(g, st);
     case EPI_TABLE_F32: return launch_gemm_epi<EPI_TABLE_F32>(g, st);
     default: return hipErrorInvalidValue;
   }
@@ -425,6 +434,7 @@ int gemm256_bulk_mtiles(int M, int N, int n_cu) {
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
   if ((g.epi == EPI_BIAS_BF16 || g.epi == EPI_BIAS_QGELU_BF16 || g.epi == EPI_BIAS_GELU_BF16) && !g.rowscale) return hipErrorInvalidValue;
+  if (g.f16 && g.epi != EPI_BIAS_BF16 && g.epi != EPI_BIAS_QGELU_BF16 && g.epi != EPI_BIAS_GELU_BF16) return hipErrorInvalidValue;
   if (g.variant >= 2 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
     const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
     // small problems (query-side B = 1: M = 257 or 77 rows) would put one 256x256 tile on each of a handful of CUs;
@@ -446,7 +456,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       r.splitk_ws = nullptr;  // rows of one large batch are computed the same way whichever kernel they land in
       r.A = g.A + (size_t)b.M * g.K;
       r.M = g.M - b.M;
-      const size_t esz = (g.epi == EPI_BIAS_RESID_F32 || g.epi == EPI_TABLE_F32) ? 4 : 2;
+      const size_t esz = (g.epi == EPI_BIAS_RESID_F32 || g.epi == EPI_TABLE_F32) ? 4 : 2;  // (EPI_BIAS_RESID_H16: fp16 rows)
       r.out = reinterpret_cast<char*>(g.out) + (size_t)b.M * g.N * esz;
       r.row0 = g.row0 + b.M;
       if (g.rowscale) r.rowscale = g.rowscale + b.M;
@@ -462,7 +472,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
 // =============================================================================================
 // LayerNorm: one wave per row, fp32 statistics (two-pass in registers)
 // =============================================================================================
-template <int NV, bool OUT_BF16>  // d = NV * 256
+template <int NV, int OUT>  // d = NV * 256; OUT 0: f32 (+ optional bf16 copy), 1: bf16, 2: IEEE fp16
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, void* __restrict__ y, int M,
                                                        float eps, bf16* __restrict__ y16) {
@@ -498,10 +508,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     o.y = (v[e].y - mean) * rstd * g4.y + b4.y;
     o.z = (v[e].z - mean) * rstd * g4.z + b4.z;
     o.w = (v[e].w - mean) * rstd * g4.w + b4.w;
-    if (OUT_BF16) {
+    if (OUT == 1) {
       bf16x4 ob;
       ob[0] = (bf16)o.x; ob[1] = (bf16)o.y; ob[2] = (bf16)o.z; ob[3] = (bf16)o.w;
       reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(y) + (size_t)row * d)[c4] = ob;
+    } else if (OUT == 2) {
+      f16x4 oh;
+      oh[0] = (_Float16)o.x; oh[1] = (_Float16)o.y; oh[2] = (_Float16)o.z; oh[3] = (_Float16)o.w;
+      reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(y) + (size_t)row * d)[c4] = oh;
     } else {
       reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (size_t)row * d)[c4] = o;
       if (y16) {
@@ -514,20 +528,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // rstd of the bf16 shadow rows (see clip_kernels.h: launch_rowstats); d = NV * 512: a lane holds NV x 8 consecutive values
-template <int NV2>  // d = NV2 * 256 (NV2 x 4 values per lane)
-__global__ __launch_bounds__(256) void rowstats_kernel(const bf16* __restrict__ x16, float* __restrict__ rstd, int M, float eps) {
+template <int NV2, bool F16>  // d = NV2 * 256 (NV2 x 4 values per lane); F16: rows are IEEE fp16, else bf16
+__global__ __launch_bounds__(256) void rowstats_kernel(const void* __restrict__ x16, float* __restrict__ rstd, int M, float eps) {
   constexpr int d = NV2 * 256;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const bf16x4* xr = reinterpret_cast<const bf16x4*>(x16 + (size_t)row * d);
+  const uint2* xr = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x16) + (size_t)row * d);
   float v[NV2][4];
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < NV2; ++e) {
-    const bf16x4 h = xr[lane + 64 * e];
+    const uint2 raw = xr[lane + 64 * e];
+    if (F16) {
+      const f16x4 h = __builtin_bit_cast(f16x4, raw);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[e][j] = (float)h[j];
+      for (int j = 0; j < 4; ++j) v[e][j] = (float)h[j];
+    } else {
+      const bf16x4 h = __builtin_bit_cast(bf16x4, raw);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[e][j] = (float)h[j];
+    }
     s += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -542,10 +563,14 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const bf16* __restrict__ 
   if (lane == 0) rstd[row] = 1.f / sqrtf(q * (1.f / d) + eps);
 }
 
-hipError_t launch_rowstats(const bf16* x16, float* rstd, int M, int d, float eps, hipStream_t st) {
+hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16) {
   if (M <= 0) return hipSuccess;
   const dim3 grid((M + 3) / 4), block(256);
-#define RS_CASE(NV) case NV * 256: hipLaunchKernelGGL((rowstats_kernel<NV>), grid, block, 0, st, x16, rstd, M, eps); break;
+#define RS_CASE(NV)                                                                                        \
+  case NV * 256:                                                                                           \
+    if (f16) hipLaunchKernelGGL((rowstats_kernel<NV, true>), grid, block, 0, st, x16, rstd, M, eps);       \
+    else hipLaunchKernelGGL((rowstats_kernel<NV, false>), grid, block, 0, st, x16, rstd, M, eps);          \
+    break;
   switch (d) {
     RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
     default: return hipErrorInvalidValue;
@@ -557,7 +582,7 @@ hipError_t launch_rowstats(const bf16* x16, float* rstd, int M, int d, float eps
 // one workgroup per output row n of W [N, K]
 __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ bias,
-                                                            bf16* __restrict__ Wf, float* __restrict__ cf, int K) {
+                                                            bf16* __restrict__ Wf, float* __restrict__ cf, int K, int f16) {
   __shared__ float red[8];
   const int n = blockIdx.x, tid = threadIdx.x;
   const float* w = W + (size_t)n * K;
@@ -570,12 +595,16 @@ __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __rest
   if ((tid & 63) == 0) { red[tid >> 6] = sg; red[4 + (tid >> 6)] = sb; }
   __syncthreads();
   const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
-  for (int k = tid; k < K; k += 256) Wf[(size_t)n * K + k] = (bf16)(w[k] * gamma[k] - mean);
+  for (int k = tid; k < K; k += 256) {
+    const float v = w[k] * gamma[k] - mean;
+    if (f16) reinterpret_cast<_Float16*>(Wf)[(size_t)n * K + k] = (_Float16)v;
+    else Wf[(size_t)n * K + k] = (bf16)v;
+  }
   if (tid == 0) cf[n] = bias[n] + (red[4] + red[5] + red[6] + red[7]);
 }
 hipError_t launch_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, bf16* Wf, float* cf,
-                                 int N, int K, hipStream_t st) {
-  hipLaunchKernelGGL(fold_layernorm_kernel, dim3(N), dim3(256), 0, st, W, gamma, beta, bias, Wf, cf, K);
+                                 int N, int K, hipStream_t st, int f16) {
+  hipLaunchKernelGGL(fold_layernorm_kernel, dim3(N), dim3(256), 0, st, W, gamma, beta, bias, Wf, cf, K, f16);
   return hipGetLastError();
 }
 __global__ void fill_f32_kernel(float* __restrict__ p, float v, int64_t n) {
@@ -587,14 +616,15 @@ hipError_t launch_fill_f32(float* p, float v, int64_t n, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, int M, int d,
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_kind, int M, int d,
                             float eps, hipStream_t st, bf16* y16) {
   if (M <= 0) return hipSuccess;
   const dim3 grid((M + 3) / 4), block(256);
 #define LN_CASE(NV)                                                                                           \
   case NV * 256:                                                                                              \
-    if (out_bf16) hipLaunchKernelGGL((layernorm_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, y, M, eps, (bf16*)nullptr); \
-    else hipLaunchKernelGGL((layernorm_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, y, M, eps, y16);    \
+    if (out_kind == 1) hipLaunchKernelGGL((layernorm_kernel<NV, 1>), grid, block, 0, st, x, gamma, beta, y, M, eps, (bf16*)nullptr); \
+    else if (out_kind == 2) hipLaunchKernelGGL((layernorm_kernel<NV, 2>), grid, block, 0, st, x, gamma, beta, y, M, eps, (bf16*)nullptr); \
+    else hipLaunchKernelGGL((layernorm_kernel<NV, 0>), grid, block, 0, st, x, gamma, beta, y, M, eps, y16);    \
     break;
   switch (d) {
     LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
@@ -983,7 +1013,7 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
 // =============================================================================================
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
                                                         const float* __restrict__ pos, float* __restrict__ x, int BT,
-                                                        int T, int d, int vocab, bf16* __restrict__ x16) {
+                                                        int T, int d, int vocab, void* __restrict__ x16, int x16_f16) {
   const int d4 = d / 4;
   const int64_t total = (int64_t)BT * d4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -994,21 +1024,25 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
     const float4 a = reinterpret_cast<const float4*>(tok + (size_t)id * d)[c];
     const float4 p = reinterpret_cast<const float4*>(pos + (size_t)(row % T) * d)[c];
     const float4 o = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
-    reinterpret_cast<float4*>(x + (size_t)row * d)[c] = o;
-    if (x16) {
+    if (x) reinterpret_cast<float4*>(x + (size_t)row * d)[c] = o;
+    if (x16 && x16_f16) {
+      f16x4 h;
+      h[0] = (_Float16)o.x; h[1] = (_Float16)o.y; h[2] = (_Float16)o.z; h[3] = (_Float16)o.w;
+      reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(x16) + (size_t)row * d)[c] = h;
+    } else if (x16) {
       bf16x4 h;
       h[0] = (bf16)o.x; h[1] = (bf16)o.y; h[2] = (bf16)o.z; h[3] = (bf16)o.w;
-      reinterpret_cast<bf16x4*>(x16 + (size_t)row * d)[c] = h;
+      reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(x16) + (size_t)row * d)[c] = h;
     }
   }
 }
 
 hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T, int d,
-                             int vocab, hipStream_t st, bf16* x16) {
+                             int vocab, hipStream_t st, void* x16, int x16_f16) {
   if (B <= 0) return hipSuccess;
   const int64_t total = (int64_t)B * T * (d / 4);
   const int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(text_embed_kernel, dim3(blocks), dim3(256), 0, st, ids, tok_emb, pos_emb, x, B * T, T, d, vocab, x16);
+  hipLaunchKernelGGL(text_embed_kernel, dim3(blocks), dim3(256), 0, st, ids, tok_emb, pos_emb, x, B * T, T, d, vocab, x16, x16_f16);
   return hipGetLastError();
 }
 
@@ -1026,10 +1060,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // Two launches: (E / 64, B) workgroups each LayerNorm the sample's pooled row (recomputed per workgroup: d floats) and
 // produce 64 projection outputs with 4 threads per output; a second kernel normalises.  (One workgroup per sample doing the
 // whole d x E projection took 79 us -- 3 % of a B = 1 image query, 8 % of a text query.)
-__global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict__ x, const int32_t* __restrict__ ids,
+__global__ __launch_bounds__(256) void tail_proj_kernel(const void* __restrict__ x, const int32_t* __restrict__ ids,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const bf16* __restrict__ proj, float* __restrict__ o_raw, int T, int d,
-                                                       int E, float eps) {
+                                                       int E, float eps, int x_f16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* y = reinterpret_cast<float*>(smem);  // [d]
   float* red = y + d;                         // [4]   (all LDS in the one dynamic region: guide G17)
@@ -1047,9 +1081,12 @@ __global__ __launch_bounds__(256) void tail_proj_kernel(const float* __restrict_
     *s_posp = best;
   }
   __syncthreads();
-  const float* xr = x + ((size_t)b * T + *s_posp) * d;
+  const size_t xrow = ((size_t)b * T + *s_posp) * d;
   float s = 0.f;
-  for (int c = tid; c < d; c += 256) { y[c] = xr[c]; s += y[c]; }
+  for (int c = tid; c < d; c += 256) {
+    y[c] = x_f16 ? (float)reinterpret_cast<const _Float16*>(x)[xrow + c] : reinterpret_cast<const float*>(x)[xrow + c];
+    s += y[c];
+  }
   const float mean = block_sum_256(s, red) / d;
   float q = 0.f;
   for (int c = tid; c < d; c += 256) { const float a = y[c] - mean; q += a * a; }
@@ -1088,14 +1125,14 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(const float* __restrict_
   }
 }
 
-hipError_t launch_tail(const float* x, const int32_t* ids_or_null, const float* gamma, const float* beta, const bf16* proj,
+hipError_t launch_tail(const void* x, const int32_t* ids_or_null, const float* gamma, const float* beta, const bf16* proj,
                        uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d, int E, float eps,
-                       hipStream_t st) {
+                       hipStream_t st, int x_f16) {
   if (B <= 0) return hipSuccess;
   if (d % 32 != 0 || !scratch) return hipErrorInvalidValue;
   const size_t smem = (size_t)(d + 8) * sizeof(float);
   hipLaunchKernelGGL(tail_proj_kernel, dim3((E + 63) / 64, B), dim3(256), smem, st, x, ids_or_null, gamma, beta, proj, scratch,
-                     T, d, E, eps);
+                     T, d, E, eps, x_f16);
   hipLaunchKernelGGL(tail_norm_kernel, dim3(B), dim3(256), 0, st, scratch, out_f16, out_f32_or_null, E);
   return hipGetLastError();
 }

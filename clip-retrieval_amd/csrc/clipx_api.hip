@@ -43,8 +43,8 @@ struct LayerW {
   const float *ln1_w, *ln1_b, *qkv_b, *out_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b;  // into the f32 device blob
   bf16 *qkv_w, *out_w, *fc1_w, *fc2_w;                                          // bf16 copies
   // ln_1 is folded into the QKV projection and ln_2 into fc1 (fold_layernorm): qkv_w / fc1_w hold
-  // bf16(W gamma - rowmean(W gamma)) and these are bias + W beta; the GEMM reads the bf16 shadow of the residual stream
-  // and its epilogue multiplies by the row's 1/std (launch_rowstats)
+  // fp16(W gamma - rowmean(W gamma)) (IEEE fp16 bits behind the bf16-typed pointer) and these are bias + W beta; the GEMM
+  // reads the fp16 residual stream itself and its epilogue multiplies by the row's 1/std (launch_rowstats)
   float *qkv_c, *fc1_c;
 };
 
@@ -86,9 +86,13 @@ struct clipx_handle {
   float *mean_dev = nullptr;
 
   // activation workspace (shared by both towers)
-  float* x = nullptr;      // residual stream, f32 [rows, width]
-  float* rstd = nullptr;   // [rows] LayerNorm 1/std of the current x16 rows
-  bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;  // xn = bf16 shadow of x
+  float* x = nullptr;      // f32 [rows, width]: the patch-embedding output in front of ln_pre (vision tower only)
+  float* rstd = nullptr;   // [rows] LayerNorm 1/std of the current residual rows
+  // xn = THE residual stream, IEEE fp16 [rows, width] (fp16 bits behind the bf16-typed pointer): read as the A operand of the
+  // LayerNorm-folded GEMMs (QKV, fc1) and updated in place by the residual epilogues of out_proj / fc2.  Round 3: it replaced
+  // an f32 stream + bf16 shadow (673 MB -> 269 MB moved per residual GEMM at ViT-L/14 bs 256; same accuracy: the stream has
+  // 3 mantissa bits more than the bf16 operands it used to be rounded to).
+  bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;
   bool single_query = false;   // the API call being served is ONE sample (set by the entry points, not per chunk: the last
                                // chunk of a 7-sample call is one sample too, and must equal its row of an unchunked call)
   float* splitk_ws = nullptr;  // partial products of the small-M split-K GEMMs (clip_kernels.hip)
@@ -184,9 +188,9 @@ static int carve_layers(clipx_handle* h, Tower& t, float*& p) {
     if ((r = dev_alloc(h, (void**)&L.fc2_w, w * mlp * sizeof(bf16)))) return r;
     if ((r = dev_alloc(h, (void**)&L.qkv_c, 3 * w * sizeof(float)))) return r;
     if ((r = dev_alloc(h, (void**)&L.fc1_c, mlp * sizeof(float)))) return r;
-    HIPCHK(launch_fold_layernorm(qkv_w32, L.ln1_w, L.ln1_b, L.qkv_b, L.qkv_w, L.qkv_c, (int)(3 * w), (int)w, h->stream));
+    HIPCHK(launch_fold_layernorm(qkv_w32, L.ln1_w, L.ln1_b, L.qkv_b, L.qkv_w, L.qkv_c, (int)(3 * w), (int)w, h->stream, 1));
     HIPCHK(launch_f32_to_bf16(out_w32, L.out_w, (int64_t)(w * w), h->stream));
-    HIPCHK(launch_fold_layernorm(fc1_w32, L.ln2_w, L.ln2_b, L.fc1_b, L.fc1_w, L.fc1_c, (int)mlp, (int)w, h->stream));
+    HIPCHK(launch_fold_layernorm(fc1_w32, L.ln2_w, L.ln2_b, L.fc1_b, L.fc1_w, L.fc1_c, (int)mlp, (int)w, h->stream, 1));
     HIPCHK(launch_f32_to_bf16(fc2_w32, L.fc2_w, (int64_t)(w * mlp), h->stream));
   }
   return 0;
@@ -250,7 +254,7 @@ static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
   const size_t nx = std::max(rowsV * V.width, rowsX * X.width);
   const size_t nqkv = std::max(rowsV * 3 * V.width, rowsX * 3 * X.width);
   const size_t nh = std::max(rowsV * V.mlp, rowsX * X.mlp);
-  if ((r = dev_alloc(h, (void**)&h->x, nx * sizeof(float)))) return r;
+  if ((r = dev_alloc(h, (void**)&h->x, rowsV * V.width * sizeof(float)))) return r;
   if ((r = dev_alloc(h, (void**)&h->xn, nx * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->rstd, std::max(rowsV, rowsX) * sizeof(float)))) return r;
   if ((r = dev_alloc(h, (void**)&h->qkv, nqkv * sizeof(bf16)))) return r;
@@ -367,11 +371,11 @@ struct ProfScope {
 };
 
 static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* W, const float* bias, void* out,
-                    const float* table, int T, int M, int N, int K, int epi, const float* rowscale = nullptr, bf16* out16 = nullptr) {
+                    const float* table, int T, int M, int N, int K, int epi, const float* rowscale = nullptr, bool f16 = false) {
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.table = table; g.T = T;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant; g.n_cu = h->n_cu; g.row0 = 0;
-  g.rowscale = rowscale; g.out16 = out16;
+  g.rowscale = rowscale; g.out16 = nullptr; g.f16 = f16 ? 1 : 0;
   // split-K only on the single-query path (B == 1, KnnService.compute_query): every batch of two or more samples is computed
   // by the unsplit kernels, whose rows do not depend on the batch they travel in (bitwise); a B = 1 row differs from the same
   // sample inside a batch by f32 summation order only
@@ -385,21 +389,20 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   const int M = B * t.T, w = t.width;
   const float eps = h->desc.ln_eps;
   const int act = h->desc.act == CLIPX_ACT_QUICK_GELU ? EPI_BIAS_QGELU_BF16 : EPI_BIAS_GELU_BF16;
-  // On entry h->xn holds the bf16 shadow of the residual stream h->x (written by ln_pre / the text embedding).  Per block:
-  //   rstd = rowstats(x16);  qkv = (x16 @ Wqkv'^T) * rstd + c_qkv      [= LN1(x16) @ Wqkv^T + b: LayerNorm folded]
-  //   att = attention(qkv);  x += att @ Wout^T + b_out, x16 = bf16(x)  [residual epilogue writes both]
-  //   rstd = rowstats(x16);  h = act((x16 @ Wfc1'^T) * rstd + c_fc1);  x += h @ Wfc2^T + b_fc2, x16 = bf16(x)
+  // On entry h->xn holds the residual stream x in fp16 (written by ln_pre / the text embedding).  Per block:
+  //   rstd = rowstats(x);    qkv = (x @ Wqkv'^T) * rstd + c_qkv            [= LN1(x) @ Wqkv^T + b: LayerNorm folded; fp16 MFMA]
+  //   att = attention(qkv);  x = fp16(x + att @ Wout^T + b_out)            [in place, bf16 MFMA, f32 add]
+  //   rstd = rowstats(x);    h = act((x @ Wfc1'^T) * rstd + c_fc1);  x = fp16(x + h @ Wfc2^T + b_fc2)
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& L = t.L[l];
-    const bool last = l + 1 == t.layers;  // the tail reads the f32 stream: no shadow needed after the last block
     int r;
-    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st)); }
-    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16, h->rstd))) return r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
+    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16, h->rstd, true))) return r;
     { ProfScope ps(h, st, 1, 4.0 * B * t.heads * (double)t.T * t.T * (w / t.heads)); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st)); }
-    if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->x, nullptr, 1, M, w, w, EPI_BIAS_RESID_F32, nullptr, h->xn))) return r;
-    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st)); }
-    if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, M, t.mlp, w, act, h->rstd))) return r;
-    if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->x, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_F32, nullptr, last ? nullptr : h->xn))) return r;
+    if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->xn, nullptr, 1, M, w, w, EPI_BIAS_RESID_H16))) return r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
+    if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, M, t.mlp, w, act, h->rstd, true))) return r;
+    if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->xn, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_H16))) return r;
   }
   return 0;
 }
@@ -467,19 +470,19 @@ static int vision_chunk_body(clipx_handle* h, hipStream_t st, const void* pix_de
   { ProfScope ps(h, st, 3, 0); HIPCHK(launch_im2col(pix_dev, fmt, B, d.image_size, d.patch_size, h->Kp, d.pix_mean, inv_std, h->patches, st)); }
   int r = run_gemm(h, st, h->patches, h->conv_w, nullptr, h->x, h->clspos, V.T, M, V.width, h->Kp, EPI_TABLE_F32);
   if (r) return r;
-  { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, h->ln_pre_w, h->ln_pre_b, h->x, 0, M, V.width, d.ln_eps, st, h->xn)); }
+  { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, h->ln_pre_w, h->ln_pre_b, h->xn, 2, M, V.width, d.ln_eps, st)); }
   if ((r = run_layers(h, st, V, B, 0))) return r;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, V.T, V.width, d.embed_dim, d.ln_eps, st)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->xn, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, V.T, V.width, d.embed_dim, d.ln_eps, st, 1)); }
   return 0;
 }
 
 static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32) {
   const clipx_model_desc& d = h->desc;
   const Tower& X = h->txt;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, h->x, B, X.T, X.width, d.vocab, st, h->xn)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, nullptr, B, X.T, X.width, d.vocab, st, h->xn, 1)); }
   int r = run_layers(h, st, X, B, 1);
   if (r) return r;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->x, ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, X.T, X.width, d.embed_dim, d.ln_eps, st)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->xn, ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, X.T, X.width, d.embed_dim, d.ln_eps, st, 1)); }
   return 0;
 }
 
@@ -692,9 +695,10 @@ extern "C" int clipx_wait(clipx_ticket* t) {
 }
 
 static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M, int N, int K, int epi,
-                     const float* rowscale, void* out16, void* stream) {
+                     const float* rowscale, void* out16, void* stream, int f16 = 0) {
   if (!A_bf16 || !W_bf16 || !out || M <= 0 || N <= 0 || K <= 0) return fail(CLIPX_E_ARG, "bad gemm arguments");
-  if (epi < 0 || epi > 3 || !bias) return fail(CLIPX_E_ARG, "epi must be 0..3 and bias non-null");
+  if (!((epi >= 0 && epi <= 3) || epi == EPI_BIAS_RESID_H16) || !bias) return fail(CLIPX_E_ARG, "epi must be 0..3 or 6 and bias non-null");
+  if (f16 && epi > 2) return fail(CLIPX_E_ARG, "fp16 operands go with the bf16-output epilogues 0..2 only");
   if (N % 128 || K % 64) return fail(CLIPX_E_UNSUPPORTED, "N must be a multiple of 128 and K of 64");
   HIPCHK(hipSetDevice(device));
   GemmArgs g{};
@@ -702,6 +706,7 @@ static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const f
   g.M = M; g.N = N; g.K = K; g.epi = epi;
   g.rowscale = rowscale;
   g.out16 = epi == 3 ? (bf16*)out16 : nullptr;
+  g.f16 = f16;
   if (!g.rowscale) {  // bf16-output epilogues scale rows (LayerNorm-folded GEMMs of the encoder); a plain GEMM uses ones
     static std::mutex ones_mu;
     static float* ones[64] = {};
@@ -736,6 +741,11 @@ extern "C" int clipx_gemm_bf16_device(int device, const void* A_bf16, const void
 extern "C" int clipx_gemm_bf16_ex_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M,
                                          int N, int K, int epi, const float* rowscale_or_null, void* out16_or_null, void* stream) {
   return gemm_hook(device, A_bf16, W_bf16, bias, out, M, N, K, epi, rowscale_or_null, out16_or_null, stream);
+}
+
+extern "C" int clipx_gemm_f16_device(int device, const void* A_f16, const void* W_f16, const float* bias, void* out_bf16, int M, int N,
+                                     int K, int epi, const float* rowscale_or_null, void* stream) {
+  return gemm_hook(device, A_f16, W_f16, bias, out_bf16, M, N, K, epi, rowscale_or_null, nullptr, stream, 1);
 }
 
 extern "C" int clipx_attention_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int causal,

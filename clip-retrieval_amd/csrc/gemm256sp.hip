@@ -62,7 +62,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // DBG (ablation, EPI_BIAS_BF16 only; garbage results): 1 = no staging, 3 = no staging and no ds_reads,
 // 5 = no epilogue at all, 6 = epilogue without its global stores, 16 = phase timer (correct results),
 // 19 / 20 = phase timer + ablations 1 / 3, 21 = phase timer + L2-resident operands, 22 / 24 = no L2 prefetch (with / without timer)
-template <int EPI, int DBG>
+template <int EPI, int DBG, bool F16 = false>  // F16: A and W hold IEEE fp16 (the LayerNorm-folded GEMMs read the fp16 residual stream)
 __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #define S_WAIT_PREV() asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); S_FENCE();
 #define S_MFMA(F)                                                                                                  \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] =  \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F[4 + ni]), __builtin_bit_cast(bf16x8, F[mi]), acc[mi][ni], 0, 0, 0); \
+      mfma_32x32x16<F16>(F[4 + ni], F[mi], acc[mi][ni]);                                                            \
   S_FENCE();
 
   // One K-tile = S_KT_HEAD (k-steps 0..2 and the LDS drain), a vmcnt wait + barrier, the stage of a later K-tile into
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   // On the first K-tile after an epilogue the epilogue's own VMEM operations are younger than that stage and may stay in
   // flight: vmcnt(S_EPI_VM).  bf16 outputs: 16 stores.  f32 residual: 32 loads + 32 stores, the loads consumed already.
   constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
-  constexpr int S_EPI_VM = (DBG == 5 || DBG == 6) ? 0 : (OUT_BF16 ? 16 : (EPI == EPI_BIAS_RESID_F32 ? 40 : 32));
+  constexpr int S_EPI_VM = (DBG == 5 || DBG == 6) ? 0 : ((OUT_BF16 || EPI == EPI_BIAS_RESID_H16) ? 16 : (EPI == EPI_BIAS_RESID_F32 ? 40 : 32));
 
   // ---- prologue: K-tiles 0, 1 of the first tile; K-tile 0 landed + first fragment set read
   S_STAGE(curM, curN, 0)
@@ -527,6 +527,82 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
           }
           S_FENCE();
         }
+      } else if (EPI == EPI_BIAS_RESID_H16) {
+        // fp16 in-place residual x16 = fp16(f32(x16) + (acc + bias)): the residual stream is stored ONCE, in IEEE fp16 (what the
+        // next LayerNorm-folded GEMM reads as its A operand), so this epilogue moves 128 KiB in + 128 KiB out per tile instead of
+        // the 256 + 256 + 128 KiB of the f32 stream + bf16 shadow (EPI_BIAS_RESID_F32 above).  Four passes of a 32-row x 64-column
+        // sub-tile (one 128-B line per row): the old x rows arrive by 16-B buffer loads (lane = row 8i + rrow, chunk rch: whole
+        // lines), go through the wave's LDS scratch into the accumulator layout (lane = row l31, 4 columns), are added in f32,
+        // rounded, written back to the same scratch words and leave as 16-B buffer stores.  Same association as the 128x128
+        // kernel (gemm_store_quad): x + (acc + bias).
+        _Float16* xb = reinterpret_cast<_Float16*>(outp) + ((size_t)(m0 + wr * 128) * N + n0 + wc * 64);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xb, 0, 0x7ffffffe, 0x00020000);
+        const int voff = (rrow * N + rch * 8) * 2;
+        const int rstep = 8 * N * 2;  // 8 rows
+        float4 b4[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + (nt * 32 + 8 * g + 4 * hb) * 4);
+        S_FENCE();  // hipcc waits vmcnt(0) for the bias DMA before these LDS reads: keep the x loads behind that wait
+        u32x4 ext[2][4];
+#define S_LD_X16(set, mt_)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+    ext[set][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, ((mt_) * 4 + i) * rstep, 0);
+        S_LD_X16(0, 0)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          if (mt + 1 < 4) { S_LD_X16((mt + 1) & 1, mt + 1) }
+          S_FENCE();
+          // old rows -> scratch, in the position the read-back below (and the final store) uses
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + rrow;
+            *reinterpret_cast<u32x4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4)) = ext[mt & 1][i];
+          }
+          // read all eight 8-B slots of this lane first, then add, then write them back: written as three loops so that the
+          // LDS round trips overlap (one slot at a time hipcc emits read; wait; write eight times in a row)
+          uint2 xo[2][4];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)  // row l31, columns 32 nt + 8 g + 4 hb .. + 4: chunk (4 nt + g), half hb
+              xo[nt][g] = *reinterpret_cast<const uint2*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8);
+          S_FENCE();
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f16x4 xh = __builtin_bit_cast(f16x4, xo[nt][g]);
+              const float4 bq = b4[nt][g];
+              f16x4 o;
+              o[0] = (_Float16)((float)xh[0] + (acc[mt][nt][4 * g + 0] + bq.x));
+              o[1] = (_Float16)((float)xh[1] + (acc[mt][nt][4 * g + 1] + bq.y));
+              o[2] = (_Float16)((float)xh[2] + (acc[mt][nt][4 * g + 2] + bq.z));
+              o[3] = (_Float16)((float)xh[3] + (acc[mt][nt][4 * g + 3] + bq.w));
+              xo[nt][g] = __builtin_bit_cast(uint2, o);
+            }
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<uint2*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8) = xo[nt][g];
+          S_FENCE();
+          u32x4 q[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + rrow;
+            q[i] = *reinterpret_cast<const u32x4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4));
+          }
+          S_FENCE();
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_raw_buffer_store_b128(q[i], xr, voff, (mt * 4 + i) * rstep, 0);
+            S_STORE_GUARD(q[i]);
+          }
+          S_FENCE();
+        }
+#undef S_LD_X16
       } else {
         // + table row (patch embedding: class token / positional rows), f32 out: once per forward, plain code
         float* xo = reinterpret_cast<float*>(outp) + (size_t)(m0 + wr * 128) * N + n0 + wc * 64;
@@ -592,14 +668,14 @@ extern "C" int clipx_dbg_phase_cycles(long long* host, int n) {
 }
 #endif
 
-template <int EPI, int DBG = 0>
+template <int EPI, int DBG = 0, bool F16 = false>
 static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   int raster = 2;
 #ifdef CLIPX_ABLATE
   if (const char* fl = getenv("CLIPX_GEMM_FLAGS")) raster = atoi(fl) & 7;  // bits 0-1: raster, bit 2: 8-B shadow stores
 #endif
   const size_t smem = S_SCRATCH + 8 * 4096;  // 160 KiB: the whole LDS of the CU
-  auto kern = gemm256sp_kernel<EPI, DBG>;
+  auto kern = gemm256sp_kernel<EPI, DBG, F16>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.N, g.K, g.M / 256,
@@ -637,11 +713,20 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 43) return launch_sp_epi<EPI_BIAS_RESID_F32, 43>(g, grid, st);
   }
 #endif
+  if (g.f16) {
+    switch (g.epi) {
+      case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16, 0, true>(g, grid, st);
+      case EPI_BIAS_QGELU_BF16: return launch_sp_epi<EPI_BIAS_QGELU_BF16, 0, true>(g, grid, st);
+      case EPI_BIAS_GELU_BF16: return launch_sp_epi<EPI_BIAS_GELU_BF16, 0, true>(g, grid, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);
     case EPI_BIAS_QGELU_BF16: return launch_sp_epi<EPI_BIAS_QGELU_BF16>(g, grid, st);
     case EPI_BIAS_GELU_BF16: return launch_sp_epi<EPI_BIAS_GELU_BF16>(g, grid, st);
     case EPI_BIAS_RESID_F32: return launch_sp_epi<EPI_BIAS_RESID_F32>(g, grid, st);
+    case EPI_BIAS_RESID_H16: return launch_sp_epi<EPI_BIAS_RESID_H16>(g, grid, st);
     case EPI_TABLE_F32: return launch_sp_epi<EPI_TABLE_F32>(g, grid, st);
     default: return hipErrorInvalidValue;
   }

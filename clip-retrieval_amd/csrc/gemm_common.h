@@ -10,6 +10,16 @@ namespace clipx {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef int frag_t __attribute__((ext_vector_type(4)));  // one MFMA operand fragment: 8 x 16-bit values, type-agnostic
+
+// one v_mfma_f32_32x32x16 on 16-bit operand fragments: bf16 (F16 = false) or IEEE fp16 (same issue rate)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(frag_t a, frag_t b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -38,6 +48,7 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // consumes the raw residual stream with the LayerNorm folded into its weights (clipx_api.hip: fold_layernorm), 1 otherwise.
 // The multiply-add is ONE fma in both kernels, so a row's result does not depend on which kernel produced it.
 // f32 residual epilogue: x += acc + bias, and (out16 != null) the bf16 copy of the new x row that the next folded GEMM reads.
+// fp16 residual epilogue (EPI_BIAS_RESID_H16): x16 = fp16(f32(x16) + (acc + bias)), in place -- the same association.
 template <int EPI>
 __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, const float* __restrict__ bias,
                                                 void* __restrict__ outp, const float* __restrict__ table, int T,
@@ -73,6 +84,13 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
       h[0] = (bf16)o.x; h[1] = (bf16)o.y; h[2] = (bf16)o.z; h[3] = (bf16)o.w;
       *reinterpret_cast<bf16x4*>(out16 + (size_t)m * N + n) = h;
     }
+  } else if (EPI == EPI_BIAS_RESID_H16) {
+    f16x4* p = reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(outp) + (size_t)m * N + n);
+    const f16x4 x4 = *p;
+    f16x4 h;
+    h[0] = (_Float16)((float)x4[0] + v.x); h[1] = (_Float16)((float)x4[1] + v.y);
+    h[2] = (_Float16)((float)x4[2] + v.z); h[3] = (_Float16)((float)x4[3] + v.w);
+    *p = h;
   } else {  // EPI_TABLE_F32
     const float4 t4 = *reinterpret_cast<const float4*>(table + (size_t)((m + row0) % T) * N + n);
     v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;

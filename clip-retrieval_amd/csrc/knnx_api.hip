@@ -62,6 +62,10 @@ struct knnx_index {
   // pinned staging for host<->device hand-over
   void* pin = nullptr;
   size_t pin_bytes = 0;
+  // device scratch of reconstruct / range_fetch, kept between calls (hipMalloc + hipFree per request cost more than a
+  // small search: hipFree synchronises the device); grown on demand, released with the index.  Used under ix->mu only.
+  void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[4] = {0, 0, 0, 0};
 
   // IVF-Flat state (knnx_ivf_set_lists): rows live list-sorted and tile-padded in `rows`; see knn_kernels.hip
   int ivf_nlist = 0, ivf_nprobe = 1;
@@ -131,6 +135,19 @@ static int ensure_pin(knnx_index* ix, size_t bytes) {
   ix->pin_bytes = 0;
   HIPCHK(hipHostMalloc(&ix->pin, bytes, hipHostMallocDefault));
   ix->pin_bytes = bytes;
+  return 0;
+}
+
+static int ensure_scratch(knnx_index* ix, int slot, size_t bytes, void** out) {
+  if (ix->scratch_bytes[slot] < bytes) {
+    if (ix->scratch[slot]) hipFree(ix->scratch[slot]);
+    ix->scratch[slot] = nullptr;
+    ix->scratch_bytes[slot] = 0;
+    const size_t want = std::max(bytes, (size_t)1 << 16);
+    HIPCHK(hipMalloc(&ix->scratch[slot], want));
+    ix->scratch_bytes[slot] = want;
+  }
+  *out = ix->scratch[slot];
   return 0;
 }
 
@@ -262,6 +279,8 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->ivfb_lists);
   hipFree(ix->ivfb_pos);
   if (ix->pin) hipHostFree(ix->pin);
+  for (int i = 0; i < 4; ++i)
+    if (ix->scratch[i]) hipFree(ix->scratch[i]);
   for (auto& ev : ix->prof_events) {
     hipEventDestroy(ev.first);
     hipEventDestroy(ev.second);
@@ -731,28 +750,29 @@ extern "C" int knnx_reconstruct(knnx_index* ix, const int64_t* ids, int64_t n, f
   if (n == 0) return KNNX_OK;
   std::lock_guard<std::mutex> lk(ix->mu);
   if (set_dev(ix)) return KNNX_E_HIP;
-  const int64_t chunk = std::max<int64_t>(1, (int64_t)(32u << 20) / (ix->d * 4));
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(32u << 20) / (ix->d * 4)));
   int64_t* ids_dev = nullptr;
   float* out_dev = nullptr;
-  HIPCHK(hipMalloc(&ids_dev, (size_t)chunk * sizeof(int64_t)));
-  hipError_t e = hipMalloc(&out_dev, (size_t)chunk * ix->d * sizeof(float));
-  if (e != hipSuccess) {
-    hipFree(ids_dev);
-    return fail(KNNX_E_NOMEM, "reconstruct scratch");
-  }
+  int r = ensure_scratch(ix, 0, (size_t)chunk * sizeof(int64_t), (void**)&ids_dev);
+  if (r) return r;
+  if ((r = ensure_scratch(ix, 1, (size_t)chunk * ix->d * sizeof(float), (void**)&out_dev))) return r;
+  // pageable host memory: stage ids and rows through the pinned buffer so that the copies are truly asynchronous DMAs
+  if ((r = ensure_pin(ix, (size_t)chunk * (sizeof(int64_t) + (size_t)ix->d * sizeof(float))))) return r;
+  int64_t* ids_pin = (int64_t*)ix->pin;
+  float* out_pin = (float*)((char*)ix->pin + (size_t)chunk * sizeof(int64_t));
+  hipError_t e = hipSuccess;
   for (int64_t o = 0; o < n && e == hipSuccess; o += chunk) {
     const int64_t m = std::min(chunk, n - o);
-    e = hipMemcpyAsync(ids_dev, ids + o, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream);
+    memcpy(ids_pin, ids + o, (size_t)m * sizeof(int64_t));
+    e = hipMemcpyAsync(ids_dev, ids_pin, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream);
     if (e == hipSuccess)
       e = ix->ivf_nlist ? launch_gather_inv(ix->rows, ix->d, ix->id_base, ix->ntotal, ix->ivf_inv, ids_dev, m, out_dev, ix->stream)
                         : launch_gather(ix->rows, ix->ntotal, ix->d, ix->id_base, ids_dev, m, out_dev, ix->stream);
     if (e == hipSuccess)
-      e = hipMemcpyAsync(out + (size_t)o * ix->d, out_dev, (size_t)m * ix->d * sizeof(float), hipMemcpyDeviceToHost,
-                         ix->stream);
+      e = hipMemcpyAsync(out_pin, out_dev, (size_t)m * ix->d * sizeof(float), hipMemcpyDeviceToHost, ix->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e == hipSuccess) memcpy(out + (size_t)o * ix->d, out_pin, (size_t)m * ix->d * sizeof(float));
   }
-  hipFree(ids_dev);
-  hipFree(out_dev);
   if (e != hipSuccess) return fail(KNNX_E_HIP, std::string("reconstruct: ") + hipGetErrorString(e));
   return KNNX_OK;
 }
@@ -833,11 +853,11 @@ static int range_fetch(knnx_index* ix, int nq, const std::vector<unsigned>& coun
   int64_t* lims_dev = nullptr;
   float* D_dev = nullptr;
   int64_t* I_dev = nullptr;
-  HIPCHK(hipMalloc(&lims_dev, (nq + 1) * sizeof(int64_t)));
-  hipError_t e = hipMalloc(&D_dev, (size_t)loc[nq] * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&I_dev, (size_t)loc[nq] * sizeof(int64_t));
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(lims_dev, loc.data(), (nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream);
+  int rr = ensure_scratch(ix, 0, (nq + 1) * sizeof(int64_t), (void**)&lims_dev);
+  if (!rr) rr = ensure_scratch(ix, 1, (size_t)loc[nq] * sizeof(float), (void**)&D_dev);
+  if (!rr) rr = ensure_scratch(ix, 2, (size_t)loc[nq] * sizeof(int64_t), (void**)&I_dev);
+  if (rr) return rr;
+  hipError_t e = hipMemcpyAsync(lims_dev, loc.data(), (nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream);
   if (e == hipSuccess)
     e = launch_range_sort(ix->range_s, ix->range_i, ix->range_cnt, cap, lims_dev, ix->id_base,
                           ix->ivf_nlist ? ix->ivf_idmap : nullptr, nq, D_dev, I_dev, ix->stream);
@@ -866,9 +886,6 @@ static int range_fetch(knnx_index* ix, int nq, const std::vector<unsigned>& coun
   if (e == hipSuccess) e = hipMemcpyAsync(D, D_dev, (size_t)loc[nq] * sizeof(float), hipMemcpyDeviceToHost, ix->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(I, I_dev, (size_t)loc[nq] * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
-  hipFree(lims_dev);
-  if (D_dev) hipFree(D_dev);
-  if (I_dev) hipFree(I_dev);
   if (e != hipSuccess) return fail(KNNX_E_HIP, std::string("range fetch: ") + hipGetErrorString(e));
   return 0;
 }
@@ -1545,6 +1562,20 @@ extern "C" int knnx_get_stats(knnx_index* ix, int64_t* proof_queries, int64_t* p
   HIPCHK(hipMemcpy(h, ix->stats, sizeof(h), hipMemcpyDeviceToHost));
   if (proof_queries) *proof_queries = (int64_t)h[0];
   if (proof_failures) *proof_failures = (int64_t)h[1];
+  return KNNX_OK;
+}
+
+// IVF: 32-row tiles in the work list of the most recent scan (rows of the probed lists, padded to tiles): what that scan
+// read from HBM is tiles * 32 * d * 2 bytes -- the measured side of "(nprobe / nlist) * N * d * 2" 
+extern "C" int knnx_ivf_last_scan_tiles(knnx_index* ix, int64_t* tiles) {
+  if (!ix || !tiles) return fail(KNNX_E_ARG, "bad ivf_last_scan_tiles arguments");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!ix->ivf_nlist) return fail(KNNX_E_STATE, "not an IVF index");
+  if (set_dev(ix)) return KNNX_E_HIP;
+  unsigned n = 0;
+  HIPCHK(hipStreamSynchronize(ix->stream));
+  HIPCHK(hipMemcpy(&n, ix->ivf_nwork, sizeof(unsigned), hipMemcpyDeviceToHost));
+  *tiles = (int64_t)n;
   return KNNX_OK;
 }
 

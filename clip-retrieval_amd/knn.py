@@ -203,6 +203,12 @@ class Mi355xIndex(_FaissShaped):
         check(self._lib, self._lib.knnx_ivf_set_nprobe(self._h, int(v)), "knnx")
         self._nprobe = int(v)
 
+    def last_scan_tiles(self):
+        """IVF: 32-row tiles walked by the most recent scan (bytes read = tiles * 32 * d_padded * 2)."""
+        t = C.c_int64(0)
+        check(self._lib, self._lib.knnx_ivf_last_scan_tiles(self._h, C.byref(t)), "knnx")
+        return int(t.value)
+
     # ------------------------------------------------------------------ searching
     def _search_raw(self, q, k, want_r):
         n = q.shape[0]

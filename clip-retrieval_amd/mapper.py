@@ -65,11 +65,26 @@ class ClipMapper:
         A caller that submits batch n+1 before collecting batch n overlaps n+1's upload with n's kernels (runner.Runner).
         Batches larger than the library's max batch fall back to the synchronous call inside collect()."""
         h = {"item": item, "img": None, "txt": None}
-        if self.enable_image and len(item["image_tensor"]) <= self._enc.max_batch:
-            h["img"] = self._enc.submit_image(item["image_tensor"])
-        if self.enable_text and len(item["text_tokens"]) <= self._enc.max_batch:
-            h["txt"] = self._enc.submit_text(item["text_tokens"])
+        try:
+            if self.enable_image and len(item["image_tensor"]) <= self._enc.max_batch:
+                h["img"] = self._enc.submit_image(item["image_tensor"])
+            if self.enable_text and len(item["text_tokens"]) <= self._enc.max_batch:
+                h["txt"] = self._enc.submit_text(item["text_tokens"])
+        except BaseException:
+            self.discard(h)  # a half-submitted batch must not keep a staging slot of the (cached, long-lived) encoder
+            raise
         return h
+
+    def discard(self, h):
+        """Wait for and drop whatever tickets of `h` are still outstanding (error paths: a ticket that is never waited for
+        keeps one of the encoder's four staging slots busy for the life of the process)."""
+        for k in ("img", "txt"):
+            t = h.get(k)
+            if t is not None and t.get("ticket") is not None:
+                try:
+                    self._enc.collect(t)
+                except Exception:  # pylint: disable=broad-except
+                    pass
 
     def collect(self, h):
         item = h["item"]

@@ -10,6 +10,7 @@ With the reference's own mapper the loop is the reference's serial loop; with th
 batch deep on the asynchronous tickets of the C ABI (upload of batch n+1 under the kernels of batch n).
 """
 
+import sys
 import time
 
 
@@ -45,6 +46,12 @@ class _Prefetcher:
         self._q = queue.Queue(maxsize=depth)
         self._done = False
         self._stop = threading.Event()
+        # torch's current device is per thread: the producer (which collates into pinned memory) must page-lock against the
+        # GPU its creator is bound to, not GPU 0 (one process per GPU: worker.gpu_worker)
+        self._device = None
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            self._device = torch.cuda.current_device()
         self._t = threading.Thread(target=self._run, args=(iter(it),), daemon=True)
         self._t.start()
 
@@ -61,6 +68,8 @@ class _Prefetcher:
 
     def _run(self, it):
         try:
+            if self._device is not None:
+                sys.modules["torch"].cuda.set_device(self._device)
             for item in it:
                 if not self._put(("ok", item)):
                     return
@@ -116,6 +125,7 @@ class Runner:
         source = _Prefetcher(reader, self.prefetch) if (pipelined and self.prefetch > 0) else None
         batches = iter(source if source is not None else reader)
         pending = None  # (handle, batch sample count, wall0, read_duration, submit_duration)
+        handle = inflight = None  # inflight: the handle being collected (its tickets may be half waited for when collect raises)
         exhausted = False
         last_end = None
         try:
@@ -141,7 +151,9 @@ class Runner:
                         continue
                     h, count, w0, read_d, sub_d = done
                     t3 = time.perf_counter()
+                    inflight = h
                     embeddings = mapper.collect(h)
+                    inflight = None
                     t4 = time.perf_counter()
                     writer(embeddings)
                     t5 = time.perf_counter()
@@ -165,6 +177,21 @@ class Runner:
                     logger({"start_time": wall0, "end_time": wall1, "read_duration": t1 - t0,
                             "inference_duration": t3 - t1, "write_duration": t4 - t3,
                             "total_duration": wall1 - wall0, "sample_count": batch[key].shape[0]})
+        except BaseException:
+            # A submitted ticket owns one of the encoder's staging slots (and keeps its pinned input referenced) until it is
+            # collected; the encoder outlives this partition (cached per model and device), so a ticket leaked here would
+            # starve every later partition of this process.  Collect and drop whatever is still in flight.
+            if pipelined:
+                drop = getattr(mapper, "discard", None) or mapper.collect
+                seen = []
+                for h in (inflight, pending[0] if pending else None, handle):
+                    if h is not None and not any(h is s for s in seen):
+                        seen.append(h)
+                        try:
+                            drop(h)
+                        except Exception:  # pylint: disable=broad-except
+                            pass
+            raise
         finally:
             if source is not None:
                 source.close()

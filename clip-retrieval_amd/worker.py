@@ -114,31 +114,52 @@ def gpu_worker(**worker_args):
     rank = int(os.environ.get("RANK", os.environ.get("SLURM_PROCID", "0")))
     local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("SLURM_LOCALID", "0")))
     if os.environ.get("WORKER_ARGS_PATH"):
+        # explicit keyword arguments win over the file; options the caller left unset (None) take the file's value
         with open(os.environ["WORKER_ARGS_PATH"], "r", encoding="utf-8") as f:
-            worker_args = {**json.load(f), **worker_args}
+            worker_args = {**json.load(f), **{k: v for k, v in worker_args.items() if v is not None}}
+    worker_args = {k: v for k, v in worker_args.items() if v is not None}
+    missing = [k for k in ("input_dataset", "output_folder", "output_partition_count") if k not in worker_args]
+    if missing:
+        raise ValueError(f"gpu_worker: {missing} given neither as arguments nor in WORKER_ARGS_PATH")
     num_tasks = int(os.environ.get("NUM_TASKS", worker_args["output_partition_count"]))
     tasks = get_task_list(num_tasks, world, rank, local_rank)
     print(f"worker global rank:{rank}\tlocal rank: {local_rank}\tprocessing tasks {tasks}", flush=True)
+    _bind_torch_to_device(local_rank)
     worker(tasks, device=local_rank, **worker_args)
+
+
+def _bind_torch_to_device(local_rank):
+    """One process per GPU: the HIP library is bound to LOCAL_RANK through `device=`; torch (pinned collation buffers of the
+    readers, torch.cuda calls of user code) must follow, or every rank opens a context and page-locks memory against GPU 0."""
+    try:
+        import torch  # pylint: disable=import-outside-toplevel
+
+        if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
+            torch.cuda.set_device(local_rank)
+    except ImportError:
+        pass
 
 
 def _main(argv=None):
     import argparse
 
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
-    ap.add_argument("--input_dataset", required=True)
-    ap.add_argument("--output_folder", required=True)
-    ap.add_argument("--output_partition_count", type=int, required=True)
-    ap.add_argument("--input_format", default="files")
+    # every option defaults to None = "not given": gpu_worker fills those from WORKER_ARGS_PATH (the json the reference's slurm
+    # distributor writes), then from worker()'s own defaults
+    truth = lambda v: v.lower() in ("1", "true")  # noqa: E731
+    ap.add_argument("--input_dataset")
+    ap.add_argument("--output_folder")
+    ap.add_argument("--output_partition_count", type=int)
+    ap.add_argument("--input_format")
     ap.add_argument("--cache_path")
-    ap.add_argument("--batch_size", type=int, default=256)
-    ap.add_argument("--num_prepro_workers", type=int, default=4)
-    ap.add_argument("--enable_text", type=lambda v: v.lower() in ("1", "true"), default=True)
-    ap.add_argument("--enable_image", type=lambda v: v.lower() in ("1", "true"), default=True)
-    ap.add_argument("--enable_metadata", type=lambda v: v.lower() in ("1", "true"), default=False)
-    ap.add_argument("--wds_image_key", default="jpg")
-    ap.add_argument("--wds_caption_key", default="txt")
-    ap.add_argument("--clip_model", default="ViT-B/32")
+    ap.add_argument("--batch_size", type=int)
+    ap.add_argument("--num_prepro_workers", type=int)
+    ap.add_argument("--enable_text", type=truth)
+    ap.add_argument("--enable_image", type=truth)
+    ap.add_argument("--enable_metadata", type=truth)
+    ap.add_argument("--wds_image_key")
+    ap.add_argument("--wds_caption_key")
+    ap.add_argument("--clip_model")
     ap.add_argument("--clip_cache_path")
     gpu_worker(**vars(ap.parse_args(argv)))
 

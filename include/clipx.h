@@ -9,8 +9,9 @@
  * (clip_back.py:230, 244).  Plain pointers and sizes only; no torch types.  Every function
  * returns 0 or a negative CLIPX_E_* code and never throws; clipx_last_error() is thread-local.
  *
- * Arithmetic: bf16 MFMA operands with fp32 accumulation; residual stream, LayerNorm and
- * softmax in fp32.  Outputs are unit-L2-norm rows rounded to IEEE fp16, exactly the
+ * Arithmetic: 16-bit MFMA operands (bf16; IEEE fp16 where the operand is the residual stream) with fp32 accumulation; the
+ * residual stream is stored in fp16 and added to in fp32, LayerNorm statistics and softmax are fp32.  Outputs are unit-L2-norm
+ * rows rounded to IEEE fp16, exactly the
  * `image_embs` / `text_embs` arrays the reference writer stores (writer.py:67-75).
  */
 #ifndef CLIPX_H
@@ -132,6 +133,13 @@ int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, c
  * new f32 rows -- the shadow of the residual stream the next folded GEMM reads). */
 int clipx_gemm_bf16_ex_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M, int N,
                               int K, int epi, const float* rowscale_or_null, void* out16_or_null, void* stream);
+/* (the _ex entry point also takes epi 6: out is IEEE fp16 [M, N], updated in place, out = fp16(f32(out) + acc + bias) -- the
+ * residual epilogue of out_proj / fc2 in the encoder, whose residual stream is stored in fp16) */
+
+/* The LayerNorm-folded GEMMs of the encoder (QKV, fc1) read that fp16 residual stream as their A operand: A and W are IEEE
+ * fp16 (v_mfma_f32_32x32x16_f16, the same rate as bf16), out bf16 [M, N]; epi 0..2 and rowscale as above. */
+int clipx_gemm_f16_device(int device, const void* A_f16, const void* W_f16, const float* bias, void* out_bf16, int M, int N, int K,
+                          int epi, const float* rowscale_or_null, void* stream);
 
 /* The attention and LayerNorm kernels in isolation (device pointers), for per-kernel parity tests:
  * qkv bf16 [B*T, 3*H*64] -> out bf16 [B*T, H*64];  x f32 [M, d] -> y (bf16 if out_bf16 else f32). */

@@ -178,6 +178,10 @@ int knnx_shards_range_search(knnx_shards* s, const float* q, int n, float thresh
  * exactness proof failed and were re-run by the exact 32-query scan (each failure costs one more pass over HBM). */
 int knnx_get_stats(knnx_index* ix, int64_t* proof_queries, int64_t* proof_failures);
 
+/* IVF: number of 32-row tiles the most recent scan walked (the probed lists of its <= 32 queries, padded to tiles);
+ * bytes read from HBM = tiles * 32 * d * 2, to be compared with (nprobe / nlist) * N * d * 2. */
+int knnx_ivf_last_scan_tiles(knnx_index* ix, int64_t* tiles);
+
 /* Live kernel timing for bench.py: when enabled, every scan launch is bracketed with
  * hipEvents on its own stream; get returns launches and summed milliseconds, then resets. */
 int knnx_profile_enable(knnx_index* ix, int on);

@@ -503,3 +503,50 @@ def test_large_batch_persistent_kernel_path_equals_128_path():
         assert not np.isnan(a.astype(np.float32)).any() and np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"text B={B}"
     enc.close()
     ref.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 1024), (65792, 1024, 4096), (19712, 768, 768), (1000, 1024, 1024), (257, 1280, 1280)])
+def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
+    """Round 3: the residual stream lives in IEEE fp16.  (1) epi 6, out16 = fp16(f32(out16) + acc + bias) in place (bf16
+    operands): against torch fp32 on the same operands to half an fp16 ulp + accumulation noise, and bit-identical between the
+    persistent 256x256 kernel and the 128x128 kernel; (2) fp16 operands (clipx_gemm_f16_device, the LayerNorm-folded QKV / fc1):
+    out = act(acc * rowscale + bias) against torch fp32, bit-identical between the kernels."""
+    from clip_retrieval_amd._lib import check
+
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N)
+    A = (torch.randn(M, K, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    Ah = (torch.randn(M, K, generator=g, device="cuda") * 3.0).to(torch.float16)   # an un-normalised residual stream
+    Ah[:, 5] += 40.0                                                                # with a 'massive activation' channel
+    Wh = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(torch.float16)
+    Ah[:, 0] += (torch.arange(M, device="cuda") % 97).to(torch.float16) * 0.01
+    bias = torch.randn(N, generator=g, device="cuda")
+    x0 = (torch.randn(M, N, generator=g, device="cuda") * 4).to(torch.float16)
+    rs = torch.rand(M, generator=g, device="cuda") * 0.3 + 0.05
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for variant in (3, 1):
+        os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
+        x = x0.clone()
+        check(lib, lib.clipx_gemm_bf16_ex_device(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(x), M, N, K, 6, None, None, C.c_void_p(st)), "clipx")
+        ys = []
+        for epi in (0, 1, 2):
+            y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            check(lib, lib.clipx_gemm_f16_device(0, _ptr(Ah), _ptr(Wh), _ptr(bias), _ptr(y), M, N, K, epi, _ptr(rs), C.c_void_p(st)), "clipx")
+            ys.append(y)
+        torch.cuda.synchronize()
+        outs[variant] = [x] + ys
+    os.environ.pop("CLIPX_GEMM_VARIANT")
+    for i, (a, b) in enumerate(zip(outs[3], outs[1])):
+        bad = (a.view(torch.int16) != b.view(torch.int16)).nonzero()
+        assert bad.numel() == 0, f"output {i}: the two kernels differ at {bad[:5].tolist()} ({bad.shape[0]} elements)"
+    want = x0.float() + (A.float() @ W.float().T + bias)
+    err = (outs[3][0].float() - want).abs()
+    tol = 1e-3 + 1.2e-3 * want.abs()   # fp16: 2^-11 relative rounding + fp32 accumulation-order noise
+    assert (err <= tol).all(), f"fp16 residual: max err {float(err.max()):.4g} at {(err > tol).nonzero()[:4].tolist()}"
+    ref = (Ah.float() @ Wh.float().T) * rs[:, None] + bias
+    for epi, y in zip((0, 1, 2), outs[3][1:]):
+        w = ref if epi == 0 else (ref * torch.sigmoid(1.702 * ref) if epi == 1 else torch.nn.functional.gelu(ref))
+        e = (y.float() - w).abs()
+        t = 2e-3 + 4e-3 * w.abs()
+        assert (e <= t).all(), f"f16 operands epi {epi}: max err {float(e.max()):.4g}"

@@ -556,3 +556,49 @@ def test_config1_plumbing_with_the_oracle_mapper(tmp_path):
         st = json.loads((out / "stats" / f"{i}.json").read_text())  # LoggerWriter: summed stats of the partition (logger.py:13-62)
         assert st["sample_count"] == 50 and not (out / "stats" / f"wip_{i}.json").exists()
     assert total == 100
+
+
+def test_pipelined_runner_drops_in_flight_tickets_when_a_batch_fails(tmp_path, image_folder):
+    """if collect / the writer raises, the batch that was already submitted must still be waited for (discarded),
+    otherwise its staging slot of the long-lived encoder is never released."""
+    from clip_retrieval_amd.reader import FilesReader, clip_preprocess
+    from clip_retrieval_amd.runner import NullLogger, Runner
+
+    class Mapper(_AsyncFakeMapper):
+        def __init__(self, log):
+            super().__init__(log)
+            self.outstanding = set()
+
+        def submit(self, item):
+            h = super().submit(item)
+            self.outstanding.add(id(h))
+            return h
+
+        def collect(self, h):
+            self.outstanding.discard(id(h))
+            return super().collect(h)
+
+        def discard(self, h):
+            self.log.append(("discard", h["item"]["image_filename"][0]))
+            self.outstanding.discard(id(h))
+
+    class BadWriter:
+        def __init__(self):
+            self.n = 0
+
+        def __call__(self, emb):
+            self.n += 1
+            if self.n == 2:
+                raise RuntimeError("disk full")
+
+        def flush(self):
+            pass
+
+    log = []
+    m = Mapper(log)
+    r = Runner(lambda s: FilesReader(s, clip_preprocess, None, str(image_folder), 2, 2, enable_text=False), lambda: m,
+               lambda i: BadWriter(), lambda i: NullLogger(i), 1)
+    with pytest.raises(RuntimeError, match="disk full"):
+        r(0)
+    assert not m.outstanding, f"tickets left in flight: {log}"
+    assert any(k == "discard" for k, _ in log)

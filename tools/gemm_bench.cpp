@@ -3,6 +3,8 @@
 //
 //   hipcc -O2 -o tools/gemm_bench tools/gemm_bench.cpp -ldl
 //   tools/gemm_bench [-r reps] M,N,K,epi [M,N,K,epi ...] -- variant[:dbg[:flags]] [variant[:dbg[:flags]] ...]
+//   epi 0..3 as in include/clipx.h; 6 = fp16 in-place residual (the encoder's out_proj / fc2); 16 / 17 / 18 = epi 0 / 1 / 2 with
+//   IEEE fp16 operands (clipx_gemm_f16_device: the encoder's QKV / fc1)
 //
 // Every configuration (CLIPX_GEMM_VARIANT / _DBG / _FLAGS, read by the launcher at each call) runs interleaved with the
 // others; dbg == 0 results are compared bit-for-bit with variant 0 (the 128x128 kernel accumulates in the same order).
@@ -20,6 +22,8 @@ typedef int (*gemm_fn)(int, const void*, const void*, const float*, void*, int, 
 typedef int (*gemm_ex_fn)(int, const void*, const void*, const float*, void*, int, int, int, int, const float*, void*, void*);
 static gemm_ex_fn g_ex = nullptr;
 static void* g_shadow = nullptr;  // GEMM_BENCH_SHADOW=1: epi 3 also writes the bf16 shadow (clipx_gemm_bf16_ex_device)
+typedef int (*gemm_f16_fn)(int, const void*, const void*, const float*, void*, int, int, int, int, const float*, void*);
+static gemm_f16_fn g_f16 = nullptr;
 typedef const char* (*err_fn)(void);
 
 #define CK(x)                                                                 \
@@ -52,8 +56,11 @@ int main(int argc, char** argv) {
   }
   gemm_fn gemm0 = (gemm_fn)dlsym(h, "clipx_gemm_bf16_device");
   g_ex = (gemm_ex_fn)dlsym(h, "clipx_gemm_bf16_ex_device");
+  g_f16 = (gemm_f16_fn)dlsym(h, "clipx_gemm_f16_device");
   const bool want_shadow = getenv("GEMM_BENCH_SHADOW") && g_ex;
   auto gemm = [&](int dev, const void* A, const void* W, const float* b, void* o, int M, int N, int K, int epi, void* st) -> int {
+    if (epi >= 16) return g_f16 ? g_f16(dev, A, W, b, o, M, N, K, epi - 16, nullptr, st) : -99;
+    if (epi == 6) return g_ex ? g_ex(dev, A, W, b, o, M, N, K, 6, nullptr, nullptr, st) : -99;
     if (want_shadow && epi == 3 && g_shadow) return g_ex(dev, A, W, b, o, M, N, K, epi, nullptr, g_shadow, st);
     return gemm0(dev, A, W, b, o, M, N, K, epi, st);
   };
@@ -100,8 +107,10 @@ int main(int argc, char** argv) {
     unsigned r = 12345u + M + 3 * N + 7 * K;
     auto rnd = [&]() { r = r * 1664525u + 1013904223u; return ((int)(r >> 9) & 0xffff) / 32768.f - 1.f; };
     auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16); };
-    for (auto& v : hA) v = bf(rnd());
-    for (auto& v : hW) v = bf(rnd() * 0.05f);
+    auto hf = [](float f) { _Float16 hv = (_Float16)f; uint16_t u; memcpy(&u, &hv, 2); return u; };
+    const bool f16ops = epi >= 16;
+    for (auto& v : hA) v = f16ops ? hf(rnd()) : bf(rnd());
+    for (auto& v : hW) v = f16ops ? hf(rnd() * 0.05f) : bf(rnd() * 0.05f);
     for (auto& v : hb) v = rnd();
     void *dA, *dW, *dO, *dRef, *dInit;
     float* db;
@@ -112,11 +121,16 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dA, hA.data(), nA * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
-    {  // residual input (epi 3 accumulates into out): small deterministic values
+    {  // residual input (epi 3 / 6 accumulate into out): small deterministic values
       std::vector<float> hi(f32out ? nO : 1);
       for (auto& v : hi) v = rnd();
       CK(hipMemset(dInit, 0, ob));
       if (f32out) CK(hipMemcpy(dInit, hi.data(), ob, hipMemcpyHostToDevice));
+      if (epi == 6) {
+        std::vector<uint16_t> h16(nO);
+        for (auto& v : h16) v = hf(rnd() * 4.f);
+        CK(hipMemcpy(dInit, h16.data(), ob, hipMemcpyHostToDevice));
+      }
     }
     // reference = variant 0
     Cfg ref{"0", "0", "", ""};
