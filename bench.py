@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="torch threads of the CPU baseline (all 256 cores of the GPU box oversubscribe torch's CPU GEMMs: 0.07 samples/s)")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: the line is marked parity=null")
+    ap.add_argument("--ivf", action="store_true", help="also run BASELINE config 5's per-GPU shard (tools/config5.py: IVF-Flat 125 M x 1024, "
+                    "nlist 65 536, built on the device, served) and embed its object as `ivf` (adds ~3 minutes)")
+    ap.add_argument("--ivf-rows", type=int, default=125_000_000)
     args = ap.parse_args()
     refuse_debug_environment()
 
@@ -173,11 +176,11 @@ def main():
     # the committed counter passes were taken on the default workload only
     traffic, traffic_unit = pmc_traffic("gemm") if (args.model == "ViT-L/14" and B == 256) else (None, None)
     # one denominator throughout: everything below is PER STEP (one batch of 256 through both towers)
-    roofline = {"bound": "mfma", "kernel": "gemm256sp_kernel (+ gemm_bf16_kernel on the peeled 257th m-tile)", "achieved": round(gemm_tflops, 1),
+    roofline = {"bound": "mfma", "kernel": "gemm256sp_kernel (+ gemm_bf16_kernel on the peeled 257th m-tile); bf16 / fp16 operands, f32 accumulate", "achieved": round(gemm_tflops, 1),
                 "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / BF16_PEAK_TFLOPS, 4),
                 "per": "step", "launches_per_step": g["launches"] // max(args.steps, 1), "ms_per_step": round(g["ms"] / max(args.steps, 1), 3),
                 "algorithmic_tflop_per_step": round(gemm_tflops * g["ms"] / max(args.steps, 1) / 1e3, 3),
-                "traffic": traffic, "traffic_unit": traffic_unit,
+                "traffic": traffic, "traffic_unit": traffic_unit, "traffic_run": "separate --pmc pass" if traffic else None,
                 "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command (tools/gpu_round.sh); counters cannot be read inside the timed run" if traffic else None}
 
     # image-only / text-only rates (untimed extras)
@@ -271,14 +274,21 @@ def main():
             passes = nl / max(args.knn_scans, 1)
             scan_gbs = rows * d * 2 / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
             qpp = nq / max(passes, 1)
+            kern = ("knn_rq_scan_kernel (register-stationary queries, up to 256 per pass)" if qpp > 64 else
+                    "knn_scan_kernel<QB=2> (64-query wide scan + exactness proof)" if qpp > 32 else "knn_scan_kernel<QB=1> (32-query exact scan)")
+            # a pass is HBM-bound below ~312 queries per pass (2.5 PF / 8 TB/s); every row carries both fractions
+            mfma_tf = 2.0 * rows * d * qpp / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
             by_batch.append({"B": nq, "qps": round(args.knn_scans * nq / dk, 1), "ms_per_batch": round(dk / args.knn_scans * 1e3, 3),
+                             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(scan_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(scan_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(scan_ms, 3),
+                                          "algorithmic_bytes_per_launch": rows * d * 2, "mfma_frac": round(mfma_tf / BF16_PEAK_TFLOPS, 4)},
                              "passes_over_hbm": round(passes, 2), "scan_ms": round(scan_ms, 3), "scan_GBps": round(scan_gbs, 1),
                              "hbm_frac": round(scan_gbs / HBM_PEAK_GBS, 4),
                              "scan_mfma_tflops": round(2.0 * rows * d * qpp / (scan_ms * 1e-3) / 1e12, 1) if scan_ms > 0 else None,
                              "qps_ceiling_at_8TBps": round(nq / (rows * d * 2 / (HBM_PEAK_GBS * 1e9)), 1),
                              "planted_neighbour_top1": hit, "proof_served": s1[0] - s0[0], "proof_failures": s1[1] - s0[1]})
         best = max(by_batch, key=lambda r: r["qps"])
-        head = next((r for r in by_batch if r["B"] == 64), best)  # the roofline object describes the 64-query scan kernel
+        head = best  # knn.roofline describes the kernel that produced knn.qps; every by_batch row has its own
 
         if single and want_parity:
             # (a) exact id lists vs the numpy oracle on the first 1 M rows (SURVEY config 3): a second, small index filled by
@@ -304,7 +314,7 @@ def main():
             small.close()
             del ora
             # (b) the whole index against chunked torch fp32 matmul + topk (independent arithmetic on the same bytes)
-            nqc = min(64, nq_max)
+            nqc = nq_max  # ALL queries: at B = 256 this is the register-stationary scan that produces knn.qps
             D, I = sh.search_device(q[:nqc], k)
             bs_, bi_ = None, None
             CH = 2_000_000
@@ -349,12 +359,25 @@ def main():
                "queries_per_scan": head["B"], "ms_per_batch": head["ms_per_batch"],
                "planted_neighbour_top1": all(r["planted_neighbour_top1"] for r in by_batch),
                "wide_fallbacks": sum(r["proof_failures"] for r in by_batch),
-               "roofline": {"bound": "hbm", "kernel": "knn_scan_kernel (64-query wide scan)", "achieved": head["scan_GBps"], "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": head["hbm_frac"], "traffic": ktraffic, "avg_launch_ms": head["scan_ms"],
-                            "algorithmic_bytes_per_launch": rows * d * 2},
+               "roofline": {**head["roofline"], "traffic": ktraffic, "traffic_run": "separate --pmc pass" if ktraffic else None},
                "by_batch": by_batch, "checks": checks or None, "cpu_baseline": cpu_knn}
         ix.close()
         del X
+
+    # ---- BASELINE config 5 (opt-in: minutes): one GPU's IVF-Flat shard at its stated size, built on the device, served
+    ivf = None
+    if args.ivf and single:
+        import importlib.util
+
+        enc.close()
+        torch.cuda.empty_cache()
+        spec = importlib.util.spec_from_file_location("config5", os.path.join(ROOT, "tools", "config5.py"))
+        c5 = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(c5)
+        ivf = c5.run(rows=args.ivf_rows, device=local_rank, log=lambda m: sys.stderr.write(m + "\n"))
+        rec = [r["recall_at_40_vs_exact_whole_shard"] for r in ivf["by_nprobe"]]
+        if any(b < a - 1e-3 for a, b in zip(rec, rec[1:])) or ivf["exact"]["planted_top1"] < 0.999:
+            failures.append(f"IVF: recall must not fall with nprobe and the exact scan must find every planted row: {rec}, {ivf['exact']}")
 
     if failures:
         sys.stderr.write("bench.py: parity gate FAILED, no result line is printed:\n  " + "\n  ".join(failures) + "\n")
@@ -366,11 +389,14 @@ def main():
             "metric": f"images/sec embedded ({args.model} bs={B}; each sample = image + caption through both towers)",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16", "dtype_detail": "bf16 MFMA operands (IEEE fp16 where the operand is the fp16 residual stream), f32 accumulate, f32 softmax / LayerNorm statistics", "data": "synthetic",
             "config": {"workload": f"{args.model} image+text encode, bs={B} per GPU, f32 NCHW pixels + int32 tokens resident in HBM "
-                                   "(BASELINE.json configs[1]); random-init weights",
+                                   "(BASELINE.json configs[1]); random-init weights"
+                                   + (f" | kNN: flat IP top-40 over {knn['rows_per_gpu']} x 768 fp16 rows per GPU resident in HBM, query batches "
+                                      f"{args.knn_batches} (configs[2]; reported under `knn`)" if knn else "")
+                                   + (" | IVF-Flat shard of configs[4] under `ivf`" if ivf else ""),
                        "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)"},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "knn": knn, **extras,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "knn": knn, "ivf": ivf, **extras,
         }
         print(json.dumps(line))
     if world > 1:
