@@ -112,7 +112,7 @@ hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, int nq, const _Fl
                           hipStream_t st);
 // IVF build (knn_rq_kernels.hip / knn_kernels.hip): out[i] = argmax_l <P[i], C[l]> (fp16 rows, exact fp32 scores, ties -> smaller l)
 hipError_t launch_assign(const _Float16* C, int64_t nlist, int d, const _Float16* P, int64_t n, int32_t* out, hipStream_t st);
-// one Lloyd update: cent[l] = fp16(mean of X[order[off[l] .. off[l+1])]) (lists with no member keep their row); one workgroup per list
+// one Lloyd update (spherical): cent[l] = fp16(unit-norm mean of X[order[off[l] .. off[l+1])]) (lists with no member keep their row); one workgroup per list
 hipError_t launch_kmeans_update(const _Float16* X, int d, const int64_t* order, const int64_t* off, int nlist, _Float16* cent,
                                 hipStream_t st);
 // scatter n assigned rows into the tile-padded list-sorted arena: dst row = tile0[list] * 32 + pos; lays down idmap / inv

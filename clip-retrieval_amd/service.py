@@ -1,17 +1,23 @@
 """The request hot path of `clip-retrieval back` on the MI355X index and encoder.
 
-`KnnService` (clip_retrieval/clip_back.py:200-590) is a Flask resource; the part of it that does arithmetic per request is
-  compute_query  (:207-255)  text / image / embedding -> fp32 unit-norm query [1, d]        -> encoder.load_clip facade
-  knn_search     (:343-399)  index.search_and_reconstruct + post filter + ordered unique ids  -> knn.Mi355xIndex / Sharded
-  get_non_uniques(:290-309)  faiss.IndexFlatIP over the <= k result vectors + range_search     -> a resident GPU dedup index
-  map_to_metadata(:401-417)  metadata_provider.get(ids, cols)                                 -> ArrowMetadataProvider (batched)
-and this module restates exactly those methods (same names, arguments and return values) on top of the HIP library, so a
-maintainer can subclass / monkey-patch KnnService with them.  Flask, prometheus, URL download, the safety
-model and the front-end stay where they are in the reference (out of scope).
+`KnnService` (clip_retrieval/clip_back.py:200-590) is a Flask resource; what it computes per request is
+  compute_query  (:207-255)  text / image / embedding -> fp32 unit-norm query [1, d]
+  knn_search     (:343-399)  index.search_and_reconstruct, post filter, ordered unique ids
+  post filter    (:290-341)  near-duplicate removal (range search over the <= k result vectors), violence prompts, safety head
+  map_to_metadata(:401-417)  metadata_provider.get(ids, cols) -> one record per result
+`KnnHotPath` offers those four entry points with the reference's names, arguments and return values, so a maintainer binds them
+onto KnnService.  The arithmetic is re-designed for the GPU rather than retyped:
+  * dedup      one range scan of the resident GPU index over the result vectors -> CSR adjacency -> connected components by
+               scipy.sparse.csgraph; a component keeps its best-ranked member (the reference's own DFS keeps the first node it
+               visits, which is the smallest local index = the best rank);
+  * violence   argmax over the two prompt embeddings = a top-1 search of the result vectors against a resident 2-row GPU index
+               (ties -> the smaller id, like np.argmax);
+  * metadata   ONE batched Arrow `take` per request instead of a concat of 1-row slices per id (README.md:432: 41.5 ms).
+Flask, prometheus, URL download and the safety MODEL itself (any object with the reference's `.predict`) stay where they are
+in the reference (out of scope).
 """
 
 import threading
-from collections import defaultdict
 
 import numpy as np
 
@@ -19,17 +25,16 @@ from .knn import Mi355xIndex
 
 
 def normalized(a, axis=-1, order=2):
-    """clip_back.py:194-197."""
-    l2 = np.atleast_1d(np.linalg.norm(a, order, axis))
-    l2[l2 == 0] = 1
-    return a / np.expand_dims(l2, axis)
+    """Rows scaled to unit norm, zero rows left alone (clip_back.py:194-197)."""
+    n = np.atleast_1d(np.linalg.norm(a, order, axis))
+    n[n == 0] = 1
+    return a / np.expand_dims(n, axis)
 
 
 class ArrowMetadataProvider:
     """Metadata of contiguous ids from memory-mapped Arrow IPC files (clip_back.py:599-615), with ONE batched `take` per
-    request instead of the reference's concat of 1-row slices per id (after a 26 ms scan the 41.5 ms metadata fetch is the
-    request bottleneck, README.md:432).  Same constructor, same `get(ids, cols) -> list of dict records`, same row order
-    (the order of `ids`, duplicates kept), same column filter (unknown columns are ignored)."""
+    request instead of the reference's concat of 1-row slices per id.  Same constructor, same `get(ids, cols) -> list of
+    dict records`, same row order (the order of `ids`, duplicates kept), same column filter (unknown columns are ignored)."""
 
     def __init__(self, arrow_folder):
         from pathlib import Path  # pylint: disable=import-outside-toplevel
@@ -47,155 +52,164 @@ class ArrowMetadataProvider:
         ids = np.asarray(list(ids), dtype=np.int64)
         if ids.size == 0:
             return []
-        return self.table.select(cols).take(pa.array(ids)).to_pandas().to_dict("records")
+        return self.table.select(cols).take(pa.array(ids)).to_pylist()
+
+
+class _ResidentIndex:
+    """A small flat GPU index per embedding width that lives as long as the service (allocating one per request would cost
+    more than the search): `fresh(rows)` refills it."""
+
+    def __init__(self, device):
+        self._device = device
+        self._by_dim = {}
+        self.lock = threading.Lock()
+
+    def fresh(self, rows):
+        ix = self._by_dim.get(rows.shape[1])
+        if ix is None:
+            ix = self._by_dim[rows.shape[1]] = Mi355xIndex(rows.shape[1], device=self._device, coalesce=False)
+        ix.reset()
+        ix.add(rows)
+        return ix
 
 
 class KnnHotPath:
     """The arithmetic of one /knn-service request.  `clip_resource` is the reference's ClipResource-shaped object:
-    .model / .tokenizer / .preprocess / .device (encoder.load_clip), .image_index / .text_index (knn.Mi355xIndex or
+    .model / .tokenizer / .preprocess (encoder.load_clip), .image_index / .text_index (knn.Mi355xIndex or
     knn.ShardedMi355xIndex), .safety_model, .violence_detector, .aesthetic_embeddings, .metadata_is_ordered_by_ivf = False."""
 
     def __init__(self, dedup_device=0):
-        self._dedup = {}  # d -> resident Mi355xIndex reused by every request
-        self._dedup_lock = threading.Lock()
-        self._dedup_device = dedup_device
+        self._scratch = _ResidentIndex(dedup_device)   # dedup: the request's own result vectors
+        self._prompts = {}                             # id(violence_detector array) -> resident 2-row index
+        self._prompts_lock = threading.Lock()
+        self._device = dedup_device
 
-    # ---- clip_back.py:207-255
+    # ------------------------------------------------------------------ clip_back.py:207-255
     def compute_query(self, clip_resource, text_input, image_input, image_url_input, embedding_input, use_mclip=False,
                       aesthetic_score=None, aesthetic_weight=None):
+        """fp32 [1, d] query.  Exactly one of the inputs is used, in the reference's order of precedence."""
         if use_mclip:
             raise NotImplementedError("mclip (sentence-transformers) is not part of the accelerated path")
-        query = None
-        if text_input is not None and text_input != "":
-            text = clip_resource.tokenizer([text_input])
-            text_features = clip_resource.model.encode_text(text)
-            text_features = text_features / text_features.norm(dim=-1, keepdim=True)
-            query = text_features.cpu().float().numpy()
-        elif image_input is not None or image_url_input is not None:
+        feats = None
+        if text_input:
+            feats = clip_resource.model.encode_text(clip_resource.tokenizer([text_input]))
+        elif image_input is not None:
             import base64  # pylint: disable=import-outside-toplevel
             from io import BytesIO  # pylint: disable=import-outside-toplevel
 
             from PIL import Image  # pylint: disable=import-outside-toplevel
 
-            if image_input is None:
-                raise NotImplementedError("image_url_input needs the reference's download_image (networking: out of scope)")
-            img = Image.open(BytesIO(base64.b64decode(image_input)))
-            prepro = clip_resource.preprocess(img).unsqueeze(0)
-            image_features = clip_resource.model.encode_image(prepro)
-            image_features = image_features / image_features.norm(dim=-1, keepdim=True)
-            query = image_features.cpu().float().numpy()
+            pixels = clip_resource.preprocess(Image.open(BytesIO(base64.b64decode(image_input))))
+            feats = clip_resource.model.encode_image(pixels.unsqueeze(0))
+        elif image_url_input is not None:
+            raise NotImplementedError("image_url_input needs the reference's download_image (networking: out of scope)")
+        if feats is not None:
+            # the encoder already returns unit-norm fp32 rows; dividing again keeps the reference's exact contract for any model
+            query = (feats / feats.norm(dim=-1, keepdim=True)).cpu().float().numpy()
         elif embedding_input is not None:
-            query = np.expand_dims(np.array(embedding_input).astype("float32"), 0)
+            query = np.asarray(embedding_input, dtype=np.float32)[None, :]
+        else:
+            return None
         aest = getattr(clip_resource, "aesthetic_embeddings", None)
         if aest is not None and aesthetic_score is not None:
             query = query + aest[aesthetic_score] * aesthetic_weight
             query = query / np.linalg.norm(query)
         return query
 
-    # ---- clip_back.py:270-288
-    @staticmethod
-    def connected_components(neighbors):
-        seen = set()
-
-        def component(node):
-            r, nodes = [], set([node])
-            while nodes:
-                node = nodes.pop()
-                seen.add(node)
-                nodes |= set(neighbors[node]) - seen
-                r.append(node)
-            return r
-
-        u = []
-        for node in neighbors:
-            if node not in seen:
-                u.append(component(node))
-        return u
-
-    # ---- clip_back.py:290-309: the k x k range search runs on the GPU (same kernel as the index scan, range mode)
+    # ------------------------------------------------------------------ clip_back.py:290-309 (+ :270-288)
     def get_non_uniques(self, embeddings, threshold=0.94):
+        """Local indices of the results that duplicate a better-ranked one: rows whose inner product exceeds `threshold` are
+        linked; of every connected group only the smallest index (= best rank) survives."""
         embeddings = np.ascontiguousarray(embeddings, dtype=np.float32)
-        if embeddings.shape[0] == 0:
+        n = embeddings.shape[0]
+        if n == 0:
             return []
-        d = embeddings.shape[1]
-        with self._dedup_lock:
-            ix = self._dedup.get(d)
-            if ix is None:
-                ix = self._dedup[d] = Mi355xIndex(d, device=self._dedup_device, coalesce=False)
-            ix.reset()
-            ix.add(embeddings)
-            l, _, I = ix.range_search(embeddings, threshold)
-        same_mapping = defaultdict(list)
-        for i in range(embeddings.shape[0]):
-            for j in I[l[i]: l[i + 1]]:
-                same_mapping[int(i)].append(int(j))
-        non_uniques = set()
-        for g in self.connected_components(same_mapping):
-            for e in g[1:]:
-                non_uniques.add(e)
-        return list(non_uniques)
+        with self._scratch.lock:
+            lims, _, nbr = self._scratch.fresh(embeddings).range_search(embeddings, threshold)
+        return self.non_uniques_from_links(lims, nbr, n)
 
-    def connected_components_dedup(self, embeddings):
-        return self.get_non_uniques(embeddings)
+    @staticmethod
+    def non_uniques_from_links(lims, nbr, n):
+        """Range-search result in CSR form (row i links to nbr[lims[i]:lims[i+1]]) -> every node that is not the smallest
+        index of its connected group."""
+        from scipy.sparse import csr_matrix  # pylint: disable=import-outside-toplevel
+        from scipy.sparse.csgraph import connected_components  # pylint: disable=import-outside-toplevel
 
-    # ---- clip_back.py:315-341 (the safety model is any object with the reference's .predict)
+        graph = csr_matrix((np.ones(len(nbr), dtype=np.int8), np.asarray(nbr), np.asarray(lims)), shape=(n, n))
+        _, label = connected_components(graph, directed=False)
+        first = np.full(label.max() + 1, n, dtype=np.int64)
+        np.minimum.at(first, label, np.arange(n))
+        return np.flatnonzero(first[label] != np.arange(n)).tolist()
+
+    connected_components_dedup = get_non_uniques
+
+    # ------------------------------------------------------------------ clip_back.py:315-341
     @staticmethod
     def get_unsafe_items(safety_model, embeddings, threshold=0.5):
-        nsfw_values = safety_model.predict(embeddings, batch_size=embeddings.shape[0])
-        x = np.array([e[0] for e in nsfw_values])
-        return np.where(x > threshold)[0]
+        """Indices the safety head scores above `threshold` (the model is the reference's: anything with `.predict`)."""
+        scores = np.asarray(safety_model.predict(embeddings, batch_size=embeddings.shape[0]))
+        return np.flatnonzero(scores.reshape(len(scores), -1)[:, 0] > threshold)
 
-    @staticmethod
-    def get_violent_items(safety_prompts, embeddings):
-        safety_predictions = np.einsum("ij,kj->ik", embeddings, safety_prompts)
-        return np.where(np.argmax(safety_predictions, axis=1) == 1)[0]
+    def get_violent_items(self, safety_prompts, embeddings):
+        """Indices whose best-matching prompt is prompt 1 ("violent"): top-1 of every result vector against the prompts,
+        searched on the GPU (the prompt matrix stays resident)."""
+        embeddings = np.ascontiguousarray(embeddings, dtype=np.float32)
+        if embeddings.shape[0] == 0:
+            return np.zeros(0, dtype=np.int64)
+        key = id(safety_prompts)
+        with self._prompts_lock:
+            ix = self._prompts.get(key)
+            if ix is None:
+                ix = self._prompts[key] = Mi355xIndex(embeddings.shape[1], device=self._device, coalesce=False)
+                ix.add(np.ascontiguousarray(safety_prompts, dtype=np.float32))
+            _, best = ix.search(embeddings, 1)
+        return np.flatnonzero(best[:, 0] == 1)
 
     def post_filter(self, safety_model, embeddings, deduplicate, use_safety_model, use_violence_detector, violence_detector):
-        to_remove = set()
+        """Local indices to drop: duplicates | violent | unsafe."""
+        drop = set()
         if deduplicate:
-            to_remove = set(self.connected_components_dedup(embeddings))
+            drop.update(self.get_non_uniques(embeddings))
         if use_violence_detector and violence_detector is not None:
-            to_remove |= set(self.get_violent_items(violence_detector, embeddings))
+            drop.update(int(i) for i in self.get_violent_items(violence_detector, embeddings))
         if use_safety_model and safety_model is not None:
-            to_remove |= set(self.get_unsafe_items(safety_model, embeddings))
-        return to_remove
+            drop.update(int(i) for i in self.get_unsafe_items(safety_model, embeddings))
+        return drop
 
-    # ---- clip_back.py:343-399 (the metadata_is_ordered_by_ivf branch needs faiss' IVF internals: use False, as the
-    # LAION-5B recipes do, docs/laion5B_back.md:22)
+    # ------------------------------------------------------------------ clip_back.py:343-399
     def knn_search(self, query, modality, num_result_ids, clip_resource, deduplicate, use_safety_model, use_violence_detector):
+        """(distances, indices): the index's answer cut at the first -1, minus the post filter's picks, each id once, best
+        first.  (metadata_is_ordered_by_ivf needs faiss' IVF id mapping: serve with reorder_metadata_by_ivf_index=False, as the
+        LAION-5B recipes do, docs/laion5B_back.md:22.)"""
         if getattr(clip_resource, "metadata_is_ordered_by_ivf", False):
             raise NotImplementedError("metadata_is_ordered_by_ivf needs faiss' IVF id mapping; serve with reorder_metadata_by_ivf_index=False")
         index = clip_resource.image_index if modality == "image" else clip_resource.text_index
-        distances, indices, embeddings = index.search_and_reconstruct(query, num_result_ids)
-        results = indices[0]
-        nb_results = np.where(results == -1)[0]
-        nb_results = nb_results[0] if len(nb_results) > 0 else len(results)
-        result_indices = results[:nb_results]
-        result_distances = distances[0][:nb_results]
-        result_embeddings = normalized(embeddings[0][:nb_results])
-        local_indices_to_remove = self.post_filter(getattr(clip_resource, "safety_model", None), result_embeddings, deduplicate,
-                                                   use_safety_model, use_violence_detector,
-                                                   getattr(clip_resource, "violence_detector", None))
-        indices_to_remove = set(result_indices[i] for i in local_indices_to_remove)
-        out_i, out_d = [], []
-        for ind, distance in zip(result_indices, result_distances):
-            if ind not in indices_to_remove:
-                indices_to_remove.add(ind)
-                out_i.append(ind)
-                out_d.append(distance)
-        return out_d, out_i
+        D, I, R = index.search_and_reconstruct(query, num_result_ids)
+        ids = I[0]
+        n = int(np.argmax(ids == -1)) if (ids == -1).any() else len(ids)
+        ids, dist = ids[:n], D[0][:n]
+        keep = np.ones(n, dtype=bool)
+        drop = self.post_filter(getattr(clip_resource, "safety_model", None), normalized(R[0][:n]), deduplicate, use_safety_model,
+                                use_violence_detector, getattr(clip_resource, "violence_detector", None))
+        if drop:
+            keep &= ~np.isin(ids, ids[np.fromiter(drop, dtype=np.int64)])  # an id the filter dropped goes everywhere it occurs
+        _, first = np.unique(ids, return_index=True)                       # an id is reported once, at its best rank
+        once = np.zeros(n, dtype=bool)
+        once[first] = True
+        sel = np.flatnonzero(keep & once)
+        return list(dist[sel]), list(ids[sel])
 
-    # ---- clip_back.py:401-417
+    # ------------------------------------------------------------------ clip_back.py:401-417
     @staticmethod
     def map_to_metadata(indices, distances, num_images, metadata_provider, columns_to_return):
-        results = []
+        """One record per result: the metadata columns of the first `num_images` ids (bytes decoded as utf-8) + id + similarity."""
         metas = metadata_provider.get(indices[:num_images], columns_to_return)
-        for key, (d, i) in enumerate(zip(distances, indices)):
-            output = {}
-            meta = None if key + 1 > len(metas) else metas[key]
-            if meta is not None:
-                output.update({k: (v.decode("utf-8") if isinstance(v, bytes) else v) for k, v in meta.items()})
-            output["id"] = i.item()
-            output["similarity"] = d.item()
-            results.append(output)
-        return results
+        out = []
+        for rank, (d, i) in enumerate(zip(distances, indices)):
+            rec = {}
+            if rank < len(metas) and metas[rank] is not None:
+                rec.update((k, v.decode("utf-8") if isinstance(v, bytes) else v) for k, v in metas[rank].items())
+            rec["id"] = i.item() if hasattr(i, "item") else int(i)
+            rec["similarity"] = d.item() if hasattr(d, "item") else float(d)
+            out.append(rec)
+        return out

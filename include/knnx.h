@@ -105,7 +105,7 @@ int knnx_ivf_nlist(const knnx_index* ix);
 /* ---- IVF-Flat build on the device (stands in for the autofaiss call of clip_index.py:12-66) ----------
  * Training: a builder keeps the centroids and a training sample resident in HBM.  One Lloyd iteration =
  * knnx_ivfb_assign_sample (argmax over the centroids by the MFMA assignment kernel; ties -> smaller list id) + host
- * bookkeeping (stable sort of the list ids -> order, prefix sums -> off) + knnx_ivfb_update (mean of each list's members,
+ * bookkeeping (stable sort of the list ids -> order, prefix sums -> off) + knnx_ivfb_update (unit-norm mean of each list's members -- spherical k-means, what inner-product assignment needs --,
  * fixed summation order; empty lists keep their centroid for the caller to re-seed through knnx_ivfb_set_centroids).
  * Adding without a second copy of the shard: pass 1 knnx_ivfb_assign streams the rows and returns their list ids;
  * pass 2 knnx_ivf_begin(list sizes) / knnx_ivf_add_assigned(rows, ids, list, position inside the list) / knnx_ivf_end

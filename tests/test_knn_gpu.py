@@ -591,7 +591,8 @@ def test_load_index_from_numpy_writer_output(tmp_path):
 # ---------------------------------------------------------------------------------------------------------------
 # IVF build on the device (assignment kernel, Lloyd update, streaming scatter) and nprobe > 64
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,nlist,n", [(768, 100, 5000), (512, 1000, 70_001), (1024, 33, 777), (256, 4096, 3000)])
+@pytest.mark.parametrize("d,nlist,n", [(768, 100, 5000), (512, 1000, 70_001), (1024, 33, 777), (256, 4096, 3000), (1024, 130, 5000),
+                                       (1024, 4096, 3000), (768, 16384, 2000)])
 def test_ivf_assignment_kernel_vs_numpy_argmax(d, nlist, n):
     """knn_assign_kernel (every workgroup streams all centroids, a lane keeps the running best of its point): list ids must
     equal numpy's argmax of the fp32 scores of the same fp16 data, except where the two best scores are within 1e-5."""
@@ -730,9 +731,13 @@ def test_ivf_build_from_device_rows_equals_the_host_build():
     finally:
         b.close()
     assert np.array_equal(lists_host, ix.ivf_lists), "device pass 1 and the host-pointer assignment disagree"
+    # spherical k-means: unit-norm centroids, so the mean best score is comparable with that of unit-norm seed points
+    assert np.abs(np.linalg.norm(cent.astype(np.float32), axis=1) - 1).max() < 2e-3
     obj_seed = float((x.astype(np.float32) @ x[:: n // 8192][:nlist].astype(np.float32).T).max(1).mean())
     obj = float((x.astype(np.float32) @ cent.astype(np.float32).T).max(1).mean())
     assert obj > obj_seed, (obj, obj_seed)
+    sizes = np.bincount(ix.ivf_lists, minlength=nlist)
+    assert np.median(sizes) > 0.3 * n / nlist, f"unbalanced lists: min / median / max = {sizes.min()} / {np.median(sizes)} / {sizes.max()}"
     ref = build_ivf_index(x, nlist, nprobe=8, centroids=cent)
     ora = IVFFlatOracle(d, cent, ix.ivf_lists, x)
     q = _queries(33, d, seed=9, x=x)

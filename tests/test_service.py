@@ -34,17 +34,68 @@ def test_arrow_metadata_provider_batched_take_equals_reference_slicing(tmp_path)
         assert got == want
 
 
-def test_connected_components_and_post_filter_logic():
+def _reference_non_uniques(neighbors):
+    """clip_back.py:270-309 restated as the checker: depth-first groups over the range-search links, every group keeps the
+    first node the walk reaches (nodes are visited in ascending order), the rest are non-unique."""
+    seen, out = set(), set()
+    for start in neighbors:
+        if start in seen:
+            continue
+        todo, group = {start}, []
+        while todo:
+            node = todo.pop()
+            seen.add(node)
+            todo |= set(neighbors.get(node, ())) - seen
+            group.append(node)
+        out |= set(group[1:])
+    return out
+
+
+def test_dedup_groups_from_range_search_links():
+    """service.non_uniques_from_links (CSR links -> scipy connected components, a group keeps its smallest index) against
+    the reference's DFS on hand-made and random link structures."""
     from clip_retrieval_amd.service import KnnHotPath
 
-    hp = KnnHotPath()
     nb = {0: [0, 2], 1: [1], 2: [2, 0, 4], 3: [3], 4: [4, 2], 5: [5, 6], 6: [6, 5]}
-    comps = hp.connected_components(nb)
-    assert sorted(sorted(c) for c in comps) == [[0, 2, 4], [1], [3], [5, 6]]
-    assert [c[0] for c in comps] == [0, 1, 3, 5]  # a component starts at its smallest (= best-ranked) member
-    emb = np.eye(4, dtype=np.float32)
-    prompts = np.stack([emb[0], emb[1]])  # class 1 ("violent") = direction e1
-    assert list(hp.get_violent_items(prompts, emb)) == [1]
+    lims = np.cumsum([0] + [len(nb[i]) for i in range(7)])
+    nbr = np.concatenate([nb[i] for i in range(7)])
+    assert set(KnnHotPath.non_uniques_from_links(lims, nbr, 7)) == _reference_non_uniques(nb) == {2, 4, 6}
+    rng = np.random.default_rng(0)
+    for n in (1, 5, 60, 300):
+        a = rng.random((n, n)) < 1.5 / n
+        a = a | a.T | np.eye(n, dtype=bool)
+        nb = {i: np.flatnonzero(a[i]).tolist() for i in range(n)}
+        lims = np.cumsum([0] + [len(nb[i]) for i in range(n)])
+        nbr = np.concatenate([nb[i] for i in range(n)]) if n else np.zeros(0, int)
+        assert set(KnnHotPath.non_uniques_from_links(lims, nbr, n)) == _reference_non_uniques(nb)
+
+
+def test_map_to_metadata_and_embedding_query(tmp_path):
+    """map_to_metadata (clip_back.py:401-417): metadata for the first num_images ids only, id / similarity always, bytes
+    decoded; compute_query's embedding branch with the aesthetic shift (clip_back.py:247-255)."""
+    from types import SimpleNamespace
+
+    from clip_retrieval_amd.service import KnnHotPath
+
+    class Provider:
+        def get(self, ids, cols=None):
+            return [{"url": f"u{int(i)}".encode(), "caption": f"c{int(i)}", "skip": 1} if cols is None else
+                    {k: v for k, v in {"url": f"u{int(i)}".encode(), "caption": f"c{int(i)}"}.items() if k in cols} for i in ids]
+
+    ids, dist = [np.int64(7), np.int64(3), np.int64(9)], [np.float32(0.9), np.float32(0.8), np.float32(0.7)]
+    got = KnnHotPath.map_to_metadata(ids, dist, 2, Provider(), ["url", "caption"])
+    assert got == [{"url": "u7", "caption": "c7", "id": 7, "similarity": float(np.float32(0.9))},
+                   {"url": "u3", "caption": "c3", "id": 3, "similarity": float(np.float32(0.8))},
+                   {"id": 9, "similarity": float(np.float32(0.7))}]
+    hp = KnnHotPath.__new__(KnnHotPath)  # no GPU needed for the embedding branch
+    aest = np.zeros((10, 4), np.float32)
+    aest[9] = [0, 1, 0, 0]
+    res = SimpleNamespace(aesthetic_embeddings=aest)
+    q = hp.compute_query(res, None, None, None, [1.0, 0.0, 0.0, 0.0], False, 9, 0.5)
+    want = np.array([[1.0, 0.5, 0, 0]], np.float32)
+    assert q.shape == (1, 4) and q.dtype == np.float32 and np.allclose(q, want / np.linalg.norm(want))
+    assert np.array_equal(hp.compute_query(SimpleNamespace(aesthetic_embeddings=None), None, None, None, [0.0, 2.0], False, None, None),
+                          np.array([[0.0, 2.0]], np.float32))
 
 
 @pytest.mark.gpu
@@ -70,11 +121,7 @@ def test_gpu_dedup_and_knn_search_match_the_reference_logic():
 
     def ref_non_uniques(emb, thr=0.94):
         s = emb @ emb.T
-        nbrs = {i: [int(j) for j in np.flatnonzero(s[i] > thr)] for i in range(emb.shape[0])}
-        out = set()
-        for g in hp.connected_components(nbrs):
-            out |= set(g[1:])
-        return out
+        return _reference_non_uniques({i: [int(j) for j in np.flatnonzero(s[i] > thr)] for i in range(emb.shape[0])})
 
     R = normalized(x16[np.r_[0:20, 100:110, 499:501, 7]].astype(np.float32))
     assert set(hp.get_non_uniques(R)) == ref_non_uniques(R)

@@ -1,0 +1,241 @@
+"""GPU tests of the product code round 2 left unexercised (VERDICT r2, next-round item 3 a / b / e):
+checkpoint + vocabulary loading through `ClipMapper(clip_model=..., clip_cache_path=...)` / `load_clip`, the request path
+`KnnHotPath.compute_query -> knn_search -> map_to_metadata`, and `worker.worker()` itself over tar shards."""
+import base64
+import gzip
+import io
+import json
+import os
+import tarfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+COS_BAR = 1.0 - 1e-3
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def _openai_state_dict(W, arch):
+    """The oracle's unpacked weights under OpenAI `clip` / open_clip state-dict names (visual.proj and text_projection are
+    stored [width, embed] there)."""
+    sd = {"visual.conv1.weight": W["conv"].reshape(arch.v_width, 3, arch.patch_size, arch.patch_size), "visual.class_embedding": W["cls"],
+          "visual.positional_embedding": W["vpos"], "visual.ln_pre.weight": W["ln_pre_w"], "visual.ln_pre.bias": W["ln_pre_b"],
+          "visual.ln_post.weight": W["ln_post_w"], "visual.ln_post.bias": W["ln_post_b"], "visual.proj": W["vproj"].T.contiguous(),
+          "token_embedding.weight": W["tok"], "positional_embedding": W["tpos"], "ln_final.weight": W["ln_final_w"],
+          "ln_final.bias": W["ln_final_b"], "text_projection": W["tproj"].T.contiguous(), "logit_scale": torch.tensor(4.6)}
+    names = {"ln1_w": "ln_1.weight", "ln1_b": "ln_1.bias", "qkv_w": "attn.in_proj_weight", "qkv_b": "attn.in_proj_bias",
+             "out_w": "attn.out_proj.weight", "out_b": "attn.out_proj.bias", "ln2_w": "ln_2.weight", "ln2_b": "ln_2.bias",
+             "fc1_w": "mlp.c_fc.weight", "fc1_b": "mlp.c_fc.bias", "fc2_w": "mlp.c_proj.weight", "fc2_b": "mlp.c_proj.bias"}
+    for prefix, layers in (("visual.transformer", W["vlayers"]), ("transformer", W["tlayers"])):
+        for i, L in enumerate(layers):
+            for k, n in names.items():
+                sd[f"{prefix}.resblocks.{i}.{n}"] = L[k]
+    return {k: v.clone() for k, v in sd.items()}
+
+
+def _merges_file(folder):
+    """A CLIP-format merges file (synthetic: the real one is not available offline) under the name find_bpe_file looks for."""
+    from clip_retrieval_amd.tokenizer import BPE_FILE_NAME, bytes_to_unicode
+
+    b2u = bytes_to_unicode()
+    pairs = []
+    for w in ("photo", "cat", "dog", "the", "of", "a"):
+        sym = [b2u[b] for b in w.encode()]
+        sym[-1] += "</w>"
+        while len(sym) > 1:
+            pairs.append((sym[0], sym[1]))
+            sym = [sym[0] + sym[1]] + sym[2:]
+    seen, merges = set(), []
+    for p in pairs:
+        if p not in seen:
+            seen.add(p)
+            merges.append(p)
+    path = os.path.join(folder, BPE_FILE_NAME)
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        f.write("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n")
+    return path
+
+
+@pytest.fixture(scope="module")
+def tiny_checkpoints(tmp_path_factory):
+    """tmp/<hf|openai>/tiny-test.{safetensors,pt} of the tiny ViT-B/32-shaped oracle + a merges file beside each."""
+    from safetensors.torch import save_file
+
+    import clip_retrieval_amd.encoder as E
+    from oracle.clip_oracle import ARCHS, HFClipOracle, unpack_blob
+
+    arch = ARCHS["tiny-B/32"]
+    oracle = HFClipOracle(arch, seed=0)
+    root = tmp_path_factory.mktemp("ckpt")
+    hf, oa = root / "hf", root / "openai"
+    hf.mkdir()
+    oa.mkdir()
+    sd = {k: v.contiguous() for k, v in oracle.model.state_dict().items() if v.dtype.is_floating_point}
+    save_file(sd, str(hf / "tiny-test.safetensors"))
+    W = unpack_blob(torch.from_numpy(oracle.export_blob()), arch)
+    torch.save({"state_dict": {"module." + k: v for k, v in _openai_state_dict(W, arch).items()}}, str(oa / "tiny-test.pt"))
+    for d in (hf, oa):
+        _merges_file(str(d))
+    E.ARCHS["tiny-test"] = E.ClipArch(**{k: getattr(arch, k) for k in E.ClipArch.__dataclass_fields__})
+    yield arch, oracle, {"hf": str(hf), "openai": str(oa)}
+    E.ARCHS.pop("tiny-test", None)
+    with E._registry_lock:  # pylint: disable=protected-access
+        for key in [k for k in E._registry if k[0] == "tiny-test"]:  # pylint: disable=protected-access
+            E._registry.pop(key).close()  # pylint: disable=protected-access
+
+
+@pytest.mark.parametrize("kind", ["hf", "openai"])
+def test_checkpoint_and_vocabulary_are_loaded_from_clip_cache_path(tiny_checkpoints, kind):
+    """mapper.py:36-41 `load_clip(clip_model, clip_cache_path=...)`: the weights come from a file on disk (HF-keyed
+    .safetensors / OpenAI-keyed .pt saved from a wrapper with a `module.` prefix) and the tokenizer from the merges file next to
+    it; `ClipMapper.__call__` on real caption strings and image tensors must match the oracle that owns those weights."""
+    import clip_retrieval_amd.encoder as E
+    from clip_retrieval_amd.mapper import ClipMapper
+    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, synth_pixels_u8
+
+    arch, oracle, dirs = tiny_checkpoints
+    with E._registry_lock:  # pylint: disable=protected-access
+        for key in [k for k in E._registry if k[0] == "tiny-test"]:  # the two checkpoints share the model name
+            E._registry.pop(key).close()  # pylint: disable=protected-access
+    model, preprocess, tokenizer = E.load_clip("tiny-test", use_jit=False, warmup_batch_size=1, clip_cache_path=dirs[kind])
+    caps = ["a photo of a cat", "the dog of the cat", "a"]
+    tokens = tokenizer(caps)
+    assert tuple(tokens.shape) == (3, arch.ctx_len) and int(tokens[0, 0]) == tokenizer.sot_token and int(tokens.max()) == tokenizer.eot_token
+    pix = torch.from_numpy(normalise_u8_nhwc(synth_pixels_u8(3, seed=4)))
+    mapper = ClipMapper(enable_image=True, enable_text=True, enable_metadata=False, use_mclip=False, clip_model="tiny-test",
+                        use_jit=False, mclip_model="", warmup_batch_size=1, clip_cache_path=dirs[kind])
+    out = mapper({"image_tensor": pix, "text_tokens": tokens, "image_filename": ["a", "b", "c"], "text": caps, "metadata": None})
+    _, wi = mapper_semantics(oracle.encode_image(pix))
+    _, wt = mapper_semantics(oracle.encode_text(tokens))
+    assert out["image_embs"].dtype == np.float16 and out["image_embs"].shape == (3, arch.embed_dim)
+    assert _cos(out["image_embs"], wi).min() >= COS_BAR and _cos(out["text_embs"], wt).min() >= COS_BAR, kind
+    assert out["text"] == caps
+    ft = model.encode_text(tokens)
+    assert ft.dtype == torch.float32 and _cos(ft.numpy(), wt).min() >= COS_BAR
+
+
+def test_request_path_compute_query_knn_search_map_to_metadata(tiny_checkpoints, tmp_path):
+    """One /knn-service request end to end on the GPU (clip_back.py:419-470 = compute_query -> knn_search -> map_to_metadata):
+    text, base64-image and embedding queries with the aesthetic shift; the index holds the oracle's embeddings of 300 synthetic
+    images + captions, so the expected neighbours come from the numpy oracle; metadata through ArrowMetadataProvider."""
+    from types import SimpleNamespace
+
+    import pyarrow as pa
+    from PIL import Image
+
+    import clip_retrieval_amd.encoder as E
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from clip_retrieval_amd.reader import clip_preprocess
+    from clip_retrieval_amd.service import ArrowMetadataProvider, KnnHotPath
+    from oracle.clip_oracle import mapper_semantics, synth_pixels_u8
+    from oracle.knn_oracle import FlatIPOracle
+
+    arch, oracle, dirs = tiny_checkpoints
+    model, preprocess, tokenizer = E.load_clip("tiny-test", use_jit=False, warmup_batch_size=1, clip_cache_path=dirs["hf"])
+    n = 300
+    u8 = synth_pixels_u8(n, arch.image_size, seed=11)
+    pix = torch.from_numpy(np.stack([clip_preprocess(Image.fromarray(im), size=arch.image_size) for im in u8]))
+    emb16, _ = mapper_semantics(oracle.encode_image(pix))
+    ix, ora = Mi355xIndex(arch.embed_dim), FlatIPOracle(arch.embed_dim)
+    ix.add(emb16)
+    ora.add(emb16)
+    t = pa.table({"url": [f"http://x/{i}" for i in range(n)], "caption": [f"caption {i}".encode() for i in range(n)]})
+    with pa.OSFile(str(tmp_path / "0.arrow"), "wb") as sink:
+        with pa.ipc.new_file(sink, t.schema) as w:
+            w.write_table(t)
+    provider = ArrowMetadataProvider(str(tmp_path))
+    aest = np.random.default_rng(0).standard_normal((10, arch.embed_dim)).astype(np.float32)
+    aest /= np.linalg.norm(aest, axis=1, keepdims=True)
+    prompts = np.stack([emb16[0].astype(np.float32), emb16[5].astype(np.float32)])  # "violent" = looks like image 5
+    res = SimpleNamespace(model=model, tokenizer=tokenizer, preprocess=preprocess, device="cuda:0", image_index=ix, text_index=ix,
+                          metadata_is_ordered_by_ivf=False, safety_model=None, violence_detector=prompts, aesthetic_embeddings=aest)
+    hp = KnnHotPath()
+
+    # image query: the PNG of image 7, base64 like the front-end sends it
+    buf = io.BytesIO()
+    Image.fromarray(u8[7]).save(buf, format="PNG")
+    q = hp.compute_query(res, None, base64.b64encode(buf.getvalue()).decode(), None, None, False, None, None)
+    _, want = mapper_semantics(oracle.encode_image(pix[7:8]))
+    assert q.shape == (1, arch.embed_dim) and q.dtype == np.float32 and _cos(q, want).min() >= COS_BAR
+    dist, ind = hp.knn_search(q, "image", 10, res, False, False, False)
+    Do, Io = ora.search(q, 10)
+    assert [int(i) for i in ind] == Io[0].tolist() and int(ind[0]) == 7 and np.allclose(dist, Do[0], atol=1e-5)
+    recs = hp.map_to_metadata(ind, dist, 4, provider, ["url", "caption"])
+    assert len(recs) == 10 and recs[0] == {"url": "http://x/7", "caption": "caption 7", "id": 7, "similarity": float(dist[0])}
+    assert set(recs[3]) == {"url", "caption", "id", "similarity"} and set(recs[4]) == {"id", "similarity"}
+
+    # text query with the aesthetic shift (clip_back.py:251-254)
+    q = hp.compute_query(res, "a photo of a cat", None, None, None, False, 9, 0.5)
+    _, wt = mapper_semantics(oracle.encode_text(tokenizer(["a photo of a cat"])))
+    wq = wt + aest[9] * 0.5
+    wq /= np.linalg.norm(wq)
+    assert _cos(q, wq).min() >= COS_BAR and abs(np.linalg.norm(q) - 1) < 1e-5
+    dist, ind = hp.knn_search(q, "text", 8, res, False, False, False)
+    Do, Io = ora.search(q, 8)
+    assert [int(i) for i in ind] == Io[0].tolist()
+
+    # embedding query, violence filter on: results that look more like prompt 1 (image 5) than prompt 0 (image 0) are dropped
+    q = hp.compute_query(res, None, None, None, emb16[5].astype(np.float32).tolist(), False, None, None)
+    dist, ind = hp.knn_search(q, "image", 40, res, False, False, True)
+    Do, Io, Ro = ora.search_and_reconstruct(q, 40)
+    Rn = Ro[0] / np.linalg.norm(Ro[0], axis=1, keepdims=True)
+    s = Rn @ prompts.T
+    keep = [int(i) for i, row in zip(Io[0], s) if not (np.argmax(row) == 1 and abs(row[0] - row[1]) > 1e-3)]
+    maybe = [int(i) for i, row in zip(Io[0], s) if abs(row[0] - row[1]) <= 1e-3]
+    got = [int(i) for i in ind]
+    assert 5 not in got and [i for i in got if i not in maybe] == [i for i in keep if i not in maybe]
+    ix.close()
+
+
+def test_worker_on_the_gpu_over_tar_shards(tiny_checkpoints, tmp_path):
+    """worker.worker() as the reference runs it (worker.py:22-127): tar shards of JPEGs + captions -> WebdatasetReader (uint8
+    pixels, normalised on the GPU) -> pipelined Runner -> ClipMapper -> NumpyWriter.  Every written embedding must match the
+    oracle on the SAME decoded pixels and the same tokens."""
+    import pandas as pd
+    from PIL import Image
+
+    from clip_retrieval_amd.reader import clip_preprocess
+    from clip_retrieval_amd.worker import worker
+    from oracle.clip_oracle import mapper_semantics
+
+    arch, oracle, dirs = tiny_checkpoints
+    rng = np.random.default_rng(0)
+    shards, jpegs, k = [], [], 0
+    for t in range(2):
+        p = tmp_path / f"{t:03d}.tar"
+        with tarfile.open(p, "w") as tf:
+            for _ in range(9):
+                g = np.linspace(0, 255, 96, dtype=np.float32)
+                img = (g[None, :, None] * 0.5 + g[:, None, None] * 0.5 + rng.normal(0, 8, (96, 96, 3))).clip(0, 255).astype(np.uint8)
+                buf = io.BytesIO()
+                Image.fromarray(img).save(buf, format="JPEG", quality=92)
+                jpegs.append(buf.getvalue())
+                for ext, data in (("jpg", buf.getvalue()), ("txt", ("a photo of a cat" if k % 2 else "the dog").encode())):
+                    ti = tarfile.TarInfo(f"{k:06d}.{ext}")
+                    ti.size = len(data)
+                    tf.addfile(ti, io.BytesIO(data))
+                k += 1
+        shards.append(str(p))
+    out = tmp_path / "out"
+    worker(tasks=[0, 1], input_dataset=shards, output_folder=str(out), output_partition_count=2, input_format="webdataset",
+           batch_size=4, num_prepro_workers=2, enable_text=True, enable_image=True, enable_metadata=False, clip_model="tiny-test",
+           clip_cache_path=dirs["openai"], device=0, gpu_normalise=True)
+    from clip_retrieval_amd.tokenizer import SimpleTokenizer
+
+    tok = SimpleTokenizer(clip_cache_path=dirs["openai"], context_length=arch.ctx_len)
+    for i in range(2):
+        img = np.load(out / "img_emb" / f"img_emb_{i}.npy")
+        txt = np.load(out / "text_emb" / f"text_emb_{i}.npy")
+        meta = pd.read_parquet(out / "metadata" / f"metadata_{i}.parquet")
+        assert img.shape == (9, arch.embed_dim) == txt.shape and len(meta) == 9
+        pix = torch.from_numpy(np.stack([clip_preprocess(Image.open(io.BytesIO(j)), size=arch.image_size) for j in jpegs[9 * i:9 * i + 9]]))
+        _, wi = mapper_semantics(oracle.encode_image(pix))
+        _, wt = mapper_semantics(oracle.encode_text(tok(list(meta["caption"]))))
+        assert _cos(img, wi).min() >= COS_BAR and _cos(txt, wt).min() >= COS_BAR
+        assert json.loads((out / "stats" / f"{i}.json").read_text())["sample_count"] == 9
