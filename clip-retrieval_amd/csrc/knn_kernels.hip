@@ -1026,6 +1026,35 @@ hipError_t launch_kmeans_update(const _Float16* X, int d, const int64_t* order, 
   return hipGetLastError();
 }
 
+// one wave per row: copy into its slot of the list-sorted arena
+__global__ __launch_bounds__(256) void ivf_scatter_kernel(const _Float16* __restrict__ src, int64_t n, int d,
+                                                         const int32_t* __restrict__ lists, const int32_t* __restrict__ pos,
+                                                         const int64_t* __restrict__ ids, int64_t id0,
+                                                         const unsigned* __restrict__ tile0, int64_t id_lo, int64_t n_ids,
+                                                         _Float16* __restrict__ dst,
+                                                         int64_t* __restrict__ idmap, uint32_t* __restrict__ inv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const size_t drow = (size_t)tile0[lists[r]] * 32 + (size_t)pos[r];
+  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)r * d);
+  uint4* o = reinterpret_cast<uint4*>(dst + drow * d);
+  for (int c = lane; c < d / 8; c += 64) o[c] = s[c];
+  if (lane == 0) {
+    const int64_t id = ids ? ids[r] : id0 + r;  // ids == null: consecutive ids id0, id0 + 1, ... (a device-resident chunk of the corpus)
+    idmap[drow] = id;
+    if (id >= id_lo && id - id_lo < n_ids) inv[id - id_lo] = (uint32_t)drow;
+  }
+}
+hipError_t launch_ivf_scatter(const _Float16* src, int64_t n, int d, const int32_t* lists, const int32_t* pos, const int64_t* ids,
+                              int64_t id0, const unsigned* tile0, int64_t id_lo, int64_t n_ids, _Float16* dst, int64_t* idmap,
+                              uint32_t* inv, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src, n, d, lists, pos, ids, id0, tile0, id_lo,
+                     n_ids, dst, idmap, inv);
+  return hipGetLastError();
+}
+
 // dst[dst_rows[i], :] = src[src_rows[i], :] (k-means seeding: centroid <- sample row); one wave per pair
 __global__ __launch_bounds__(256) void copy_rows_kernel(const _Float16* __restrict__ src, int d, const int64_t* __restrict__ src_rows,
                                                        const int32_t* __restrict__ dst_rows, int64_t n, _Float16* __restrict__ dst) {
