@@ -37,12 +37,16 @@ struct GemmArgs {
   bf16* out16;            // EPI_BIAS_RESID_F32: also store the new x row as bf16 here (null: do not)
   float* splitk_ws;       // device scratch for split-K partial products (null: never split), splitk_ws_bytes of it
   size_t splitk_ws_bytes;
+  int tail_m0, tail_nb;   // set by launch_gemm for the persistent kernel: rows [tail_m0, tail_m0 + 256) beyond the whole
+                          // m-tiles are computed inside the same launch, 32 x (tail_nb x 32) per workgroup (0: none)
   int f16;                // A and W hold IEEE fp16 instead of bf16 (v_mfma_f32_32x32x16_f16, same rate): the LayerNorm-folded
                           // GEMMs, whose A operand is the fp16 residual stream itself.  bf16-output epilogues (0..2) and RAW only.
 };
 
 // number of 256-row m-tiles variant 3 hands to the 256x256 kernel for an [M, N] output
 int gemm256_bulk_mtiles(int M, int N, int n_cu);
+// blocks of 32 columns per workgroup when ONE ragged m-tile of 256 rows rides in the persistent launch (0: not possible)
+int gemm256_tail_blocks(int N, int K, int n_cu);
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 

@@ -431,6 +431,19 @@ int gemm256_bulk_mtiles(int M, int N, int n_cu) {
   return best;
 }
 
+// One ragged m-tile (256 rows) inside the persistent launch: 8 row blocks x (N / 32) column blocks of 32 x 32 are dealt to the
+// workgroups as strips of NB consecutive column blocks; NB <= 4 (the strip's operands must fit the LDS ring), NB | N / 32, and
+// every strip needs a workgroup.
+int gemm256_tail_blocks(int N, int K, int n_cu) {
+  int grid = (n_cu > 0 ? n_cu : 256) & ~7;
+  if (grid < 8) grid = 8;
+  if (N % 32 || K % 128 || (size_t)32 * K * 2 >= ((size_t)1 << 31)) return 0;
+  const int cb = N / 32;
+  for (int nb = 1; nb <= 4; ++nb)
+    if (cb % nb == 0 && 8 * (cb / nb) <= grid) return nb;
+  return 0;
+}
+
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
   if ((g.epi == EPI_BIAS_BF16 || g.epi == EPI_BIAS_QGELU_BF16 || g.epi == EPI_BIAS_GELU_BF16) && !g.rowscale) return hipErrorInvalidValue;
@@ -443,6 +456,14 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
     if (bulk > 0 && (int64_t)bulk * (g.N / 256) >= cu / 2) {
       GemmArgs b = g;
       b.M = bulk * 256;
+      b.tail_m0 = b.tail_nb = 0;
+      // exactly one m-tile left over (ViT-L/14 at bs 256: 257 m-tiles on 256 CUs): it rides in the same launch
+      // (gemm256sp.hip: gemm256_tail) instead of a second, nearly empty one.  CLIPX_GEMM_VARIANT=4 keeps the separate launch (A/B).
+      if (g.M - b.M == 256 && g.variant == 3 && g.row0 == 0) {
+        b.tail_nb = gemm256_tail_blocks(g.N, g.K, g.n_cu);
+        b.tail_m0 = b.M;
+      }
+      const bool tail_inside = b.tail_nb > 0;
 #ifdef CLIPX_ABLATE
       // variant 5 (tools build only): the two-workgroups-per-CU experiment of gemm2wg.hip (bitwise equal, 25-35 % slower)
       hipError_t e = g.variant == 5 ? launch_gemm2wg(b, g.n_cu, st) : launch_gemm256sp(b, g.n_cu, st);
@@ -450,7 +471,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       hipError_t e = launch_gemm256sp(b, g.n_cu, st);
 #endif
       if (e != hipSuccess) return e;
-      if (b.M == g.M) return hipSuccess;
+      if (b.M == g.M || tail_inside) return hipSuccess;
       GemmArgs r = g;  // remaining rows [bulk*256, M)
       r.variant = 1;
       r.splitk_ws = nullptr;  // rows of one large batch are computed the same way whichever kernel they land in

@@ -59,6 +59,81 @@ __device__ long long g_sp_phase[2048 * 8];
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// ---- the tail: one ragged m-tile without a second launch -------------------------------------------------------------
+// ViT-L/14 at bs 256 has M = 257 x 256 rows: 256 m-tiles fill the 256 CUs in whole rounds and the 257th used to be a separate
+// launch of the 128x128 kernel -- 16 .. 64 workgroups on an otherwise idle chip, 14 - 34 us each, 144 launches = 2.25 ms per step
+// (5 % of the GEMM time for 0.4 % of the rows).  Here every workgroup, when its tile list is done, takes ONE strip
+// of those 256 rows: 32 rows x (NB x 32) columns (NB = 1 at N = 1024, 3 at 3072, 4 at 4096: 256 x N / 256 CUs), i.e. NB MFMA
+// blocks of 32 x 32, one per wave, the full K loop each -- the accumulation order of every output element is the k-step order of
+// the other kernels, so rows stay bit-identical whichever path computes them.  Operands arrive by LDS-DMA in fragment shape
+// (a k-step of 32 rows = 1 KiB, lane-linear: conflict-free ds_read_b128) through a ring of R stages of 8 k-steps; wave w fetches
+// k-step w of every operand of a stage, waves < NB multiply.  One barrier per stage.  The epilogue is gemm_store_quad (the code
+// of the 128x128 kernel).
+template <int EPI, bool F16, int NB>
+__device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
+                                             void* __restrict__ outp, const float* __restrict__ table, int T, int N, int K,
+                                             const float* __restrict__ rowscale, bf16* __restrict__ out16, int tail_m0,
+                                             unsigned char* smem, unsigned lds_base, int w, int lane) {
+  constexpr int NOP = 1 + NB;     // operands of a stage: the 32 activation rows and NB blocks of 32 weight rows
+  constexpr int SB = NOP * 8192;  // stage = 8 k-steps x 1 KiB per operand
+  constexpr int R = 131072 / SB;  // ring depth: 8 / 5 / 4 / 3 stages in the 128 KiB the K-tile buffers occupied
+  const int ncg = (N >> 5) / NB;  // column groups of a 32-row strip
+  const int strip = blockIdx.x;
+  if (strip >= 8 * ncg) return;   // (uniform per workgroup; the host makes sure every strip has a workgroup)
+  const int rb = strip & 7, cg = strip >> 3;
+  const int tm = tail_m0 + rb * 32, tn = cg * NB * 32;
+  const int l31 = lane & 31, hb = lane >> 5;
+  const unsigned voff = (unsigned)((l31 * K + 8 * hb) * 2);  // row l31 of the operand, 16 B of the k-step
+  const char* baseA = reinterpret_cast<const char*>(A) + (size_t)tm * K * 2 + w * 32;  // + w * 32: this wave's k-step in a stage
+  const char* baseW = reinterpret_cast<const char*>(W) + (size_t)tn * K * 2 + w * 32;
+  const int nch = K >> 7;
+#define T_DMA(off, base, dst) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory")
+  auto issue = [&](int c, int slot) {
+    const int cc = c < nch ? c : nch - 1;  // past the end: reload the last stage (keeps the vmcnt arithmetic uniform)
+    const unsigned dst = lds_base + slot * SB + w * 1024;
+    T_DMA(voff, baseA + (size_t)cc * 256, dst);
+#pragma unroll
+    for (int o = 0; o < NB; ++o) T_DMA(voff, baseW + (size_t)o * 64 * K + (size_t)cc * 256, dst + (1 + o) * 8192);
+    S_FENCE();
+  };
+#pragma unroll
+  for (int c = 0; c < R - 1; ++c) issue(c, c);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int slot = 0;
+  for (int c = 0; c < nch; ++c) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NOP) : "memory");  // this wave's share of stage c has landed
+    S_FENCE();
+    __builtin_amdgcn_s_barrier();  // ... and everyone's; every wave is past stage c - 1, whose slot the refill takes
+    S_FENCE();
+    issue(c + R - 1, slot == 0 ? R - 1 : slot - 1);
+    if (w < NB) {
+      const unsigned char* st = smem + slot * SB + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const frag_t af = *reinterpret_cast<const frag_t*>(st + ks * 1024);
+        const frag_t wf = *reinterpret_cast<const frag_t*>(st + (1 + w) * 8192 + ks * 1024);
+        acc = mfma_32x32x16<F16>(wf, af, acc);
+      }
+    }
+    slot = slot + 1 == R ? 0 : slot + 1;
+  }
+#undef T_DMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail reloads still in flight
+  S_FENCE();
+  if (w < NB) {
+    const int m = tm + l31;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = tn + w * 32 + 8 * g + 4 * hb;
+      const float4 v = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+      gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, 0, rowscale, out16);
+    }
+  }
+}
+
 // DBG (ablation, EPI_BIAS_BF16 only; garbage results): 1 = no staging, 3 = no staging and no ds_reads,
 // 5 = no epilogue at all, 6 = epilogue without its global stores, 16 = phase timer (correct results),
 // 19 / 20 = phase timer + ablations 1 / 3, 21 = phase timer + L2-resident operands, 22 / 24 = no L2 prefetch (with / without timer)
@@ -67,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
                                                           int ntn, const float* __restrict__ rowscale, bf16* __restrict__ out16,
-                                                          int raster) {
+                                                          int raster, int tail_m0, int tail_nb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool DBG_TIMER = DBG == 16 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22;
   constexpr bool DBG_L2HOT = DBG == 21;
@@ -654,6 +729,17 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     sM = nxtM + 256;
     sN = nxtN + 256;
   }
+  // ---- the ragged 257th m-tile (see gemm256_tail above): every workgroup takes one 32-row strip of it
+  if (tail_nb > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last epilogue's stores count in vmcnt: start the tail's arithmetic at zero
+    S_FENCE();
+    __builtin_amdgcn_s_barrier();                     // every wave is done with the K-tile buffers
+    S_FENCE();
+    if (tail_nb == 1) gemm256_tail<EPI, F16, 1>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane);
+    else if (tail_nb == 2) gemm256_tail<EPI, F16, 2>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane);
+    else if (tail_nb == 3) gemm256_tail<EPI, F16, 3>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane);
+    else gemm256_tail<EPI, F16, 4>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane);
+  }
   if (DBG_TIMER && tid == 0 && blockIdx.x < 2048) {
     ph[7] = (long long)__builtin_readcyclecounter() - tstart;
 #pragma unroll
@@ -679,7 +765,7 @@ static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.N, g.K, g.M / 256,
-                     g.N / 256, g.rowscale, g.out16, raster);
+                     g.N / 256, g.rowscale, g.out16, raster, g.tail_m0, g.tail_nb);
   return hipGetLastError();
 }
 
