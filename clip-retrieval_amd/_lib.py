@@ -50,6 +50,7 @@ SIGNATURES = {
     "knnx_search_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "knnx_reconstruct": (C.c_int, [_P, _P, C.c_int64, _P]),
     "knnx_range_search": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P, _P]),
+    "knnx_range_search_once": (C.c_int, [_P, _P, C.c_int, C.c_float, _P, _P, _P, C.c_int64]),
     "knnx_ivf_set_lists": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "knnx_ivf_set_nprobe": (C.c_int, [_P, C.c_int]),
     "knnx_ivf_nlist": (C.c_int, [_P]),
@@ -113,6 +114,8 @@ SIGNATURES = {
     "clipx_attention_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_attention_dh_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_layernorm_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "clipx_rowstats_device": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P]),
+    "clipx_rowstats_merge_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "clipx_profile_enable": (C.c_int, [_P, C.c_int]),
     "clipx_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "clipx_last_error": (C.c_char_p, []),

@@ -42,6 +42,27 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v + 0.5f * fabsf(v) * erf_abs;           // 0.5 v (1 + sign(v) erf(|v|/sqrt 2))
 }
 
+// LayerNorm statistics folded into the residual epilogues (round 3: replaces the rowstats pass over the stream).  A residual
+// epilogue holds, per output row, 32-column blocks of the NEW row split over the lane pair (l, l ^ 32), 16 values each; it
+// writes (mean, M2 = sum (v - mean)^2) of every block to stats[m * (N / 32) + n / 32] and rowstats_merge_kernel combines the
+// N / 32 partials of a row (Chan's formula) into 1 / sqrt(var + eps).  Two-pass inside a block (no cancellation), fixed
+// summation order, the same helper in every kernel: a row's statistics do not depend on which kernel produced it.
+__device__ __forceinline__ float2 block_stats32(const float (&v)[16]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += v[i];
+  s += __shfl_xor(s, 32);
+  const float mean = s * (1.f / 32.f);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float d = v[i] - mean;
+    q = __builtin_fmaf(d, d, q);
+  }
+  q += __shfl_xor(q, 32);
+  return make_float2(mean, q);
+}
+
 // One accumulator quad of the transposed-product layout both kernels use (MFMA A operand = weight rows, B operand
 // = activation rows): the lane owns output row m and four consecutive columns n..n+3.
 // bf16-output epilogues: out = act(acc * rowscale[m] + bias[n]) -- rowscale is the row's LayerNorm 1/std when the GEMM
@@ -52,7 +73,9 @@ __device__ __forceinline__ float gelu_erf(float v) {
 template <int EPI>
 __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, const float* __restrict__ bias,
                                                 void* __restrict__ outp, const float* __restrict__ table, int T,
-                                                int row0, const float* __restrict__ rowscale, bf16* __restrict__ out16) {
+                                                int row0, const float* __restrict__ rowscale, bf16* __restrict__ out16,
+                                                float* __restrict__ o_f32 = nullptr) {
+  // o_f32 (EPI_BIAS_RESID_H16 only, may be null): the four new row values as f32(fp16(.)) -- what block_stats32 is fed with
   constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
   if (EPI == EPI_RAW_F32) {  // a split-K partial product: the accumulators as they are
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n) = v;
@@ -91,6 +114,7 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
     h[0] = (_Float16)((float)x4[0] + v.x); h[1] = (_Float16)((float)x4[1] + v.y);
     h[2] = (_Float16)((float)x4[2] + v.z); h[3] = (_Float16)((float)x4[3] + v.w);
     *p = h;
+    if (o_f32) { o_f32[0] = (float)h[0]; o_f32[1] = (float)h[1]; o_f32[2] = (float)h[2]; o_f32[3] = (float)h[3]; }
   } else {  // EPI_TABLE_F32
     const float4 t4 = *reinterpret_cast<const float4*>(table + (size_t)((m + row0) % T) * N + n);
     v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;

@@ -922,59 +922,178 @@ extern "C" int knnx_range_search(knnx_index* ix, const float* q, int n, float th
   return KNNX_OK;
 }
 
-// k > 64: threshold descent on the range kernel.  The top-64 fast path gives the 64 best scores;
-// the k-th best is then bracketed by range scans whose threshold is lowered geometrically (step =
-// spread of the top-64, doubling) until >= k hits exist; the hits are ranked on the host (k log k,
-// tiny next to a scan).  Exact; costs 2-6 scans, which is what the reference's rare large-k
-// requests (front-end num_result_ids=3000; clip_back.py:358 k>=100000 branch) can afford.
+// range_search in ONE pass when the caller's buffers are large enough: lims [n + 1] is always filled; D / I (capacity entries)
+// receive the hits if lims[n] <= capacity (return KNNX_OK), otherwise nothing is written to them and the return value is 1 --
+// the caller then allocates lims[n] entries and uses knnx_range_search's filling call.  Saves the counting scan of the two-call
+// protocol for callers with a good guess (the per-request dedup of clip_back.py:290-294: ~k hits for k result vectors).
+extern "C" int knnx_range_search_once(knnx_index* ix, const float* q, int n, float thresh, int64_t* lims, float* D, int64_t* I,
+                                      int64_t capacity) {
+  if (!ix || !lims || (n > 0 && !q) || n < 0 || capacity < 0 || (capacity > 0 && (!D || !I))) return fail(KNNX_E_ARG, "bad range_search_once arguments");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (set_dev(ix)) return KNNX_E_HIP;
+  int64_t run = 0;
+  bool fits = true;
+  std::vector<unsigned> counts;
+  lims[0] = 0;
+  for (int o = 0; o < n; o += KNN_NQ) {
+    const int nq = std::min(KNN_NQ, n - o);
+    unsigned cap = 0;
+    int r = range_scan(ix, q + (size_t)o * ix->d, nq, thresh, counts, &cap);
+    if (r) return r;
+    const int64_t first = run;
+    for (int i = 0; i < nq; ++i) {
+      run += counts[i];
+      lims[o + i + 1] = run;
+    }
+    if (run > capacity) fits = false;
+    if (fits) {
+      r = range_fetch(ix, nq, counts, cap, D + first, I + first);
+      if (r) return r;
+    }
+  }
+  return fits ? KNNX_OK : 1;
+}
+
+// k > 64 (the front-end's num_result_ids = 3000, clip_back.py:358 asks for up to 1e5): one range scan with a threshold that
+// lets >= k rows through, the hits ranked on the host (k log k, tiny next to a scan).  Exact: every row scoring above the
+// threshold is a hit, so cnt >= k hits contain the top k.  The threshold:
+//   * flat index with N >= 128 k rows: the j-th best EXACT score of a strided sample (every S-th 32-row tile, the 32-query scan
+//     with tstride = S: 1 / S of the bytes), S and j <= 48 chosen so that j S ~ 1.5 k rows are expected above it.  The count
+//     above the j-th best of a 1 / S sample is ~ S Gamma(j) whatever the score distribution (the argument of the RQ scan's
+//     thresholds, knn_kernels.h), so cnt < k has a probability of a few per cent; then the 64-th sample score is tried
+//     (~ S * 64 hits) before the descent below takes over.  Cost: ~1.01 scans instead of the 2 - 6 of round 2 -- and instead of
+//     the 10.9 s measured at 100 M rows in round 3 (profiles/r03b_request.log), where a query with one very close neighbour
+//     (top - s64 = 0.8) made the first descent step jump below zero and 50 M rows had to be fetched and sorted;
+//   * otherwise (small or IVF index): descent from the top-64 scores.  The first step extrapolates the LOCAL score density
+//     (32 rows lie between the 32nd and the 64th score), doubling while cnt < k; when a step overshoots by more than 16 x the
+//     threshold is bisected back (at most 4 times) before the hits are fetched.
 // Caller holds ix->mu.
+static int sample_scores_locked(knnx_index* ix, const float* qq, int tstride, float* d64) {
+  hipStream_t st = ix->stream;
+  int r = ensure_pin(ix, (size_t)ix->d * sizeof(float) + KNNX_MAX_K_FAST * sizeof(float));
+  if (r) return r;
+  if (scratch_acquire(ix, st)) return KNNX_E_HIP;
+  memcpy(ix->pin, qq, (size_t)ix->d * sizeof(float));
+  HIPCHK(hipMemcpyAsync(ix->q_dev, ix->pin, (size_t)ix->d * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(launch_prep(ix->q_dev, 1, ix->d, ix->qfrag, ix->thr_g, nullptr, 0, nullptr, st));
+  ScanArgs a{};
+  a.X = ix->rows;
+  a.N = ix->ntotal;
+  a.d = ix->d;
+  a.qfrag = ix->qfrag;
+  a.nq = 1;
+  a.k = KNNX_MAX_K_FAST;
+  a.cap = scan_cap(ix->d, KNNX_MAX_K_FAST);
+  a.grid = ix->n_cu;
+  a.mode = 0;
+  a.tstride = tstride;
+  a.thr_g = ix->thr_g;
+  a.part_s = ix->part_s;
+  a.part_i = ix->part_i;
+  a.part_n = ix->part_n;
+  if (a.cap < 0) return fail(KNNX_E_UNSUPPORTED, "k too large for the LDS queues at this d");
+  HIPCHK(launch_scan(a, st));
+  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ, KNNX_MAX_K_FAST, 1, KNNX_MAX_K_FAST, 0, nullptr, ix->D_dev,
+                          ix->I_dev, nullptr, st));
+  float* out = (float*)((char*)ix->pin + (size_t)ix->d * sizeof(float));
+  HIPCHK(hipMemcpyAsync(out, ix->D_dev, KNNX_MAX_K_FAST * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  memcpy(d64, out, KNNX_MAX_K_FAST * sizeof(float));
+  if (scratch_release(ix, st)) return KNNX_E_HIP;
+  return 0;
+}
+
 static int search_large_k_locked(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I) {
   std::vector<float> d64((size_t)KNNX_MAX_K_FAST);
   std::vector<int64_t> i64((size_t)KNNX_MAX_K_FAST);
   const int64_t N = ix->ntotal;
+  const int64_t want = std::min<int64_t>(k, N);
   for (int qi = 0; qi < n; ++qi) {
     const float* qq = q + (size_t)qi * ix->d;
     float* Dq = D + (size_t)qi * k;
     int64_t* Iq = I + (size_t)qi * k;
-    int r = search_fast_locked(ix, qq, 1, KNNX_MAX_K_FAST, d64.data(), i64.data());
-    if (r) return r;
-    int have = 0;
-    while (have < KNNX_MAX_K_FAST && i64[have] >= 0) ++have;
     std::vector<std::pair<float, int64_t>> hits;
-    if (have < KNNX_MAX_K_FAST) {
-      for (int j = 0; j < have; ++j) hits.emplace_back(d64[j], i64[j]);
-    } else {
-      const float top = d64[0], s64 = d64[have - 1];
-      float step = std::max(top - s64, 1e-3f * std::max(1.f, fabsf(top)));
-      float thr = s64 - step;
-      std::vector<unsigned> counts;
-      int64_t prev_cnt = -1;
-      int stalled = 0;
-      for (int it = 0;; ++it) {
-        unsigned cap = 0;
+    std::vector<unsigned> counts;
+    unsigned cap = 0;
+    int r;
+    bool done = false;
+    auto fetch = [&](int64_t cnt) -> int {
+      std::vector<float> hd((size_t)cnt);
+      std::vector<int64_t> hi((size_t)cnt);
+      int rr = range_fetch(ix, 1, counts, cap, hd.data(), hi.data());
+      if (rr) return rr;
+      hits.reserve((size_t)cnt);
+      for (int64_t j = 0; j < cnt; ++j) hits.emplace_back(hd[j], hi[j]);
+      return 0;
+    };
+    float thr_hi = FLT_MAX;  // a threshold known to let fewer than k rows through (descent / bisection bracket)
+    if (!ix->ivf_nlist && N >= (int64_t)128 * k) {
+      // ---- sampled threshold: S tiles apart, j-th best sample score, j S ~ 1.5 k
+      const int S = (int)std::max<int64_t>(2, (3 * (int64_t)k / 2 + 47) / 48);
+      const int j = (int)std::min<int64_t>(48, std::max<int64_t>(8, (3 * (int64_t)k / 2 + S - 1) / S));
+      r = sample_scores_locked(ix, qq, S, d64.data());
+      if (r) return r;
+      for (int attempt = 0; attempt < 2 && !done; ++attempt) {
+        const float sj = d64[attempt == 0 ? j - 1 : KNNX_MAX_K_FAST - 1];
+        if (!(sj > -FLT_MAX)) break;  // fewer sample rows than that
+        const float thr = nextafterf(sj, -FLT_MAX);  // the range is strict (>): keep the sample row itself
         r = range_scan(ix, qq, 1, thr, counts, &cap);
         if (r) return r;
-        const int64_t cnt = counts[0];
-        // an IVF index only reaches the rows of the probed lists: when three ever larger steps add nothing, take what there is.
-        // Flat indexes never take this shortcut: a tight cluster of 64 <= C < k near-duplicates stalls the count
-        // while the next row is many steps away, and thr = -FLT_MAX there would fetch and sort all N rows; the step doubles
-        // every round, so cnt >= min(k, N) is reached after O(log(gap / spread)) scans.
-        stalled = (ix->ivf_nlist && cnt == prev_cnt) ? stalled + 1 : 0;
-        prev_cnt = cnt;
-        if (stalled >= 3 && thr > -FLT_MAX) {
-          thr = -FLT_MAX;
-          continue;
+        if ((int64_t)counts[0] >= want) {
+          if ((r = fetch(counts[0]))) return r;
+          done = true;
+        } else {
+          thr_hi = thr;
         }
-        if (cnt >= std::min<int64_t>(k, N) || !(thr > -FLT_MAX)) {
-          std::vector<float> hd((size_t)cnt);
-          std::vector<int64_t> hi((size_t)cnt);
-          r = range_fetch(ix, 1, counts, cap, hd.data(), hi.data());
+      }
+    }
+    if (!done) {
+      r = search_fast_locked(ix, qq, 1, KNNX_MAX_K_FAST, d64.data(), i64.data());
+      if (r) return r;
+      int have = 0;
+      while (have < KNNX_MAX_K_FAST && i64[have] >= 0) ++have;
+      if (have < KNNX_MAX_K_FAST) {  // the whole index (or all probed lists) is smaller than 64 rows
+        for (int j = 0; j < have; ++j) hits.emplace_back(d64[j], i64[j]);
+      } else {
+        const float s32 = d64[KNNX_MAX_K_FAST / 2 - 1], s64 = d64[KNNX_MAX_K_FAST - 1];
+        // local density: 32 rows within s32 - s64; k - 64 more rows are ~ (k - 64) / 32 such gaps away (fewer: the density grows)
+        float step = std::max((s32 - s64) * std::min(64.f, (float)(k - KNNX_MAX_K_FAST) / 32.f) * 0.5f, 1e-4f * std::max(1.f, fabsf(s64)));
+        float thr = std::min(s64 - step, thr_hi < FLT_MAX ? nextafterf(thr_hi, -FLT_MAX) : FLT_MAX);
+        float lo_ok = -FLT_MAX;  // lowest threshold tried so far (lets >= k rows through once found)
+        int64_t prev_cnt = -1;
+        int stalled = 0, bisections = 0;
+        thr_hi = std::min(thr_hi, s64);
+        for (int it = 0;; ++it) {
+          r = range_scan(ix, qq, 1, thr, counts, &cap);
           if (r) return r;
-          for (int64_t j = 0; j < cnt; ++j) hits.emplace_back(hd[j], hi[j]);
+          const int64_t cnt = counts[0];
+          // an IVF index only reaches the rows of the probed lists: when three ever larger steps add nothing, take what there
+          // is.  Flat indexes never take this shortcut: cnt >= min(k, N) is reached after O(log) doublings.
+          stalled = (ix->ivf_nlist && cnt == prev_cnt) ? stalled + 1 : 0;
+          prev_cnt = cnt;
+          if (cnt < want && thr > -FLT_MAX && stalled < 3 && it < 60) {
+            thr_hi = thr;
+            step *= 2.f;
+            thr = (thr - step > -FLT_MAX) ? thr - step : -FLT_MAX;
+            continue;
+          }
+          if (cnt < want && thr > -FLT_MAX) {  // stalled (IVF) or out of patience: everything the scan can reach
+            thr = -FLT_MAX;
+            stalled = 0;
+            continue;
+          }
+          // enough rows.  Far too many (an overshooting step)?  Bisect back towards the last threshold that had too few.
+          if (cnt > 16 * want && cnt > 65536 && bisections < 4 && thr_hi < FLT_MAX && thr > -FLT_MAX) {
+            lo_ok = thr;
+            thr = 0.5f * (thr + thr_hi);
+            ++bisections;
+            // (a middle that has too few rows raises thr_hi above and steps down again, towards lo_ok)
+            step = 0.5f * (thr - lo_ok);
+            continue;
+          }
+          if ((r = fetch(cnt))) return r;
           break;
         }
-        step *= 2.f;
-        thr = (it > 48 || !(thr - step > -FLT_MAX)) ? -FLT_MAX : thr - step;
       }
     }
     std::sort(hits.begin(), hits.end(), [](const std::pair<float, int64_t>& a, const std::pair<float, int64_t>& b) {

@@ -232,7 +232,17 @@ class Mi355xIndex(_FaissShaped):
         q = np.ascontiguousarray(self._pad(_as_queries(x, self.d)))
         n = q.shape[0]
         lims = np.zeros(n + 1, dtype=np.int64)
-        check(self._lib, self._lib.knnx_range_search(self._h, q.ctypes.data, n, C.c_float(thresh), lims.ctypes.data, None, None), "knnx")
+        # one pass when the hits fit a guessed capacity (the per-request dedup finds ~n hits for n vectors); the two-call
+        # protocol (count, then fill) otherwise
+        guess = max(4096, 16 * n)
+        D = np.empty(guess, dtype=np.float32)
+        I = np.empty(guess, dtype=np.int64)
+        rc = self._lib.knnx_range_search_once(self._h, q.ctypes.data, n, C.c_float(thresh), lims.ctypes.data, D.ctypes.data, I.ctypes.data, guess)
+        if rc == 0:
+            total = int(lims[n])
+            return lims, D[:total].copy(), I[:total].copy()
+        if rc < 0:
+            check(self._lib, rc, "knnx")
         total = int(lims[n])
         D = np.empty(total, dtype=np.float32)
         I = np.empty(total, dtype=np.int64)

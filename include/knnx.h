@@ -88,6 +88,11 @@ int knnx_reconstruct(knnx_index* ix, const int64_t* ids, int64_t n, float* out);
  * then call again with buffers of lims[n] entries.  Ids ascending inside each query. */
 int knnx_range_search(knnx_index* ix, const float* q, int n, float thresh, int64_t* lims,
                       float* D, int64_t* I);
+/* The same in ONE pass for a caller with a good guess of the result size (the per-request dedup, clip_back.py:290-294):
+ * lims [n + 1] is always filled; if lims[n] <= capacity the hits are written to D / I and the call returns 0, otherwise
+ * D / I are left alone and it returns 1 (retry with knnx_range_search and lims[n] entries). */
+int knnx_range_search_once(knnx_index* ix, const float* q, int n, float thresh, int64_t* lims, float* D, int64_t* I,
+                           int64_t capacity);
 
 /* faiss IndexIVFFlat(quantizer=IndexFlatIP, d, nlist, METRIC_INNER_PRODUCT) (the index family of BASELINE config 5;
  * the reference gets its indices from autofaiss, clip_index.py:12-66).  Protocol: knnx_add_* the rows GROUPED BY LIST
