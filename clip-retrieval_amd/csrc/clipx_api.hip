@@ -71,6 +71,7 @@ struct clipx_handle {
                          // at B=256: chunks of 32/64/128/256 -> 92/65/58/56.5 ms, small chunks lose more GEMM efficiency than
                          // the overlap wins
   int gemm_variant = 3;
+  bool fused_stats = true;  // CLIPX_FUSED_STATS=0: LayerNorm statistics by a pass over the stream (A/B; bench.py refuses the switch)
   int n_cu = 256;
   std::mutex mu;
   hipStream_t stream = nullptr, copy_stream = nullptr;
@@ -306,6 +307,8 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   const char* hc = getenv("CLIPX_HOST_CHUNK");
   if (hc && atoi(hc) > 0) h->host_chunk = atoi(hc);
   h->host_chunk = std::min(h->host_chunk, h->max_batch);
+  const char* fs = getenv("CLIPX_FUSED_STATS");
+  if (fs && fs[0] == '0') h->fused_stats = false;
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   if (gv) h->gemm_variant = std::min(5, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -400,7 +403,7 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   // per-block (mean, M2) partials of the rows it wrote and a tiny merge kernel turns them into rstd -- the 134 MB re-read of
   // the stream per LayerNorm is gone.  Single-sample calls (split-K GEMMs, whose reduction kernel has no lane pairs to
   // reduce over) keep the pass over the stream.
-  const bool fused = !h->single_query;
+  const bool fused = !h->single_query && h->fused_stats;
   { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& L = t.L[l];

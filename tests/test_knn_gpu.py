@@ -29,7 +29,7 @@ def _queries(nq, d, seed, x=None):
     return q.astype(np.float32)
 
 
-def _check(D, I, Do, Io, ctx):
+def _check(D, I, Do, Io, ctx, min_exact=0.98):
     from oracle.knn_oracle import topk_sets_equal
 
     assert D.shape == Do.shape and I.shape == Io.shape and I.dtype == np.int64 and D.dtype == np.float32, ctx
@@ -43,7 +43,7 @@ def _check(D, I, Do, Io, ctx):
     bad = topk_sets_equal(I, D, Io, Do)
     assert not bad, f"{ctx}: id sets differ beyond near-ties: {bad[:5]}"
     exact = float((I == Io).mean())
-    assert exact > 0.98, f"{ctx}: only {exact:.3f} of positions identical"
+    assert exact > min_exact, f"{ctx}: only {exact:.3f} of positions identical"
 
 
 @pytest.mark.parametrize("n,d", [(1, 256), (31, 768), (33, 768), (1000, 768), (4097, 512), (70001, 768), (5000, 1024)])
@@ -851,5 +851,7 @@ def test_large_k_with_a_tight_cluster_of_near_duplicates():
     q = base.reshape(1, -1).astype(np.float32)
     D, I = ix.search(q, k)
     Do, Io = o.search(q, k)
-    _check(D, I, Do, Io, "tight cluster, k=300")
+    # the 100 near-duplicates score within ~1e-6 of each other: their relative ORDER is fp32-summation noise (sets and scores
+    # are still held to the usual bar)
+    _check(D, I, Do, Io, "tight cluster, k=300", min_exact=0.6)
     ix.close()
