@@ -89,7 +89,7 @@ struct clipx_handle {
   // activation workspace (shared by both towers)
   float* x = nullptr;      // f32 [rows, width]: the patch-embedding output in front of ln_pre (vision tower only)
   float* rstd = nullptr;   // [rows] LayerNorm 1/std of the current residual rows
-  float2* lnstats = nullptr;  // [rows, width / 32] (mean, M2) partials of the rows a residual epilogue just wrote (gemm_common.h)
+  float2* lnstats = nullptr;  // [width / 16, rows] (mean, M2) partials of the rows a residual epilogue just wrote (gemm_common.h)
   // xn = THE residual stream, IEEE fp16 [rows, width] (fp16 bits behind the bf16-typed pointer): read as the A operand of the
   // LayerNorm-folded GEMMs (QKV, fc1) and updated in place by the residual epilogues of out_proj / fc2.  Round 3: it replaced
   // an f32 stream + bf16 shadow (673 MB -> 269 MB moved per residual GEMM at ViT-L/14 bs 256; same accuracy: the stream has
@@ -259,7 +259,7 @@ static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
   if ((r = dev_alloc(h, (void**)&h->x, rowsV * V.width * sizeof(float)))) return r;
   if ((r = dev_alloc(h, (void**)&h->xn, nx * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->rstd, std::max(rowsV, rowsX) * sizeof(float)))) return r;
-  if ((r = dev_alloc(h, (void**)&h->lnstats, std::max(rowsV * V.width, rowsX * X.width) / 32 * sizeof(float2)))) return r;
+  if ((r = dev_alloc(h, (void**)&h->lnstats, std::max(rowsV * V.width, rowsX * X.width) / 16 * sizeof(float2)))) return r;
   if ((r = dev_alloc(h, (void**)&h->qkv, nqkv * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->att, nx * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->hbuf, nh * sizeof(bf16)))) return r;
@@ -381,7 +381,7 @@ static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* 
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.table = table; g.T = T;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant; g.n_cu = h->n_cu; g.row0 = 0;
-  g.rowscale = rowscale; g.out16 = nullptr; g.f16 = f16 ? 1 : 0; g.stats = stats;
+  g.rowscale = rowscale; g.out16 = nullptr; g.f16 = f16 ? 1 : 0; g.stats = stats; g.stats_ld = M;
   // split-K only on the single-query path (B == 1, KnnService.compute_query): every batch of two or more samples is computed
   // by the unsplit kernels, whose rows do not depend on the batch they travel in (bitwise); a B = 1 row differs from the same
   // sample inside a batch by f32 summation order only
@@ -729,6 +729,7 @@ static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const f
   g.rowscale = rowscale;
   g.out16 = epi == 3 ? (bf16*)out16 : nullptr;
   g.stats = epi == EPI_BIAS_RESID_H16 ? (float2*)out16 : nullptr;
+  g.stats_ld = M;
   g.f16 = f16;
   if (!g.rowscale) {  // bf16-output epilogues scale rows (LayerNorm-folded GEMMs of the encoder); a plain GEMM uses ones
     static std::mutex ones_mu;
@@ -811,7 +812,7 @@ extern "C" int clipx_rowstats_device(int device, const void* x16, int is_f16, fl
 
 extern "C" int clipx_rowstats_merge_device(int device, const void* partials, float* rstd, int M, int d, float eps, void* stream) {
   if (!partials || !rstd || M <= 0) return fail(CLIPX_E_ARG, "bad rowstats_merge arguments");
-  if (d % 32 || d / 32 > 64) return fail(CLIPX_E_UNSUPPORTED, "d must be a multiple of 32, <= 2048");
+  if (d % 16) return fail(CLIPX_E_UNSUPPORTED, "d must be a multiple of 16");
   HIPCHK(hipSetDevice(device));
   HIPCHK(launch_rowstats_merge((const float2*)partials, rstd, M, d, eps, (hipStream_t)stream));
   return CLIPX_OK;

@@ -73,7 +73,7 @@ template <int EPI, bool F16, int NB>
 __device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
                                              void* __restrict__ outp, const float* __restrict__ table, int T, int N, int K,
                                              const float* __restrict__ rowscale, bf16* __restrict__ out16, int tail_m0,
-                                             unsigned char* smem, unsigned lds_base, int w, int lane_unused, float2* __restrict__ stats) {
+                                             unsigned char* smem, unsigned lds_base, int w, int lane_unused, float2* __restrict__ stats, int stats_ld) {
   // the lane id is recomputed here (2 instructions) instead of being kept alive across the main loop: a value carried that far
   // gets spilled to scratch, and its reload would wait vmcnt(0) in the middle of the DMA ring
   (void)lane_unused;
@@ -136,10 +136,8 @@ __device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const b
       const float4 v = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
       gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, 0, rowscale, out16, (EPI == EPI_BIAS_RESID_H16 && stats) ? &o[4 * g] : nullptr);
     }
-    if (EPI == EPI_BIAS_RESID_H16 && stats) {  // the wave's block IS one 32-column block of its 32 rows
-      const float2 ps = block_stats32(o);
-      if (hb == 0) stats[(size_t)m * (N >> 5) + ((tn + w * 32) >> 5)] = ps;
-    }
+    if (EPI == EPI_BIAS_RESID_H16 && stats)  // (gemm_common.h: group_stats16) the lane's 16 values of the wave's 32-column block
+      stats[(size_t)(2 * ((tn + w * 32) >> 5) + hb) * stats_ld + m] = group_stats16(o);
   }
 }
 
@@ -151,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
                                                           int ntn, const float* __restrict__ rowscale, bf16* __restrict__ out16,
-                                                          int raster, int tail_m0, int tail_nb, float2* __restrict__ stats) {
+                                                          int raster, int tail_m0, int tail_nb, float2* __restrict__ stats, int stats_ld) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool DBG_TIMER = DBG == 16 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22;
   constexpr bool DBG_L2HOT = DBG == 21;
@@ -675,10 +673,8 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                 ov[4 * g + 2] = (float)o[2]; ov[4 * g + 3] = (float)o[3];
               }
             }
-            if (stats) {  // (gemm_common.h: block_stats32) row 32 mt + l31, column block nt of this wave's 64 columns
-              const float2 ps = block_stats32(ov);
-              if (hb == 0) stats[(size_t)(m0 + wr * 128 + mt * 32 + l31) * (N >> 5) + ((n0 + wc * 64 + nt * 32) >> 5)] = ps;
-            }
+            if (stats)  // (gemm_common.h: group_stats16) row 32 mt + l31, this lane's 16 values of column block nt
+              stats[(size_t)(2 * ((n0 + wc * 64 + nt * 32) >> 5) + hb) * stats_ld + (m0 + wr * 128 + mt * 32 + l31)] = group_stats16(ov);
           }
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
@@ -758,10 +754,10 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     S_FENCE();
     __builtin_amdgcn_s_barrier();                     // every wave is done with the K-tile buffers
     S_FENCE();
-    if (tail_nb == 1) gemm256_tail<EPI, F16, 1>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats);
-    else if (tail_nb == 2) gemm256_tail<EPI, F16, 2>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats);
-    else if (tail_nb == 3) gemm256_tail<EPI, F16, 3>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats);
-    else gemm256_tail<EPI, F16, 4>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats);
+    if (tail_nb == 1) gemm256_tail<EPI, F16, 1>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats, stats_ld);
+    else if (tail_nb == 2) gemm256_tail<EPI, F16, 2>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats, stats_ld);
+    else if (tail_nb == 3) gemm256_tail<EPI, F16, 3>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats, stats_ld);
+    else gemm256_tail<EPI, F16, 4>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats, stats_ld);
   }
   if (DBG_TIMER && tid == 0 && blockIdx.x < 2048) {
     ph[7] = (long long)__builtin_readcyclecounter() - tstart;
@@ -788,7 +784,7 @@ static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.N, g.K, g.M / 256,
-                     g.N / 256, g.rowscale, g.out16, raster, g.tail_m0, g.tail_nb, g.epi == EPI_BIAS_RESID_H16 ? g.stats : nullptr);
+                     g.N / 256, g.rowscale, g.out16, raster, g.tail_m0, g.tail_nb, g.epi == EPI_BIAS_RESID_H16 ? g.stats : nullptr, g.stats_ld);
   return hipGetLastError();
 }
 

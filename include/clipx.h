@@ -135,8 +135,8 @@ int clipx_gemm_bf16_ex_device(int device, const void* A_bf16, const void* W_bf16
                               int K, int epi, const float* rowscale_or_null, void* out16_or_null, void* stream);
 /* (the _ex entry point also takes epi 6: out is IEEE fp16 [M, N], updated in place, out = fp16(f32(out) + acc + bias) -- the
  * residual epilogue of out_proj / fc2 in the encoder, whose residual stream is stored in fp16.  With epi 6, out16_or_null is
- * instead an optional float2 [M, N / 32] buffer that receives (mean, sum of squared deviations) of every 32-column block of the
- * new rows: the LayerNorm statistics the epilogue computes on the fly; clipx_rowstats_merge_device turns them into 1 / std) */
+ * instead an optional float2 [N / 16, M] buffer (group-major) that receives (mean, sum of squared deviations) of 16-value groups
+ * of the new rows: the LayerNorm statistics the epilogue computes on the fly; clipx_rowstats_merge_device turns them into 1 / std) */
 
 /* The LayerNorm-folded GEMMs of the encoder (QKV, fc1) read that fp16 residual stream as their A operand: A and W are IEEE
  * fp16 (v_mfma_f32_32x32x16_f16, the same rate as bf16), out bf16 [M, N]; epi 0..2 and rowscale as above. */
@@ -154,7 +154,7 @@ int clipx_layernorm_device(int device, const float* x, const float* gamma, const
                            int M, int d, float eps, void* stream);
 /* LayerNorm statistics of the residual stream, the two ways the encoder obtains them (per-kernel parity tests):
  * rstd[m] = 1 / sqrt(var(x16[m, :]) + eps) by a pass over the 16-bit rows (is_f16: IEEE fp16, else bf16), and the same from
- * the [M, d / 32] float2 partials a residual epilogue wrote (epi 6 above). */
+ * the [d / 16, M] float2 partials a residual epilogue wrote (epi 6 above). */
 int clipx_rowstats_device(int device, const void* x16, int is_f16, float* rstd, int M, int d, float eps, void* stream);
 int clipx_rowstats_merge_device(int device, const void* partials_f32x2, float* rstd, int M, int d, float eps, void* stream);
 

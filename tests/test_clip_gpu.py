@@ -528,7 +528,7 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
     for variant in (3, 1):
         os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
         x = x0.clone()
-        part = torch.full((M, N // 32, 2), float("nan"), device="cuda")
+        part = torch.full((N // 16, M, 2), float("nan"), device="cuda")
         check(lib, lib.clipx_gemm_bf16_ex_device(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(x), M, N, K, 6, None, _ptr(part), C.c_void_p(st)), "clipx")
         # (3) the LayerNorm statistics the epilogue leaves behind: merged partials vs a pass over the rows it wrote
         if N % 256 == 0:
@@ -537,7 +537,7 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
             check(lib, lib.clipx_rowstats_device(0, _ptr(x), 1, _ptr(r_pass), M, N, C.c_float(1e-5), C.c_void_p(st)), "clipx")
             torch.cuda.synchronize()
             want_r = 1.0 / torch.sqrt(x.float().var(dim=1, unbiased=False) + 1e-5)
-            assert not torch.isnan(part).any(), "a (row, block) partial was not written"
+            assert not torch.isnan(part).any(), "a (group, row) partial was not written"
             assert torch.allclose(r_fused, r_pass, rtol=2e-5, atol=0) and torch.allclose(r_fused, want_r, rtol=1e-4, atol=0)
         ys = [part]
         for epi in (0, 1, 2):
