@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0      # HBM3E spec
 
 def refuse_debug_environment():
     """A timed region must run the product kernels: refuse any switch that changes what the hot path computes."""
-    bad = [k for k in os.environ if (k.startswith("CLIPX_") and ("DBG" in k or "CFG" in k)) or k in ("CLIPX_GEMM_VARIANT", "CLIPX_FUSED_STATS", "KNNX_WIDE", "KNNX_RQ", "KNNX_RQ_MIN_ROWS", "KNNX_GRID", "KNNX_NT")]
+    bad = [k for k in os.environ if (k.startswith("CLIPX_") and ("DBG" in k or "CFG" in k)) or k in ("CLIPX_GEMM_VARIANT", "KNNX_WIDE", "KNNX_RQ", "KNNX_RQ_MIN_ROWS", "KNNX_GRID", "KNNX_NT")]
     if bad:
         raise SystemExit(f"bench.py refuses to run with debug/ablation switches set: {sorted(bad)}")
 

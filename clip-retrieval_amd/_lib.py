@@ -115,7 +115,6 @@ SIGNATURES = {
     "clipx_attention_dh_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "clipx_layernorm_device": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "clipx_rowstats_device": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_float, _P]),
-    "clipx_rowstats_merge_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "clipx_profile_enable": (C.c_int, [_P, C.c_int]),
     "clipx_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "clipx_last_error": (C.c_char_p, []),

@@ -37,8 +37,6 @@ struct GemmArgs {
   bf16* out16;            // EPI_BIAS_RESID_F32: also store the new x row as bf16 here (null: do not)
   float* splitk_ws;       // device scratch for split-K partial products (null: never split), splitk_ws_bytes of it
   size_t splitk_ws_bytes;
-  float2* stats;          // EPI_BIAS_RESID_H16: (mean, M2) of 16-value groups of the new rows, [N / 16, stats_ld] group-major (null:
-  int stats_ld;           // none); stats_ld = rows of the whole GEMM.  Combined by launch_rowstats_merge (gemm_common.h)
   int tail_m0, tail_nb;   // set by launch_gemm for the persistent kernel: rows [tail_m0, tail_m0 + 256) beyond the whole
                           // m-tiles are computed inside the same launch, 32 x (tail_nb x 32) per workgroup (0: none)
   int f16;                // A and W hold IEEE fp16 instead of bf16 (v_mfma_f32_32x32x16_f16, same rate): the LayerNorm-folded
@@ -61,9 +59,6 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 // (two-pass, fp32).  The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias
 // absorbs beta: clipx_api.hip fold_layernorm), whose epilogue multiplies by rstd[m].  One wave per row.
 hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16 = 0);
-
-// rstd[m] from the d / 16 group partials the residual epilogues wrote (GemmArgs.stats, [d / 16, M]): one thread per row
-hipError_t launch_rowstats_merge(const float2* stats, float* rstd, int M, int d, float eps, hipStream_t st);
 
 // LayerNorm-folded weights: Wf[n, k] = r16(W[n,k] gamma[k] - mean_k(W[n,:] gamma)), cf[n] = bias[n] + sum_k beta[k] W[n,k];
 // r16 = bf16 rounding, or IEEE fp16 when f16 != 0

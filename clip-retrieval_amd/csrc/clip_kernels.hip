@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int M, int N,
                                                           int K, int row0, const float* __restrict__ rowscale,
-                                                          bf16* __restrict__ out16, int kz, float2* __restrict__ stats, int stats_ld) {
+                                                          bf16* __restrict__ out16, int kz) {
   // kz > 0 (EPI_RAW_F32, DEEP only): split-K -- workgroup column blockIdx.y multiplies K-tiles [y * kz, (y + 1) * kz) and
   // writes its raw accumulators to outp + y * M * N
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -276,26 +276,6 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
   }
 
   // ---- epilogue: lane (m = l31, n = (r&3) + 8*(r>>2) + 4*hb) of each 32x32 sub-tile
-  if (EPI == EPI_BIAS_RESID_H16 && stats) {
-    // with the LayerNorm partials of the new rows (gemm_common.h: group_stats16)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + wm * 64 + j * 32 + l31;
-      if (m >= M) continue;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float o[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * hb;
-          const float4 v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-          gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, row0, rowscale, out16, &o[4 * g]);
-        }
-        stats[(size_t)(2 * ((n0 + wn * 64 + i * 32) >> 5) + hb) * stats_ld + m] = group_stats16(o);
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = m0 + wm * 64 + j * 32 + l31;
@@ -323,17 +303,17 @@ static hipError_t launch_gemm_epi(const GemmArgs& g, hipStream_t st) {
     const size_t smem4 = 4 * G_STAGE_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem4, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0, g.stats, g.stats_ld);
+    hipLaunchKernelGGL(kern, grid, block, smem4, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
   } else if (g.variant == 1) {
     auto kern = gemm_bf16_kernel<EPI, true, false, F16>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0, g.stats, g.stats_ld);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
   } else {
     auto kern = gemm_bf16_kernel<EPI, false, false, F16>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0, g.stats, g.stats_ld);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.M, g.N, g.K, g.row0, g.rowscale, g.out16, 0);
   }
   return hipGetLastError();
 }
@@ -363,7 +343,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // number of K splits for an [M, N, K] problem on n_cu compute units (1 = do not split)
 static int splitk_factor(const GemmArgs& g) {
-  if (!g.splitk_ws || g.M > 1024 || g.epi == EPI_TABLE_F32 || g.epi == EPI_RAW_F32 || g.stats) return 1;
+  if (!g.splitk_ws || g.M > 1024 || g.epi == EPI_TABLE_F32 || g.epi == EPI_RAW_F32) return 1;
   const int nk = g.K / G_BK;
   // Measured at M = 257 (profiles/r02j_b1_kernels.txt): every launch has a floor of ~4.5 us, a split GEMM + its reduction
   // cost 9.9 + 5.0 us whatever K is, the unsplit kernel 12 us at K = 1024 and 36 us at K = 4096: only long K loops pay.
@@ -391,7 +371,7 @@ static hipError_t launch_splitk_epi(const GemmArgs& g, int S, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(ntm * ntn, S), dim3(256), smem4, st, g.A, g.W, nullptr, g.splitk_ws, nullptr, 1, g.M, g.N, g.K, 0,
-                     nullptr, nullptr, (g.K / G_BK) / S, (float2*)nullptr, 0);
+                     nullptr, nullptr, (g.K / G_BK) / S);
   const int64_t quads = (int64_t)g.M * (g.N / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, g.splitk_ws, S, g.M, g.N,
                      g.bias, g.out, g.rowscale, g.out16);
@@ -502,7 +482,6 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       r.row0 = g.row0 + b.M;
       if (g.rowscale) r.rowscale = g.rowscale + b.M;
       if (g.out16) r.out16 = g.out16 + (size_t)b.M * g.N;
-      if (g.stats) r.stats = g.stats + b.M;  // group-major [N / 16, stats_ld]: the remaining rows start b.M entries further
       return launch_gemm128(r, st);
     }
   }
@@ -618,31 +597,6 @@ hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps
     default: return hipErrorInvalidValue;
   }
 #undef RS_CASE
-  return hipGetLastError();
-}
-
-// rstd from the (mean, M2) partials of the 16-value groups of a row (written by the residual epilogues, [G = d / 16, M]
-// group-major): one thread per row, consecutive threads read consecutive rows of every group (coalesced).  Chan's update in
-// the fixed order g = 0 .. G - 1:  n' = n + 16;  delta = mean_g - mean;  mean += delta 16 / n';  M2 += M2_g + delta^2 n 16 / n'.
-__global__ __launch_bounds__(256) void rowstats_merge_kernel(const float2* __restrict__ stats, float* __restrict__ rstd, int M, int G,
-                                                            float eps) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  if (row >= M) return;
-  float mean = 0.f, m2 = 0.f, n = 0.f;
-  for (int g = 0; g < G; ++g) {
-    const float2 p = stats[(size_t)g * M + row];
-    const float nn = n + 16.f;
-    const float delta = p.x - mean;
-    mean += delta * (16.f / nn);
-    m2 += p.y + delta * delta * (n * 16.f / nn);
-    n = nn;
-  }
-  rstd[row] = 1.f / sqrtf(m2 / n + eps);
-}
-hipError_t launch_rowstats_merge(const float2* stats, float* rstd, int M, int d, float eps, hipStream_t st) {
-  if (M <= 0) return hipSuccess;
-  if (d % 16 != 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rowstats_merge_kernel, dim3((M + 255) / 256), dim3(256), 0, st, stats, rstd, M, d / 16, eps);
   return hipGetLastError();
 }
 

@@ -71,7 +71,6 @@ struct clipx_handle {
                          // at B=256: chunks of 32/64/128/256 -> 92/65/58/56.5 ms, small chunks lose more GEMM efficiency than
                          // the overlap wins
   int gemm_variant = 3;
-  bool fused_stats = true;  // CLIPX_FUSED_STATS=0: LayerNorm statistics by a pass over the stream (A/B; bench.py refuses the switch)
   int n_cu = 256;
   std::mutex mu;
   hipStream_t stream = nullptr, copy_stream = nullptr;
@@ -89,7 +88,6 @@ struct clipx_handle {
   // activation workspace (shared by both towers)
   float* x = nullptr;      // f32 [rows, width]: the patch-embedding output in front of ln_pre (vision tower only)
   float* rstd = nullptr;   // [rows] LayerNorm 1/std of the current residual rows
-  float2* lnstats = nullptr;  // [width / 16, rows] (mean, M2) partials of the rows a residual epilogue just wrote (gemm_common.h)
   // xn = THE residual stream, IEEE fp16 [rows, width] (fp16 bits behind the bf16-typed pointer): read as the A operand of the
   // LayerNorm-folded GEMMs (QKV, fc1) and updated in place by the residual epilogues of out_proj / fc2.  Round 3: it replaced
   // an f32 stream + bf16 shadow (673 MB -> 269 MB moved per residual GEMM at ViT-L/14 bs 256; same accuracy: the stream has
@@ -259,7 +257,6 @@ static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
   if ((r = dev_alloc(h, (void**)&h->x, rowsV * V.width * sizeof(float)))) return r;
   if ((r = dev_alloc(h, (void**)&h->xn, nx * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->rstd, std::max(rowsV, rowsX) * sizeof(float)))) return r;
-  if ((r = dev_alloc(h, (void**)&h->lnstats, std::max(rowsV * V.width, rowsX * X.width) / 16 * sizeof(float2)))) return r;
   if ((r = dev_alloc(h, (void**)&h->qkv, nqkv * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->att, nx * sizeof(bf16)))) return r;
   if ((r = dev_alloc(h, (void**)&h->hbuf, nh * sizeof(bf16)))) return r;
@@ -307,8 +304,6 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   const char* hc = getenv("CLIPX_HOST_CHUNK");
   if (hc && atoi(hc) > 0) h->host_chunk = atoi(hc);
   h->host_chunk = std::min(h->host_chunk, h->max_batch);
-  const char* fs = getenv("CLIPX_FUSED_STATS");
-  if (fs && fs[0] == '0') h->fused_stats = false;
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   if (gv) h->gemm_variant = std::min(5, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -376,12 +371,11 @@ struct ProfScope {
 };
 
 static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* W, const float* bias, void* out,
-                    const float* table, int T, int M, int N, int K, int epi, const float* rowscale = nullptr, bool f16 = false,
-                    float2* stats = nullptr) {
+                    const float* table, int T, int M, int N, int K, int epi, const float* rowscale = nullptr, bool f16 = false) {
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.table = table; g.T = T;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant; g.n_cu = h->n_cu; g.row0 = 0;
-  g.rowscale = rowscale; g.out16 = nullptr; g.f16 = f16 ? 1 : 0; g.stats = stats; g.stats_ld = M;
+  g.rowscale = rowscale; g.out16 = nullptr; g.f16 = f16 ? 1 : 0;
   // split-K only on the single-query path (B == 1, KnnService.compute_query): every batch of two or more samples is computed
   // by the unsplit kernels, whose rows do not depend on the batch they travel in (bitwise); a B = 1 row differs from the same
   // sample inside a batch by f32 summation order only
@@ -396,35 +390,22 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   const float eps = h->desc.ln_eps;
   const int act = h->desc.act == CLIPX_ACT_QUICK_GELU ? EPI_BIAS_QGELU_BF16 : EPI_BIAS_GELU_BF16;
   // On entry h->xn holds the residual stream x in fp16 (written by ln_pre / the text embedding).  Per block:
-  //   qkv = (x @ Wqkv'^T) * rstd + c_qkv                                   [= LN1(x) @ Wqkv^T + b: LayerNorm folded; fp16 MFMA]
-  //   att = attention(qkv);  x = fp16(x + att @ Wout^T + b_out)            [in place, bf16 MFMA, f32 add] + LN partials of x
-  //   rstd = merge(partials); h = act((x @ Wfc1'^T) * rstd + c_fc1);  x = fp16(x + h @ Wfc2^T + b_fc2) + LN partials
-  // rstd of the FIRST block comes from a pass over the stream (launch_rowstats); afterwards every residual epilogue leaves
-  // per-block (mean, M2) partials of the rows it wrote and a tiny merge kernel turns them into rstd -- the 134 MB re-read of
-  // the stream per LayerNorm is gone.  Single-sample calls (split-K GEMMs, whose reduction kernel has no lane pairs to
-  // reduce over) keep the pass over the stream.
-  const bool fused = !h->single_query && h->fused_stats;
-  { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
+  //   rstd = rowstats(x);    qkv = (x @ Wqkv'^T) * rstd + c_qkv            [= LN1(x) @ Wqkv^T + b: LayerNorm folded; fp16 MFMA]
+  //   att = attention(qkv);  x = fp16(x + att @ Wout^T + b_out)            [in place, bf16 MFMA, f32 add]
+  //   rstd = rowstats(x);    h = act((x @ Wfc1'^T) * rstd + c_fc1);  x = fp16(x + h @ Wfc2^T + b_fc2)
+  // (LayerNorm partial statistics computed by the residual epilogues instead of the rowstats pass were built twice in round 3
+  // and measured slower on the same box -- the extra epilogue work costs more GEMM time than the 134 MB re-read it saves:
+  // profiles/r03_rejected/fused_layernorm_stats.patch)
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& L = t.L[l];
-    const bool last = l + 1 == t.layers;
     int r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
     if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16, h->rstd, true))) return r;
     { ProfScope ps(h, st, 1, 4.0 * B * t.heads * (double)t.T * t.T * (w / t.heads)); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st)); }
-    if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->xn, nullptr, 1, M, w, w, EPI_BIAS_RESID_H16, nullptr, false, fused ? h->lnstats : nullptr))) return r;
-    {
-      ProfScope ps(h, st, 2, 0);
-      if (fused) HIPCHK(launch_rowstats_merge(h->lnstats, h->rstd, M, w, eps, st));
-      else HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1));
-    }
+    if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->xn, nullptr, 1, M, w, w, EPI_BIAS_RESID_H16))) return r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
     if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, M, t.mlp, w, act, h->rstd, true))) return r;
-    // (the tail reads the stream itself: no statistics needed after the last block)
-    if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->xn, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_H16, nullptr, false, (fused && !last) ? h->lnstats : nullptr))) return r;
-    if (!last) {
-      ProfScope ps(h, st, 2, 0);
-      if (fused) HIPCHK(launch_rowstats_merge(h->lnstats, h->rstd, M, w, eps, st));
-      else HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1));
-    }
+    if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->xn, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_H16))) return r;
   }
   return 0;
 }
@@ -728,8 +709,6 @@ static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const f
   g.M = M; g.N = N; g.K = K; g.epi = epi;
   g.rowscale = rowscale;
   g.out16 = epi == 3 ? (bf16*)out16 : nullptr;
-  g.stats = epi == EPI_BIAS_RESID_H16 ? (float2*)out16 : nullptr;
-  g.stats_ld = M;
   g.f16 = f16;
   if (!g.rowscale) {  // bf16-output epilogues scale rows (LayerNorm-folded GEMMs of the encoder); a plain GEMM uses ones
     static std::mutex ones_mu;
@@ -807,14 +786,6 @@ extern "C" int clipx_rowstats_device(int device, const void* x16, int is_f16, fl
   if (d % 256 || d > 2048) return fail(CLIPX_E_UNSUPPORTED, "d must be a multiple of 256, <= 2048");
   HIPCHK(hipSetDevice(device));
   HIPCHK(launch_rowstats(x16, rstd, M, d, eps, (hipStream_t)stream, is_f16 ? 1 : 0));
-  return CLIPX_OK;
-}
-
-extern "C" int clipx_rowstats_merge_device(int device, const void* partials, float* rstd, int M, int d, float eps, void* stream) {
-  if (!partials || !rstd || M <= 0) return fail(CLIPX_E_ARG, "bad rowstats_merge arguments");
-  if (d % 16) return fail(CLIPX_E_UNSUPPORTED, "d must be a multiple of 16");
-  HIPCHK(hipSetDevice(device));
-  HIPCHK(launch_rowstats_merge((const float2*)partials, rstd, M, d, eps, (hipStream_t)stream));
   return CLIPX_OK;
 }
 

@@ -73,11 +73,7 @@ template <int EPI, bool F16, int NB>
 __device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
                                              void* __restrict__ outp, const float* __restrict__ table, int T, int N, int K,
                                              const float* __restrict__ rowscale, bf16* __restrict__ out16, int tail_m0,
-                                             unsigned char* smem, unsigned lds_base, int w, int lane_unused, float2* __restrict__ stats, int stats_ld) {
-  // the lane id is recomputed here (2 instructions) instead of being kept alive across the main loop: a value carried that far
-  // gets spilled to scratch, and its reload would wait vmcnt(0) in the middle of the DMA ring
-  (void)lane_unused;
-  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                                             unsigned char* smem, unsigned lds_base, int w, int lane) {
   constexpr int NOP = 1 + NB;     // operands of a stage: the 32 activation rows and NB blocks of 32 weight rows
   constexpr int SB = NOP * 8192;  // stage = 8 k-steps x 1 KiB per operand
   constexpr int R = 131072 / SB;  // ring depth: 8 / 5 / 4 / 3 stages in the 128 KiB the K-tile buffers occupied
@@ -129,15 +125,12 @@ __device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const b
   S_FENCE();
   if (w < NB) {
     const int m = tm + l31;
-    float o[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = tn + w * 32 + 8 * g + 4 * hb;
       const float4 v = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-      gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, 0, rowscale, out16, (EPI == EPI_BIAS_RESID_H16 && stats) ? &o[4 * g] : nullptr);
+      gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, 0, rowscale, out16);
     }
-    if (EPI == EPI_BIAS_RESID_H16 && stats)  // (gemm_common.h: group_stats16) the lane's 16 values of the wave's 32-column block
-      stats[(size_t)(2 * ((tn + w * 32) >> 5) + hb) * stats_ld + m] = group_stats16(o);
   }
 }
 
@@ -149,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int N, int K, int ntm,
                                                           int ntn, const float* __restrict__ rowscale, bf16* __restrict__ out16,
-                                                          int raster, int tail_m0, int tail_nb, float2* __restrict__ stats, int stats_ld) {
+                                                          int raster, int tail_m0, int tail_nb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool DBG_TIMER = DBG == 16 || DBG == 19 || DBG == 20 || DBG == 21 || DBG == 22;
   constexpr bool DBG_L2HOT = DBG == 21;
@@ -627,25 +620,21 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
           for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + (nt * 32 + 8 * g + 4 * hb) * 4);
         S_FENCE();  // hipcc waits vmcnt(0) for the bias DMA before these LDS reads: keep the x loads behind that wait
-        // ONE register set for the old rows: the loads of pass mt + 1 are issued right behind the LDS writes of pass mt (the
-        // registers are free again then) and fly across the arithmetic of pass mt.  (Two sets cost 16 VGPRs the kernel does not
-        // have once the LayerNorm partials are computed here too: hipcc spilled.)
-        u32x4 ext[4];
-#define S_LD_X16(mt_)                                                                                           \
+        u32x4 ext[2][4];
+#define S_LD_X16(set, mt_)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
-    ext[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, ((mt_) * 4 + i) * rstep, 0);
-        S_LD_X16(0)
+    ext[set][i] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, ((mt_) * 4 + i) * rstep, 0);
+        S_LD_X16(0, 0)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+          if (mt + 1 < 4) { S_LD_X16((mt + 1) & 1, mt + 1) }
           S_FENCE();
           // old rows -> scratch, in the position the read-back below (and the final store) uses
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int row = 8 * i + rrow;
-            *reinterpret_cast<u32x4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4)) = ext[i];
+            *reinterpret_cast<u32x4*>(scr + row * 128 + ((rch ^ (row & 7)) << 4)) = ext[mt & 1][i];
           }
-          S_FENCE();
-          if (mt + 1 < 4) { S_LD_X16(mt + 1) }
           // read all eight 8-B slots of this lane first, then add, then write them back: written as three loops so that the
           // LDS round trips overlap (one slot at a time hipcc emits read; wait; write eight times in a row)
           uint2 xo[2][4];
@@ -656,8 +645,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
               xo[nt][g] = *reinterpret_cast<const uint2*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8);
           S_FENCE();
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            float ov[16];  // f32 of the rounded new values of this 32-column block (LayerNorm partials)
+          for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const f16x4 xh = __builtin_bit_cast(f16x4, xo[nt][g]);
@@ -668,14 +656,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
               o[2] = (_Float16)((float)xh[2] + (acc[mt][nt][4 * g + 2] + bq.z));
               o[3] = (_Float16)((float)xh[3] + (acc[mt][nt][4 * g + 3] + bq.w));
               xo[nt][g] = __builtin_bit_cast(uint2, o);
-              if (stats) {
-                ov[4 * g + 0] = (float)o[0]; ov[4 * g + 1] = (float)o[1];
-                ov[4 * g + 2] = (float)o[2]; ov[4 * g + 3] = (float)o[3];
-              }
             }
-            if (stats)  // (gemm_common.h: group_stats16) row 32 mt + l31, this lane's 16 values of column block nt
-              stats[(size_t)(2 * ((n0 + wc * 64 + nt * 32) >> 5) + hb) * stats_ld + (m0 + wr * 128 + mt * 32 + l31)] = group_stats16(ov);
-          }
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -754,10 +735,10 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     S_FENCE();
     __builtin_amdgcn_s_barrier();                     // every wave is done with the K-tile buffers
     S_FENCE();
-    if (tail_nb == 1) gemm256_tail<EPI, F16, 1>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats, stats_ld);
-    else if (tail_nb == 2) gemm256_tail<EPI, F16, 2>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats, stats_ld);
-    else if (tail_nb == 3) gemm256_tail<EPI, F16, 3>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats, stats_ld);
-    else gemm256_tail<EPI, F16, 4>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane, stats, stats_ld);
+    if (tail_nb == 1) gemm256_tail<EPI, F16, 1>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane);
+    else if (tail_nb == 2) gemm256_tail<EPI, F16, 2>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane);
+    else if (tail_nb == 3) gemm256_tail<EPI, F16, 3>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane);
+    else gemm256_tail<EPI, F16, 4>(A, W, bias, outp, table, T, N, K, rowscale, out16, tail_m0, smem, lds_base, w, lane);
   }
   if (DBG_TIMER && tid == 0 && blockIdx.x < 2048) {
     ph[7] = (long long)__builtin_readcyclecounter() - tstart;
@@ -784,7 +765,7 @@ static hipError_t launch_sp_epi(const GemmArgs& g, int grid, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g.A, g.W, g.bias, g.out, g.table, g.T, g.N, g.K, g.M / 256,
-                     g.N / 256, g.rowscale, g.out16, raster, g.tail_m0, g.tail_nb, g.epi == EPI_BIAS_RESID_H16 ? g.stats : nullptr, g.stats_ld);
+                     g.N / 256, g.rowscale, g.out16, raster, g.tail_m0, g.tail_nb);
   return hipGetLastError();
 }
 

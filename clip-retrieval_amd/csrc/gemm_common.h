@@ -42,27 +42,6 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v + 0.5f * fabsf(v) * erf_abs;           // 0.5 v (1 + sign(v) erf(|v|/sqrt 2))
 }
 
-// LayerNorm statistics folded into the residual epilogues (round 3: replaces the rowstats pass over the stream).  In every
-// kernel a lane of a residual epilogue holds 16 values of one NEW row (the quads 8 g + 4 hb .. + 4, g = 0 .. 3, of a 32-column
-// block): it writes (mean, M2 = sum (v - mean)^2) of those 16 to stats[group * ld + m], group = 2 * (n / 32) + hb, ld = rows of
-// the whole GEMM -- group-major, so the 32 lanes of a half-wave (32 consecutive rows) store 256 contiguous bytes -- and
-// rowstats_merge_kernel folds the N / 16 partials of a row (Chan's update, fixed order) into 1 / sqrt(var + eps).  No
-// cross-lane traffic; two-pass inside a group (no cancellation); the same helper in every kernel, so a row's statistics do not
-// depend on which kernel produced it.
-__device__ __forceinline__ float2 group_stats16(const float (&v)[16]) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s += v[i];
-  const float mean = s * (1.f / 16.f);
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float d = v[i] - mean;
-    q = __builtin_fmaf(d, d, q);
-  }
-  return make_float2(mean, q);
-}
-
 // One accumulator quad of the transposed-product layout both kernels use (MFMA A operand = weight rows, B operand
 // = activation rows): the lane owns output row m and four consecutive columns n..n+3.
 // bf16-output epilogues: out = act(acc * rowscale[m] + bias[n]) -- rowscale is the row's LayerNorm 1/std when the GEMM
@@ -73,9 +52,7 @@ __device__ __forceinline__ float2 group_stats16(const float (&v)[16]) {
 template <int EPI>
 __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, const float* __restrict__ bias,
                                                 void* __restrict__ outp, const float* __restrict__ table, int T,
-                                                int row0, const float* __restrict__ rowscale, bf16* __restrict__ out16,
-                                                float* __restrict__ o_f32 = nullptr) {
-  // o_f32 (EPI_BIAS_RESID_H16 only, may be null): the four new row values as f32(fp16(.)) -- what group_stats16 is fed with
+                                                int row0, const float* __restrict__ rowscale, bf16* __restrict__ out16) {
   constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
   if (EPI == EPI_RAW_F32) {  // a split-K partial product: the accumulators as they are
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n) = v;
@@ -114,7 +91,6 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
     h[0] = (_Float16)((float)x4[0] + v.x); h[1] = (_Float16)((float)x4[1] + v.y);
     h[2] = (_Float16)((float)x4[2] + v.z); h[3] = (_Float16)((float)x4[3] + v.w);
     *p = h;
-    if (o_f32) { o_f32[0] = (float)h[0]; o_f32[1] = (float)h[1]; o_f32[2] = (float)h[2]; o_f32[3] = (float)h[3]; }
   } else {  // EPI_TABLE_F32
     const float4 t4 = *reinterpret_cast<const float4*>(table + (size_t)((m + row0) % T) * N + n);
     v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;

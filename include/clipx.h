@@ -134,9 +134,7 @@ int clipx_gemm_bf16_device(int device, const void* A_bf16, const void* W_bf16, c
 int clipx_gemm_bf16_ex_device(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M, int N,
                               int K, int epi, const float* rowscale_or_null, void* out16_or_null, void* stream);
 /* (the _ex entry point also takes epi 6: out is IEEE fp16 [M, N], updated in place, out = fp16(f32(out) + acc + bias) -- the
- * residual epilogue of out_proj / fc2 in the encoder, whose residual stream is stored in fp16.  With epi 6, out16_or_null is
- * instead an optional float2 [N / 16, M] buffer (group-major) that receives (mean, sum of squared deviations) of 16-value groups
- * of the new rows: the LayerNorm statistics the epilogue computes on the fly; clipx_rowstats_merge_device turns them into 1 / std) */
+ * residual epilogue of out_proj / fc2 in the encoder, whose residual stream is stored in fp16.) */
 
 /* The LayerNorm-folded GEMMs of the encoder (QKV, fc1) read that fp16 residual stream as their A operand: A and W are IEEE
  * fp16 (v_mfma_f32_32x32x16_f16, the same rate as bf16), out bf16 [M, N]; epi 0..2 and rowscale as above. */
@@ -152,11 +150,9 @@ int clipx_attention_dh_device(int device, const void* qkv_bf16, void* out_bf16, 
                               int causal, void* stream);
 int clipx_layernorm_device(int device, const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
                            int M, int d, float eps, void* stream);
-/* LayerNorm statistics of the residual stream, the two ways the encoder obtains them (per-kernel parity tests):
- * rstd[m] = 1 / sqrt(var(x16[m, :]) + eps) by a pass over the 16-bit rows (is_f16: IEEE fp16, else bf16), and the same from
- * the [d / 16, M] float2 partials a residual epilogue wrote (epi 6 above). */
+/* LayerNorm statistics of the residual stream as the LayerNorm-folded GEMMs consume them (per-kernel parity test):
+ * rstd[m] = 1 / sqrt(var(x16[m, :]) + eps) by a pass over the 16-bit rows (is_f16: IEEE fp16, else bf16). */
 int clipx_rowstats_device(int device, const void* x16, int is_f16, float* rstd, int M, int d, float eps, void* stream);
-int clipx_rowstats_merge_device(int device, const void* partials_f32x2, float* rstd, int M, int d, float eps, void* stream);
 
 /* Live per-kernel timing for bench.py: launches of the enabled kinds are bracketed by hipEvents on
  * their stream.  kind: 0 gemm, 1 attention, 2 layernorm, 3 other.  on: 0 off, 1 all kinds, else a bit

@@ -528,18 +528,15 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
     for variant in (3, 1):
         os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
         x = x0.clone()
-        part = torch.full((N // 16, M, 2), float("nan"), device="cuda")
-        check(lib, lib.clipx_gemm_bf16_ex_device(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(x), M, N, K, 6, None, _ptr(part), C.c_void_p(st)), "clipx")
-        # (3) the LayerNorm statistics the epilogue leaves behind: merged partials vs a pass over the rows it wrote
+        check(lib, lib.clipx_gemm_bf16_ex_device(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(x), M, N, K, 6, None, None, C.c_void_p(st)), "clipx")
+        # (3) the LayerNorm statistics of the rows it wrote, as the next LayerNorm-folded GEMM gets them
         if N % 256 == 0:
-            r_fused, r_pass = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
-            check(lib, lib.clipx_rowstats_merge_device(0, _ptr(part), _ptr(r_fused), M, N, C.c_float(1e-5), C.c_void_p(st)), "clipx")
+            r_pass = torch.empty(M, device="cuda")
             check(lib, lib.clipx_rowstats_device(0, _ptr(x), 1, _ptr(r_pass), M, N, C.c_float(1e-5), C.c_void_p(st)), "clipx")
             torch.cuda.synchronize()
             want_r = 1.0 / torch.sqrt(x.float().var(dim=1, unbiased=False) + 1e-5)
-            assert not torch.isnan(part).any(), "a (group, row) partial was not written"
-            assert torch.allclose(r_fused, r_pass, rtol=2e-5, atol=0) and torch.allclose(r_fused, want_r, rtol=1e-4, atol=0)
-        ys = [part]
+            assert torch.allclose(r_pass, want_r, rtol=1e-4, atol=0)
+        ys = []
         for epi in (0, 1, 2):
             y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             check(lib, lib.clipx_gemm_f16_device(0, _ptr(Ah), _ptr(Wh), _ptr(bias), _ptr(y), M, N, K, epi, _ptr(rs), C.c_void_p(st)), "clipx")
@@ -555,7 +552,7 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
     tol = 1e-3 + 1.2e-3 * want.abs()   # fp16: 2^-11 relative rounding + fp32 accumulation-order noise
     assert (err <= tol).all(), f"fp16 residual: max err {float(err.max()):.4g} at {(err > tol).nonzero()[:4].tolist()}"
     ref = (Ah.float() @ Wh.float().T) * rs[:, None] + bias
-    for epi, y in zip((0, 1, 2), outs[3][2:]):
+    for epi, y in zip((0, 1, 2), outs[3][1:]):
         w = ref if epi == 0 else (ref * torch.sigmoid(1.702 * ref) if epi == 1 else torch.nn.functional.gelu(ref))
         e = (y.float() - w).abs()
         t = 2e-3 + 4e-3 * w.abs()
