@@ -105,6 +105,7 @@ SIGNATURES = {
     "clipx_wait": (C.c_int, [_P]),
     "clipx_encode_image_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "clipx_encode_text_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "clipx_resize_crop_u8_device": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "clipx_max_batch": (C.c_int, [_P]),
     "clipx_graphs_cached": (C.c_int, [_P]),
     "clipx_embed_dim": (C.c_int, [_P]),

@@ -36,6 +36,8 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 extern "C" const char* clipx_last_error(void) { return g_err.c_str(); }
+// used by preprocess.hip (same library, other translation unit): set the thread-local message
+extern "C" int clipx_set_error(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
 namespace {
 

@@ -283,6 +283,37 @@ class ClipEncoder:
         check(self._lib, fn(self._h, a.ctypes.data, a.shape[0], out.ctypes.data), "clipx")
         return out
 
+    # ---- decoded sources of any size: resize + centre crop on the GPU (csrc/preprocess.hip), then the image tower
+    def resize_crop_device(self, raw, stream=None):
+        """`raw` = {"pixels": uint8 1-D torch tensor (page-locked or not) with the packed RGB sources, "offsets": int64 [B],
+        "hw": int32 [B, 2]} (reader._collate) -> uint8 [B, S, S, 3] torch tensor on this encoder's GPU, bit-identical to
+        Pillow's bicubic resize + centre crop (the reference's image_transform, reader.py:83,87)."""
+        import torch  # pylint: disable=import-outside-toplevel
+
+        dev = torch.device("cuda", self.device)
+        B, S = int(raw["hw"].shape[0]), self.arch.image_size
+        src = raw["pixels"].to(dev, non_blocking=True)
+        offsets = np.ascontiguousarray(raw["offsets"], dtype=np.int64)
+        hw = np.ascontiguousarray(raw["hw"], dtype=np.int32)
+        out = torch.empty((B, S, S, 3), dtype=torch.uint8, device=dev)
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        check(self._lib, self._lib.clipx_resize_crop_u8_device(self.device, C.c_void_p(src.data_ptr()), offsets.ctypes.data, hw.ctypes.data,
+                                                               B, S, C.c_void_p(out.data_ptr()), C.c_void_p(st) if st else None), "clipx")
+        out._clipx_src = src  # the kernel reads `src` asynchronously: keep it alive as long as the result
+        return out
+
+    def encode_image_raw(self, raw) -> np.ndarray:
+        """fp16 [B, E] unit-norm rows from decoded sources (see resize_crop_device): upload once, resize / crop / normalise and
+        encode on the GPU."""
+        import torch  # pylint: disable=import-outside-toplevel
+
+        dev = torch.device("cuda", self.device)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        u8 = self.resize_crop_device(raw, st)
+        out = torch.empty((u8.shape[0], self.embed_dim), dtype=torch.float16, device=dev)
+        self.encode_image_device(u8.data_ptr(), u8.shape[0], PIX_U8_NHWC, out.data_ptr(), None, st)
+        return out.cpu().numpy()
+
     # ---- asynchronous tickets (clipx_encode_*_async / clipx_wait): submit now, collect later
     def submit_image(self, pixels):
         a, fmt = self._image_array(pixels)

@@ -60,14 +60,21 @@ class ClipMapper:
                 self._enc.encode_text(ids)
             self._enc._warm = True  # pylint: disable=protected-access
 
+    def _encode_images(self, item):
+        """`image_tensor` (the reference's batch: f32 NCHW, or uint8 NHWC crops) or `image_raw` (decoded sources of any size:
+        resize + centre crop on the GPU too, reader.decode_rgb_u8)."""
+        if "image_raw" in item:
+            return self._enc.encode_image_raw(item["image_raw"])
+        return self._enc.encode_image(item["image_tensor"])
+
     def submit(self, item):
         """Stage the batch and enqueue its upload + kernels (clipx_encode_*_async); returns a handle for collect().
         A caller that submits batch n+1 before collecting batch n overlaps n+1's upload with n's kernels (runner.Runner).
         Batches larger than the library's max batch fall back to the synchronous call inside collect()."""
         h = {"item": item, "img": None, "txt": None}
         try:
-            if self.enable_image and len(item["image_tensor"]) <= self._enc.max_batch:
-                h["img"] = self._enc.submit_image(item["image_tensor"])
+            if self.enable_image and "image_raw" not in item and len(item["image_tensor"]) <= self._enc.max_batch:
+                h["img"] = self._enc.submit_image(item["image_tensor"])  # (decoded sources: resized + encoded in collect())
             if self.enable_text and len(item["text_tokens"]) <= self._enc.max_batch:
                 h["txt"] = self._enc.submit_text(item["text_tokens"])
         except BaseException:
@@ -90,7 +97,7 @@ class ClipMapper:
         item = h["item"]
         image_embs = text_embs = image_filename = text = metadata = None
         if self.enable_image:
-            image_embs = self._enc.collect(h["img"]) if h["img"] is not None else self._enc.encode_image(item["image_tensor"])
+            image_embs = self._enc.collect(h["img"]) if h["img"] is not None else self._encode_images(item)
             image_filename = item["image_filename"]
         if self.enable_text:
             text_embs = self._enc.collect(h["txt"]) if h["txt"] is not None else self._enc.encode_text(item["text_tokens"])
@@ -108,7 +115,7 @@ class ClipMapper:
     def __call__(self, item):
         image_embs = text_embs = image_filename = text = metadata = None
         if self.enable_image:
-            image_embs = self._enc.encode_image(item["image_tensor"])
+            image_embs = self._encode_images(item)
             image_filename = item["image_filename"]
         if self.enable_text:
             text_embs = self._enc.encode_text(item["text_tokens"])

@@ -60,6 +60,18 @@ def clip_preprocess_u8(image, size=224):
     return np.asarray(image.crop((left, top, left + size, top + size)).convert("RGB"), dtype=np.uint8)
 
 
+def decode_rgb_u8(image):
+    """No geometry on the host at all: PIL image -> its decoded RGB pixels, uint8 [h, w, 3] of whatever size it has.  A reader
+    built with this preprocess hands batches over as `image_raw` (one packed page-locked buffer + per-image offsets and sizes)
+    and the resize / centre crop run on the GPU, bit-identical to Pillow (csrc/preprocess.hip, clipx_resize_crop_u8_device;
+    SURVEY 8 row f2).  Worth it when the host's decode processes are the bottleneck and the sources are not much larger than
+    the crop: the decoded source travels through the pipes and PCIe instead of the 150 KB crop."""
+    return np.asarray(image.convert("RGB"), dtype=np.uint8)
+
+
+decode_rgb_u8.raw_images = True  # readers: collate as `image_raw`, not as a stacked `image_tensor`
+
+
 class ClipTransform:
     """`preprocess` as `load_clip` returns it (all_clip's second result; the reference uses it at reader.py:83,144 and
     clip_back.py:241): PIL image -> torch f32 [3, size, size].  A class, not a closure, so that it can be pickled."""
@@ -150,7 +162,20 @@ def _collate(samples, enable_image, enable_text, enable_metadata, pin):
     import torch  # pylint: disable=import-outside-toplevel
 
     batch = {}
-    if enable_image:
+    if enable_image and "image_raw" in samples[0]:
+        # decoded sources of different sizes: ONE packed (page-locked) byte buffer + host-side offsets and (h, w) per image --
+        # the layout clipx_resize_crop_u8_device takes
+        sizes = np.asarray([s["image_raw"].shape[:2] for s in samples], dtype=np.int32)
+        nbytes = sizes[:, 0].astype(np.int64) * sizes[:, 1] * 3
+        offsets = np.zeros(len(samples), dtype=np.int64)
+        np.cumsum(nbytes[:-1], out=offsets[1:])
+        packed = torch.empty(int(nbytes.sum()), dtype=torch.uint8, pin_memory=bool(pin))
+        flat = packed.numpy()
+        for s, o, n in zip(samples, offsets, nbytes):
+            flat[o:o + n] = s["image_raw"].reshape(-1)
+        batch["image_raw"] = {"pixels": packed, "offsets": offsets, "hw": sizes}
+        batch["image_filename"] = [s["image_filename"] for s in samples]
+    elif enable_image:
         first = samples[0]["image_tensor"]
         if pin:  # rows go straight into the page-locked batch (one copy instead of stack + pin_memory)
             t = torch.empty((len(samples),) + first.shape, dtype=torch.from_numpy(np.empty(0, first.dtype)).dtype, pin_memory=True)
@@ -180,7 +205,10 @@ def _decode_sample(raw, preprocess, tokenizer, enable_image, enable_text, enable
             print(f"Failed to load image {raw['key']}. Error: {e}. Skipping.")
             return None
         img = img.numpy() if hasattr(img, "numpy") else np.asarray(img)
-        out["image_tensor"] = img if img.dtype == np.uint8 else img.astype(np.float32, copy=False)  # uint8 HWC: normalised on the GPU
+        if getattr(preprocess, "raw_images", False):
+            out["image_raw"] = np.ascontiguousarray(img, dtype=np.uint8)  # decoded source of its own size: resized on the GPU
+        else:
+            out["image_tensor"] = img if img.dtype == np.uint8 else img.astype(np.float32, copy=False)  # uint8 HWC: normalised on the GPU
         out["image_filename"] = raw["key"]
     if enable_text:
         out["text"] = raw["text"]

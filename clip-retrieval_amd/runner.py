@@ -96,6 +96,14 @@ class _Prefetcher:
         self._stop.set()
 
 
+def _batch_rows(batch):
+    if "image_tensor" in batch:
+        return batch["image_tensor"].shape[0]
+    if "image_raw" in batch:  # decoded sources, resized on the GPU (reader.decode_rgb_u8)
+        return batch["image_raw"]["hw"].shape[0]
+    return batch["text_tokens"].shape[0]
+
+
 class Runner:
     """Runs one output partition end to end.
 
@@ -144,8 +152,7 @@ class Runner:
                 if pipelined:
                     done, todo = pending, None
                     if batch is not None:
-                        key = "image_tensor" if "image_tensor" in batch else "text_tokens"
-                        todo = (handle, batch[key].shape[0], wall0, t1 - t0, t2 - t1)
+                        todo = (handle, _batch_rows(batch), wall0, t1 - t0, t2 - t1)
                     pending = todo
                     if done is None:
                         continue
@@ -173,10 +180,9 @@ class Runner:
                     writer(embeddings)
                     t4 = time.perf_counter()
                     wall1 = time.time()
-                    key = "image_tensor" if "image_tensor" in batch else "text_tokens"
                     logger({"start_time": wall0, "end_time": wall1, "read_duration": t1 - t0,
                             "inference_duration": t3 - t1, "write_duration": t4 - t3,
-                            "total_duration": wall1 - wall0, "sample_count": batch[key].shape[0]})
+                            "total_duration": wall1 - wall0, "sample_count": _batch_rows(batch)})
         except BaseException:
             # A submitted ticket owns one of the encoder's staging slots (and keeps its pinned input referenced) until it is
             # collected; the encoder outlives this partition (cached per model and device), so a ticket leaked here would

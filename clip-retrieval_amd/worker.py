@@ -18,7 +18,7 @@ import re
 
 from .encoder import load_clip
 from .mapper import ClipMapper
-from .reader import FilesReader, WebdatasetReader, clip_preprocess_u8
+from .reader import FilesReader, WebdatasetReader, clip_preprocess_u8, decode_rgb_u8
 from .runner import LoggerWriter, Runner, get_task_list
 from .writer import NumpyWriter
 
@@ -64,9 +64,11 @@ def worker(
     clip_cache_path=None,
     device=0,
     gpu_normalise=True,
+    gpu_resize=False,
 ):
     """Start a worker.  gpu_normalise (not in the reference): the readers resize / crop on the host and hand uint8 pixels to
-    the mapper, which normalises on the GPU; False reproduces the reference's float32 `image_tensor` batches."""
+    the mapper, which normalises on the GPU; False reproduces the reference's float32 `image_tensor` batches.  gpu_resize (not in
+    the reference): the readers only DECODE; resize + centre crop run on the GPU too, bit-identical to Pillow (csrc/preprocess.hip)."""
     print("Starting the worker", flush=True)
     if input_format == "webdataset" and not isinstance(input_dataset, list):
         input_dataset = braceexpand(input_dataset)
@@ -75,7 +77,9 @@ def worker(
     def reader_builder(sampler):
         model, preprocess, tokenizer = load_clip(clip_model=clip_model, use_jit=use_jit, warmup_batch_size=0,
                                                  clip_cache_path=clip_cache_path, device=device)
-        if gpu_normalise:
+        if gpu_resize:
+            preprocess = decode_rgb_u8  # decode only; geometry and normalisation on the GPU
+        elif gpu_normalise:
             size = model._enc.arch.image_size  # pylint: disable=protected-access
             preprocess = functools.partial(clip_preprocess_u8, size=size)  # picklable: travels to the decode processes
         if input_format == "files":

@@ -113,6 +113,15 @@ int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, in
 int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,
                              float* out_f32_or_null, void* stream);
 
+/* The geometric half of the reference's image transform on the GPU (reader.py:83,87 `self.image_transform(image)` = CLIP's
+ * Resize(S, BICUBIC) + CenterCrop(S) on a PIL image), bit-identical to Pillow's 8-bit bicubic resample: B decoded RGB images of
+ * any sizes, packed in one device buffer (image i = uint8 [hw[2i], hw[2i+1], 3] at byte offset offsets[i]), become the uint8
+ * [B, S, S, 3] batch that clipx_encode_image_device takes as CLIPX_PIX_U8_NHWC.  offsets / hw are HOST arrays; the filter weights
+ * are computed on the host in Pillow's arithmetic (a few KB per image), the pixel work runs on `stream` (asynchronous).
+ * CLIPX_E_UNSUPPORTED for down-scales beyond ~30 x (a band of output rows no longer fits the LDS). */
+int clipx_resize_crop_u8_device(int device, const void* src_dev, const int64_t* offsets, const int32_t* hw, int B, int S, void* out_dev,
+                                void* stream);
+
 /* Largest batch one launch sequence handles (workspace is sized for it at create time;
  * CLIPX_MAX_BATCH env var, default 256).  Bigger B is processed in chunks of this size. */
 int clipx_max_batch(const clipx_handle* h);

@@ -211,8 +211,9 @@ def test_worker_on_the_gpu_over_tar_shards(tiny_checkpoints, tmp_path):
         p = tmp_path / f"{t:03d}.tar"
         with tarfile.open(p, "w") as tf:
             for _ in range(9):
-                g = np.linspace(0, 255, 96, dtype=np.float32)
-                img = (g[None, :, None] * 0.5 + g[:, None, None] * 0.5 + rng.normal(0, 8, (96, 96, 3))).clip(0, 255).astype(np.uint8)
+                hh, ww = ((96, 96), (70, 131), (150, 64), (33, 47))[k % 4]  # sources of different sizes and aspect ratios
+                gy, gx = np.linspace(0, 255, hh, dtype=np.float32), np.linspace(0, 255, ww, dtype=np.float32)
+                img = (gx[None, :, None] * 0.5 + gy[:, None, None] * 0.5 + rng.normal(0, 8, (hh, ww, 3))).clip(0, 255).astype(np.uint8)
                 buf = io.BytesIO()
                 Image.fromarray(img).save(buf, format="JPEG", quality=92)
                 jpegs.append(buf.getvalue())
@@ -239,3 +240,13 @@ def test_worker_on_the_gpu_over_tar_shards(tiny_checkpoints, tmp_path):
         _, wt = mapper_semantics(oracle.encode_text(tok(list(meta["caption"]))))
         assert _cos(img, wi).min() >= COS_BAR and _cos(txt, wt).min() >= COS_BAR
         assert json.loads((out / "stats" / f"{i}.json").read_text())["sample_count"] == 9
+    # the same job with the resize + centre crop on the GPU as well (row f2): the decode processes hand over the decoded sources;
+    # the kernel is bit-identical to Pillow, so every written embedding must be the SAME BYTES as above
+    out2 = tmp_path / "out_gpu_resize"
+    worker(tasks=[0, 1], input_dataset=shards, output_folder=str(out2), output_partition_count=2, input_format="webdataset",
+           batch_size=4, num_prepro_workers=2, enable_text=True, enable_image=True, enable_metadata=False, clip_model="tiny-test",
+           clip_cache_path=dirs["openai"], device=0, gpu_resize=True)
+    for i in range(2):
+        assert np.array_equal(np.load(out / "img_emb" / f"img_emb_{i}.npy"), np.load(out2 / "img_emb" / f"img_emb_{i}.npy"))
+        assert np.array_equal(np.load(out / "text_emb" / f"text_emb_{i}.npy"), np.load(out2 / "text_emb" / f"text_emb_{i}.npy"))
+        assert json.loads((out2 / "stats" / f"{i}.json").read_text())["sample_count"] == 9
