@@ -304,15 +304,22 @@ class ClipEncoder:
 
     def encode_image_raw(self, raw) -> np.ndarray:
         """fp16 [B, E] unit-norm rows from decoded sources (see resize_crop_device): upload once, resize / crop / normalise and
-        encode on the GPU."""
+        encode on the GPU.  Everything is ordered on one side stream of this encoder (a NULL stream handle would make the
+        library fall back to its own stream and lose the ordering against the resize kernel)."""
         import torch  # pylint: disable=import-outside-toplevel
 
         dev = torch.device("cuda", self.device)
-        st = torch.cuda.current_stream(dev).cuda_stream
-        u8 = self.resize_crop_device(raw, st)
-        out = torch.empty((u8.shape[0], self.embed_dim), dtype=torch.float16, device=dev)
-        self.encode_image_device(u8.data_ptr(), u8.shape[0], PIX_U8_NHWC, out.data_ptr(), None, st)
-        return out.cpu().numpy()
+        if getattr(self, "_raw_stream", None) is None:
+            self._raw_stream = torch.cuda.Stream(dev)
+        s = self._raw_stream
+        with torch.cuda.stream(s):
+            u8 = self.resize_crop_device(raw, s.cuda_stream)
+            out = torch.empty((u8.shape[0], self.embed_dim), dtype=torch.float16, device=dev)
+            self.encode_image_device(u8.data_ptr(), u8.shape[0], PIX_U8_NHWC, out.data_ptr(), None, s.cuda_stream)
+            host = torch.empty(out.shape, dtype=torch.float16, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+        s.synchronize()
+        return host.numpy()
 
     # ---- asynchronous tickets (clipx_encode_*_async / clipx_wait): submit now, collect later
     def submit_image(self, pixels):

@@ -62,12 +62,13 @@ def test_kernel_equals_the_oracle_and_saturates_like_pillow(lib):
     from oracle.resample_oracle import clip_resize_crop_u8
 
     imgs = []
-    for h, w, p in ((300, 300, 1), (300, 451, 2), (100, 90, 3), (640, 480, 5)):
+    for h, w, p in ((300, 300, 1), (300, 451, 2), (100, 90, 3), (640, 480, 16), (200, 260, 50)):
         yy, xx = np.mgrid[:h, :w]
         imgs.append(np.repeat((((yy // p + xx // p) & 1) * 255).astype(np.uint8)[:, :, None], 3, axis=2))
     got = _resize_crop(lib, imgs, 224)
     for im, g in zip(imgs, got):
         assert np.array_equal(g, clip_resize_crop_u8(im, 224)), im.shape
+    for g in got[3:]:  # squares wider than the filter: flat black and white areas survive, the edges between them overshoot
         assert g.min() == 0 and g.max() == 255
 
 
