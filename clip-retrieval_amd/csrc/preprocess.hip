@@ -20,8 +20,10 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/clipx.h"
@@ -34,76 +36,149 @@ namespace {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
 constexpr int PP_LDS_BYTES = 96 * 1024;  // LDS budget of a band's horizontally resampled rows (S = 224: 146 rows)
+constexpr int PP_STAGE_BYTES = 48 * 1024;  // LDS budget of the staged source rows
 
-struct ImgDesc {      // one per image, in the coefficient buffer
+struct ImgDesc {      // one per image, at the head of the coefficient buffer
   long long src_off;  // byte offset of the image in the packed source
   int h, w;           // decoded size
   int br;             // output rows per band
   int kh, kv;         // taps per output column / row (ksize of the two passes)
   int hb_off, hk_off; // int32 offsets (from the start of the coefficient buffer): horizontal bounds [S][2], weights [S][kh]
   int vb_off, vk_off; // vertical bounds [S][2], weights [S][kv]
+  int c0, ncols;      // source columns the cropped output columns touch: [c0, c0 + ncols)
+  int pitch, R;       // staging: bytes per staged source row (16-aligned, room for the alignment shift), rows per chunk
+  int tmp_bytes;      // LDS bytes of the horizontally resampled rows of the largest band (16-aligned)
+  int pad;
 };
+
+constexpr int STAGE_ROWS = 8;  // source rows resampled horizontally per pass: one weight load feeds STAGE_ROWS x 3 multiply-adds
 
 __device__ __forceinline__ int clip8(int v) {
   v >>= PRECISION_BITS;
-  return v < 0 ? 0 : (v > 255 ? 255 : v);
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  // Opaque to the optimiser on purpose.  ROCm 7.2's LLVM fuses two of these shift-and-saturate results that are OR-ed into a
+  // dword into one v_ashr_pk_u8_i32 and then treats the upper 16 bits of its destination as zero; on gfx950 the instruction
+  // leaves them as they were, so bytes 2 and 3 of the packed dword picked up whatever the register held before (measured: the
+  // filter weight).  Kept as separate v_med3 results, the pack is plain shifts and ORs.
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
-__global__ __launch_bounds__(256) void resize_crop_kernel(const unsigned char* __restrict__ src, const int* __restrict__ cb,
-                                                        const ImgDesc* __restrict__ descs, int S,
+// LDS: [tmp: horizontally resampled rows of the band, uint8 [rows][S][3]] [stg: STAGE_ROWS raw source rows] [vks: the band's
+// vertical weights].  Source bytes reach the multiply-adds through LDS only: 16-byte global loads stage them, ds_read_u8 feeds
+// the taps (a tap window is an arbitrary, unaligned byte range of the row).
+__global__ __launch_bounds__(256) void resize_crop_kernel(const unsigned char* __restrict__ src, long long src_bytes,
+                                                        const int* __restrict__ cb, const ImgDesc* __restrict__ descs, int S,
                                                         unsigned char* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char tmp[];  // [rows][S][3]
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const ImgDesc d = descs[blockIdx.y];
   const int yy0 = blockIdx.x * d.br;
   if (yy0 >= S) return;
   const int yy1 = min(S, yy0 + d.br);
+  const int tid = threadIdx.x;
   const int* hb = cb + d.hb_off;
   const int* hk = cb + d.hk_off;
   const int* vb = cb + d.vb_off;
   const int* vk = cb + d.vk_off;
+  unsigned char* tmp = lds;
+  unsigned char* stg = lds + d.tmp_bytes;
+  int* vks = reinterpret_cast<int*>(stg + (size_t)d.R * d.pitch);
   const int r0 = vb[2 * yy0];                                   // first source row any window of this band touches
   const int r1 = vb[2 * (yy1 - 1)] + vb[2 * (yy1 - 1) + 1];     // one past the last (windows move monotonically)
   const int nrows = r1 - r0;
-  const unsigned char* img = src + d.src_off;
-  // ---- phase 1: horizontal pass of rows [r0, r1), output columns = the cropped S columns
-  for (int idx = threadIdx.x; idx < nrows * S; idx += 256) {
-    const int row = idx / S, xx = idx - row * S;
-    const int xmin = hb[2 * xx], xmax = hb[2 * xx + 1];
-    const unsigned char* p = img + ((size_t)(r0 + row) * d.w + xmin) * 3;
-    const int* k = hk + xx * d.kh;
-    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
-    for (int x = 0; x < xmax; ++x) {
-      const int kw = k[x];
-      s0 += (int)p[3 * x] * kw;
-      s1 += (int)p[3 * x + 1] * kw;
-      s2 += (int)p[3 * x + 2] * kw;
+  for (int i = tid; i < (yy1 - yy0) * d.kv; i += 256) vks[i] = vk[yy0 * d.kv + i];
+  const int rowbytes = S * 3;
+  const int nvec = d.pitch >> 4;
+  // ---- phase 1: horizontal pass of source rows [r0, r1) in chunks of R rows, output columns = the cropped S columns
+  for (int rb = 0; rb < nrows; rb += d.R) {
+    const int nr = min(d.R, nrows - rb);
+    // stage: row r of the chunk = source bytes [a, a + ncols * 3) with a = src_off + ((r0 + rb + r) * w + c0) * 3, copied from the
+    // 16-byte boundary below a (the shift a & 15 is re-derived by the readers); vectors that cross the ends of the packed source
+    // are fetched byte by byte
+    for (int i = tid; i < nr * nvec; i += 256) {
+      const int r = i / nvec, v = i - r * nvec;
+      const long long a = d.src_off + ((long long)(r0 + rb + r) * d.w + d.c0) * 3;
+      const long long g = (a & ~15LL) + 16LL * v;
+      uint4 val;
+      if (g >= 0 && g + 16 <= src_bytes && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        val = *reinterpret_cast<const uint4*>(src + g);
+      } else {
+        unsigned char b[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[j] = (g + j >= 0 && g + j < src_bytes) ? src[g + j] : 0;
+        val = *reinterpret_cast<const uint4*>(b);
+      }
+      *reinterpret_cast<uint4*>(stg + (size_t)r * d.pitch + 16 * v) = val;
     }
-    unsigned char* t = tmp + (size_t)idx * 3;
-    t[0] = (unsigned char)clip8(s0);
-    t[1] = (unsigned char)clip8(s1);
-    t[2] = (unsigned char)clip8(s2);
+    __syncthreads();
+    for (int xx = tid; xx < S; xx += 256) {
+      const int xmin = hb[2 * xx], xmax = hb[2 * xx + 1];
+      const int* k = hk + xx * d.kh;
+      int acc[STAGE_ROWS][3];
+      const unsigned char* p[STAGE_ROWS];
+#pragma unroll
+      for (int r = 0; r < STAGE_ROWS; ++r) {
+        acc[r][0] = acc[r][1] = acc[r][2] = 1 << (PRECISION_BITS - 1);
+        const long long a = d.src_off + ((long long)(r0 + rb + min(r, nr - 1)) * d.w + d.c0) * 3;
+        p[r] = stg + (size_t)min(r, nr - 1) * d.pitch + (int)(a & 15) + (xmin - d.c0) * 3;
+      }
+      for (int x = 0; x < xmax; ++x) {
+        const int kw = k[x];
+#pragma unroll
+        for (int r = 0; r < STAGE_ROWS; ++r) {
+          acc[r][0] += (int)p[r][3 * x] * kw;
+          acc[r][1] += (int)p[r][3 * x + 1] * kw;
+          acc[r][2] += (int)p[r][3 * x + 2] * kw;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < STAGE_ROWS; ++r)
+        if (r < nr) {
+          unsigned char* t = tmp + ((size_t)(rb + r) * S + xx) * 3;
+          t[0] = (unsigned char)clip8(acc[r][0]);
+          t[1] = (unsigned char)clip8(acc[r][1]);
+          t[2] = (unsigned char)clip8(acc[r][2]);
+        }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // ---- phase 2: vertical pass over the LDS rows
-  unsigned char* o = out + (size_t)blockIdx.y * S * S * 3;
-  for (int idx = threadIdx.x; idx < (yy1 - yy0) * S; idx += 256) {
-    const int y = idx / S, xx = idx - y * S;
-    const int yy = yy0 + y;
-    const int ymin = vb[2 * yy], ymax = vb[2 * yy + 1];
-    const unsigned char* t = tmp + ((size_t)(ymin - r0) * S + xx) * 3;
-    const int* k = vk + yy * d.kv;
-    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
-    for (int j = 0; j < ymax; ++j) {
-      const int kw = k[j];
-      s0 += (int)t[0] * kw;
-      s1 += (int)t[1] * kw;
-      s2 += (int)t[2] * kw;
-      t += (size_t)S * 3;
+  // ---- phase 2: vertical pass over the LDS rows; four output bytes per item where the rows are whole dwords
+  unsigned char* o = out + (size_t)blockIdx.y * S * rowbytes;
+  if ((rowbytes & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+    const int n4 = rowbytes >> 2;
+    for (int idx = tid; idx < (yy1 - yy0) * n4; idx += 256) {
+      const int y = idx / n4, q = idx - y * n4;
+      const int yy = yy0 + y;
+      const int ymin = vb[2 * yy], ymax = vb[2 * yy + 1];
+      const unsigned char* t = tmp + (size_t)(ymin - r0) * rowbytes + 4 * q;
+      const int* k = vks + y * d.kv;
+      int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+      for (int j = 0; j < ymax; ++j) {
+        const int kw = k[j];
+        const unsigned wv = *reinterpret_cast<const unsigned*>(t);
+        s0 += (int)(wv & 255u) * kw;
+        s1 += (int)((wv >> 8) & 255u) * kw;
+        s2 += (int)((wv >> 16) & 255u) * kw;
+        s3 += (int)(wv >> 24) * kw;
+        t += rowbytes;
+      }
+      const unsigned res = (unsigned)clip8(s0) | ((unsigned)clip8(s1) << 8) | ((unsigned)clip8(s2) << 16) | ((unsigned)clip8(s3) << 24);
+      *reinterpret_cast<unsigned*>(o + (size_t)yy * rowbytes + 4 * q) = res;
     }
-    unsigned char* q = o + ((size_t)yy * S + xx) * 3;
-    q[0] = (unsigned char)clip8(s0);
-    q[1] = (unsigned char)clip8(s1);
-    q[2] = (unsigned char)clip8(s2);
+  } else {
+    for (int idx = tid; idx < (yy1 - yy0) * rowbytes; idx += 256) {
+      const int y = idx / rowbytes, q = idx - y * rowbytes;
+      const int yy = yy0 + y;
+      const int ymin = vb[2 * yy], ymax = vb[2 * yy + 1];
+      const unsigned char* t = tmp + (size_t)(ymin - r0) * rowbytes + q;
+      const int* k = vks + y * d.kv;
+      int s0 = 1 << (PRECISION_BITS - 1);
+      for (int j = 0; j < ymax; ++j) {
+        s0 += (int)t[0] * k[j];
+        t += rowbytes;
+      }
+      o[(size_t)yy * rowbytes + q] = (unsigned char)clip8(s0);
+    }
   }
 }
 
@@ -157,6 +232,41 @@ void axis_coeffs(int in_size, int out_size, int o0, int n, int* ksize_out, std::
   }
 }
 
+// Datasets repeat sizes (img2dataset writes 256 x 256, or one side 256): the weights of an axis are kept per (in, out, first
+// output coordinate, count).  A few KB each; the table is dropped when it reaches 4096 entries.
+struct AxisKey {
+  int in_size, out_size, o0, n;
+  bool operator==(const AxisKey& o) const { return in_size == o.in_size && out_size == o.out_size && o0 == o.o0 && n == o.n; }
+};
+struct AxisKeyHash {
+  size_t operator()(const AxisKey& k) const {
+    uint64_t h = ((uint64_t)(uint32_t)k.in_size << 32) ^ (uint32_t)k.out_size;
+    h = (h ^ ((uint64_t)(uint32_t)k.o0 << 20) ^ (uint64_t)(uint32_t)k.n) * 0x9E3779B97F4A7C15ull;
+    return (size_t)(h ^ (h >> 29));
+  }
+};
+struct AxisCoeffs {
+  int ksize = 0;
+  std::vector<int> bounds, kk;
+};
+std::mutex g_axis_mu;
+std::unordered_map<AxisKey, std::shared_ptr<const AxisCoeffs>, AxisKeyHash> g_axis_cache;
+
+std::shared_ptr<const AxisCoeffs> axis_coeffs_cached(int in_size, int out_size, int o0, int n) {
+  const AxisKey key{in_size, out_size, o0, n};
+  {
+    std::lock_guard<std::mutex> lk(g_axis_mu);
+    auto it = g_axis_cache.find(key);
+    if (it != g_axis_cache.end()) return it->second;
+  }
+  auto c = std::make_shared<AxisCoeffs>();
+  axis_coeffs(in_size, out_size, o0, n, &c->ksize, c->bounds, c->kk);
+  std::lock_guard<std::mutex> lk(g_axis_mu);
+  if (g_axis_cache.size() >= 4096) g_axis_cache.clear();
+  g_axis_cache.emplace(key, c);
+  return c;
+}
+
 // device-side coefficient buffers: a small ring per device, each slot guarded by the event of the launch that last read it
 struct CoefSlot {
   void* dev = nullptr;
@@ -193,9 +303,12 @@ extern "C" int clipx_resize_crop_u8_device(int device, const void* src_dev, cons
   static_assert(sizeof(ImgDesc) % 8 == 0, "descriptors are read as an array at the head of the buffer");
   const size_t desc_ints = (size_t)B * sizeof(ImgDesc) / 4;
   cb.resize(desc_ints);
-  int max_bands = 1, max_rows = 1;
+  std::unordered_map<const AxisCoeffs*, std::pair<int, int>> placed;
+  std::vector<std::shared_ptr<const AxisCoeffs>> held;  // (the cache may be cleared by another thread mid-call)
+  int max_bands = 1;
+  size_t max_lds = 0;
+  long long src_bytes = 0;
   const int rows_max = PP_LDS_BYTES / (S * 3);
-  std::vector<int> hbv, hkv, vbv, vkv;
   for (int i = 0; i < B; ++i) {
     const int h = hw[2 * i], w = hw[2 * i + 1];
     if (h <= 0 || w <= 0) return fail(CLIPX_E_ARG, "image with a non-positive size");
@@ -207,8 +320,12 @@ extern "C" int clipx_resize_crop_u8_device(int device, const void* src_dev, cons
     d.src_off = offsets[i];
     d.h = h;
     d.w = w;
-    axis_coeffs(w, nw, left, S, &d.kh, hbv, hkv);
-    axis_coeffs(h, nh, top, S, &d.kv, vbv, vkv);
+    const auto hc = axis_coeffs_cached(w, nw, left, S), vc = axis_coeffs_cached(h, nh, top, S);
+    const std::vector<int>&hbv = hc->bounds, &hkv = hc->kk, &vbv = vc->bounds, &vkv = vc->kk;
+    held.push_back(hc);
+    held.push_back(vc);
+    d.kh = hc->ksize;
+    d.kv = vc->ksize;
     // rows per band: 16 where the band's vertical windows fit the LDS budget, fewer for large down-scales
     int br = 16, need = 0;
     for (;;) {
@@ -221,13 +338,33 @@ extern "C" int clipx_resize_crop_u8_device(int device, const void* src_dev, cons
       if (br == 1) return fail(CLIPX_E_UNSUPPORTED, "down-scale too large for the GPU resample (one output row needs more source rows than fit the LDS)");
       br /= 2;
     }
-    max_rows = std::max(max_rows, need);
     d.br = br;
+    d.tmp_bytes = ((need * S * 3) + 15) & ~15;
+    d.c0 = hbv[0];
+    d.ncols = hbv[2 * (S - 1)] + hbv[2 * (S - 1) + 1] - d.c0;
+    d.pitch = ((d.ncols * 3 + 15 + 15) / 16) * 16;  // the row starts up to 15 bytes into its first 16-byte vector
+    if (d.pitch > PP_STAGE_BYTES) return fail(CLIPX_E_UNSUPPORTED, "image too wide for the GPU resample (one source row does not fit the LDS staging)");
+    d.R = std::max(1, std::min(STAGE_ROWS, PP_STAGE_BYTES / d.pitch));
+    d.pad = 0;
+    max_lds = std::max(max_lds, (size_t)d.tmp_bytes + (size_t)d.R * d.pitch + (size_t)br * d.kv * 4);
     max_bands = std::max(max_bands, (S + br - 1) / br);
-    d.hb_off = (int)cb.size(); cb.insert(cb.end(), hbv.begin(), hbv.end());
-    d.hk_off = (int)cb.size(); cb.insert(cb.end(), hkv.begin(), hkv.end());
-    d.vb_off = (int)cb.size(); cb.insert(cb.end(), vbv.begin(), vbv.end());
-    d.vk_off = (int)cb.size(); cb.insert(cb.end(), vkv.begin(), vkv.end());
+    src_bytes = std::max(src_bytes, (long long)offsets[i] + (long long)h * w * 3);
+    if (offsets[i] < 0) return fail(CLIPX_E_ARG, "negative image offset");
+    // one copy of an axis' tables per call, however many images of the batch share it
+    auto place = [&](const std::shared_ptr<const AxisCoeffs>& c, int* b_off, int* k_off) {
+      auto it = placed.find(c.get());
+      if (it == placed.end()) {
+        const int bo = (int)cb.size();
+        cb.insert(cb.end(), c->bounds.begin(), c->bounds.end());
+        const int ko = (int)cb.size();
+        cb.insert(cb.end(), c->kk.begin(), c->kk.end());
+        it = placed.emplace(c.get(), std::make_pair(bo, ko)).first;
+      }
+      *b_off = it->second.first;
+      *k_off = it->second.second;
+    };
+    place(hc, &d.hb_off, &d.hk_off);
+    place(vc, &d.vb_off, &d.vk_off);
   }
   memcpy(cb.data(), descs.data(), (size_t)B * sizeof(ImgDesc));
   const size_t bytes = cb.size() * sizeof(int);
@@ -254,10 +391,10 @@ extern "C" int clipx_resize_crop_u8_device(int device, const void* src_dev, cons
     }
     memcpy(sl->host, cb.data(), bytes);
     PPCHK(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, st));
-    const size_t smem = (size_t)max_rows * S * 3;  // what the largest band of this batch needs (small for mild down-scales: more workgroups per CU)
+    const size_t smem = max_lds;  // what the largest band of this batch needs (small for mild down-scales: more workgroups per CU)
     PPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_crop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(resize_crop_kernel, dim3(max_bands, B), dim3(256), smem, st, (const unsigned char*)src_dev, (const int*)sl->dev,
-                       (const ImgDesc*)sl->dev, S, (unsigned char*)out_dev);
+    hipLaunchKernelGGL(resize_crop_kernel, dim3(max_bands, B), dim3(256), smem, st, (const unsigned char*)src_dev, src_bytes,
+                       (const int*)sl->dev, (const ImgDesc*)sl->dev, S, (unsigned char*)out_dev);
     PPCHK(hipGetLastError());
     PPCHK(hipEventRecord(sl->ev, st));
     sl->used = true;

@@ -83,6 +83,27 @@ def test_batches_and_repeat_calls_are_independent(lib):
     assert np.array_equal(_resize_crop(lib, imgs[::-1], 224)[::-1], whole)
 
 
+def test_unaligned_source_and_repeated_sizes(lib):
+    """A packed source that does not start on a 16-byte boundary takes the byte-wise staging path; images of one size share
+    one copy of the weight tables (host cache + per-call placement).  Same bytes as Pillow either way."""
+    from PIL import Image
+
+    from clip_retrieval_amd.reader import clip_preprocess_u8
+
+    imgs = [_synthetic(h, w, 5 * i + h) for i, (h, w) in enumerate(((256, 256), (256, 256), (300, 451), (256, 256), (300, 451), (97, 131)))]
+    flat, off, hw = _pack(imgs)
+    buf = torch.zeros(flat.size + 64, dtype=torch.uint8, device="cuda")
+    for shift in (0, 1, 7):
+        buf[shift:shift + flat.size] = torch.from_numpy(flat).cuda()
+        out = torch.empty((len(imgs), 224, 224, 3), dtype=torch.uint8, device="cuda")
+        rc = lib.clipx_resize_crop_u8_device(0, C.c_void_p(buf.data_ptr() + shift), off.ctypes.data, hw.ctypes.data, len(imgs), 224,
+                                             C.c_void_p(out.data_ptr()), None)
+        assert rc == 0, lib.clipx_last_error()
+        torch.cuda.synchronize()
+        for im, g in zip(imgs, out.cpu().numpy()):
+            assert np.array_equal(g, np.asarray(clip_preprocess_u8(Image.fromarray(im), size=224))), (shift, im.shape)
+
+
 def test_bad_arguments_are_refused(lib):
     im = _synthetic(40, 50, 1)
     flat, off, hw = _pack([im])
