@@ -82,6 +82,9 @@ hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const flo
 // pooled row (CLS, or argmax(ids) for text) -> LayerNorm -> @ proj^T [E, d] -> / L2 norm -> fp16 [B, E]
 // x: the residual stream, f32 [B*T, d] or (x_f16 != 0) IEEE fp16
 // scratch: B * E floats of device memory (the un-normalised projection between the two kernels)
+// pooled rows (token 0, or the EOT token of `ids`) of att [B*T, d] bf16 and x16 [B*T, d] fp16 -> attc / xc [B, d]
+hipError_t launch_gather_pooled(const bf16* att, const void* x16, const int32_t* ids_or_null, bf16* attc, void* xc, int B, int T,
+                                int d, hipStream_t st);
 hipError_t launch_tail(const void* x, const int32_t* ids_or_null, const float* gamma, const float* beta,
                        const bf16* proj, uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d,
                        int E, float eps, hipStream_t st, int x_f16 = 0);

@@ -1146,6 +1146,46 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(const float* __restrict_
   }
 }
 
+// The rows the embedding is read from -- token 0 of every image, the EOT token (highest id, first occurrence) of every caption --
+// copied out of the [B * T, d] attention output and residual stream into two compact [B, d] buffers: the last block's
+// out-proj / MLP then run on B rows instead of B * T (nothing else of that block's output is ever read).
+__global__ __launch_bounds__(256) void gather_pooled_kernel(const bf16* __restrict__ att, const _Float16* __restrict__ x,
+                                                           const int32_t* __restrict__ ids, bf16* __restrict__ attc,
+                                                           _Float16* __restrict__ xc, int T, int d) {
+  __shared__ int s_pos;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int best = 0;
+    if (ids) {
+      int bv = ids[(size_t)b * T];
+      for (int t = 1; t < T; ++t) {
+        const int v = ids[(size_t)b * T + t];
+        if (v > bv) { bv = v; best = t; }
+      }
+    }
+    s_pos = best;
+  }
+  __syncthreads();
+  const size_t row = (size_t)b * T + s_pos;
+  const uint4* a = reinterpret_cast<const uint4*>(att + row * d);
+  const uint4* xs = reinterpret_cast<const uint4*>(x + row * d);
+  uint4* ao = reinterpret_cast<uint4*>(attc + (size_t)b * d);
+  uint4* xo = reinterpret_cast<uint4*>(xc + (size_t)b * d);
+  for (int c = tid; c < d / 8; c += 256) {
+    ao[c] = a[c];
+    xo[c] = xs[c];
+  }
+}
+
+hipError_t launch_gather_pooled(const bf16* att, const void* x16, const int32_t* ids_or_null, bf16* attc, void* xc, int B, int T,
+                                int d, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  if (d % 8 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_pooled_kernel, dim3(B), dim3(256), 0, st, att, reinterpret_cast<const _Float16*>(x16), ids_or_null, attc,
+                     reinterpret_cast<_Float16*>(xc), T, d);
+  return hipGetLastError();
+}
+
 hipError_t launch_tail(const void* x, const int32_t* ids_or_null, const float* gamma, const float* beta, const bf16* proj,
                        uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d, int E, float eps,
                        hipStream_t st, int x_f16) {

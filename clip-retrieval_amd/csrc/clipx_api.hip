@@ -125,6 +125,7 @@ struct clipx_handle {
   std::map<GraphKey, int> graph_seen;  // a launch sequence is captured the SECOND time its key shows up: a caller that brings
                                        // fresh buffers on every call (new addresses) never pays for captures it cannot reuse
   bool graphs_on = true;
+  bool pool_last_block = true;  // last block past the attention on the pooled rows only (CLIPX_FULL_LAST_BLOCK=1: all rows)
   int prof = 0;  // bit k set: launches of kind k (0 gemm, 1 attention, 2 layernorm, 3 other) are bracketed by hipEvents
   std::vector<ProfEvent> prof_events;
 };
@@ -308,6 +309,8 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   h->host_chunk = std::min(h->host_chunk, h->max_batch);
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   if (gv) h->gemm_variant = std::min(5, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
+  const char* fl = getenv("CLIPX_FULL_LAST_BLOCK");
+  if (fl && atoi(fl) > 0) h->pool_last_block = false;
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   r = create_impl(h, blob, blob_floats);
   if (r) {
@@ -387,7 +390,14 @@ static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* 
   return 0;
 }
 
-static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, int causal) {
+// where run_layers leaves the pooled rows (fp16 [B, width]) when it pools the last block: behind the gathered attention rows
+static const void* pooled_rows(const clipx_handle* h, int B, int width) {
+  return reinterpret_cast<const char*>(h->x) + (((size_t)B * width * sizeof(bf16) + 255) & ~(size_t)255);
+}
+
+// Returns in *pooled whether the residual stream that leaves the last block is the compact [B, width] buffer of pooled rows
+// (h->x reused) instead of h->xn [B * T, width].
+static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, int causal, const int32_t* ids, bool* pooled) {
   const int M = B * t.T, w = t.width;
   const float eps = h->desc.ln_eps;
   const int act = h->desc.act == CLIPX_ACT_QUICK_GELU ? EPI_BIAS_QGELU_BF16 : EPI_BIAS_GELU_BF16;
@@ -404,11 +414,27 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
     { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
     if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16, h->rstd, true))) return r;
     { ProfScope ps(h, st, 1, 4.0 * B * t.heads * (double)t.T * t.T * (w / t.heads)); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st)); }
+    if (l == t.layers - 1 && h->pool_last_block && t.T > 1) {
+      // The embedding reads ONE row of this block's output per sample (token 0 / the EOT token: launch_tail), and past the
+      // attention every operation of a block is row-wise: out-proj, both residual adds, LayerNorm 2 and the MLP run on those B
+      // rows only.  Same kernels, and a GEMM row does not depend on the rows it travels with (bitwise): the embeddings are the
+      // bytes the full block gives (tests/test_clip_gpu.py; CLIPX_FULL_LAST_BLOCK=1 runs the full block).
+      bf16* attc = reinterpret_cast<bf16*>(h->x);
+      void* xc = reinterpret_cast<char*>(h->x) + (((size_t)B * w * sizeof(bf16) + 255) & ~(size_t)255);
+      { ProfScope ps(h, st, 3, 0); HIPCHK(launch_gather_pooled(h->att, h->xn, ids, attc, xc, B, t.T, w, st)); }
+      if ((r = run_gemm(h, st, attc, L.out_w, L.out_b, xc, nullptr, 1, B, w, w, EPI_BIAS_RESID_H16))) return r;
+      { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(xc, h->rstd, B, w, eps, st, 1)); }
+      if ((r = run_gemm(h, st, reinterpret_cast<const bf16*>(xc), L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, B, t.mlp, w, act, h->rstd, true))) return r;
+      if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, xc, nullptr, 1, B, w, t.mlp, EPI_BIAS_RESID_H16))) return r;
+      *pooled = true;
+      return 0;
+    }
     if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->xn, nullptr, 1, M, w, w, EPI_BIAS_RESID_H16))) return r;
     { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
     if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, M, t.mlp, w, act, h->rstd, true))) return r;
     if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->xn, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_H16))) return r;
   }
+  *pooled = false;
   return 0;
 }
 
@@ -476,8 +502,10 @@ static int vision_chunk_body(clipx_handle* h, hipStream_t st, const void* pix_de
   int r = run_gemm(h, st, h->patches, h->conv_w, nullptr, h->x, h->clspos, V.T, M, V.width, h->Kp, EPI_TABLE_F32);
   if (r) return r;
   { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, h->ln_pre_w, h->ln_pre_b, h->xn, 2, M, V.width, d.ln_eps, st)); }
-  if ((r = run_layers(h, st, V, B, 0))) return r;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->xn, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, V.T, V.width, d.embed_dim, d.ln_eps, st, 1)); }
+  bool pooled = false;
+  if ((r = run_layers(h, st, V, B, 0, nullptr, &pooled))) return r;
+  const void* xf = pooled ? pooled_rows(h, B, V.width) : h->xn;
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(xf, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, pooled ? 1 : V.T, V.width, d.embed_dim, d.ln_eps, st, 1)); }
   return 0;
 }
 
@@ -485,9 +513,11 @@ static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_d
   const clipx_model_desc& d = h->desc;
   const Tower& X = h->txt;
   { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, nullptr, B, X.T, X.width, d.vocab, st, h->xn, 1)); }
-  int r = run_layers(h, st, X, B, 1);
+  bool pooled = false;
+  int r = run_layers(h, st, X, B, 1, ids_dev, &pooled);
   if (r) return r;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(h->xn, ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, X.T, X.width, d.embed_dim, d.ln_eps, st, 1)); }
+  const void* xf = pooled ? pooled_rows(h, B, X.width) : h->xn;
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(xf, pooled ? nullptr : ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, pooled ? 1 : X.T, X.width, d.embed_dim, d.ln_eps, st, 1)); }
   return 0;
 }
 

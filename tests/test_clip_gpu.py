@@ -196,6 +196,32 @@ def test_chunked_batches_equal_unchunked(tiny):
     small.close()
 
 
+def test_last_block_on_the_pooled_rows_equals_the_full_block(tiny):
+    """The encoder runs the last block's out-proj / LayerNorm 2 / MLP on the pooled rows only (token 0, the EOT token): the
+    embedding reads nothing else of that block.  CLIPX_FULL_LAST_BLOCK=1 runs the block on every row; batches of two or more
+    must give the same bytes (a GEMM row does not depend on the rows it travels with), the split-K single-query path the same
+    embedding up to f32 summation order."""
+    from clip_retrieval_amd.encoder import ClipEncoder
+    from oracle.clip_oracle import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    os.environ["CLIPX_FULL_LAST_BLOCK"] = "1"
+    try:
+        full = ClipEncoder(_product_arch(arch), oracle.export_blob(), 0)
+    finally:
+        os.environ.pop("CLIPX_FULL_LAST_BLOCK")
+    for B in (2, 5, 9, 33):
+        pix, ids = normalise_u8_nhwc(synth_pixels_u8(B, seed=40 + B)), synth_tokens(B, seed=50 + B)
+        ids[0, :] = 0
+        ids[0, 3] = arch.vocab - 1  # EOT early in the caption: the pooled row is not the last one
+        assert np.array_equal(enc.encode_image(pix), full.encode_image(pix)), f"{name} image B={B}"
+        assert np.array_equal(enc.encode_text(ids), full.encode_text(ids)), f"{name} text B={B}"
+    pix, ids = normalise_u8_nhwc(synth_pixels_u8(1, seed=3)), synth_tokens(1, seed=4)
+    assert _cos(enc.encode_image(pix), full.encode_image(pix).astype(np.float32)).min() > 1 - 1e-5
+    assert _cos(enc.encode_text(ids), full.encode_text(ids).astype(np.float32)).min() > 1 - 1e-5
+    full.close()
+
+
 def test_small_batches_replayed_from_graphs_equal_the_plain_launches(tiny):
     """Batches of <= 8 (the B = 1 query encode of clip_back.py:207-255) are captured into a hipGraph per (tower, B, buffers)
     and replayed; a batch of 12 takes the plain launches.  Rows do not depend on the batch they travel in (bitwise), so
@@ -494,15 +520,23 @@ def test_large_batch_persistent_kernel_path_equals_128_path():
         ref = ClipEncoder(arch, blob, 0)
     finally:
         os.environ.pop("CLIPX_GEMM_VARIANT")
+    os.environ["CLIPX_FULL_LAST_BLOCK"] = "1"
+    try:
+        full = ClipEncoder(arch, blob, 0)  # every row through the last block (the default pools it: see the test above)
+    finally:
+        os.environ.pop("CLIPX_FULL_LAST_BLOCK")
     for B in (64, 256):
         pix = normalise_u8_nhwc(synth_pixels_u8(B, arch.image_size, seed=1))
         ids = synth_tokens(B, arch.ctx_len, arch.vocab, seed=2)
-        a, b = enc.encode_image(pix), ref.encode_image(pix)
+        a, b, c = enc.encode_image(pix), ref.encode_image(pix), full.encode_image(pix)
         assert not np.isnan(a.astype(np.float32)).any() and np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"image B={B}"
-        a, b = enc.encode_text(ids), ref.encode_text(ids)
+        assert np.array_equal(a.view(np.uint16), c.view(np.uint16)), f"image B={B}: pooled last block != full last block"
+        a, b, c = enc.encode_text(ids), ref.encode_text(ids), full.encode_text(ids)
         assert not np.isnan(a.astype(np.float32)).any() and np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"text B={B}"
+        assert np.array_equal(a.view(np.uint16), c.view(np.uint16)), f"text B={B}: pooled last block != full last block"
     enc.close()
     ref.close()
+    full.close()
 
 
 @pytest.mark.parametrize("M,N,K", [(16384, 1024, 1024), (65792, 1024, 4096), (19712, 768, 768), (1000, 1024, 1024), (257, 1280, 1280)])
