@@ -73,6 +73,9 @@ SIGNATURES = {
     "knnx_ivfb_list_sizes": (C.c_int, [_P, _P, C.c_int]),
     "knnx_ivf_add_assigned_device": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "knnx_synth_rows_device": (C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int64, _P]),
+    "knnx_mlp_create": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "knnx_mlp_forward": (C.c_int, [_P, _P, C.c_int, _P]),
+    "knnx_mlp_destroy": (C.c_int, [_P]),
     "knnx_merge_topk_device": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "knnx_shards_create": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "knnx_shards_adopt": (C.c_int, [C.c_int, _P, _P, _P, C.POINTER(_P)]),

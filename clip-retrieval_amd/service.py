@@ -13,14 +13,19 @@ onto KnnService.  The arithmetic is re-designed for the GPU rat
   * violence   argmax over the two prompt embeddings = a top-1 search of the result vectors against a resident 2-row GPU index
                (ties -> the smaller id, like np.argmax);
   * metadata   ONE batched Arrow `take` per request instead of a concat of 1-row slices per id (README.md:432: 41.5 ms).
-Flask, prometheus, URL download and the safety MODEL itself (any object with the reference's `.predict`) stay where they are
-in the reference (out of scope).
+  * safety     the H14 detector (h14_nsfw_model.py:16-34: seven fp32 Linear layers, ReLU between) runs on the GPU behind the
+               reference's `.predict(embeddings, batch_size)` (`Mi355xSafetyHead`, csrc/postfilter.hip); any other object with
+               `.predict` (the autokeras L/14 model) is called as the reference calls it.
+Flask, prometheus and URL download stay where they are in the reference (out of scope).
 """
 
+import ctypes as C
+import os
 import threading
 
 import numpy as np
 
+from ._lib import check, load_library
 from .knn import Mi355xIndex
 
 
@@ -29,6 +34,74 @@ def normalized(a, axis=-1, order=2):
     n = np.atleast_1d(np.linalg.norm(a, order, axis))
     n[n == 0] = 1
     return a / np.expand_dims(n, axis)
+
+
+class Mi355xSafetyHead:
+    """Drop-in for `H14_NSFW_Detector` (clip_retrieval/h14_nsfw_model.py:10-50) in `clip_resource.safety_model`: the same
+    `.predict(x, batch_size) -> float32 [n, out]`, computed on the GPU in fp32.
+
+    state_dict: the detector's `layers.<i>.weight` / `layers.<i>.bias` tensors (numpy arrays or torch tensors), as saved in
+    `<cache>/h14_nsfw_model/model.pt`.  The position numbers are those of its nn.Sequential (Linear, ReLU, Dropout, Linear, ...):
+    a ReLU follows a Linear exactly when the next Linear does not sit at the very next position (positions 15 and 16 of the H14
+    stack are back-to-back Linears, no activation between), never after the last one.  `relu=[...]` overrides."""
+
+    def __init__(self, state_dict, device=0, relu=None):
+        def arr(v):
+            v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            return np.ascontiguousarray(v, dtype=np.float32)
+
+        pos = sorted({int(k.split(".")[-2]) for k in state_dict if k.endswith(".weight")})
+        if not pos:
+            raise ValueError("no `<prefix>.<i>.weight` entries in the state dict")
+        prefix = next(k for k in state_dict if k.endswith(f".{pos[0]}.weight"))[: -len(f"{pos[0]}.weight")]
+        self._w = [arr(state_dict[f"{prefix}{i}.weight"]) for i in pos]
+        self._b = [arr(state_dict[f"{prefix}{i}.bias"]) if f"{prefix}{i}.bias" in state_dict else None for i in pos]
+        for a, b in zip(self._w[:-1], self._w[1:]):
+            if a.ndim != 2 or b.ndim != 2 or b.shape[1] != a.shape[0]:
+                raise ValueError(f"layer shapes do not chain: {a.shape} -> {b.shape}")
+        if relu is None:
+            relu = [j + 1 < len(pos) and pos[j + 1] != pos[j] + 1 for j in range(len(pos))]
+        self.relu = [bool(r) for r in relu]
+        self.dims = [self._w[0].shape[1]] + [w.shape[0] for w in self._w]
+        self.input_size = self.dims[0]
+        self._lib = load_library()
+        n = len(pos)
+        dims = (C.c_int32 * (n + 1))(*self.dims)
+        wp = (C.c_void_p * n)(*[w.ctypes.data for w in self._w])
+        bp = (C.c_void_p * n)(*[b.ctypes.data if b is not None else None for b in self._b])
+        rl = (C.c_uint8 * n)(*[1 if r else 0 for r in self.relu])
+        h = C.c_void_p()
+        check(self._lib, self._lib.knnx_mlp_create(int(device), n, dims, wp, bp, rl, C.byref(h)), "knnx")
+        self._h = h
+
+    @classmethod
+    def from_cache(cls, cache_folder=os.path.expanduser("~/.cache/clip_retrieval"), device=0):
+        """The reference's file location (h14_nsfw_model.py:58-72); no download here: the file has to be there."""
+        import torch  # pylint: disable=import-outside-toplevel
+
+        path = os.path.join(cache_folder, "h14_nsfw_model", "model.pt")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: the H14 detector's weights are not cached (the reference downloads h14_nsfw.pth there)")
+        return cls(torch.load(path, map_location="cpu"), device=device)
+
+    def predict(self, x, batch_size=None):  # pylint: disable=unused-argument
+        x = np.ascontiguousarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.dims[0]:
+            raise ValueError(f"expected [n, {self.dims[0]}] inputs, got {x.shape}")
+        y = np.empty((x.shape[0], self.dims[-1]), dtype=np.float32)
+        check(self._lib, self._lib.knnx_mlp_forward(self._h, x.ctypes.data, x.shape[0], y.ctypes.data), "knnx")
+        return y
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.knnx_mlp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
 
 
 class ArrowMetadataProvider:

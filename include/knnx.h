@@ -204,6 +204,19 @@ int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed);
 int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed,
                            int kind, int64_t n_clusters, void* stream);
 
+/* ---- post filter: the safety head on the GPU --------------------------------------------------------
+ * Replaces `safety_model.predict(embeddings, batch_size)` of clip_retrieval/clip_back.py:315-325 for a model that is a stack
+ * of fp32 Linear layers with ReLU between them -- the H14 detector of clip_retrieval/h14_nsfw_model.py:16-34
+ * (1024 -> 1024 -> 2048 -> 1024 -> 256 -> 128 -> 16 -> 1, Dropout = identity in eval mode).  dims: n_layers + 1 widths;
+ * weights[l]: f32 [dims[l+1], dims[l]] row-major (torch.nn.Linear.weight), biases[l]: f32 [dims[l+1]] or NULL;
+ * relu[l] != 0: ReLU after layer l (NULL: after every layer but the last).  fp32 FMA, f32 accumulate in k order. */
+typedef struct knnx_mlp knnx_mlp;
+int knnx_mlp_create(int device, int n_layers, const int32_t* dims, const float* const* weights, const float* const* biases,
+                    const uint8_t* relu, knnx_mlp** out);
+/* x: host f32 [n, dims[0]] -> y: host f32 [n, dims[n_layers]]; synchronous; calls on one handle are serialised. */
+int knnx_mlp_forward(knnx_mlp* m, const float* x_host, int n, float* y_host);
+int knnx_mlp_destroy(knnx_mlp* m);
+
 const char* knnx_last_error(void);
 
 #ifdef __cplusplus

@@ -250,3 +250,92 @@ def test_worker_on_the_gpu_over_tar_shards(tiny_checkpoints, tmp_path):
         assert np.array_equal(np.load(out / "img_emb" / f"img_emb_{i}.npy"), np.load(out2 / "img_emb" / f"img_emb_{i}.npy"))
         assert np.array_equal(np.load(out / "text_emb" / f"text_emb_{i}.npy"), np.load(out2 / "text_emb" / f"text_emb_{i}.npy"))
         assert json.loads((out2 / "stats" / f"{i}.json").read_text())["sample_count"] == 9
+
+
+def _h14_state_dict(seed=0, input_size=1024):
+    """A state dict with the H14 detector's keys and shapes (h14_nsfw_model.py:16-34), seeded random weights scaled like
+    torch's Linear init so the activations keep O(1) magnitude through the stack."""
+    rng = np.random.default_rng(seed)
+    widths = [input_size, 1024, 2048, 1024, 256, 128, 16, 1]
+    positions = [0, 3, 6, 9, 12, 15, 16]
+    sd = {}
+    for p, (i, o) in zip(positions, zip(widths[:-1], widths[1:])):
+        sd[f"layers.{p}.weight"] = (rng.uniform(-1, 1, (o, i)) * np.sqrt(3.0 / i)).astype(np.float32)
+        sd[f"layers.{p}.bias"] = (rng.uniform(-1, 1, o) * 0.1).astype(np.float32)
+    return sd, positions
+
+
+def _h14_forward_f64(sd, positions, x):
+    """h14_nsfw_model.py:16-34 + 40-42 restated in float64: Linear, ReLU (Dropout = identity in eval) ... Linear(128, 16),
+    Linear(16, 1) with no activation between the last two."""
+    y = x.astype(np.float64)
+    for j, p in enumerate(positions):
+        y = y @ sd[f"layers.{p}.weight"].astype(np.float64).T + sd[f"layers.{p}.bias"].astype(np.float64)
+        if j + 1 < len(positions) and positions[j + 1] != p + 1:
+            y = np.maximum(y, 0)
+    return y
+
+
+@pytest.mark.parametrize("n", [1, 37, 3000])
+def test_safety_head_on_the_gpu_matches_the_h14_detector(n):
+    """`Mi355xSafetyHead.predict` == the reference detector's forward (torch fp32 on the CPU, and a float64 restatement) on the
+    same state dict; `KnnHotPath.get_unsafe_items` flags the same rows."""
+    from clip_retrieval_amd.service import KnnHotPath, Mi355xSafetyHead
+
+    sd, positions = _h14_state_dict(seed=n)
+    head = Mi355xSafetyHead({k: torch.from_numpy(v) for k, v in sd.items()}, device=0)
+    assert head.dims == [1024, 1024, 2048, 1024, 256, 128, 16, 1] and head.relu == [True] * 5 + [False, False]
+    rng = np.random.default_rng(n + 1)
+    x = rng.standard_normal((n, 1024)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x *= 30.0  # spread the outputs around the 0.5 threshold
+    got = head.predict(x, batch_size=n)
+    want = _h14_forward_f64(sd, positions, x)
+    assert got.shape == (n, 1) and got.dtype == np.float32
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= 2e-5 * scale, (np.abs(got - want).max(), scale)
+    # the reference module itself (same layer stack, eval mode), fp32 on the CPU
+    layers = []
+    widths = head.dims
+    for j, p in enumerate(positions):
+        lin = torch.nn.Linear(widths[j], widths[j + 1])
+        lin.weight.data = torch.from_numpy(sd[f"layers.{p}.weight"])
+        lin.bias.data = torch.from_numpy(sd[f"layers.{p}.bias"])
+        layers.append(lin)
+        if head.relu[j]:
+            layers += [torch.nn.ReLU(), torch.nn.Dropout(0.2)]
+    ref = torch.nn.Sequential(*layers).eval()
+    with torch.no_grad():
+        ref_y = ref(torch.from_numpy(x)).numpy()
+    assert np.abs(got - ref_y).max() <= 4e-5 * scale
+
+    class RefModel:
+        def predict(self, e, batch_size):
+            with torch.no_grad():
+                return ref(torch.from_numpy(e)).numpy()
+
+    hp = KnnHotPath()
+    a, b = hp.get_unsafe_items(head, x), hp.get_unsafe_items(RefModel(), x)
+    near = np.flatnonzero(np.abs(want[:, 0] - 0.5) < 1e-3)  # rows on the threshold may legitimately land on either side
+    assert set(a) - set(near) == set(b) - set(near)
+    if n >= 37:
+        assert 0 < len(b) < n  # both classes occur: the comparison means something
+    head.close()
+
+
+def test_safety_head_arguments():
+    from clip_retrieval_amd._lib import HipLibraryError
+    from clip_retrieval_amd.service import Mi355xSafetyHead
+
+    sd, _ = _h14_state_dict(seed=1, input_size=64)
+    head = Mi355xSafetyHead(sd, device=0)
+    assert head.predict(np.zeros((0, 64), dtype=np.float32)).shape == (0, 1)
+    with pytest.raises(ValueError):
+        head.predict(np.zeros((3, 65), dtype=np.float32))
+    head.close()
+    with pytest.raises(ValueError):
+        Mi355xSafetyHead({"layers.0.weight": np.zeros((8, 4), np.float32), "layers.1.weight": np.zeros((2, 9), np.float32)})
+    with pytest.raises(ValueError):
+        Mi355xSafetyHead({})
+    with pytest.raises(FileNotFoundError):
+        Mi355xSafetyHead.from_cache("/nonexistent-cache")

@@ -159,6 +159,31 @@ def main():
             _, m, p50, mx = timed(request, max(3, a.reps // (1 if k <= 64 else 4)))
             out["requests"].append({"k": k, "deduplicate": True, "mean_ms": round(m, 3), "p50_ms": round(p50, 3), "max_ms": round(mx, 3)})
             stages[f"WHOLE REQUEST text -> k={k} +dedup -> metadata"] = (m, p50, mx)
+    # safety head of the post filter (clip_back.py:315-325; H14 detector stack, h14_nsfw_model.py:16-34) on k result embeddings:
+    # GPU (service.Mi355xSafetyHead) vs the reference's torch fp32 module on this box's host cores (random weights: same arithmetic)
+    from clip_retrieval_amd.service import Mi355xSafetyHead
+
+    widths, positions = [1024, 1024, 2048, 1024, 256, 128, 16, 1], [0, 3, 6, 9, 12, 15, 16]
+    sd, layers = {}, []
+    for j, p_ in enumerate(positions):
+        lin = torch.nn.Linear(widths[j], widths[j + 1])
+        sd[f"layers.{p_}.weight"], sd[f"layers.{p_}.bias"] = lin.weight.data, lin.bias.data
+        layers.append(lin)
+        if j + 1 < len(positions) and positions[j + 1] != p_ + 1:
+            layers += [torch.nn.ReLU(), torch.nn.Dropout(0.2)]
+    ref_head = torch.nn.Sequential(*layers).eval()
+    head = Mi355xSafetyHead(sd, device=0)
+    for k in (40, 3000):
+        e = rng.standard_normal((k, 1024)).astype(np.float32)
+        _, m, p50, mx = timed(lambda: head.predict(e, batch_size=k), a.reps)
+        stages[f"safety head k={k}: GPU (incl. H2D / D2H)"] = (m, p50, mx)
+
+        def ref_predict():
+            with torch.no_grad():
+                return ref_head(torch.from_numpy(e)).numpy()
+
+        _, m, p50, mx = timed(ref_predict, a.reps)
+        stages[f"safety head k={k}: reference torch fp32 on the host"] = (m, p50, mx)
     print(f"{'stage':70s} {'mean ms':>10s} {'p50 ms':>10s} {'max ms':>10s}")
     for name, (m, p50, mx) in stages.items():
         print(f"{name:70s} {m:10.3f} {p50:10.3f} {mx:10.3f}")
