@@ -283,12 +283,14 @@ def test_safety_head_on_the_gpu_matches_the_h14_detector(n):
     from clip_retrieval_amd.service import KnnHotPath, Mi355xSafetyHead
 
     sd, positions = _h14_state_dict(seed=n)
-    head = Mi355xSafetyHead({k: torch.from_numpy(v) for k, v in sd.items()}, device=0)
-    assert head.dims == [1024, 1024, 2048, 1024, 256, 128, 16, 1] and head.relu == [True] * 5 + [False, False]
     rng = np.random.default_rng(n + 1)
     x = rng.standard_normal((n, 1024)).astype(np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
-    x *= 30.0  # spread the outputs around the 0.5 threshold
+    x *= 30.0
+    # centre the outputs on the 0.5 threshold so that both classes occur
+    sd["layers.16.bias"] = (sd["layers.16.bias"] + 0.5 - np.median(_h14_forward_f64(sd, positions, x))).astype(np.float32)
+    head = Mi355xSafetyHead({k: torch.from_numpy(v) for k, v in sd.items()}, device=0)
+    assert head.dims == [1024, 1024, 2048, 1024, 256, 128, 16, 1] and head.relu == [True] * 5 + [False, False]
     got = head.predict(x, batch_size=n)
     want = _h14_forward_f64(sd, positions, x)
     assert got.shape == (n, 1) and got.dtype == np.float32
