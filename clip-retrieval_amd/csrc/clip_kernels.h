@@ -72,7 +72,8 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
                          const float* inv_std, bf16* out, hipStream_t st);
 
 // qkv bf16 [B*T, 3*H*dh] -> out bf16 [B*T, H*dh]; softmax(q k^T / sqrt(dh) [+ causal]) v, head dim dh = 64 or 80
-hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st);
+// q_blocks > 0: only the first q_blocks 32-row query blocks are computed (rows past them are left untouched); 0 = all
+hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st, int q_blocks = 0);
 
 // ids int32 [B, T] -> tok_emb[id] + pos_emb[t] as x f32 [B*T, d] (may be null) and / or x16 [B*T, d] (may be null; bf16, or
 // IEEE fp16 when x16_f16 != 0: the text tower's residual stream)

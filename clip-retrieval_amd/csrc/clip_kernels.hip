@@ -724,7 +724,7 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 __device__ long long g_attn_phase[8192 * 4];
 template <int DH, int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP, bool TIMER = false>
 __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
-                                                              int H, float scale_log2e, int dbg) {
+                                                              int H, float scale_log2e, int dbg, int q_blocks) {
   constexpr int TP = NKB * 32;
   constexpr int CH = DH / 8;                      // 16-B chunks per key row
   constexpr int KS = DH / 16;                     // MFMA k-steps of the QK^T product
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 #pragma unroll
   for (int qi = 0; qi < QPW; ++qi) {
     const int qb = qi * NW + w;
-    if (qb >= NKB) break;
+    if (qb >= q_blocks) break;  // q_blocks = NKB, or 1 when only the rows of query block 0 are read afterwards (last block, token 0)
     const int qpos = qb * 32 + l31;
     bf16x8 qf[KS];
 #pragma unroll
@@ -955,7 +955,8 @@ extern "C" int clipx_dbg_attn_phase(long long* host, int n) {
 #endif
 
 template <int DH, int NKB, int NW, int QPW, bool RECOMP = false>
-static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st) {
+static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st, int q_blocks) {
+  q_blocks = q_blocks > 0 && q_blocks < NKB ? q_blocks : NKB;
   constexpr int KROW = DH == 64 ? 128 : 176, DV = (DH + 31) / 32 * 32;
   const size_t smem = (size_t)NKB * 32 * KROW + (size_t)DV * (NKB * 64 + 8);
   const float scale_log2e = (1.f / sqrtf((float)DH)) * 1.4426950408889634f;
@@ -969,50 +970,50 @@ static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T,
     auto kern = attention_kernel<DH, NKB, NW, QPW, true, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg, q_blocks);
   } else {
     auto kern = attention_kernel<DH, NKB, NW, QPW, false, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg, q_blocks);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st) {
+hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st, int q_blocks) {
   if (B <= 0) return hipSuccess;
   const int nkb = (T + 31) / 32;
   if (dh == 80) {  // ViT-H/14 image tower (T = 257), ViT-bigG is dh 104: not built
     switch (nkb) {
-      case 1: return launch_attention_cfg<80, 1, 1, 1>(qkv, out, B, T, H, causal, st);
-      case 2: return launch_attention_cfg<80, 2, 2, 1>(qkv, out, B, T, H, causal, st);
-      case 3: return launch_attention_cfg<80, 3, 3, 1>(qkv, out, B, T, H, causal, st);
-      case 9: return launch_attention_cfg<80, 9, 9, 1, true>(qkv, out, B, T, H, causal, st);
+      case 1: return launch_attention_cfg<80, 1, 1, 1>(qkv, out, B, T, H, causal, st, q_blocks);
+      case 2: return launch_attention_cfg<80, 2, 2, 1>(qkv, out, B, T, H, causal, st, q_blocks);
+      case 3: return launch_attention_cfg<80, 3, 3, 1>(qkv, out, B, T, H, causal, st, q_blocks);
+      case 9: return launch_attention_cfg<80, 9, 9, 1, true>(qkv, out, B, T, H, causal, st, q_blocks);
       default: return hipErrorInvalidValue;
     }
   }
   if (dh != 64) return hipErrorInvalidValue;
   switch (nkb) {
-    case 1: return launch_attention_cfg<64, 1, 1, 1>(qkv, out, B, T, H, causal, st);
-    case 2: return launch_attention_cfg<64, 2, 2, 1>(qkv, out, B, T, H, causal, st);   // ViT-B/32 image (T=50)
-    case 3: return launch_attention_cfg<64, 3, 3, 1>(qkv, out, B, T, H, causal, st);   // text (T=77)
-    case 4: return launch_attention_cfg<64, 4, 4, 1>(qkv, out, B, T, H, causal, st);
-    case 5: return launch_attention_cfg<64, 5, 3, 2>(qkv, out, B, T, H, causal, st);
-    case 6: return launch_attention_cfg<64, 6, 3, 2>(qkv, out, B, T, H, causal, st);
-    case 7: return launch_attention_cfg<64, 7, 4, 2>(qkv, out, B, T, H, causal, st);   // ViT-B/16 image (T=197)
-    case 8: return launch_attention_cfg<64, 8, 4, 2>(qkv, out, B, T, H, causal, st);
+    case 1: return launch_attention_cfg<64, 1, 1, 1>(qkv, out, B, T, H, causal, st, q_blocks);
+    case 2: return launch_attention_cfg<64, 2, 2, 1>(qkv, out, B, T, H, causal, st, q_blocks);   // ViT-B/32 image (T=50)
+    case 3: return launch_attention_cfg<64, 3, 3, 1>(qkv, out, B, T, H, causal, st, q_blocks);   // text (T=77)
+    case 4: return launch_attention_cfg<64, 4, 4, 1>(qkv, out, B, T, H, causal, st, q_blocks);
+    case 5: return launch_attention_cfg<64, 5, 3, 2>(qkv, out, B, T, H, causal, st, q_blocks);
+    case 6: return launch_attention_cfg<64, 6, 3, 2>(qkv, out, B, T, H, causal, st, q_blocks);
+    case 7: return launch_attention_cfg<64, 7, 4, 2>(qkv, out, B, T, H, causal, st, q_blocks);   // ViT-B/16 image (T=197)
+    case 8: return launch_attention_cfg<64, 8, 4, 2>(qkv, out, B, T, H, causal, st, q_blocks);
     case 9: {  // ViT-L/14 image (T=257)
 #ifdef CLIPX_ABLATE
       static const int cfg = getenv("CLIPX_ATTN_CFG") ? atoi(getenv("CLIPX_ATTN_CFG")) : 0;
 #else
       constexpr int cfg = 0;
 #endif
-      if (cfg == 4) return launch_attention_cfg<64, 9, 4, 3>(qkv, out, B, T, H, causal, st);
+      if (cfg == 4) return launch_attention_cfg<64, 9, 4, 3>(qkv, out, B, T, H, causal, st, q_blocks);
 #ifdef CLIPX_ABLATE
-      if (cfg == 5) return launch_attention_cfg<64, 9, 9, 1, true>(qkv, out, B, T, H, causal, st);   // 9 waves, S recomputed
-      if (cfg == 6) return launch_attention_cfg<64, 9, 5, 2>(qkv, out, B, T, H, causal, st);
-      if (cfg == 7) return launch_attention_cfg<64, 9, 9, 1>(qkv, out, B, T, H, causal, st);         // 9 waves, S kept (144 regs)
-      if (cfg == 8) return launch_attention_cfg<64, 9, 5, 2, true>(qkv, out, B, T, H, causal, st);
+      if (cfg == 5) return launch_attention_cfg<64, 9, 9, 1, true>(qkv, out, B, T, H, causal, st, q_blocks);   // 9 waves, S recomputed
+      if (cfg == 6) return launch_attention_cfg<64, 9, 5, 2>(qkv, out, B, T, H, causal, st, q_blocks);
+      if (cfg == 7) return launch_attention_cfg<64, 9, 9, 1>(qkv, out, B, T, H, causal, st, q_blocks);         // 9 waves, S kept (144 regs)
+      if (cfg == 8) return launch_attention_cfg<64, 9, 5, 2, true>(qkv, out, B, T, H, causal, st, q_blocks);
 #endif
       if (cfg == 9 && !causal) {  // phase timer
         constexpr int KROW = 128, DV = 64;
@@ -1020,10 +1021,10 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
         auto kern = attention_kernel<64, 9, 3, 3, false, false, true>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(B * H), dim3(192), smem, st, qkv, out, T, H, (1.f / 8.f) * 1.4426950408889634f, 0);
+        hipLaunchKernelGGL(kern, dim3(B * H), dim3(192), smem, st, qkv, out, T, H, (1.f / 8.f) * 1.4426950408889634f, 0, 9);
         return hipGetLastError();
       }
-      return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st);
+      return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st, q_blocks);
     }
     default: return hipErrorInvalidValue;
   }

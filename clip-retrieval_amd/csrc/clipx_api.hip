@@ -413,8 +413,12 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
     int r;
     { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
     if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16, h->rstd, true))) return r;
-    { ProfScope ps(h, st, 1, 4.0 * B * t.heads * (double)t.T * t.T * (w / t.heads)); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st)); }
-    if (l == t.layers - 1 && h->pool_last_block && t.T > 1) {
+    // last block of the image tower: only token 0's attention row is read afterwards -> query block 0 only (same arithmetic)
+    const bool pool_here = l == t.layers - 1 && h->pool_last_block && t.T > 1;
+    const int q_blocks = pool_here && !ids ? 1 : 0;
+    const double att_rows = q_blocks ? std::min(32, t.T) : t.T;
+    { ProfScope ps(h, st, 1, 4.0 * B * t.heads * att_rows * t.T * (w / t.heads)); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st, q_blocks)); }
+    if (pool_here) {
       // The embedding reads ONE row of this block's output per sample (token 0 / the EOT token: launch_tail), and past the
       // attention every operation of a block is row-wise: out-proj, both residual adds, LayerNorm 2 and the MLP run on those B
       // rows only.  Same kernels, and a GEMM row does not depend on the rows it travels with (bitwise): the embeddings are the

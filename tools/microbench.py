@@ -242,7 +242,7 @@ if "reader" in what:
     import numpy as np
     from PIL import Image
 
-    from clip_retrieval_amd.reader import HashTokenizer, WebdatasetReader, clip_preprocess, clip_preprocess_u8
+    from clip_retrieval_amd.reader import HashTokenizer, WebdatasetReader, clip_preprocess, clip_preprocess_u8, decode_rgb_u8
     from clip_retrieval_amd.runner import Sampler
 
     n = int(os.environ.get("MB_READER_SAMPLES", "4000"))
@@ -259,14 +259,14 @@ if "reader" in what:
                 ti.size = len(data)
                 tf.addfile(ti, io.BytesIO(data))
     print(f"host cores: {os.cpu_count()}", flush=True)
-    for prep in (clip_preprocess, clip_preprocess_u8):
+    for prep in (clip_preprocess, clip_preprocess_u8, decode_rgb_u8):  # decode_rgb_u8: resize / crop left to the GPU (row f2)
         for procs in (False, True):
             for workers in (8, 32):
                 for rep in range(2):  # the second pass reuses the started worker processes (as consecutive partitions do)
                     r = WebdatasetReader(Sampler(0, 1), prep, HashTokenizer(), [path], 256, workers)
                     r.use_processes = procs
                     t0 = time.perf_counter()
-                    got = sum(b["image_tensor"].shape[0] for b in r)
+                    got = sum(b["image_tensor"].shape[0] if "image_tensor" in b else b["image_raw"]["hw"].shape[0] for b in r)
                     dt = time.perf_counter() - t0
                 print(f"WebdatasetReader {got} JPEG 256x256 + captions, {prep.__name__}, {workers} decode "
                       f"{'processes' if procs else 'threads'}: {got / dt:.0f} samples/s", flush=True)
@@ -310,10 +310,12 @@ if "pipeline" in what:
     with gzip.open(bpe, "wt", encoding="utf-8") as f:
         f.write("#version: 0.2\nt h\nth e</w>\no f</w>\np h\n")
     os.environ["CLIP_BPE_PATH"] = bpe
-    for workers in (8, 32):
-        out = os.path.join(tmp, f"out{workers}")
+    pipe_model = os.environ.get("MB_PIPE_MODEL", "ViT-L/14")
+    for workers, gpu_resize in ((8, False), (32, False), (8, True), (32, True)):
+        out = os.path.join(tmp, f"out{workers}{'r' if gpu_resize else ''}")
         args = dict(input_dataset=shards, output_folder=out, output_partition_count=2, input_format="webdataset", batch_size=256,
-                    num_prepro_workers=workers, enable_text=True, enable_image=True, clip_model="random:ViT-L/14")
+                    num_prepro_workers=workers, enable_text=True, enable_image=True, clip_model="random:" + pipe_model,
+                    gpu_resize=gpu_resize)
         t0 = time.perf_counter()
         worker([0], **args)  # first partition: model build, worker start-up, warm-up
         t1 = time.perf_counter()
@@ -321,7 +323,7 @@ if "pipeline" in what:
         t2 = time.perf_counter()
         n = shards_n * per // 2
         rows = sum(np.load(f, mmap_mode="r").shape[0] for f in glob.glob(out + "/img_emb/*.npy"))
-        print(f"pipeline worker() ViT-L/14 image+text, {workers} decode processes: first partition {n / (t1 - t0):.0f} samples/s "
+        print(f"pipeline worker() {pipe_model} image+text, {workers} decode processes, resize on the {'GPU' if gpu_resize else 'host'}: first partition {n / (t1 - t0):.0f} samples/s "
               f"(with start-up), second partition {n / (t2 - t1):.0f} samples/s; {rows} embeddings written", flush=True)
         for f in sorted(glob.glob(out + "/stats/*.json"))[-1:]:
             print("    stats of the last partition:", open(f).read()[:400], flush=True)
