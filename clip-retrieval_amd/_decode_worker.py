@@ -5,6 +5,7 @@ The counterpart of the reference's DataLoader worker processes (clip_retrieval/c
 length-prefixed pickle protocol on its stdin / stdout: nothing of the parent is forked (it may hold a HIP context and
 threads) and the parent's main script is not re-imported (multiprocessing's spawn / forkserver children do that).
 """
+import os
 import pickle
 import struct
 import sys
@@ -33,13 +34,41 @@ def main():
     except Exception as e:  # pylint: disable=broad-except
         send(("error", repr(e)))
         return
+    arena, arena_np = None, None
+    spec = os.environ.get("CLIPX_DECODE_ARENA")
+    if spec:
+        try:
+            import mmap  # pylint: disable=import-outside-toplevel
+
+            import numpy as np  # pylint: disable=import-outside-toplevel
+
+            fd, size = (int(v) for v in spec.split(":"))
+            arena = mmap.mmap(fd, size)
+            arena_np = np.frombuffer(arena, dtype=np.uint8)
+        except (OSError, ValueError):
+            arena = None
     send(("ok", None))
     while True:
         raws = recv()
         if raws is None:
             return
         try:
-            send(("ok", [_decode_sample(r, *args) for r in raws]))
+            outs = [_decode_sample(r, *args) for r in raws]
+            if arena is not None:
+                # pixels go back through the shared arena; what does not fit (a chunk of very large sources) is pickled as before
+                off = 0
+                for o in outs:
+                    if o is None:
+                        continue
+                    for k in ("image_tensor", "image_raw"):
+                        a = o.get(k)
+                        if a is None or not hasattr(a, "nbytes") or off + a.nbytes > arena_np.size:
+                            continue
+                        flat = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+                        arena_np[off:off + flat.size] = flat
+                        o[k] = ("@arena", off, a.shape, a.dtype.str)
+                        off += (flat.size + 63) & ~63
+            send(("ok", outs))
         except Exception as e:  # pylint: disable=broad-except
             send(("error", repr(e)))
 

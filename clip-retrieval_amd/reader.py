@@ -192,12 +192,100 @@ def _collate(samples, enable_image, enable_text, enable_metadata, pin):
     return batch
 
 
+class _Span(tuple):
+    """(path, offset, size): bytes of a local file that the DECODING side reads (os.pread), so that image bytes never pass
+    through the parent process or its pipes."""
+
+    __slots__ = ()
+
+
+_span_fds = {}
+
+
+def _read_span(span):
+    import os  # pylint: disable=import-outside-toplevel
+
+    path, off, size = span
+    if size < 0:  # a whole file (FilesReader): no descriptor kept
+        with open(path, "rb") as f:
+            return f.read()
+    fd = _span_fds.get(path)
+    if fd is None:
+        if len(_span_fds) >= 64:
+            for f in _span_fds.values():
+                os.close(f)
+            _span_fds.clear()
+        fd = _span_fds[path] = os.open(path, os.O_RDONLY)
+    out = os.pread(fd, size, off)
+    if len(out) != size:
+        raise OSError(f"{path}: short read at {off} (+{size})")
+    return out
+
+
+def _resolve_spans(raw):
+    if isinstance(raw.get("image"), _Span):
+        raw["image"] = _read_span(raw["image"])
+    for k in ("text", "metadata"):
+        if isinstance(raw.get(k), _Span):
+            raw[k] = _read_span(raw[k]).decode("utf-8")
+    return raw
+
+
+def _scan_plain_tar(path):
+    """(member name, data offset, size) of every regular file of an UNCOMPRESSED local tar, from the 512-byte headers alone
+    (no member data is read).  Returns None for anything this quick parser does not cover -- not a ustar / GNU archive,
+    GNU long names, pax extended headers, sparse files -- and the caller streams the shard through `tarfile` instead."""
+    import os  # pylint: disable=import-outside-toplevel
+
+    out = []
+    try:
+        fd = os.open(path, os.O_RDONLY)
+    except OSError:
+        return None
+    try:
+        end = os.fstat(fd).st_size
+        off = 0
+        while off + 512 <= end:
+            h = os.pread(fd, 512, off)
+            if len(h) < 512:
+                return None
+            if h == b"\0" * 512:
+                break
+            if h[257:262] != b"ustar":
+                return None
+            t = h[156:157]
+            sz = h[124:136]
+            if sz[0] & 0x80:  # base-256 size (members over 8 GiB)
+                size = int.from_bytes(sz[1:], "big")
+            else:
+                size = int(sz.split(b"\0", 1)[0].strip() or b"0", 8)
+            if t in (b"0", b"\0", b"7"):
+                name = h[0:100].split(b"\0", 1)[0]
+                prefix = h[345:500].split(b"\0", 1)[0] if h[257:263] == b"ustar\0" else b""
+                out.append(((prefix + b"/" + name if prefix else name).decode("utf-8"), off + 512, size))
+            elif t in (b"L", b"K", b"x", b"g", b"S"):
+                return None
+            else:
+                size = size if t not in (b"1", b"2", b"3", b"4", b"5", b"6") else 0  # links, devices, directories carry no data
+            off += 512 + ((size + 511) // 512) * 512
+        return out
+    except (OSError, ValueError, UnicodeDecodeError):
+        return None
+    finally:
+        os.close(fd)
+
+
 def _decode_sample(raw, preprocess, tokenizer, enable_image, enable_text, enable_metadata):
     """raw: {"key", "image": bytes|None, "text": str|None, "metadata": str|None} -> sample dict of numpy arrays / strings, or
     None for an undecodable image (reference reader.py:100-104: print and skip)."""
     from PIL import Image, UnidentifiedImageError  # pylint: disable=import-outside-toplevel
 
     out = {}
+    try:
+        raw = _resolve_spans(raw)
+    except (OSError, UnicodeDecodeError) as e:
+        print(f"Failed to read sample {raw['key']}. Error: {e}. Skipping.")
+        return None
     if enable_image:
         try:
             img = preprocess(Image.open(io.BytesIO(raw["image"])))
@@ -222,7 +310,10 @@ def _decode_sample(raw, preprocess, tokenizer, enable_image, enable_text, enable
 class _DecodeWorker:
     """One `_decode_worker` child and its two pipes."""
 
+    ARENA_BYTES = 48 << 20  # decoded pixels of one chunk come back through this shared mapping, not through the pipe
+
     def __init__(self, blob):
+        import mmap  # pylint: disable=import-outside-toplevel
         import os  # pylint: disable=import-outside-toplevel
         import subprocess  # pylint: disable=import-outside-toplevel
         import sys  # pylint: disable=import-outside-toplevel
@@ -230,8 +321,20 @@ class _DecodeWorker:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # where the `clip_retrieval_amd` import shim lives
         env = dict(os.environ)
         env["PYTHONPATH"] = os.pathsep.join([root] + [p for p in sys.path if p] + [env.get("PYTHONPATH", "")])
+        # an anonymous memory file shared with the child (memfd: not limited by the size of /dev/shm in a container); the child
+        # writes the decoded arrays into it and the reply carries (offset, shape) instead of 150 KB of pickled pixels per image
+        self.arena, fds = None, ()
+        try:
+            fd = os.memfd_create("clipx-decode-arena")
+            os.ftruncate(fd, self.ARENA_BYTES)
+            self.arena = mmap.mmap(fd, self.ARENA_BYTES)
+            self._arena_fd = fd
+            env["CLIPX_DECODE_ARENA"] = f"{fd}:{self.ARENA_BYTES}"
+            fds = (fd,)
+        except (AttributeError, OSError):
+            env.pop("CLIPX_DECODE_ARENA", None)
         self.proc = subprocess.Popen([sys.executable, "-m", "clip_retrieval_amd._decode_worker"], stdin=subprocess.PIPE,
-                                     stdout=subprocess.PIPE, env=env)
+                                     stdout=subprocess.PIPE, env=env, pass_fds=fds)
         self._send_blob(blob)
 
     def _send_blob(self, blob):
@@ -257,14 +360,34 @@ class _DecodeWorker:
         import pickle  # pylint: disable=import-outside-toplevel
 
         self._send_blob(pickle.dumps(raws, protocol=pickle.HIGHEST_PROTOCOL))
-        return self.recv()
+        out = self.recv()
+        if self.arena is not None:
+            for sample in out:  # copy the pixels out before this worker's next chunk overwrites the arena
+                if sample is None:
+                    continue
+                for k in ("image_tensor", "image_raw"):
+                    v = sample.get(k)
+                    if isinstance(v, tuple) and v and v[0] == "@arena":
+                        _, off, shape, dtype = v
+                        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+                        sample[k] = np.frombuffer(self.arena, dtype=dtype, count=n // np.dtype(dtype).itemsize, offset=off).reshape(shape).copy()
+        return out
 
     def close(self):
+        import os  # pylint: disable=import-outside-toplevel
+
         try:
             self.proc.stdin.close()
             self.proc.wait(timeout=5)
         except Exception:  # pylint: disable=broad-except
             self.proc.kill()
+        if self.arena is not None:
+            try:
+                self.arena.close()
+                os.close(self._arena_fd)
+            except (OSError, ValueError, BufferError):
+                pass
+            self.arena = None
 
 
 class _DecodePool:
@@ -438,7 +561,7 @@ class FilesReader(_BatchingReader):
             raw = {"key": k, "image": None, "text": None, "metadata": None}
             if self.enable_image:
                 raw["key"] = str(self.image_files[k])
-                raw["image"] = self.image_files[k].read_bytes()
+                raw["image"] = _Span((str(self.image_files[k]), 0, -1))  # read by the decoding side, not here
             if self.enable_text:
                 raw["text"] = self.text_files[k].read_text()
             if self.enable_metadata:
@@ -493,8 +616,47 @@ class WebdatasetReader(_BatchingReader):
             return tarfile.open(local, "r|*")
         return tarfile.open(fileobj=fsspec.open(shard, "rb").open(), mode="r|*")
 
+    # local uncompressed shards: member offsets from the headers, bytes read by the decoding side (False: always `tarfile`)
+    scan_spans = True
+
+    def _span_samples(self, shard, members):
+        """The grouping of `_raw_samples` over (name, offset, size) triples; image / text / metadata stay `_Span`s."""
+        cur_key, fields = None, {}
+
+        def emit():
+            if self.enable_image and self.image_key not in fields:
+                return None
+            if self.enable_text and self.caption_key not in fields:
+                return None
+            if self.enable_metadata and "json" not in fields:
+                return None
+            return {"key": cur_key, "image": fields.get(self.image_key),
+                    "text": fields[self.caption_key] if self.enable_text else None,
+                    "metadata": fields["json"] if self.enable_metadata else None}
+
+        for name, off, size in members:
+            base = name.rsplit("/", 1)
+            stem, _, ext = base[-1].partition(".")
+            key = (base[0] + "/" if len(base) == 2 else "") + stem
+            if key != cur_key:
+                if cur_key is not None:
+                    s = emit()
+                    if s is not None:
+                        yield s
+                cur_key, fields = key, {}
+            fields[ext.lower()] = _Span((shard, off, size))
+        if cur_key is not None:
+            s = emit()
+            if s is not None:
+                yield s
+
     def _raw_samples(self):
         for shard in self.shards:
+            if self.scan_spans and "://" not in shard:
+                members = _scan_plain_tar(shard)
+                if members is not None:
+                    yield from self._span_samples(shard, members)
+                    continue
             try:
                 tf = self._open_shard(shard)
             except (tarfile.TarError, OSError) as e:
