@@ -472,18 +472,37 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const float4 bq = b4[nt][g];
-              // one fma per element, like gemm_store_quad (gemm_common.h): bit-identical rows from both kernels
-              float v[4] = {__builtin_fmaf(acc[mt][nt][4 * g + 0], rr[mt], bq.x), __builtin_fmaf(acc[mt][nt][4 * g + 1], rr[mt], bq.y),
-                            __builtin_fmaf(acc[mt][nt][4 * g + 2], rr[mt], bq.z), __builtin_fmaf(acc[mt][nt][4 * g + 3], rr[mt], bq.w)};
+              typedef float f32x2_t __attribute__((ext_vector_type(2)));
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              float v[4];
+              if (EPI == EPI_BIAS_QGELU_BF16) {
+                // two elements per VALU instruction for everything but the two transcendentals (v_pk_fma_f32, v_pk_mul_f32,
+                // v_pk_add_f32): each packed lane is the IEEE operation of gemm_common.h's quick_gelu, so the bits do not change
+                const f32x2_t r2 = {rr[mt], rr[mt]}, kk = {-1.702f * 1.4426950408889634f, -1.702f * 1.4426950408889634f};
+                const f32x2_t one = {1.f, 1.f};
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                if (EPI == EPI_BIAS_QGELU_BF16) v[e] = quick_gelu(v[e]);
-                if (EPI == EPI_BIAS_GELU_BF16) v[e] = gelu_erf(v[e]);
+                for (int e = 0; e < 4; e += 2) {
+                  const f32x2_t a2 = {acc[mt][nt][4 * g + e], acc[mt][nt][4 * g + e + 1]};
+                  const f32x2_t b2 = {e == 0 ? bq.x : bq.z, e == 0 ? bq.y : bq.w};
+                  const f32x2_t x2 = __builtin_elementwise_fma(a2, r2, b2);
+                  const f32x2_t t2 = x2 * kk;
+                  const f32x2_t d2 = (f32x2_t){__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])} + one;
+                  const f32x2_t y2 = x2 * (f32x2_t){__builtin_amdgcn_rcpf(d2[0]), __builtin_amdgcn_rcpf(d2[1])};
+                  v[e] = y2[0];
+                  v[e + 1] = y2[1];
+                }
+              } else {
+                // one fma per element, like gemm_store_quad (gemm_common.h): bit-identical rows from both kernels
+                v[0] = __builtin_fmaf(acc[mt][nt][4 * g + 0], rr[mt], bq.x);
+                v[1] = __builtin_fmaf(acc[mt][nt][4 * g + 1], rr[mt], bq.y);
+                v[2] = __builtin_fmaf(acc[mt][nt][4 * g + 2], rr[mt], bq.z);
+                v[3] = __builtin_fmaf(acc[mt][nt][4 * g + 3], rr[mt], bq.w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (EPI == EPI_BIAS_GELU_BF16) v[e] = gelu_erf(v[e]);
               }
               // two v_cvt_pk_bf16_f32 per quad (element-wise casts into a bf16x4 make hipcc convert one value at a time
               // and assemble the pairs with v_perm / v_alignbit: 9 VALU per quad instead of 4)
-              typedef float f32x2_t __attribute__((ext_vector_type(2)));
-              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
               const bf16x2_t o01 = __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t);
               const bf16x2_t o23 = __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t);
               uint2 o;

@@ -592,28 +592,37 @@ class WebdatasetReader(_BatchingReader):
                 "text": fields[self.caption_key].decode("utf-8") if self.enable_text else None,
                 "metadata": fields["json"].decode("utf-8") if self.enable_metadata else None}
 
-    def _open_shard(self, shard):
-        """Local paths are streamed in place; URLs (s3://, gs://, https://, pipe-less) go through fsspec, copied to
-        `cache_path` once when it is set (the reference passes cache_dir to webdataset, reader.py:138)."""
+    def _local_copy(self, shard):
+        """The local file a shard can be read from: the path itself, or the copy of a URL (s3://, gs://, https://, ...) in
+        `cache_path`, made once through fsspec (the reference passes cache_dir to webdataset, reader.py:138); None for a URL
+        without a cache (streamed)."""
         if "://" not in shard:
-            return tarfile.open(shard, "r|*")
+            return shard
+        if not self.cache_path:
+            return None
+        import hashlib  # pylint: disable=import-outside-toplevel
+        import os  # pylint: disable=import-outside-toplevel
+
         import fsspec  # pylint: disable=import-outside-toplevel
 
-        if self.cache_path:
-            import hashlib  # pylint: disable=import-outside-toplevel
-            import os  # pylint: disable=import-outside-toplevel
+        os.makedirs(self.cache_path, exist_ok=True)
+        local = os.path.join(self.cache_path, hashlib.sha1(shard.encode()).hexdigest()[:16] + "_" + shard.rsplit("/", 1)[-1])
+        if not os.path.exists(local):
+            with fsspec.open(shard, "rb") as src, open(local + ".part", "wb") as dst:
+                while True:
+                    chunk = src.read(1 << 22)
+                    if not chunk:
+                        break
+                    dst.write(chunk)
+            os.replace(local + ".part", local)
+        return local
 
-            os.makedirs(self.cache_path, exist_ok=True)
-            local = os.path.join(self.cache_path, hashlib.sha1(shard.encode()).hexdigest()[:16] + "_" + shard.rsplit("/", 1)[-1])
-            if not os.path.exists(local):
-                with fsspec.open(shard, "rb") as src, open(local + ".part", "wb") as dst:
-                    while True:
-                        chunk = src.read(1 << 22)
-                        if not chunk:
-                            break
-                        dst.write(chunk)
-                os.replace(local + ".part", local)
+    def _open_shard(self, shard, local=None):
+        """Streaming `tarfile` over the local file (path or cached copy), or over the fsspec stream of an uncached URL."""
+        if local is not None:
             return tarfile.open(local, "r|*")
+        import fsspec  # pylint: disable=import-outside-toplevel
+
         return tarfile.open(fileobj=fsspec.open(shard, "rb").open(), mode="r|*")
 
     # local uncompressed shards: member offsets from the headers, bytes read by the decoding side (False: always `tarfile`)
@@ -652,13 +661,14 @@ class WebdatasetReader(_BatchingReader):
 
     def _raw_samples(self):
         for shard in self.shards:
-            if self.scan_spans and "://" not in shard:
-                members = _scan_plain_tar(shard)
-                if members is not None:
-                    yield from self._span_samples(shard, members)
-                    continue
             try:
-                tf = self._open_shard(shard)
+                local = self._local_copy(shard)
+                if self.scan_spans and local is not None:
+                    members = _scan_plain_tar(local)
+                    if members is not None:
+                        yield from self._span_samples(local, members)
+                        continue
+                tf = self._open_shard(shard, local)
             except (tarfile.TarError, OSError) as e:
                 print(f"warn_and_continue: {shard}: {e}")
                 continue

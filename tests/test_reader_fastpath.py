@@ -173,3 +173,33 @@ def test_reference_tars_through_both_paths():
         return r
 
     _same(_read_all(make(True)), _read_all(make(False)))
+
+
+@pytest.mark.parametrize("cached", [False, True])
+def test_url_shards_go_through_fsspec_and_the_cache(tmp_path, cached):
+    """`input_dataset` entries with a scheme (s3://, gs://, https://; here file:// and memory://) are opened through fsspec and,
+    when `cache_path` is set, copied there once (the reference hands cache_dir to webdataset, reader.py:138).  Same batches as
+    the local path."""
+    import fsspec
+
+    p = str(tmp_path / "a.tar")
+    _write_tar(p, _members(6))
+    with open(p, "rb") as f:
+        blob = f.read()
+    with fsspec.open("memory://shards/b.tar", "wb") as f:
+        f.write(blob)
+    cache = str(tmp_path / "cache") if cached else None
+    want = _read_all(R.WebdatasetReader(Sampler(0, 1), R.clip_preprocess_u8, R.HashTokenizer(), [p], 4, 1))
+    for url in ("file://" + p, "memory://shards/b.tar"):
+        r = R.WebdatasetReader(Sampler(0, 1), R.clip_preprocess_u8, R.HashTokenizer(), [url], 4, 1, cache_path=cache)
+        _same(_read_all(r), want)
+    if cached:
+        files = sorted(os.listdir(cache))
+        assert len(files) == 2 and all(f.endswith(".tar") and not f.endswith(".part") for f in files)
+        # second pass: served from the cache even when the source is gone
+        fsspec.filesystem("memory").rm("/shards/b.tar")
+        r = R.WebdatasetReader(Sampler(0, 1), R.clip_preprocess_u8, R.HashTokenizer(), ["memory://shards/b.tar"], 4, 1, cache_path=cache)
+        _same(_read_all(r), want)
+    # a shard that cannot be opened is skipped with a warning, the rest of the partition is read (warn_and_continue)
+    r = R.WebdatasetReader(Sampler(0, 1), R.clip_preprocess_u8, R.HashTokenizer(), ["memory://shards/none.tar", p], 4, 1, cache_path=cache)
+    _same(_read_all(r), want)
