@@ -193,9 +193,16 @@ def main():
             step(**kw)
         barrier()
         extras[key] = round(world * max(2, args.steps // 2) * B / max_over_ranks(time.perf_counter() - t1), 1)
-    e2e_tflops = value / world * (gf_img + gf_txt) / 1e3
+    # FLOPs that RUN per step (counters of the launches: GEMMs + attention), not the model formula: the last block's out-proj / MLP
+    # (and, in the image tower, all but the first query block of its attention) are computed on the pooled rows only
+    a = prof["attention"]
+    run_tflop = gemm_tflops * g["ms"] / max(args.steps, 1) / 1e3 + ((a["tflops"] or 0.0) * a["ms"] / max(a["steps"], 1) / 1e3)
+    model_tflop = B * (gf_img + gf_txt) / 1e3
+    e2e_tflops = run_tflop / (dt / args.steps)
     extras["end_to_end_tflops_per_gpu"] = round(e2e_tflops, 1)
     extras["end_to_end_frac_of_mfma_peak"] = round(e2e_tflops / BF16_PEAK_TFLOPS, 4)
+    extras["tflop_per_step"] = {"run": round(run_tflop, 3), "full_model_formula": round(model_tflop, 3),
+                                "note": "the embedding reads one row per sample of the last block: its out-proj / MLP run on those rows only (bit-identical; CLIPX_FULL_LAST_BLOCK=1 runs every row)"}
     extras["kernel_ms_per_step"] = {k: round(v["ms"] / v["steps"], 3) for k, v in prof.items()}
 
     # ---- parity gate on the benchmark's own weights and inputs, ALL rows of the timed batch (oracle = checker), and
