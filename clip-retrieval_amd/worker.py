@@ -165,6 +165,8 @@ def _main(argv=None):
     ap.add_argument("--wds_caption_key")
     ap.add_argument("--clip_model")
     ap.add_argument("--clip_cache_path")
+    ap.add_argument("--gpu_normalise", type=truth, help="uint8 crops to the GPU, /255 - mean / std there (default true)")
+    ap.add_argument("--gpu_resize", type=truth, help="decode only on the host; resize + centre crop on the GPU too, bit-identical to Pillow (default false)")
     gpu_worker(**vars(ap.parse_args(argv)))
 
 
