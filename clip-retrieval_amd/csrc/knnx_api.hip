@@ -101,6 +101,7 @@ struct knnx_index {
   // RQ scan (register-stationary queries, up to 256 per pass; knn_rq_kernels.hip): allocated on first use
   int rq_ok = 1;               // KNNX_RQ=0 disables
   int64_t rq_min_rows = KNN_RQ_MIN_ROWS;  // KNNX_RQ_MIN_ROWS overrides (tests run the RQ path on small indexes)
+  int rq_sample_grid = 0;      // workgroups of the threshold-sample scans (0: chosen from the sample size; KNNX_RQ_SAMPLE_GRID overrides)
   _Float16* rq_qfrag = nullptr;  // [8 blocks][d/16][64][8]
   float* rq_thr = nullptr;       // [256]
   unsigned *rq_cnt = nullptr, *rq_lost = nullptr, *rq_need = nullptr, *rq_gate = nullptr;  // [256] x3, [8]
@@ -109,6 +110,16 @@ struct knnx_index {
   uint32_t* rq_hit_r = nullptr;
   float* rq_samp = nullptr;      // [256, 64] sample scores
   int64_t* rq_samp_i = nullptr;
+  // the threshold-sample scans of a batch (up to 4 groups of 64 / 32 queries) run CONCURRENTLY: groups 1 .. 3 on side streams
+  // with their own copy of the scan scratch (fragments, global thresholds, per-workgroup part lists)
+  static constexpr int RQ_SIDE = 3;
+  hipStream_t rq_side[RQ_SIDE] = {nullptr, nullptr, nullptr};
+  hipEvent_t rq_fork = nullptr, rq_join[RQ_SIDE] = {nullptr, nullptr, nullptr};
+  _Float16* rq_s_qfrag[RQ_SIDE] = {nullptr, nullptr, nullptr};
+  int* rq_s_thr_g[RQ_SIDE] = {nullptr, nullptr, nullptr};
+  float* rq_s_part_s[RQ_SIDE] = {nullptr, nullptr, nullptr};
+  uint32_t* rq_s_part_i[RQ_SIDE] = {nullptr, nullptr, nullptr};
+  int* rq_s_part_n[RQ_SIDE] = {nullptr, nullptr, nullptr};
   unsigned long long* stats = nullptr;  // device counters: [0] queries served by a proof-based path, [1] proofs that failed
 
   // scratch hand-over between streams: the per-handle scratch above is shared by every call, so each launch sequence
@@ -191,6 +202,8 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
   ix->rq_ok = (rq && rq[0] == '0') ? 0 : 1;
   const char* rqm = getenv("KNNX_RQ_MIN_ROWS");
   if (rqm && rqm[0]) ix->rq_min_rows = atoll(rqm);
+  const char* sg = getenv("KNNX_RQ_SAMPLE_GRID");
+  if (sg && atoi(sg) > 0) ix->rq_sample_grid = atoi(sg);
   const char* gr = getenv("KNNX_GRID");
   if (gr && atoi(gr) > 0) ix->n_cu = atoi(gr);
   hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
@@ -257,6 +270,16 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->rq_hit_r);
   hipFree(ix->rq_samp);
   hipFree(ix->rq_samp_i);
+  for (int i = 0; i < knnx_index::RQ_SIDE; ++i) {
+    hipFree(ix->rq_s_qfrag[i]);
+    hipFree(ix->rq_s_thr_g[i]);
+    hipFree(ix->rq_s_part_s[i]);
+    hipFree(ix->rq_s_part_i[i]);
+    hipFree(ix->rq_s_part_n[i]);
+    if (ix->rq_side[i]) (void)hipStreamDestroy(ix->rq_side[i]);
+    if (ix->rq_join[i]) (void)hipEventDestroy(ix->rq_join[i]);
+  }
+  if (ix->rq_fork) (void)hipEventDestroy(ix->rq_fork);
   if (ix->ev_scratch) hipEventDestroy(ix->ev_scratch);
   if (ix->range_s) hipFree(ix->range_s);
   if (ix->range_i) hipFree(ix->range_i);
@@ -593,6 +616,17 @@ static int rq_alloc(knnx_index* ix) {
   HIPCHK(hipMalloc(&ix->rq_hit_r, Q * KNN_RQ_CAP * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&ix->rq_samp, Q * KNN_WIDE_KW * sizeof(float)));
   HIPCHK(hipMalloc(&ix->rq_samp_i, Q * KNN_WIDE_KW * sizeof(int64_t)));
+  const size_t G = (size_t)ix->n_cu;
+  HIPCHK(hipEventCreateWithFlags(&ix->rq_fork, hipEventDisableTiming));
+  for (int i = 0; i < knnx_index::RQ_SIDE; ++i) {
+    HIPCHK(hipStreamCreateWithFlags(&ix->rq_side[i], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ix->rq_join[i], hipEventDisableTiming));
+    HIPCHK(hipMalloc(&ix->rq_s_qfrag[i], (size_t)ix->d * 128));
+    HIPCHK(hipMalloc(&ix->rq_s_thr_g[i], KNN_NQ_MAX * sizeof(int)));
+    HIPCHK(hipMalloc(&ix->rq_s_part_s[i], G * KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(float)));
+    HIPCHK(hipMalloc(&ix->rq_s_part_i[i], G * KNN_NQ_MAX * KNNX_MAX_K_FAST * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&ix->rq_s_part_n[i], G * KNN_NQ_MAX * sizeof(int)));
+  }
   return 0;
 }
 static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st) {
@@ -606,28 +640,48 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
   // rather than fp16-hi: the threshold then gets a slack of a few eps so that the sample rows themselves still reach it)
   const bool wide_samp = wide_cap(d) > 0;
   const int gsz = wide_samp ? KNN_NQ_MAX : KNN_NQ;
+  // The sample scans cost a fixed ~0.45 ms each whatever their grid (cold candidate queues: every workgroup floods and prunes
+  // its queues a few times before its thresholds bite; 256 -> 64 workgroups: same time, tools/rq_sample_grid.py), and one of
+  // them needs a whole CU's LDS per workgroup.  So the groups of a batch run side by side, each on its own quarter of the CUs
+  // (own stream, own scratch): 4 x (prep + scan + merge) in the time of one.
+  const int ngroups = (nq + gsz - 1) / gsz;
+  const int lanes = std::min(ngroups, 1 + knnx_index::RQ_SIDE);
+  const int sgrid = std::max(1, std::min(ix->n_cu, ix->rq_sample_grid > 0 ? ix->rq_sample_grid : ix->n_cu / lanes));
+  if (lanes > 1) HIPCHK(hipEventRecord(ix->rq_fork, st));
   for (int g = 0; g * gsz < nq; ++g) {
     const int q0 = g * gsz, n = std::min(gsz, nq - q0);
-    HIPCHK(launch_prep(q_dev + (size_t)q0 * d, n, d, ix->qfrag, ix->thr_g, nullptr, wide_samp ? 1 : 0, nullptr, st));
+    const int side = g % lanes;  // 0: the caller's stream and the index's own scratch
+    hipStream_t sg = side == 0 ? st : ix->rq_side[side - 1];
+    _Float16* qf = side == 0 ? ix->qfrag : ix->rq_s_qfrag[side - 1];
+    int* thr_g = side == 0 ? ix->thr_g : ix->rq_s_thr_g[side - 1];
+    float* part_s = side == 0 ? ix->part_s : ix->rq_s_part_s[side - 1];
+    uint32_t* part_i = side == 0 ? ix->part_i : ix->rq_s_part_i[side - 1];
+    int* part_n = side == 0 ? ix->part_n : ix->rq_s_part_n[side - 1];
+    if (side != 0 && g < lanes) HIPCHK(hipStreamWaitEvent(sg, ix->rq_fork, 0));
+    HIPCHK(launch_prep(q_dev + (size_t)q0 * d, n, d, qf, thr_g, nullptr, wide_samp ? 1 : 0, nullptr, sg));
     ScanArgs a{};
     a.X = ix->rows;
     a.N = ix->ntotal;
     a.d = d;
-    a.qfrag = ix->qfrag;
+    a.qfrag = qf;
     a.nq = n;
     a.k = KNN_WIDE_KW;
     a.cap = wide_samp ? wide_cap(d) : scan_cap(d, KNN_WIDE_KW);
-    a.grid = ix->n_cu;
+    a.grid = sgrid;
     a.mode = 0;
     a.wide = wide_samp ? 1 : 0;
     a.tstride = tstride;
-    a.thr_g = ix->thr_g;
-    a.part_s = ix->part_s;
-    a.part_i = ix->part_i;
-    a.part_n = ix->part_n;
-    HIPCHK(launch_scan(a, st));
-    HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, gsz, KNN_WIDE_KW, n, KNN_WIDE_KW, 0, nullptr,
-                            ix->rq_samp + (size_t)q0 * KNN_WIDE_KW, ix->rq_samp_i + (size_t)q0 * KNN_WIDE_KW, nullptr, st));
+    a.thr_g = thr_g;
+    a.part_s = part_s;
+    a.part_i = part_i;
+    a.part_n = part_n;
+    HIPCHK(launch_scan(a, sg));
+    HIPCHK(launch_merge_u32(part_s, part_i, part_n, sgrid, gsz, KNN_WIDE_KW, n, KNN_WIDE_KW, 0, nullptr,
+                            ix->rq_samp + (size_t)q0 * KNN_WIDE_KW, ix->rq_samp_i + (size_t)q0 * KNN_WIDE_KW, nullptr, sg));
+  }
+  for (int side = 1; side < lanes; ++side) {
+    HIPCHK(hipEventRecord(ix->rq_join[side - 1], ix->rq_side[side - 1]));
+    HIPCHK(hipStreamWaitEvent(st, ix->rq_join[side - 1], 0));
   }
   const int jfull = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
   const int J = tstride <= 128 ? jfull : std::max(6, std::min(jfull, (jfull * 128 + tstride - 1) / tstride));
