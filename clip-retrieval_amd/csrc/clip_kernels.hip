@@ -669,24 +669,32 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ pi
     const int64_t row = idx / nch;
     const int t = (int)(row % T), b = (int)(row / T);
     bf16x8 o;
+    // the eight loads are unconditional (coordinates clamped, the value discarded afterwards): behind a per-element
+    // `if (t > 0 && k < K)` hipcc put every load in its own branch with an s_waitcnt vmcnt(0) -- eight serialised round trips
+    const int tp = t > 0 ? t - 1 : 0;
+    const int py = tp / gdim, px = tp - py * gdim;
+    float raw[8];
+    int cc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = ch * 8 + e;
-      float v = 0.f;
-      if (t > 0 && k < K) {
-        const int c = k / PP, rem = k - c * PP;
-        const int iy = rem / P, ix = rem - iy * P;
-        const int py = (t - 1) / gdim, px = (t - 1) - py * gdim;
-        const int yy = py * P + iy, xx = px * P + ix;
-        if (FMT == 0) {
-          v = reinterpret_cast<const float*>(pixels)[(((size_t)b * 3 + c) * S + yy) * S + xx];
-        } else {
-          const float u = (float)reinterpret_cast<const unsigned char*>(pixels)[(((size_t)b * S + yy) * S + xx) * 3 + c];
-          const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), inv = c == 0 ? i0 : (c == 1 ? i1 : i2);
-          v = (u * (1.f / 255.f) - mean) * inv;
-        }
+      const int kk = k < K ? k : K - 1;
+      const int c = kk / PP, rem = kk - c * PP;
+      const int iy = rem / P, ix = rem - iy * P;
+      const int yy = py * P + iy, xx = px * P + ix;
+      cc[e] = c;
+      if (FMT == 0) raw[e] = reinterpret_cast<const float*>(pixels)[(((size_t)b * 3 + c) * S + yy) * S + xx];
+      else raw[e] = (float)reinterpret_cast<const unsigned char*>(pixels)[(((size_t)b * S + yy) * S + xx) * 3 + c];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = raw[e];
+      if (FMT != 0) {
+        const int c = cc[e];
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), inv = c == 0 ? i0 : (c == 1 ? i1 : i2);
+        v = (v * (1.f / 255.f) - mean) * inv;
       }
-      o[e] = (bf16)v;
+      o[e] = (t > 0 && ch * 8 + e < K) ? (bf16)v : (bf16)0.f;
     }
     *reinterpret_cast<bf16x8*>(out + (size_t)row * Kp + ch * 8) = o;
   }
