@@ -372,7 +372,9 @@ def main():
             cpu_knn = {"value": round(64 / (el * rows / n_cpu), 2), "unit": f"QPS@top-{k} over {rows} x {d} (extrapolated linearly from {n_cpu} rows)",
                        "cores": cpu_threads, "kind": "port", "sample": f"torch CPU fp32 matmul + topk, 64 queries x {n_cpu} rows, {el * 1e3:.0f} ms per batch"}
             del xc
-        ktraffic, _ = pmc_traffic("knn_scan_kernel") if rows == 100_000_000 else (None, None)
+        # the counter bytes of the kernel the roofline object describes (the best row's)
+        kfam = "knn_rq_scan_kernel" if "knn_rq_scan_kernel" in head["roofline"].get("kernel", "") else "knn_scan_kernel"
+        ktraffic, _ = pmc_traffic(kfam) if rows == 100_000_000 else (None, None)
         knn = {"metric": f"QPS@top-{k}, flat IP, fp16 rows in HBM", "qps": best["qps"], "qps_batch": best["B"],
                "rows_per_gpu": rows, "total_rows": rows * world, "d": d, "k": k,
                "queries_per_scan": head["B"], "ms_per_batch": head["ms_per_batch"],
