@@ -64,8 +64,8 @@ struct knnx_index {
   size_t pin_bytes = 0;
   // device scratch of reconstruct / range_fetch, kept between calls (hipMalloc + hipFree per request cost more than a
   // small search: hipFree synchronises the device); grown on demand, released with the index.  Used under ix->mu only.
-  void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_bytes[4] = {0, 0, 0, 0};
+  void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
 
   // IVF-Flat state (knnx_ivf_set_lists): rows live list-sorted and tile-padded in `rows`; see knn_kernels.hip
   int ivf_nlist = 0, ivf_nprobe = 1;
@@ -302,7 +302,7 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->ivfb_lists);
   hipFree(ix->ivfb_pos);
   if (ix->pin) hipHostFree(ix->pin);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 6; ++i)
     if (ix->scratch[i]) hipFree(ix->scratch[i]);
   for (auto& ev : ix->prof_events) {
     hipEventDestroy(ev.first);
@@ -834,6 +834,8 @@ extern "C" int knnx_reconstruct(knnx_index* ix, const int64_t* ids, int64_t n, f
 // range scan of <= KNN_NQ queries; leaves per-query counts in `counts` and the hits on the device
 // (query i's hits at range_s/range_i[i*cap .. i*cap+counts[i]), cap = range_pool / nq)
 static const size_t RANGE_POOL_MAX = (size_t)1 << 29;  // 512 Mi hits = 4 GiB of scratch
+constexpr int64_t RANGE_BATCH_MAX_ROWS = 1 << 16;  // range_scan_batched: indexes up to this many rows (a scan is launch-bound there)
+
 static int range_scan(knnx_index* ix, const float* q_host, int nq, float thr, std::vector<unsigned>& counts,
                       unsigned* cap_out) {
   hipStream_t st = ix->stream;
@@ -897,9 +899,84 @@ static int range_scan(knnx_index* ix, const float* q_host, int nq, float thr, st
   }
 }
 
+// Many queries against a SMALL flat index (the per-request dedup of clip_back.py:290-294: the k result vectors against themselves,
+// k up to 3 000): all 32-query groups are launched back to back, every group with its own counters and its own slice of the hit
+// pool, and the host synchronises ONCE for the counts -- the one-group-at-a-time loop costs two synchronisations per group
+// (94 groups at k = 3 000: 10 ms of a 45 ms request, profiles/r03h_request.log).  counts [n]; *cnt_dev_out = the device counters
+// (scratch slot 4) for range_fetch.
+static int range_scan_batched(knnx_index* ix, const float* q_host, int n, float thr, std::vector<unsigned>& counts, unsigned* cap_out,
+                              unsigned** cnt_dev_out) {
+  hipStream_t st = ix->stream;
+  const int ngroups = (n + KNN_NQ - 1) / KNN_NQ;
+  const size_t nr = (size_t)ngroups * KNN_NQ;
+  float* q_all = nullptr;
+  unsigned* cnt_all = nullptr;
+  int r = ensure_scratch(ix, 3, nr * ix->d * sizeof(float), (void**)&q_all);
+  if (!r) r = ensure_scratch(ix, 4, nr * sizeof(unsigned), (void**)&cnt_all);
+  if (r) return r;
+  if (scratch_acquire(ix, st)) return KNNX_E_HIP;
+  HIPCHK(hipMemcpyAsync(q_all, q_host, (size_t)n * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
+  for (;;) {
+    if (ix->range_pool == 0) {
+      ix->range_pool = (size_t)1 << 21;
+      HIPCHK(hipMalloc(&ix->range_s, ix->range_pool * sizeof(float)));
+      HIPCHK(hipMalloc(&ix->range_i, ix->range_pool * sizeof(uint32_t)));
+    }
+    const unsigned cap = (unsigned)std::min<size_t>(ix->range_pool / nr, 0xffffffffu);
+    unsigned mx = 0;
+    if (cap > 0) {
+      for (int g = 0; g < ngroups; ++g) {
+        const int q0 = g * KNN_NQ, nq = std::min(KNN_NQ, n - q0);
+        HIPCHK(launch_prep(q_all + (size_t)q0 * ix->d, nq, ix->d, ix->qfrag, ix->thr_g, cnt_all + q0, 0, nullptr, st));
+        ScanArgs a{};
+        a.X = ix->rows;
+        a.N = ix->ntotal;
+        a.d = ix->d;
+        a.qfrag = ix->qfrag;
+        a.nq = nq;
+        a.k = 1;
+        a.cap = 2;
+        a.grid = ix->n_cu;
+        a.mode = 1;
+        a.thr_g = ix->thr_g;
+        a.range_thr = thr;
+        a.range_cnt = cnt_all + q0;
+        a.range_cap = cap;
+        a.range_s = ix->range_s + (size_t)q0 * cap;
+        a.range_i = ix->range_i + (size_t)q0 * cap;
+        HIPCHK(launch_scan(a, st));
+      }
+      counts.assign(nr, 0u);
+      HIPCHK(hipMemcpyAsync(counts.data(), cnt_all, nr * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      for (int i = 0; i < n; ++i) mx = std::max(mx, counts[i]);
+      if (mx <= cap) {
+        *cap_out = cap;
+        *cnt_dev_out = cnt_all;
+        return 0;
+      }
+    } else {
+      mx = 1;
+    }
+    // overflow: regrow and rescan (the counts are exact even when the buffers overflowed)
+    size_t want = ix->range_pool;
+    while (want / nr < (size_t)mx) want <<= 1;
+    if (want > RANGE_POOL_MAX) return fail(KNNX_E_NOMEM, "range_search result exceeds the 512 Mi-hit scratch limit");
+    hipFree(ix->range_s);
+    hipFree(ix->range_i);
+    ix->range_s = nullptr;
+    ix->range_i = nullptr;
+    ix->range_pool = 0;
+    HIPCHK(hipMalloc(&ix->range_s, want * sizeof(float)));
+    HIPCHK(hipMalloc(&ix->range_i, want * sizeof(uint32_t)));
+    ix->range_pool = want;
+  }
+}
+
 // copy the hits of the last range_scan to the host, ids ascending inside each query
 static int range_fetch(knnx_index* ix, int nq, const std::vector<unsigned>& counts, unsigned cap, float* D,
-                       int64_t* I) {
+                       int64_t* I, const unsigned* cnt_dev = nullptr) {
+  if (!cnt_dev) cnt_dev = ix->range_cnt;
   std::vector<int64_t> loc(nq + 1);
   loc[0] = 0;
   for (int i = 0; i < nq; ++i) loc[i + 1] = loc[i] + counts[i];
@@ -913,7 +990,7 @@ static int range_fetch(knnx_index* ix, int nq, const std::vector<unsigned>& coun
   if (rr) return rr;
   hipError_t e = hipMemcpyAsync(lims_dev, loc.data(), (nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ix->stream);
   if (e == hipSuccess)
-    e = launch_range_sort(ix->range_s, ix->range_i, ix->range_cnt, cap, lims_dev, ix->id_base,
+    e = launch_range_sort(ix->range_s, ix->range_i, cnt_dev, cap, lims_dev, ix->id_base,
                           ix->ivf_nlist ? ix->ivf_idmap : nullptr, nq, D_dev, I_dev, ix->stream);
   // hit lists too long for rank-by-counting: radix sort by id, one query at a time
   unsigned longest = 0;
@@ -989,6 +1066,19 @@ extern "C" int knnx_range_search_once(knnx_index* ix, const float* q, int n, flo
   bool fits = true;
   std::vector<unsigned> counts;
   lims[0] = 0;
+  if (!ix->ivf_nlist && n > KNN_NQ && ix->ntotal <= RANGE_BATCH_MAX_ROWS) {  // small flat index, many queries: one synchronisation
+    unsigned cap = 0;
+    unsigned* cnt_dev = nullptr;
+    int r = range_scan_batched(ix, q, n, thresh, counts, &cap, &cnt_dev);
+    if (r) return r;
+    for (int i = 0; i < n; ++i) {
+      run += counts[i];
+      lims[i + 1] = run;
+    }
+    if (run > capacity) return 1;
+    counts.resize(n);
+    return range_fetch(ix, n, counts, cap, D, I, cnt_dev);
+  }
   for (int o = 0; o < n; o += KNN_NQ) {
     const int nq = std::min(KNN_NQ, n - o);
     unsigned cap = 0;

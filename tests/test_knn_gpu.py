@@ -181,6 +181,40 @@ def test_range_search_parity():
         assert lims[0] == 0 and lims[-1] == len(D) == len(I)
 
 
+def test_range_search_many_queries_on_a_small_index_is_batched():
+    """More than 32 queries against a small flat index (the dedup of a request's k result vectors: clip_back.py:290-294): every
+    32-query group is launched back to back with its own counters and slice of the hit pool, one synchronisation for all
+    (knnx_range_search_once).  Must equal the oracle: sparse results, dense results that overflow the first pool (regrow +
+    rescan), hit lists long enough for the radix sort, a ragged last group."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d = 512
+    x = _data(3001, d, 33)
+    x[1000:1040] = x[5] + 0.02 * _data(40, d, 34)  # a cluster: long lists at a high threshold
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    ix, o = Mi355xIndex(d), FlatIPOracle(d)
+    ix.add(x)
+    o.add(x)
+    xs = x.astype(np.float16).astype(np.float32)  # the stored rows
+    for nq, thr in ((3001, 0.94), (333, 0.5), (100, -1.0), (65, 0.02)):
+        q = np.ascontiguousarray(xs[:nq])
+        lims, D, I = ix.range_search(q, thr)
+        lo, Do, Io = o.range_search(q, thr)
+        s = o.scores(q)
+        assert lims[0] == 0 and lims[-1] == len(D) == len(I)
+        for i in range(nq):
+            a, b = I[lims[i]:lims[i + 1]], Io[lo[i]:lo[i + 1]]
+            if not np.array_equal(a, b):  # rows within fp32 noise of the threshold may fall either side
+                for r in set(a.tolist()) ^ set(b.tolist()):
+                    assert abs(s[i, r] - thr) < 2e-6, (nq, thr, i, r, s[i, r])
+            assert (np.diff(a) > 0).all(), "ids ascending within a query"
+            assert np.allclose(D[lims[i]:lims[i + 1]], s[i, a], atol=1e-5)
+    lims, D, I = ix.range_search(np.ascontiguousarray(xs[:100]), -1.0)
+    assert (np.diff(lims) == 3001).all()  # every row of the index for every query: 300 100 hits through the regrown pool
+    ix.close()
+
+
 @pytest.mark.parametrize("k", [65, 200, 3000])
 def test_large_k_parity(k):
     from clip_retrieval_amd.knn import Mi355xIndex

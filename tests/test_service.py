@@ -126,6 +126,9 @@ def test_gpu_dedup_and_knn_search_match_the_reference_logic():
     R = normalized(x16[np.r_[0:20, 100:110, 499:501, 7]].astype(np.float32))
     assert set(hp.get_non_uniques(R)) == ref_non_uniques(R)
     assert hp.get_non_uniques(R[:1]) == [] and hp.get_non_uniques(np.zeros((0, d), np.float32)) == []
+    # the front end's k = 3000: 94 groups of 32 result vectors, launched back to back (knnx_range_search_once, batched)
+    big = normalized(x16[:3000].astype(np.float32))
+    assert set(hp.get_non_uniques(big)) == ref_non_uniques(big)
 
     ix, o = Mi355xIndex(d), FlatIPOracle(d)
     ix.add(x16)
