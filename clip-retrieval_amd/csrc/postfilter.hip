@@ -42,12 +42,21 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
     {
       const int r = tid >> 2, kq = (tid & 3) * 4;
       const int gr = row0 + r, gc = col0 + r;
-      float xv[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
+      // unconditional loads from clamped coordinates, masked afterwards: behind per-element tests hipcc waits for every load
+      // on its own (the pattern found in the hit re-scoring kernel)
+      float xv[4], wv[4];
+      const size_t xr = (size_t)(gr < n ? gr : n - 1) * K, wr = (size_t)(gc < N ? gc : N - 1) * K;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int k = k0 + kq + e;
-        if (gr < n && k < K) xv[e] = X[(size_t)gr * K + k];
-        if (gc < N && k < K) wv[e] = W[(size_t)gc * K + k];
+        const int k = k0 + kq + e, kc = k < K ? k : K - 1;
+        xv[e] = X[xr + kc];
+        wv[e] = W[wr + kc];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool kin = k0 + kq + e < K;
+        xv[e] = (gr < n && kin) ? xv[e] : 0.f;
+        wv[e] = (gc < N && kin) ? wv[e] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
