@@ -3,7 +3,8 @@
 The reference obtains it as the third value of `load_clip` (clip_retrieval/clip_inference/worker.py:52-57) and calls it as
 `tokenizer([caption])[0]` in the readers (reader.py:83,87,144-145) and `tokenizer([text])` in the service (clip_back.py:227).
 The implementation lives in third-party wheels that are not installed here (`clip.simple_tokenizer.SimpleTokenizer`,
-re-exported by open_clip; all_clip calls it with truncate=True), so this is a restatement of the PUBLISHED algorithm:
+re-exported by open_clip; all_clip calls it with truncate=True), so this is restated from OpenAI CLIP's `simple_tokenizer.py`
+(MIT licence; bit-compatibility with its ids forces the same steps):
 
   text -> html.unescape twice, strip (ftfy.fix_text first when the `ftfy` package is importable; it is optional in CLIP
           too) -> collapse whitespace -> lower-case
