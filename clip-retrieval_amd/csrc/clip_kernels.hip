@@ -956,6 +956,228 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 #undef A_STAMP
 }
 
+// =============================================================================================
+// Persistent attention for the long image sequences (head dim 64, not causal, NKB = 9: ViT-L/14's T = 257).
+// One workgroup of 6 waves per CU walks the (batch, head) pairs; K and V of the NEXT pair arrive by LDS-DMA into the other
+// half of the LDS (2 x 72 KiB) while the current pair is computed, so the staging -- 39 % of a wave's time per head in the
+// one-head-per-workgroup kernel above (24 register loads, 12 ds_write_b128 and 96 transposing ds_write_b32 per thread), which
+// can only overlap it across the two workgroups a CU holds -- needs no registers, no LDS stores and no transposition pass:
+//   * K image as above (128-B rows, 16-B chunk position XOR ((key >> 1) & 7)), written by global_load_lds_dwordx4 with the
+//     swizzle folded into each lane's SOURCE address (the DMA writes lane-linear);
+//   * V stays row-major: two [TP keys][32 d] images (64-B rows), and the A fragments of O^T = V^T P^T -- 4 consecutive keys of
+//     ONE column per lane -- come out of ds_read_b64_tr_b16, the gfx950 transposing LDS read (a 16-lane group reads a
+//     [4 keys][16 d] tile: lane i supplies the address of row i >> 2, piece 4 (i & 3), and receives column i;
+//     tools/tr_probe.hip).  With 64-B rows the 32 lanes of a read group touch 32 distinct 8-B slots of the 256-B bank row.
+// Query blocks are dealt w, w + 6: waves 0 - 2 take two, waves 3 - 5 one (9 blocks on 6 waves) -- and waves 3 - 5 issue all of
+// the DMAs (an LDS-DMA issue holds its wave for ~100 cycles; spread over all six waves the kernel was no faster than the one
+// above, issued by the waves with time to spare it is 6 % faster: 174 vs 186 us at B H = 4096, same box, alternating).  The
+// S^T / softmax / PV arithmetic is the kernel's above, operation for operation: the outputs are the same bits.
+// (Also built and measured: two 3-wave workgroups per CU, one LDS image each, K of the next pair requested as soon as the last
+// S phase is over and V at the top of its own pair: every wave issues 24 DMAs per pair -- 212 us.
+// profiles/r03_rejected/attention_persistent_3wave_split_dma.patch)
+// =============================================================================================
+template <int NKB>
+__global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T, int H,
+                                                            int nheads, float scale_log2e, int q_blocks) {
+  constexpr int DH = 64, KS = 4, NW = 6, NDW = 3, QPW = (NKB + NW - 1) / NW, TP = NKB * 32, KROW = 128, NB = 2;
+  constexpr int KBYTES = TP * KROW, VHALF = TP * 64, BUF = KBYTES + 2 * VHALF;
+  constexpr int KDMA = TP * 8 / 64 / NDW, VDMA = 2 * TP * 4 / 64 / NDW;
+  static_assert(TP * 8 % (64 * NDW) == 0, "the DMA pieces must divide evenly among the issuing waves");
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hb = lane >> 5, l31 = lane & 31;
+  const int ld = 3 * H * DH;  // qkv row stride (elements)
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+
+  // ---- DMA of one pair into LDS half `buf`, by waves NW - NDW .. NW - 1.  Per-lane source offsets (bytes from the pair's q
+  // base) are recomputed per piece -- a handful of VALU on waves that have the time.  The lane id goes through an opaque asm per
+  // call: the offsets are loop-invariant, and hoisted out of the pair loop they would occupy 24 registers for the whole kernel.
+  auto issue = [&](int hd, int buf) {
+    if (w < NW - NDW) return;  // wave-uniform
+    const int ww = w - (NW - NDW);
+    const int b = hd / H, h = hd - b * H;
+    const char* base = reinterpret_cast<const char*>(qkv + (size_t)b * T * ld + h * DH);
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));
+#pragma unroll
+    for (int j = 0; j < KDMA; ++j) {
+      const int c = (ww * KDMA + j) * 64 + lane_v;  // 16-B chunk of the K image, lane-linear
+      const int key = c >> 3, pos = c & 7;
+      const int kk = key < T ? key : T - 1;  // rows past T repeat the last one (masked in S, finite in V)
+      const unsigned off = (unsigned)((kk * ld + H * DH + ((pos ^ ((key >> 1) & 7)) << 3)) * 2);
+      const unsigned m0 = lds_base + buf * BUF + (ww * KDMA + j) * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(m0) : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < VDMA; ++j) {
+      const int c = (ww * VDMA + j) * 64 + lane_v;  // chunk of the two V images [nb][key][4 chunks]
+      const int nbh = c / (TP * 4), rem = c - nbh * (TP * 4);
+      const int key = rem >> 2, pos = rem & 3;
+      const int kk = key < T ? key : T - 1;
+      const unsigned off = (unsigned)((kk * ld + 2 * H * DH + 32 * nbh + 8 * pos) * 2);
+      const unsigned m0 = lds_base + buf * BUF + KBYTES + (ww * VDMA + j) * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(m0) : "memory");
+    }
+  };
+  // Q fragments (B operand: lane (q = l31, hb) holds Q[q][16s + 8hb .. +8]).  A block's fragments are dead once its S phase is
+  // over: the NEXT pair's are requested into the same registers right there, behind the next pair's DMA (hipcc's own vmcnt for
+  // them then covers the DMAs it cannot see, never the other way round).
+  bf16x8 qn[QPW][KS];
+  auto load_q = [&](int hd, int qi) {
+    const int b = hd / H, h = hd - b * H;
+    const bf16* qbase = qkv + (size_t)b * T * ld + h * DH;
+    const int qpos = (qi * NW + w) * 32 + l31;
+    const int qrow = qpos < T ? qpos : T - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint4 v = *reinterpret_cast<const uint4*>(qbase + (size_t)qrow * ld + 16 * s + 8 * hb);
+      qn[qi][s] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  };
+
+  int hd = blockIdx.x;
+  if (hd >= nheads) return;
+  issue(hd, 0);
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi) load_q(hd, qi);
+  const int ksw = (l31 >> 1) & 7;
+  const unsigned vlane = (unsigned)(((lane & 15) >> 2) * 64 + (16 * ((lane >> 4) & 1)) * 2 + (lane & 3) * 8);
+  int buf = 0;
+  for (; hd < nheads; hd += gridDim.x, buf ^= 1) {
+    // the issuing waves' shares of the pair's K / V have landed, then the barrier tells everyone; every wave is also done
+    // reading the other half, which the next pair's DMA is about to overwrite.  (Waves 0 - 2 issue no DMA: they do not wait
+    // here for their own output stores, the critical path of the pair.)
+    if (w >= NW - NDW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nxt = hd + gridDim.x;
+    if (nxt < nheads) issue(nxt, buf ^ 1);
+    const unsigned char* sK = smem + buf * BUF;
+    const unsigned char* sV = sK + KBYTES;
+    const int b = hd / H, h = hd - b * H;
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+      const int qb = qi * NW + w;
+      if (qb >= NKB || qb >= q_blocks) break;
+      const int qpos = qb * 32 + l31;
+      bf16x8 qf[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) qf[s] = qn[qi][s];
+      f32x16 sacc[NKB];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        f32x16 sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sb[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int c = 2 * s + hb;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * KROW + ((c ^ ksw) << 4));
+          sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sb, 0, 0, 0);
+        }
+        if (kb == NKB - 1) {  // keys past T
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+            sb[r] = key < T ? sb[r] : -INFINITY;
+          }
+        }
+        sacc[kb] = sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sb[r]);
+      }
+      if (nxt < nheads) load_q(nxt, qi);  // this block's Q is dead: the next pair's lands under exp + PV
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (mx == -INFINITY) mx = 0.f;
+      const float nmx = -mx * scale_log2e;
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      f32x2_t sum2 = {0.f, 0.f};
+      const int tail_keys = T - (NKB - 1) * 32;
+      f32x16 oacc[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        bf16x8 pf[2];
+        const f32x16 sb = sacc[kb];
+        unsigned pw[8];
+        const bool short_tail = kb == NKB - 1 && tail_keys <= 4;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          if (short_tail && r >= 4) {
+            pw[r >> 1] = 0u;
+            continue;
+          }
+          const f32x2_t e = (f32x2_t){sb[r], sb[r + 1]} * (f32x2_t){scale_log2e, scale_log2e} + (f32x2_t){nmx, nmx};
+          const f32x2_t pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          sum2 += pp;
+          pw[r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(pp, bf16x2_t));
+        }
+        {
+          const uint4 w0 = make_uint4(pw[0], pw[1], pw[2], pw[3]), w1 = make_uint4(pw[4], pw[5], pw[6], pw[7]);
+          pf[0] = *reinterpret_cast<const bf16x8*>(&w0);
+          pf[1] = *reinterpret_cast<const bf16x8*>(&w1);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            // lane (d = 32nb + l31, hb): keys kb*32 + 16*s2 + 4hb + {0..3} and + 8 + {0..3}, each quad one transposing read
+            const unsigned char* vp = sV + nb * VHALF + (kb * 32 + 16 * s2 + 4 * hb) * 64 + vlane;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vp));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vp + 8 * 64));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s2], oacc[nb], 0, 0, 0);
+          }
+      }
+      float sum = sum2[0] + sum2[1];
+      sum += __shfl_xor(sum, 32);
+      const float inv = sum > 0.f ? 1.f / sum : 0.f;
+      if (qpos < T) {
+        bf16* orow = out + ((size_t)b * T + qpos) * (H * DH) + h * DH;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nb][4 * g + e] * inv);
+            *reinterpret_cast<bf16x4*>(orow + 32 * nb + 8 * g + 4 * hb) = o;
+          }
+      }
+    }
+  }
+}
+
+static int attn_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+static hipError_t launch_attention_pk9(const bf16* qkv, bf16* out, int B, int T, int H, hipStream_t st, int q_blocks) {
+  constexpr int NKB = 9, TP = NKB * 32;
+  const size_t smem = (size_t)2 * (TP * 128 + 2 * TP * 64);
+  auto kern = attention_pk_kernel<NKB>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  const int nheads = B * H, grid = std::min(nheads, attn_cu_count());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(384), smem, st, qkv, out, T, H, nheads, (1.f / 8.f) * 1.4426950408889634f,
+                     q_blocks > 0 && q_blocks < NKB ? q_blocks : NKB);
+  return hipGetLastError();
+}
+
 #ifdef CLIPX_ABLATE
 extern "C" int clipx_dbg_attn_phase(long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_phase), (size_t)n * sizeof(long long));
@@ -1032,7 +1254,12 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
         hipLaunchKernelGGL(kern, dim3(B * H), dim3(192), smem, st, qkv, out, T, H, (1.f / 8.f) * 1.4426950408889634f, 0, 9);
         return hipGetLastError();
       }
-      return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st, q_blocks);
+#ifdef CLIPX_ABLATE
+      if (cfg == 10 || causal) return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st, q_blocks);  // the one-head-per-workgroup kernel (A/B)
+#else
+      if (causal) return launch_attention_cfg<64, 9, 3, 3>(qkv, out, B, T, H, causal, st, q_blocks);
+#endif
+      return launch_attention_pk9(qkv, out, B, T, H, st, q_blocks);
     }
     default: return hipErrorInvalidValue;
   }
