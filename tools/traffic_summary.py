@@ -19,7 +19,7 @@ import json
 import sys
 
 GROUPS = {"knn_rq_scan_kernel": "knn_rq_scan_kernel", "knn_scan_kernel": "knn_scan_kernel", "gemm256sp_kernel": "gemm", "gemm_bf16_kernel": "gemm",
-          "attention_kernel": "attention", "layernorm_kernel": "layernorm"}
+          "attention_kernel": "attention", "attention_pk_kernel": "attention", "layernorm_kernel": "layernorm"}
 SCANS = ("knn_scan_kernel", "knn_rq_scan_kernel")
 
 
