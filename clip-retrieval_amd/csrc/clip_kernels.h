@@ -73,19 +73,22 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 
 // qkv bf16 [B*T, 3*H*dh] -> out bf16 [B*T, H*dh]; softmax(q k^T / sqrt(dh) [+ causal]) v, head dim dh = 64 or 80
 // q_blocks > 0: only the first q_blocks 32-row query blocks are computed (rows past them are left untouched); 0 = all
-hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st, int q_blocks = 0);
+// offs / lens (both or neither; head dim 64, T <= 128): ragged batch -- sample b owns rows offs[b] .. offs[b] + lens[b] - 1
+hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st, int q_blocks = 0,
+                            const int* offs = nullptr, const int* lens = nullptr);
 
 // ids int32 [B, T] -> tok_emb[id] + pos_emb[t] as x f32 [B*T, d] (may be null) and / or x16 [B*T, d] (may be null; bf16, or
 // IEEE fp16 when x16_f16 != 0: the text tower's residual stream)
 hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T,
-                             int d, int vocab, hipStream_t st, void* x16 = nullptr, int x16_f16 = 0);
+                             int d, int vocab, hipStream_t st, void* x16 = nullptr, int x16_f16 = 0, const int* rowmap = nullptr,
+                             int nrows = 0);
 
 // pooled row (CLS, or argmax(ids) for text) -> LayerNorm -> @ proj^T [E, d] -> / L2 norm -> fp16 [B, E]
 // x: the residual stream, f32 [B*T, d] or (x_f16 != 0) IEEE fp16
 // scratch: B * E floats of device memory (the un-normalised projection between the two kernels)
 // pooled rows (token 0, or the EOT token of `ids`) of att [B*T, d] bf16 and x16 [B*T, d] fp16 -> attc / xc [B, d]
 hipError_t launch_gather_pooled(const bf16* att, const void* x16, const int32_t* ids_or_null, bf16* attc, void* xc, int B, int T,
-                                int d, hipStream_t st);
+                                int d, hipStream_t st, const int* rows_or_null = nullptr);
 hipError_t launch_tail(const void* x, const int32_t* ids_or_null, const float* gamma, const float* beta,
                        const bf16* proj, uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d,
                        int E, float eps, hipStream_t st, int x_f16 = 0);

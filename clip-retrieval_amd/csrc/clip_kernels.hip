@@ -731,8 +731,9 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 // TIMER (CLIPX_ATTN_DBG=9, tools/attn_bench): per-wave shader-cycle totals of staging / S + max / exp + PV / store
 __device__ long long g_attn_phase[8192 * 4];
 template <int DH, int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP, bool TIMER = false>
-__global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T,
-                                                              int H, float scale_log2e, int dbg, int q_blocks) {
+__global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int Tin,
+                                                              int H, float scale_log2e, int dbg, int q_blocks,
+                                                              const int* __restrict__ offs, const int* __restrict__ lens) {
   constexpr int TP = NKB * 32;
   constexpr int CH = DH / 8;                      // 16-B chunks per key row
   constexpr int KS = DH / 16;                     // MFMA k-steps of the QK^T product
@@ -749,7 +750,10 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 #define A_STAMP(i) if (TIMER) { const long long n_ = (long long)__builtin_readcyclecounter(); tph[i] += n_ - tst; tst = n_; }
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int ld = 3 * H * DH;  // qkv row stride (elements)
-  const bf16* qbase = qkv + (size_t)b * T * ld + h * DH;
+  // ragged batches (the causal text tower: rows past a caption's EOT are never read): sample b owns rows offs[b] .. + lens[b]
+  const int T = lens ? lens[b] : Tin;
+  const size_t row0 = offs ? (size_t)offs[b] : (size_t)b * Tin;
+  const bf16* qbase = qkv + row0 * ld + h * DH;
   const bf16* kbase = qbase + H * DH;
   const bf16* vbase = qbase + 2 * H * DH;
   auto kchunk = [](int key, int c) -> int { return DH == 64 ? (c ^ ((key >> 1) & 7)) : c; };
@@ -935,7 +939,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
     if (TIMER) { asm volatile("" : "+v"(oacc[0]), "+v"(oacc[NB - 1])); A_STAMP(2) }
     // ---- store: lane owns query qpos, d = 32nb + 8g + 4hb + {0..3}
     if (qpos < T) {
-      bf16* orow = out + ((size_t)b * T + qpos) * (H * DH) + h * DH;
+      bf16* orow = out + (row0 + qpos) * (H * DH) + h * DH;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1185,7 +1189,8 @@ extern "C" int clipx_dbg_attn_phase(long long* host, int n) {
 #endif
 
 template <int DH, int NKB, int NW, int QPW, bool RECOMP = false>
-static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st, int q_blocks) {
+static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T, int H, int causal, hipStream_t st, int q_blocks,
+                                       const int* offs = nullptr, const int* lens = nullptr) {
   q_blocks = q_blocks > 0 && q_blocks < NKB ? q_blocks : NKB;
   constexpr int KROW = DH == 64 ? 128 : 176, DV = (DH + 31) / 32 * 32;
   const size_t smem = (size_t)NKB * 32 * KROW + (size_t)DV * (NKB * 64 + 8);
@@ -1200,18 +1205,21 @@ static hipError_t launch_attention_cfg(const bf16* qkv, bf16* out, int B, int T,
     auto kern = attention_kernel<DH, NKB, NW, QPW, true, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg, q_blocks);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg, q_blocks, offs, lens);
   } else {
     auto kern = attention_kernel<DH, NKB, NW, QPW, false, RECOMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg, q_blocks);
+    hipLaunchKernelGGL(kern, grid, block, smem, st, qkv, out, T, H, scale_log2e, dbg, q_blocks, offs, lens);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st, int q_blocks) {
+hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int dh, int causal, hipStream_t st, int q_blocks,
+                            const int* offs, const int* lens) {
   if (B <= 0) return hipSuccess;
+  if ((offs != nullptr) != (lens != nullptr)) return hipErrorInvalidValue;
+  if (offs && (dh != 64 || (T + 31) / 32 > 4)) return hipErrorInvalidValue;  // ragged batches: the short-sequence configurations only
   const int nkb = (T + 31) / 32;
   if (dh == 80) {  // ViT-H/14 image tower (T = 257), ViT-bigG is dh 104: not built
     switch (nkb) {
@@ -1224,10 +1232,10 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
   }
   if (dh != 64) return hipErrorInvalidValue;
   switch (nkb) {
-    case 1: return launch_attention_cfg<64, 1, 1, 1>(qkv, out, B, T, H, causal, st, q_blocks);
-    case 2: return launch_attention_cfg<64, 2, 2, 1>(qkv, out, B, T, H, causal, st, q_blocks);   // ViT-B/32 image (T=50)
-    case 3: return launch_attention_cfg<64, 3, 3, 1>(qkv, out, B, T, H, causal, st, q_blocks);   // text (T=77)
-    case 4: return launch_attention_cfg<64, 4, 4, 1>(qkv, out, B, T, H, causal, st, q_blocks);
+    case 1: return launch_attention_cfg<64, 1, 1, 1>(qkv, out, B, T, H, causal, st, q_blocks, offs, lens);
+    case 2: return launch_attention_cfg<64, 2, 2, 1>(qkv, out, B, T, H, causal, st, q_blocks, offs, lens);   // ViT-B/32 image (T=50)
+    case 3: return launch_attention_cfg<64, 3, 3, 1>(qkv, out, B, T, H, causal, st, q_blocks, offs, lens);   // text (T=77)
+    case 4: return launch_attention_cfg<64, 4, 4, 1>(qkv, out, B, T, H, causal, st, q_blocks, offs, lens);
     case 5: return launch_attention_cfg<64, 5, 3, 2>(qkv, out, B, T, H, causal, st, q_blocks);
     case 6: return launch_attention_cfg<64, 6, 3, 2>(qkv, out, B, T, H, causal, st, q_blocks);
     case 7: return launch_attention_cfg<64, 7, 4, 2>(qkv, out, B, T, H, causal, st, q_blocks);   // ViT-B/16 image (T=197)
@@ -1251,7 +1259,7 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
         auto kern = attention_kernel<64, 9, 3, 3, false, false, true>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(B * H), dim3(192), smem, st, qkv, out, T, H, (1.f / 8.f) * 1.4426950408889634f, 0, 9);
+        hipLaunchKernelGGL(kern, dim3(B * H), dim3(192), smem, st, qkv, out, T, H, (1.f / 8.f) * 1.4426950408889634f, 0, 9, (const int*)nullptr, (const int*)nullptr);
         return hipGetLastError();
       }
 #ifdef CLIPX_ABLATE
@@ -1270,16 +1278,18 @@ hipError_t launch_attention(const bf16* qkv, bf16* out, int B, int T, int H, int
 // =============================================================================================
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
                                                         const float* __restrict__ pos, float* __restrict__ x, int BT,
-                                                        int T, int d, int vocab, void* __restrict__ x16, int x16_f16) {
+                                                        int T, int d, int vocab, void* __restrict__ x16, int x16_f16,
+                                                        const int* __restrict__ rowmap) {
   const int d4 = d / 4;
   const int64_t total = (int64_t)BT * d4;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx % d4);
     const int row = (int)(idx / d4);
-    int id = ids[row];
+    const int src = rowmap ? rowmap[row] : row;  // ragged: output row `row` is token src = b T + t of the rectangular batch
+    int id = ids[src];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const float4 a = reinterpret_cast<const float4*>(tok + (size_t)id * d)[c];
-    const float4 p = reinterpret_cast<const float4*>(pos + (size_t)(row % T) * d)[c];
+    const float4 p = reinterpret_cast<const float4*>(pos + (size_t)(src % T) * d)[c];
     const float4 o = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
     if (x) reinterpret_cast<float4*>(x + (size_t)row * d)[c] = o;
     if (x16 && x16_f16) {
@@ -1295,11 +1305,13 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
 }
 
 hipError_t launch_text_embed(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int T, int d,
-                             int vocab, hipStream_t st, void* x16, int x16_f16) {
+                             int vocab, hipStream_t st, void* x16, int x16_f16, const int* rowmap, int nrows) {
   if (B <= 0) return hipSuccess;
-  const int64_t total = (int64_t)B * T * (d / 4);
+  const int rows = rowmap ? nrows : B * T;
+  if (rows <= 0) return hipSuccess;
+  const int64_t total = (int64_t)rows * (d / 4);
   const int blocks = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(text_embed_kernel, dim3(blocks), dim3(256), 0, st, ids, tok_emb, pos_emb, x, B * T, T, d, vocab, x16, x16_f16);
+  hipLaunchKernelGGL(text_embed_kernel, dim3(blocks), dim3(256), 0, st, ids, tok_emb, pos_emb, x, rows, T, d, vocab, x16, x16_f16, rowmap);
   return hipGetLastError();
 }
 
@@ -1387,12 +1399,12 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(const float* __restrict_
 // out-proj / MLP then run on B rows instead of B * T (nothing else of that block's output is ever read).
 __global__ __launch_bounds__(256) void gather_pooled_kernel(const bf16* __restrict__ att, const _Float16* __restrict__ x,
                                                            const int32_t* __restrict__ ids, bf16* __restrict__ attc,
-                                                           _Float16* __restrict__ xc, int T, int d) {
+                                                           _Float16* __restrict__ xc, int T, int d, const int* __restrict__ rows) {
   __shared__ int s_pos;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
     int best = 0;
-    if (ids) {
+    if (ids && !rows) {
       int bv = ids[(size_t)b * T];
       for (int t = 1; t < T; ++t) {
         const int v = ids[(size_t)b * T + t];
@@ -1402,7 +1414,7 @@ __global__ __launch_bounds__(256) void gather_pooled_kernel(const bf16* __restri
     s_pos = best;
   }
   __syncthreads();
-  const size_t row = (size_t)b * T + s_pos;
+  const size_t row = rows ? (size_t)rows[b] : (size_t)b * T + s_pos;  // ragged batches bring the pooled row of every sample
   const uint4* a = reinterpret_cast<const uint4*>(att + row * d);
   const uint4* xs = reinterpret_cast<const uint4*>(x + row * d);
   uint4* ao = reinterpret_cast<uint4*>(attc + (size_t)b * d);
@@ -1414,11 +1426,11 @@ __global__ __launch_bounds__(256) void gather_pooled_kernel(const bf16* __restri
 }
 
 hipError_t launch_gather_pooled(const bf16* att, const void* x16, const int32_t* ids_or_null, bf16* attc, void* xc, int B, int T,
-                                int d, hipStream_t st) {
+                                int d, hipStream_t st, const int* rows_or_null) {
   if (B <= 0) return hipSuccess;
   if (d % 8 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gather_pooled_kernel, dim3(B), dim3(256), 0, st, att, reinterpret_cast<const _Float16*>(x16), ids_or_null, attc,
-                     reinterpret_cast<_Float16*>(xc), T, d);
+                     reinterpret_cast<_Float16*>(xc), T, d, rows_or_null);
   return hipGetLastError();
 }
 

@@ -126,6 +126,19 @@ struct clipx_handle {
                                        // fresh buffers on every call (new addresses) never pays for captures it cannot reuse
   bool graphs_on = true;
   bool pool_last_block = true;  // last block past the attention on the pooled rows only (CLIPX_FULL_LAST_BLOCK=1: all rows)
+  // Ragged text tower (CLIPX_RAGGED_TEXT=0: off).  The text transformer is causal and the embedding is read at the EOT token:
+  // rows after a caption's EOT influence nothing that is read, so batches above the hipGraph sizes run every layer on
+  // sum(eot_i + 1) rows instead of B x ctx_len.  Per call: lens / offsets / row map / pooled rows, built on the host from the
+  // token ids, in a ring of RG_SLOTS page-locked + device buffers (a slot is reused when the event of its upload has passed).
+  static constexpr int RG_SLOTS = 4;
+  bool ragged_text = true;
+  int* rg_host[RG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  int* rg_dev[RG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t rg_ev[RG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  bool rg_used[RG_SLOTS] = {false, false, false, false};
+  int rg_next = 0;
+  int32_t* rg_ids_host = nullptr;          // device-pointer calls: the ids come back through this page-locked buffer
+  const int32_t* text_ids_host = nullptr;  // host-pointer calls: the caller's ids of the chunk in flight (set by slot_submit)
   int prof = 0;  // bit k set: launches of kind k (0 gemm, 1 attention, 2 layernorm, 3 other) are bracketed by hipEvents
   std::vector<ProfEvent> prof_events;
 };
@@ -280,6 +293,15 @@ static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
     HIPCHK(hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
   }
   HIPCHK(hipEventCreateWithFlags(&h->ev_ws, hipEventDisableTiming));
+  {
+    const size_t rg_ints = (size_t)Bm * (X.T + 3);
+    for (int i = 0; i < clipx_handle::RG_SLOTS; ++i) {
+      HIPCHK(hipHostMalloc((void**)&h->rg_host[i], rg_ints * sizeof(int), hipHostMallocDefault));
+      if ((r = dev_alloc(h, (void**)&h->rg_dev[i], rg_ints * sizeof(int)))) return r;
+      HIPCHK(hipEventCreateWithFlags(&h->rg_ev[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipHostMalloc((void**)&h->rg_ids_host, (size_t)Bm * X.T * sizeof(int32_t), hipHostMallocDefault));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -309,6 +331,8 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   h->host_chunk = std::min(h->host_chunk, h->max_batch);
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   if (gv) h->gemm_variant = std::min(5, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
+  const char* rgt = getenv("CLIPX_RAGGED_TEXT");
+  if (rgt && rgt[0] == '0') h->ragged_text = false;
   const char* fl = getenv("CLIPX_FULL_LAST_BLOCK");
   if (fl && atoi(fl) > 0) h->pool_last_block = false;
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -342,6 +366,11 @@ extern "C" void clipx_destroy(clipx_handle* h) {
     if (h->ev_done[s]) (void)hipEventDestroy(h->ev_done[s]);
   }
   if (h->ev_ws) (void)hipEventDestroy(h->ev_ws);
+  for (int i = 0; i < clipx_handle::RG_SLOTS; ++i) {
+    if (h->rg_host[i]) (void)hipHostFree(h->rg_host[i]);
+    if (h->rg_ev[i]) (void)hipEventDestroy(h->rg_ev[i]);
+  }
+  if (h->rg_ids_host) (void)hipHostFree(h->rg_ids_host);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   delete h;
@@ -395,10 +424,20 @@ static const void* pooled_rows(const clipx_handle* h, int B, int width) {
   return reinterpret_cast<const char*>(h->x) + (((size_t)B * width * sizeof(bf16) + 255) & ~(size_t)255);
 }
 
+struct Ragged {  // device arrays of one ragged text batch (see clipx_handle::ragged_text)
+  int M;                // rows in all: sum of the lengths
+  const int* offs;      // [B] first row of sample b
+  const int* lens;      // [B] rows of sample b (EOT position + 1)
+  const int* rowmap;    // [M] compact row -> b * ctx_len + t
+  const int* poolrows;  // [B] compact row of the EOT token
+  double att_flops;     // 4 heads dh sum(len^2)
+};
+
 // Returns in *pooled whether the residual stream that leaves the last block is the compact [B, width] buffer of pooled rows
 // (h->x reused) instead of h->xn [B * T, width].
-static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, int causal, const int32_t* ids, bool* pooled) {
-  const int M = B * t.T, w = t.width;
+static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, int causal, const int32_t* ids, bool* pooled,
+                      const Ragged* rg = nullptr) {
+  const int M = rg ? rg->M : B * t.T, w = t.width;
   const float eps = h->desc.ln_eps;
   const int act = h->desc.act == CLIPX_ACT_QUICK_GELU ? EPI_BIAS_QGELU_BF16 : EPI_BIAS_GELU_BF16;
   // On entry h->xn holds the residual stream x in fp16 (written by ln_pre / the text embedding).  Per block:
@@ -417,7 +456,8 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
     const bool pool_here = l == t.layers - 1 && h->pool_last_block && t.T > 1;
     const int q_blocks = pool_here && !ids ? 1 : 0;
     const double att_rows = q_blocks ? std::min(32, t.T) : t.T;
-    { ProfScope ps(h, st, 1, 4.0 * B * t.heads * att_rows * t.T * (w / t.heads)); HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st, q_blocks)); }
+    { ProfScope ps(h, st, 1, rg ? rg->att_flops * t.heads * (w / t.heads) : 4.0 * B * t.heads * att_rows * t.T * (w / t.heads));
+      HIPCHK(launch_attention(h->qkv, h->att, B, t.T, t.heads, w / t.heads, causal, st, q_blocks, rg ? rg->offs : nullptr, rg ? rg->lens : nullptr)); }
     if (pool_here) {
       // The embedding reads ONE row of this block's output per sample (token 0 / the EOT token: launch_tail), and past the
       // attention every operation of a block is row-wise: out-proj, both residual adds, LayerNorm 2 and the MLP run on those B
@@ -425,7 +465,7 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
       // bytes the full block gives (tests/test_clip_gpu.py; CLIPX_FULL_LAST_BLOCK=1 runs the full block).
       bf16* attc = reinterpret_cast<bf16*>(h->x);
       void* xc = reinterpret_cast<char*>(h->x) + (((size_t)B * w * sizeof(bf16) + 255) & ~(size_t)255);
-      { ProfScope ps(h, st, 3, 0); HIPCHK(launch_gather_pooled(h->att, h->xn, ids, attc, xc, B, t.T, w, st)); }
+      { ProfScope ps(h, st, 3, 0); HIPCHK(launch_gather_pooled(h->att, h->xn, ids, attc, xc, B, t.T, w, st, rg ? rg->poolrows : nullptr)); }
       if ((r = run_gemm(h, st, attc, L.out_w, L.out_b, xc, nullptr, 1, B, w, w, EPI_BIAS_RESID_H16))) return r;
       { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(xc, h->rstd, B, w, eps, st, 1)); }
       if ((r = run_gemm(h, st, reinterpret_cast<const bf16*>(xc), L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, B, t.mlp, w, act, h->rstd, true))) return r;
@@ -513,12 +553,62 @@ static int vision_chunk_body(clipx_handle* h, hipStream_t st, const void* pix_de
   return 0;
 }
 
+// Builds the ragged description of a text batch from its ids (host) and uploads it.  The pooling rule is launch_tail's /
+// gather_pooled's: the highest id, first occurrence (torch.argmax of the reference model).
+static int ragged_prepare(clipx_handle* h, hipStream_t st, const int32_t* ids_host, int B, Ragged* rg) {
+  const int T = h->txt.T;
+  const int s = h->rg_next;
+  h->rg_next = (s + 1) % clipx_handle::RG_SLOTS;
+  if (h->rg_used[s]) HIPCHK(hipEventSynchronize(h->rg_ev[s]));  // the upload that last read this slot's host buffer is done
+  int* host = h->rg_host[s];
+  int* offs = host, *lens = host + B, *pool = host + 2 * B, *rowmap = host + 3 * B;
+  int M = 0;
+  double f = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const int32_t* row = ids_host + (size_t)b * T;
+    int best = 0, bv = row[0];
+    for (int t = 1; t < T; ++t)
+      if (row[t] > bv) { bv = row[t]; best = t; }
+    const int len = best + 1;
+    offs[b] = M;
+    lens[b] = len;
+    pool[b] = M + best;
+    for (int t = 0; t < len; ++t) rowmap[M + t] = b * T + t;
+    M += len;
+    f += 4.0 * (double)len * len;
+  }
+  int* dev = h->rg_dev[s];
+  HIPCHK(hipMemcpyAsync(dev, host, ((size_t)3 * B + M) * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(h->rg_ev[s], st));
+  h->rg_used[s] = true;
+  rg->M = M;
+  rg->offs = dev;
+  rg->lens = dev + B;
+  rg->poolrows = dev + 2 * B;
+  rg->rowmap = dev + 3 * B;
+  rg->att_flops = f;
+  return 0;
+}
+
 static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32) {
   const clipx_model_desc& d = h->desc;
   const Tower& X = h->txt;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, nullptr, B, X.T, X.width, d.vocab, st, h->xn, 1)); }
+  Ragged rgv{};
+  const Ragged* rg = nullptr;
+  if (h->ragged_text && h->pool_last_block && B > GRAPH_MAX_B && X.T <= 128 && X.width / X.heads == 64) {
+    const int32_t* ids_host = h->text_ids_host;
+    if (!ids_host) {  // device-resident ids: one synchronisation of `st` to read them (CLIPX_RAGGED_TEXT=0 keeps the call asynchronous)
+      HIPCHK(hipMemcpyAsync(h->rg_ids_host, ids_dev, (size_t)B * X.T * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      ids_host = h->rg_ids_host;
+    }
+    int rr = ragged_prepare(h, st, ids_host, B, &rgv);
+    if (rr) return rr;
+    rg = &rgv;
+  }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_text_embed(ids_dev, h->tok_emb, h->txt_pos, nullptr, B, X.T, X.width, d.vocab, st, h->xn, 1, rg ? rg->rowmap : nullptr, rg ? rg->M : 0)); }
   bool pooled = false;
-  int r = run_layers(h, st, X, B, 1, ids_dev, &pooled);
+  int r = run_layers(h, st, X, B, 1, ids_dev, &pooled, rg);
   if (r) return r;
   const void* xf = pooled ? pooled_rows(h, B, X.width) : h->xn;
   { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(xf, pooled ? nullptr : ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, pooled ? 1 : X.T, X.width, d.embed_dim, d.ln_eps, st, 1)); }
@@ -618,8 +708,10 @@ static int slot_submit(clipx_handle* h, int kind, const char* src, size_t in_byt
   int r = ws_acquire(h, h->stream);
   if (r) return r;
   float* o32 = want32 ? h->dev_out32[s] : nullptr;
+  if (kind == KIND_TEXT) h->text_ids_host = reinterpret_cast<const int32_t*>(src);  // the ragged text tower reads the ids on the host
   r = kind == KIND_IMAGE ? vision_chunk(h, h->stream, h->dev_in[s], nb, pix_fmt, h->dev_out[s], o32)
                          : text_chunk(h, h->stream, (const int32_t*)h->dev_in[s], nb, h->dev_out[s], o32);
+  h->text_ids_host = nullptr;
   if (r) return r;
   if ((r = ws_release(h, h->stream))) return r;
   char* po = (char*)h->pin_out[s];

@@ -107,7 +107,10 @@ int clipx_wait(clipx_ticket* ticket);
  * hipMemcpyAsync double-buffering).  `stream` is a hipStream_t (NULL = the handle's stream);
  * asynchronous on that stream.  out_f32_or_null: optional f32 [B, embed_dim] copy of the
  * normalised embedding before the fp16 rounding (parity tests measure cosine on it).  The handle's activation workspace
- * is shared by all calls: consecutive calls are ordered by an event even when they use different streams. */
+ * is shared by all calls: consecutive calls are ordered by an event even when they use different streams.
+ * clipx_encode_text_device with B > 8 synchronises `stream` ONCE before its kernels are queued: it reads the token ids back
+ * to find every caption's EOT position, and then runs the (causal) text tower on the rows up to the EOT only -- the same
+ * embeddings, bit for bit (environment CLIPX_RAGGED_TEXT=0: every row, and a fully asynchronous call). */
 int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, int pix_fmt, uint16_t* out_f16_dev,
                               float* out_f32_or_null, void* stream);
 int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,

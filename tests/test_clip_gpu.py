@@ -222,6 +222,41 @@ def test_last_block_on_the_pooled_rows_equals_the_full_block(tiny):
     full.close()
 
 
+def test_ragged_text_tower_equals_the_rectangular_one(tiny):
+    """The text transformer is causal and the embedding is read at the EOT token, so rows after a caption's EOT are never read:
+    batches above the hipGraph sizes run every layer on sum(eot + 1) rows.  Same kernels on a subset of the rows -- and a row
+    does not depend on the rows it travels with -- so the embeddings must be the same BYTES as with CLIPX_RAGGED_TEXT=0, through
+    host and device pointers, for captions of every length (EOT first, EOT last, no early maximum), and match the oracle."""
+    from clip_retrieval_amd.encoder import ClipEncoder
+    from oracle.clip_oracle import mapper_semantics, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    os.environ["CLIPX_RAGGED_TEXT"] = "0"
+    try:
+        rect = ClipEncoder(_product_arch(arch), oracle.export_blob(), 0)
+    finally:
+        os.environ.pop("CLIPX_RAGGED_TEXT")
+    for B in (9, 33, 70):
+        ids = synth_tokens(B, seed=60 + B)
+        ids[0, :] = 5
+        ids[0, 0] = arch.vocab - 1          # EOT at position 0: one row
+        ids[1, :] = 7
+        ids[1, -1] = arch.vocab - 1         # EOT at the last position: all rows
+        ids[2, :] = np.arange(arch.ctx_len) % 11 + 1
+        ids[2, 20] = 400                    # no EOT token at all: the pooling rule is "highest id, first occurrence"
+        ids[2, 40] = 400
+        a, b = enc.encode_text(ids), rect.encode_text(ids)
+        assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), f"{name} B={B}: ragged != rectangular (host ids)"
+        dev_ids = torch.from_numpy(ids).cuda()
+        o16 = torch.empty(B, arch.embed_dim, dtype=torch.float16, device="cuda")
+        enc.encode_text_device(dev_ids.data_ptr(), B, o16.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(o16.cpu().numpy().view(np.uint16), b.view(np.uint16)), f"{name} B={B}: ragged != rectangular (device ids)"
+        _, want = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
+        assert _cos(a, want).min() >= COS_BAR
+    rect.close()
+
+
 def test_small_batches_replayed_from_graphs_equal_the_plain_launches(tiny):
     """Batches of <= 8 (the B = 1 query encode of clip_back.py:207-255) are captured into a hipGraph per (tower, B, buffers)
     and replayed; a batch of 12 takes the plain launches.  Rows do not depend on the batch they travel in (bitwise), so
