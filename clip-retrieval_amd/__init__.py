@@ -7,4 +7,4 @@ Nothing here computes on the CPU: every product entry point goes through `lib/li
 
 __version__ = "0.1.0"
 
-from ._lib import HipLibraryError, load_library, library_path  # noqa: F401
+from ._lib import HipLibraryError, ResidualStreamOverflow, load_library, library_path  # noqa: F401

@@ -18,6 +18,11 @@ class HipLibraryError(RuntimeError):
     """The HIP extension is missing/unloadable or a call into it failed."""
 
 
+class ResidualStreamOverflow(HipLibraryError):
+    """CLIPX_E_RANGE (include/clipx.h): the fp16 residual stream overflowed for these weights / inputs; the embeddings of the
+    call are invalid and were not returned."""
+
+
 def library_path():
     return _LIB_PATH
 
@@ -109,6 +114,9 @@ SIGNATURES = {
     "clipx_encode_image_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "clipx_encode_text_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "clipx_resize_crop_u8_device": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "clipx_range_check": (C.c_int, [_P, _P]),
+    "clipx_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
+    "clipx_get_option": (C.c_int, [_P, C.c_int]),
     "clipx_max_batch": (C.c_int, [_P]),
     "clipx_graphs_cached": (C.c_int, [_P]),
     "clipx_embed_dim": (C.c_int, [_P]),
@@ -155,4 +163,6 @@ def check(lib, rc, which):
     if rc != 0:
         fn = lib.knnx_last_error if which == "knnx" else lib.clipx_last_error
         msg = fn()
+        if which == "clipx" and rc == -6:
+            raise ResidualStreamOverflow(f"clipx call failed (code {rc}): {msg.decode() if msg else '?'}")
         raise HipLibraryError(f"{which} call failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -14,8 +14,11 @@ enum GemmEpilogue {
   EPI_BIAS_RESID_F32 = 3,   // out f32 [M,N] += acc + bias   (in place residual) (out_proj, fc2)
   EPI_TABLE_F32 = 4,        // out f32 = acc + table[m % T][n]                   (patch embed + cls/pos)
   EPI_RAW_F32 = 5,          // internal (split-K): out f32 [M,N] = acc, no bias; the reduction kernel applies the epilogue
-  EPI_BIAS_RESID_H16 = 6    // out fp16 [M,N] = fp16(f32(out) + (acc + bias)): the encoder's residual stream lives in IEEE fp16
+  EPI_BIAS_RESID_H16 = 6,   // out fp16 [M,N] = fp16(f32(out) + (acc + bias)): the encoder's residual stream lives in IEEE fp16
                             // (out_proj, fc2): a third of the bytes of the f32 read-modify-write + bf16 shadow of EPI 3
+  EPI_BIAS_F16 = 7          // out IEEE fp16 [M,N] = acc * rowscale + bias: EPI 0 with three more mantissa bits.  The QKV projection
+                            // (round 4): q and k feed the softmax logits, where the bf16 rounding of EPI 0 was the largest single
+                            // error of the encoder on weights with large LayerNorm gains (tools/emulate_fp16_stream.py)
 };
 
 struct GemmArgs {
@@ -58,7 +61,7 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 // LayerNorm statistics of the 16-bit residual stream rows (f16 != 0: IEEE fp16, else bf16): rstd[m] = 1 / sqrt(var(x16[m, :]) + eps)
 // (two-pass, fp32).  The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias
 // absorbs beta: clipx_api.hip fold_layernorm), whose epilogue multiplies by rstd[m].  One wave per row.
-hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16 = 0);
+hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16 = 0, int* range_flag = nullptr);
 
 // LayerNorm-folded weights: Wf[n, k] = r16(W[n,k] gamma[k] - mean_k(W[n,:] gamma)), cf[n] = bias[n] + sum_k beta[k] W[n,k];
 // r16 = bf16 rounding, or IEEE fp16 when f16 != 0
@@ -69,7 +72,7 @@ hipError_t launch_fill_f32(float* p, float v, int64_t n, hipStream_t st);
 // pixels -> bf16 patch matrix [B*T, Kp] (row b*T is the all-zero class-token row; k = c*P*P + iy*P + ix)
 // fmt 0: f32 NCHW already normalised (the reference's `image_tensor`); fmt 1: u8 NHWC, normalised here
 hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int Kp, const float* mean,
-                         const float* inv_std, bf16* out, hipStream_t st);
+                         const float* stdv, bf16* out, hipStream_t st);
 
 // qkv bf16 [B*T, 3*H*dh] -> out bf16 [B*T, H*dh]; softmax(q k^T / sqrt(dh) [+ causal]) v, head dim dh = 64 or 80
 // q_blocks > 0: only the first q_blocks 32-row query blocks are computed (rows past them are left untouched); 0 = all
@@ -91,7 +94,7 @@ hipError_t launch_gather_pooled(const bf16* att, const void* x16, const int32_t*
                                 int d, hipStream_t st, const int* rows_or_null = nullptr);
 hipError_t launch_tail(const void* x, const int32_t* ids_or_null, const float* gamma, const float* beta,
                        const bf16* proj, uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d,
-                       int E, float eps, hipStream_t st, int x_f16 = 0);
+                       int E, float eps, hipStream_t st, int x_f16 = 0, int* range_flag = nullptr);
 
 hipError_t launch_f32_to_bf16(const float* in, bf16* out, int64_t n, hipStream_t st);
 // conv weight [width, 3*P*P] f32 -> bf16 [width, Kp] zero padded

@@ -384,6 +384,7 @@ static hipError_t launch_gemm128(const GemmArgs& g, hipStream_t st) {
   if (S > 1) {
     switch (g.epi) {
       case EPI_BIAS_BF16: return launch_splitk_epi<EPI_BIAS_BF16>(g, S, st);
+      case EPI_BIAS_F16: return launch_splitk_epi<EPI_BIAS_F16>(g, S, st);
       case EPI_BIAS_QGELU_BF16: return launch_splitk_epi<EPI_BIAS_QGELU_BF16>(g, S, st);
       case EPI_BIAS_GELU_BF16: return launch_splitk_epi<EPI_BIAS_GELU_BF16>(g, S, st);
       case EPI_BIAS_RESID_F32: return launch_splitk_epi<EPI_BIAS_RESID_F32>(g, S, st);
@@ -394,6 +395,7 @@ static hipError_t launch_gemm128(const GemmArgs& g, hipStream_t st) {
   if (g.f16) {  // fp16 operands exist for the bf16-output epilogues only (the LayerNorm-folded GEMMs)
     switch (g.epi) {
       case EPI_BIAS_BF16: return launch_gemm_epi<EPI_BIAS_BF16, true>(g, st);
+      case EPI_BIAS_F16: return launch_gemm_epi<EPI_BIAS_F16, true>(g, st);
       case EPI_BIAS_QGELU_BF16: return launch_gemm_epi<EPI_BIAS_QGELU_BF16, true>(g, st);
       case EPI_BIAS_GELU_BF16: return launch_gemm_epi<EPI_BIAS_GELU_BF16, true>(g, st);
       default: return hipErrorInvalidValue;
@@ -401,6 +403,7 @@ static hipError_t launch_gemm128(const GemmArgs& g, hipStream_t st) {
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_gemm_epi<EPI_BIAS_BF16>(g, st);
+    case EPI_BIAS_F16: return launch_gemm_epi<EPI_BIAS_F16>(g, st);
     case EPI_BIAS_QGELU_BF16: return launch_gemm_epi<EPI_BIAS_QGELU_BF16>(g, st);
     case EPI_BIAS_GELU_BF16: return launch_gemm_epi<EPI_BIAS_GELU_BF16>(g, st);
     case EPI_BIAS_RESID_F32: return launch_gemm_epi<EPI_BIAS_RESID_F32>(g, st);
@@ -446,8 +449,9 @@ int gemm256_tail_blocks(int N, int K, int n_cu) {
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
-  if ((g.epi == EPI_BIAS_BF16 || g.epi == EPI_BIAS_QGELU_BF16 || g.epi == EPI_BIAS_GELU_BF16) && !g.rowscale) return hipErrorInvalidValue;
-  if (g.f16 && g.epi != EPI_BIAS_BF16 && g.epi != EPI_BIAS_QGELU_BF16 && g.epi != EPI_BIAS_GELU_BF16) return hipErrorInvalidValue;
+  const bool out16 = g.epi == EPI_BIAS_BF16 || g.epi == EPI_BIAS_QGELU_BF16 || g.epi == EPI_BIAS_GELU_BF16 || g.epi == EPI_BIAS_F16;
+  if (out16 && !g.rowscale) return hipErrorInvalidValue;
+  if (g.f16 && !out16) return hipErrorInvalidValue;
   if (g.variant >= 2 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
     const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
     // small problems (query-side B = 1: M = 257 or 77 rows) would put one 256x256 tile on each of a handful of CUs;
@@ -550,7 +554,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // rstd of the bf16 shadow rows (see clip_kernels.h: launch_rowstats); d = NV * 512: a lane holds NV x 8 consecutive values
 template <int NV2, bool F16>  // d = NV2 * 256 (NV2 x 4 values per lane); F16: rows are IEEE fp16, else bf16
-__global__ __launch_bounds__(256) void rowstats_kernel(const void* __restrict__ x16, float* __restrict__ rstd, int M, float eps) {
+__global__ __launch_bounds__(256) void rowstats_kernel(const void* __restrict__ x16, float* __restrict__ rstd, int M, float eps,
+                                                       int* __restrict__ range_flag) {
   constexpr int d = NV2 * 256;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -573,6 +578,11 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const void* __restrict__ 
     s += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  // Range guard of the fp16 residual stream (clipx.h: CLIPX_E_RANGE).  The residual epilogues round f32 -> fp16 to nearest, so a
+  // value beyond 65 504 is stored as inf; every state of the stream passes through this kernel (or tail_proj_kernel) before it
+  // is used, and a row holding inf / NaN has a non-finite sum (d finite fp16 values cannot overflow an f32).  Free: one
+  // compare on a value the kernel has anyway.
+  if (range_flag && lane == 0 && !(fabsf(s) <= 3.0e38f)) atomicOr(range_flag, 1);
   const float mean = s * (1.f / d);
   float q = 0.f;
 #pragma unroll
@@ -584,13 +594,13 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const void* __restrict__ 
   if (lane == 0) rstd[row] = 1.f / sqrtf(q * (1.f / d) + eps);
 }
 
-hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16) {
+hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16, int* range_flag) {
   if (M <= 0) return hipSuccess;
   const dim3 grid((M + 3) / 4), block(256);
 #define RS_CASE(NV)                                                                                        \
   case NV * 256:                                                                                           \
-    if (f16) hipLaunchKernelGGL((rowstats_kernel<NV, true>), grid, block, 0, st, x16, rstd, M, eps);       \
-    else hipLaunchKernelGGL((rowstats_kernel<NV, false>), grid, block, 0, st, x16, rstd, M, eps);          \
+    if (f16) hipLaunchKernelGGL((rowstats_kernel<NV, true>), grid, block, 0, st, x16, rstd, M, eps, range_flag);       \
+    else hipLaunchKernelGGL((rowstats_kernel<NV, false>), grid, block, 0, st, x16, rstd, M, eps, range_flag);          \
     break;
   switch (d) {
     RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
@@ -691,8 +701,11 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ pi
       float v = raw[e];
       if (FMT != 0) {
         const int c = cc[e];
-        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), inv = c == 0 ? i0 : (c == 1 ? i1 : i2);
-        v = (v * (1.f / 255.f) - mean) * inv;
+        // torchvision's arithmetic, operation for operation (ToTensor: x / 255; Normalize: (x - mean) / std, IEEE f32 divisions):
+        // the f32 value is the reference reader's `image_tensor` element bit for bit (pinned against the reference-held
+        // tests/test_clip_inference/test_tensors/*.pkl), so raw uint8 pixels and the reader's f32 tensor give the same patches
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? i0 : (c == 1 ? i1 : i2);
+        v = __fdiv_rn(__fsub_rn(__fdiv_rn(v, 255.f), mean), sd);
       }
       o[e] = (t > 0 && ch * 8 + e < K) ? (bf16)v : (bf16)0.f;
     }
@@ -701,7 +714,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ pi
 }
 
 hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int Kp, const float* mean,
-                         const float* inv_std, bf16* out, hipStream_t st) {
+                         const float* stdv, bf16* out, hipStream_t st) {
   if (B <= 0) return hipSuccess;
   const int gdim = S / P, T = gdim * gdim + 1;
   const int64_t total = (int64_t)B * T * (Kp / 8);
@@ -710,7 +723,7 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
     hipLaunchKernelGGL(im2col_kernel<0>, dim3(blocks), dim3(256), 0, st, pixels, B, S, P, Kp, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, out);
   else
     hipLaunchKernelGGL(im2col_kernel<1>, dim3(blocks), dim3(256), 0, st, pixels, B, S, P, Kp, mean[0], mean[1], mean[2],
-                       inv_std[0], inv_std[1], inv_std[2], out);
+                       stdv[0], stdv[1], stdv[2], out);
   return hipGetLastError();
 }
 
@@ -729,6 +742,20 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 // registers, for configurations where one query block per wave and many waves per workgroup pay.
 // =============================================================================================
 // TIMER (CLIPX_ATTN_DBG=9, tools/attn_bench): per-wave shader-cycle totals of staging / S + max / exp + PV / store
+// Operand type of the attention products (round 4): q, k, v arrive as IEEE fp16 (the QKV projection's EPI_BIAS_F16 epilogue) and
+// the probabilities P are rounded to fp16 as well: v_mfma_f32_32x32x16_f16 issues at the rate of the bf16 form, and the three extra
+// mantissa bits of q and k are worth an order of magnitude in the embedding's error where LayerNorm gains are large (the
+// logits q.k are where the bf16 rounding hurt most: tools/emulate_fp16_stream.py).  The 16-bit values keep travelling
+// through `bf16`-typed pointers and fragments: every load, LDS staging step and transposition moves bits.
+__device__ __forceinline__ f32x16 attn_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned attn_pack_p(float p0, float p1) {  // one v_cvt_pk_f16_f32 (round to nearest even)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){p0, p1}, f16x2_t));
+}
+
 __device__ long long g_attn_phase[8192 * 4];
 template <int DH, int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP, bool TIMER = false>
 __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int Tin,
@@ -856,7 +883,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
         for (int s = 0; s < KS; ++s) {
           const int c = 2 * s + hb;
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * KROW + ((DH == 64 ? (c ^ ksw) : c) << 4));
-          sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sb, 0, 0, 0);
+          sb = attn_mfma(kf, qf[s], sb);
         }
       }
       // masking is needed only in the last key block (padding past T) and, for causal, on/after the diagonal
@@ -914,7 +941,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
         const f32x2_t e = (f32x2_t){sb[r], sb[r + 1]} * (f32x2_t){scale_log2e, scale_log2e} + (f32x2_t){nmx, nmx};
         const f32x2_t pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
         sum2 += pp;
-        pw[r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(pp, bf16x2_t));
+        pw[r >> 1] = attn_pack_p(pp[0], pp[1]);
       }
       {
         const uint4 w0 = make_uint4(pw[0], pw[1], pw[2], pw[3]), w1 = make_uint4(pw[4], pw[5], pw[6], pw[7]);
@@ -930,7 +957,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
           const uint2 lo = *reinterpret_cast<const uint2*>(vp);
           const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
           uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&vv), pf[s2], oacc[nb], 0, 0, 0);
+          oacc[nb] = attn_mfma(*reinterpret_cast<bf16x8*>(&vv), pf[s2], oacc[nb]);
         }
     }
     float sum = sum2[0] + sum2[1];
@@ -1080,7 +1107,7 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
         for (int s = 0; s < KS; ++s) {
           const int c = 2 * s + hb;
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * KROW + ((c ^ ksw) << 4));
-          sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sb, 0, 0, 0);
+          sb = attn_mfma(kf, qf[s], sb);
         }
         if (kb == NKB - 1) {  // keys past T
 #pragma unroll
@@ -1121,7 +1148,7 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
           const f32x2_t e = (f32x2_t){sb[r], sb[r + 1]} * (f32x2_t){scale_log2e, scale_log2e} + (f32x2_t){nmx, nmx};
           const f32x2_t pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
           sum2 += pp;
-          pw[r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(pp, bf16x2_t));
+          pw[r >> 1] = attn_pack_p(pp[0], pp[1]);
         }
         {
           const uint4 w0 = make_uint4(pw[0], pw[1], pw[2], pw[3]), w1 = make_uint4(pw[4], pw[5], pw[6], pw[7]);
@@ -1138,7 +1165,7 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vp + 8 * 64));
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            oacc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[s2], oacc[nb], 0, 0, 0);
+            oacc[nb] = attn_mfma(__builtin_bit_cast(bf16x8, vv), pf[s2], oacc[nb]);
           }
       }
       float sum = sum2[0] + sum2[1];
@@ -1332,7 +1359,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __global__ __launch_bounds__(256) void tail_proj_kernel(const void* __restrict__ x, const int32_t* __restrict__ ids,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const bf16* __restrict__ proj, float* __restrict__ o_raw, int T, int d,
-                                                       int E, float eps, int x_f16) {
+                                                       int E, float eps, int x_f16, int* __restrict__ range_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* y = reinterpret_cast<float*>(smem);  // [d]
   float* red = y + d;                         // [4]   (all LDS in the one dynamic region: guide G17)
@@ -1356,7 +1383,9 @@ __global__ __launch_bounds__(256) void tail_proj_kernel(const void* __restrict__
     y[c] = x_f16 ? (float)reinterpret_cast<const _Float16*>(x)[xrow + c] : reinterpret_cast<const float*>(x)[xrow + c];
     s += y[c];
   }
-  const float mean = block_sum_256(s, red) / d;
+  const float tot = block_sum_256(s, red);
+  if (range_flag && tid == 0 && !(fabsf(tot) <= 3.0e38f)) atomicOr(range_flag, 1);  // the last state of the fp16 stream (rowstats_kernel)
+  const float mean = tot / d;
   float q = 0.f;
   for (int c = tid; c < d; c += 256) { const float a = y[c] - mean; q += a * a; }
   const float rstd = 1.f / sqrtf(block_sum_256(q, red) / d + eps);
@@ -1436,12 +1465,12 @@ hipError_t launch_gather_pooled(const bf16* att, const void* x16, const int32_t*
 
 hipError_t launch_tail(const void* x, const int32_t* ids_or_null, const float* gamma, const float* beta, const bf16* proj,
                        uint16_t* out_f16, float* out_f32_or_null, float* scratch, int B, int T, int d, int E, float eps,
-                       hipStream_t st, int x_f16) {
+                       hipStream_t st, int x_f16, int* range_flag) {
   if (B <= 0) return hipSuccess;
   if (d % 32 != 0 || !scratch) return hipErrorInvalidValue;
   const size_t smem = (size_t)(d + 8) * sizeof(float);
   hipLaunchKernelGGL(tail_proj_kernel, dim3((E + 63) / 64, B), dim3(256), smem, st, x, ids_or_null, gamma, beta, proj, scratch,
-                     T, d, E, eps, x_f16);
+                     T, d, E, eps, x_f16, range_flag);
   hipLaunchKernelGGL(tail_norm_kernel, dim3(B), dim3(256), 0, st, scratch, out_f16, out_f32_or_null, E);
   return hipGetLastError();
 }

@@ -113,6 +113,12 @@ struct clipx_handle {
   int slot_next = 0;
   size_t in_slot_bytes = 0, out_slot_bytes = 0;
   hipEvent_t ev_copied[NSLOT] = {}, ev_done[NSLOT] = {};
+  // Range guard of the fp16 residual stream (clipx.h, CLIPX_E_RANGE): one device flag per staging slot + one for the *_device
+  // entry points (index NSLOT), raised by rowstats_kernel / tail_proj_kernel when a row of the stream holds inf / NaN; read back
+  // with the slot's results (page-locked copies below) or by clipx_range_check().
+  int* range_flags = nullptr;       // device [NSLOT + 1]
+  int* range_host = nullptr;        // page-locked [NSLOT + 1]
+  int* cur_flag = nullptr;          // the flag the launch sequence being enqueued reports to
   // the activation workspace is shared by every call: a launch sequence first waits for the event the previous one
   // recorded, whichever stream that ran on (callers of the *_device entry points may bring their own streams)
   hipEvent_t ev_ws = nullptr;
@@ -293,6 +299,11 @@ static int create_impl(clipx_handle* h, const float* blob, size_t blob_floats) {
     HIPCHK(hipEventCreateWithFlags(&h->ev_done[s], hipEventDisableTiming));
   }
   HIPCHK(hipEventCreateWithFlags(&h->ev_ws, hipEventDisableTiming));
+  if ((r = dev_alloc(h, (void**)&h->range_flags, (clipx_handle::NSLOT + 1) * sizeof(int)))) return r;
+  HIPCHK(hipMemsetAsync(h->range_flags, 0, (clipx_handle::NSLOT + 1) * sizeof(int), h->stream));
+  HIPCHK(hipHostMalloc((void**)&h->range_host, (clipx_handle::NSLOT + 1) * sizeof(int), hipHostMallocDefault));
+  memset(h->range_host, 0, (clipx_handle::NSLOT + 1) * sizeof(int));
+  h->cur_flag = h->range_flags + clipx_handle::NSLOT;
   {
     const size_t rg_ints = (size_t)Bm * (X.T + 3);
     for (int i = 0; i < clipx_handle::RG_SLOTS; ++i) {
@@ -371,11 +382,29 @@ extern "C" void clipx_destroy(clipx_handle* h) {
     if (h->rg_ev[i]) (void)hipEventDestroy(h->rg_ev[i]);
   }
   if (h->rg_ids_host) (void)hipHostFree(h->rg_ids_host);
+  if (h->range_host) (void)hipHostFree(h->range_host);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   delete h;
 }
 
+extern "C" int clipx_set_option(clipx_handle* h, int option, int value) {
+  if (!h) return fail(CLIPX_E_ARG, "handle is null");
+  std::lock_guard<std::mutex> lk(h->mu);
+  switch (option) {
+    case CLIPX_OPT_RAGGED_TEXT: h->ragged_text = value != 0; return CLIPX_OK;
+    case CLIPX_OPT_POOL_LAST_BLOCK: h->pool_last_block = value != 0; return CLIPX_OK;
+    default: return fail(CLIPX_E_ARG, "unknown option");
+  }
+}
+extern "C" int clipx_get_option(const clipx_handle* h, int option) {
+  if (!h) return -1;
+  switch (option) {
+    case CLIPX_OPT_RAGGED_TEXT: return h->ragged_text ? 1 : 0;
+    case CLIPX_OPT_POOL_LAST_BLOCK: return h->pool_last_block ? 1 : 0;
+    default: return -1;
+  }
+}
 extern "C" int clipx_max_batch(const clipx_handle* h) { return h ? h->max_batch : 0; }
 extern "C" int clipx_graphs_cached(const clipx_handle* h) { return h ? (int)h->graphs.size() : 0; }
 extern "C" int clipx_embed_dim(const clipx_handle* h) { return h ? h->desc.embed_dim : 0; }
@@ -441,7 +470,7 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   const float eps = h->desc.ln_eps;
   const int act = h->desc.act == CLIPX_ACT_QUICK_GELU ? EPI_BIAS_QGELU_BF16 : EPI_BIAS_GELU_BF16;
   // On entry h->xn holds the residual stream x in fp16 (written by ln_pre / the text embedding).  Per block:
-  //   rstd = rowstats(x);    qkv = (x @ Wqkv'^T) * rstd + c_qkv            [= LN1(x) @ Wqkv^T + b: LayerNorm folded; fp16 MFMA]
+  //   rstd = rowstats(x);    qkv = fp16((x @ Wqkv'^T) * rstd + c_qkv)      [= LN1(x) @ Wqkv^T + b: LayerNorm folded; fp16 MFMA, fp16 out]
   //   att = attention(qkv);  x = fp16(x + att @ Wout^T + b_out)            [in place, bf16 MFMA, f32 add]
   //   rstd = rowstats(x);    h = act((x @ Wfc1'^T) * rstd + c_fc1);  x = fp16(x + h @ Wfc2^T + b_fc2)
   // (LayerNorm partial statistics computed by the residual epilogues instead of the rowstats pass were built twice in round 3
@@ -450,8 +479,8 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& L = t.L[l];
     int r;
-    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
-    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_BF16, h->rstd, true))) return r;
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1, h->cur_flag)); }
+    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_F16, h->rstd, true))) return r;
     // last block of the image tower: only token 0's attention row is read afterwards -> query block 0 only (same arithmetic)
     const bool pool_here = l == t.layers - 1 && h->pool_last_block && t.T > 1;
     const int q_blocks = pool_here && !ids ? 1 : 0;
@@ -467,14 +496,14 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
       void* xc = reinterpret_cast<char*>(h->x) + (((size_t)B * w * sizeof(bf16) + 255) & ~(size_t)255);
       { ProfScope ps(h, st, 3, 0); HIPCHK(launch_gather_pooled(h->att, h->xn, ids, attc, xc, B, t.T, w, st, rg ? rg->poolrows : nullptr)); }
       if ((r = run_gemm(h, st, attc, L.out_w, L.out_b, xc, nullptr, 1, B, w, w, EPI_BIAS_RESID_H16))) return r;
-      { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(xc, h->rstd, B, w, eps, st, 1)); }
+      { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(xc, h->rstd, B, w, eps, st, 1, h->cur_flag)); }
       if ((r = run_gemm(h, st, reinterpret_cast<const bf16*>(xc), L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, B, t.mlp, w, act, h->rstd, true))) return r;
       if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, xc, nullptr, 1, B, w, t.mlp, EPI_BIAS_RESID_H16))) return r;
       *pooled = true;
       return 0;
     }
     if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->xn, nullptr, 1, M, w, w, EPI_BIAS_RESID_H16))) return r;
-    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1)); }
+    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1, h->cur_flag)); }
     if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, M, t.mlp, w, act, h->rstd, true))) return r;
     if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->xn, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_H16))) return r;
   }
@@ -541,15 +570,14 @@ static int vision_chunk_body(clipx_handle* h, hipStream_t st, const void* pix_de
   const clipx_model_desc& d = h->desc;
   const Tower& V = h->vis;
   const int M = B * V.T;
-  float inv_std[3] = {1.f / d.pix_std[0], 1.f / d.pix_std[1], 1.f / d.pix_std[2]};
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_im2col(pix_dev, fmt, B, d.image_size, d.patch_size, h->Kp, d.pix_mean, inv_std, h->patches, st)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_im2col(pix_dev, fmt, B, d.image_size, d.patch_size, h->Kp, d.pix_mean, d.pix_std, h->patches, st)); }
   int r = run_gemm(h, st, h->patches, h->conv_w, nullptr, h->x, h->clspos, V.T, M, V.width, h->Kp, EPI_TABLE_F32);
   if (r) return r;
   { ProfScope ps(h, st, 2, 0); HIPCHK(launch_layernorm(h->x, h->ln_pre_w, h->ln_pre_b, h->xn, 2, M, V.width, d.ln_eps, st)); }
   bool pooled = false;
   if ((r = run_layers(h, st, V, B, 0, nullptr, &pooled))) return r;
   const void* xf = pooled ? pooled_rows(h, B, V.width) : h->xn;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(xf, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, pooled ? 1 : V.T, V.width, d.embed_dim, d.ln_eps, st, 1)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(xf, nullptr, V.lnf_w, V.lnf_b, V.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, pooled ? 1 : V.T, V.width, d.embed_dim, d.ln_eps, st, 1, h->cur_flag)); }
   return 0;
 }
 
@@ -595,7 +623,13 @@ static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_d
   const Tower& X = h->txt;
   Ragged rgv{};
   const Ragged* rg = nullptr;
-  if (h->ragged_text && h->pool_last_block && B > GRAPH_MAX_B && X.T <= 128 && X.width / X.heads == 64) {
+  bool ragged = h->ragged_text && h->pool_last_block && B > GRAPH_MAX_B && X.T <= 128 && X.width / X.heads == 64;
+  if (ragged && !h->text_ids_host) {  // device-resident ids need one synchronisation: impossible on a capturing stream
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusNone) ragged = false;
+  }
+  if (ragged) {
     const int32_t* ids_host = h->text_ids_host;
     if (!ids_host) {  // device-resident ids: one synchronisation of `st` to read them (CLIPX_RAGGED_TEXT=0 keeps the call asynchronous)
       HIPCHK(hipMemcpyAsync(h->rg_ids_host, ids_dev, (size_t)B * X.T * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -611,7 +645,7 @@ static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_d
   int r = run_layers(h, st, X, B, 1, ids_dev, &pooled, rg);
   if (r) return r;
   const void* xf = pooled ? pooled_rows(h, B, X.width) : h->xn;
-  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(xf, pooled ? nullptr : ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, pooled ? 1 : X.T, X.width, d.embed_dim, d.ln_eps, st, 1)); }
+  { ProfScope ps(h, st, 3, 0); HIPCHK(launch_tail(xf, pooled ? nullptr : ids_dev, X.lnf_w, X.lnf_b, X.proj, out_f16, out_f32, reinterpret_cast<float*>(h->qkv), B, pooled ? 1 : X.T, X.width, d.embed_dim, d.ln_eps, st, 1, h->cur_flag)); }
   return 0;
 }
 
@@ -639,6 +673,7 @@ extern "C" int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   const size_t ib = pix_bytes_per_image(h->desc, pix_fmt), E = h->desc.embed_dim;
   h->single_query = B == 1;
+  h->cur_flag = h->range_flags + clipx_handle::NSLOT;
   if (ws_acquire(h, st)) return CLIPX_E_HIP;
   for (int o = 0; o < B; o += h->max_batch) {
     const int nb = std::min(h->max_batch, B - o);
@@ -658,6 +693,7 @@ extern "C" int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev,
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   const size_t E = h->desc.embed_dim;
   h->single_query = B == 1;
+  h->cur_flag = h->range_flags + clipx_handle::NSLOT;
   if (ws_acquire(h, st)) return CLIPX_E_HIP;
   for (int o = 0; o < B; o += h->max_batch) {
     const int nb = std::min(h->max_batch, B - o);
@@ -666,6 +702,26 @@ extern "C" int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev,
     if (r) return r;
   }
   if (ws_release(h, st)) return CLIPX_E_HIP;
+  return CLIPX_OK;
+}
+
+static const char* kRangeMsg =
+    "the residual stream left the range of IEEE fp16 (|x| > 65504 became inf) for at least one row of this batch: these weights "
+    "cannot be served by the fp16-stream encoder; the embeddings written for this call must be discarded";
+
+extern "C" int clipx_range_check(clipx_handle* h, void* stream) {
+  if (!h) return fail(CLIPX_E_ARG, "handle is null");
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  const int i = clipx_handle::NSLOT;
+  HIPCHK(hipMemcpyAsync(h->range_host + i, h->range_flags + i, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemsetAsync(h->range_flags + i, 0, sizeof(int), st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (h->range_host[i]) {
+    h->range_host[i] = 0;
+    return fail(CLIPX_E_RANGE, kRangeMsg);
+  }
   return CLIPX_OK;
 }
 
@@ -709,6 +765,7 @@ static int slot_submit(clipx_handle* h, int kind, const char* src, size_t in_byt
   if (r) return r;
   float* o32 = want32 ? h->dev_out32[s] : nullptr;
   if (kind == KIND_TEXT) h->text_ids_host = reinterpret_cast<const int32_t*>(src);  // the ragged text tower reads the ids on the host
+  h->cur_flag = h->range_flags + s;
   r = kind == KIND_IMAGE ? vision_chunk(h, h->stream, h->dev_in[s], nb, pix_fmt, h->dev_out[s], o32)
                          : text_chunk(h, h->stream, (const int32_t*)h->dev_in[s], nb, h->dev_out[s], o32);
   h->text_ids_host = nullptr;
@@ -717,6 +774,8 @@ static int slot_submit(clipx_handle* h, int kind, const char* src, size_t in_byt
   char* po = (char*)h->pin_out[s];
   HIPCHK(hipMemcpyAsync(po, h->dev_out[s], (size_t)nb * E * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
   if (want32) HIPCHK(hipMemcpyAsync(po + h->out_slot_bytes, o32, (size_t)nb * E * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->range_host + s, h->range_flags + s, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemsetAsync(h->range_flags + s, 0, sizeof(int), h->stream));
   HIPCHK(hipEventRecord(h->ev_done[s], h->stream));
   h->slot_busy[s] = true;
   return s;
@@ -733,6 +792,10 @@ static int slot_collect(clipx_handle* h, int s, int nb, uint16_t* out16, float* 
   }
   h->slot_busy[s] = false;
   if (e != hipSuccess) return fail(CLIPX_E_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+  if (h->range_host[s]) {
+    h->range_host[s] = 0;
+    return fail(CLIPX_E_RANGE, kRangeMsg);
+  }
   return 0;
 }
 
@@ -828,7 +891,7 @@ extern "C" int clipx_wait(clipx_ticket* t) {
 static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M, int N, int K, int epi,
                      const float* rowscale, void* out16, void* stream, int f16 = 0) {
   if (!A_bf16 || !W_bf16 || !out || M <= 0 || N <= 0 || K <= 0) return fail(CLIPX_E_ARG, "bad gemm arguments");
-  if (!((epi >= 0 && epi <= 3) || epi == EPI_BIAS_RESID_H16) || !bias) return fail(CLIPX_E_ARG, "epi must be 0..3 or 6 and bias non-null");
+  if (!((epi >= 0 && epi <= 3) || epi == EPI_BIAS_RESID_H16 || epi == EPI_BIAS_F16) || !bias) return fail(CLIPX_E_ARG, "epi must be 0..3, 6 or 7 and bias non-null");
   if (f16 && epi > 2) return fail(CLIPX_E_ARG, "fp16 operands go with the bf16-output epilogues 0..2 only");
   if (N % 128 || K % 64) return fail(CLIPX_E_UNSUPPORTED, "N must be a multiple of 128 and K of 64");
   HIPCHK(hipSetDevice(device));

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   // VMEM bookkeeping (vmcnt retires in order): "the stage of the next K-tile has landed" is vmcnt(0) in steady state.
   // On the first K-tile after an epilogue the epilogue's own VMEM operations are younger than that stage and may stay in
   // flight: vmcnt(S_EPI_VM).  bf16 outputs: 16 stores.  f32 residual: 32 loads + 32 stores, the loads consumed already.
-  constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
+  constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F16;  // 16-bit outputs
   constexpr int S_EPI_VM = (DBG == 5 || DBG == 6) ? 0 : ((OUT_BF16 || EPI == EPI_BIAS_RESID_H16) ? 16 : (EPI == EPI_BIAS_RESID_F32 ? 40 : 32));
 
   // ---- prologue: K-tiles 0, 1 of the first tile; K-tile 0 landed + first fragment set read
@@ -503,11 +503,15 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
               }
               // two v_cvt_pk_bf16_f32 per quad (element-wise casts into a bf16x4 make hipcc convert one value at a time
               // and assemble the pairs with v_perm / v_alignbit: 9 VALU per quad instead of 4)
-              const bf16x2_t o01 = __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t);
-              const bf16x2_t o23 = __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t);
               uint2 o;
-              o.x = __builtin_bit_cast(unsigned, o01);
-              o.y = __builtin_bit_cast(unsigned, o23);
+              if (EPI == EPI_BIAS_F16) {  // v_cvt_pk_f16_f32: IEEE fp16, round to nearest even (the same bits as gemm_store_quad)
+                typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, f16x2_t));
+                o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, f16x2_t));
+              } else {
+                o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t));
+                o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t));
+              }
               // row l31 = [8 chunks of 16 B]; chunk (4nt + g) holds columns 32nt + 8g .. +8, half hb
               *reinterpret_cast<uint2*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8) = o;
             }
@@ -821,6 +825,7 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
   if (g.f16) {
     switch (g.epi) {
       case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16, 0, true>(g, grid, st);
+      case EPI_BIAS_F16: return launch_sp_epi<EPI_BIAS_F16, 0, true>(g, grid, st);
       case EPI_BIAS_QGELU_BF16: return launch_sp_epi<EPI_BIAS_QGELU_BF16, 0, true>(g, grid, st);
       case EPI_BIAS_GELU_BF16: return launch_sp_epi<EPI_BIAS_GELU_BF16, 0, true>(g, grid, st);
       default: return hipErrorInvalidValue;
@@ -828,6 +833,7 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
   }
   switch (g.epi) {
     case EPI_BIAS_BF16: return launch_sp_epi<EPI_BIAS_BF16>(g, grid, st);
+    case EPI_BIAS_F16: return launch_sp_epi<EPI_BIAS_F16>(g, grid, st);
     case EPI_BIAS_QGELU_BF16: return launch_sp_epi<EPI_BIAS_QGELU_BF16>(g, grid, st);
     case EPI_BIAS_GELU_BF16: return launch_sp_epi<EPI_BIAS_GELU_BF16>(g, grid, st);
     case EPI_BIAS_RESID_F32: return launch_sp_epi<EPI_BIAS_RESID_F32>(g, grid, st);

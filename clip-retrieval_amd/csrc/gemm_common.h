@@ -53,7 +53,8 @@ template <int EPI>
 __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, const float* __restrict__ bias,
                                                 void* __restrict__ outp, const float* __restrict__ table, int T,
                                                 int row0, const float* __restrict__ rowscale, bf16* __restrict__ out16) {
-  constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16;
+  // OUT_BF16: the 16-bit-output epilogues (bf16, or IEEE fp16 for EPI_BIAS_F16)
+  constexpr bool OUT_BF16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F16;
   if (EPI == EPI_RAW_F32) {  // a split-K partial product: the accumulators as they are
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + (size_t)m * N + n) = v;
     return;
@@ -70,7 +71,11 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
   }
   if (EPI == EPI_BIAS_QGELU_BF16) { v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w); }
   if (EPI == EPI_BIAS_GELU_BF16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-  if (OUT_BF16) {
+  if (EPI == EPI_BIAS_F16) {
+    f16x4 o;
+    o[0] = (_Float16)v.x; o[1] = (_Float16)v.y; o[2] = (_Float16)v.z; o[3] = (_Float16)v.w;
+    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(outp) + (size_t)m * N + n) = o;
+  } else if (OUT_BF16) {
     bf16x4 o;
     o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(outp) + (size_t)m * N + n) = o;

@@ -355,6 +355,19 @@ class ClipEncoder:
             self._h, C.c_void_p(int(ids_ptr)), int(B), C.c_void_p(int(out_f16_ptr)),
             C.c_void_p(int(out_f32_ptr)) if out_f32_ptr else None, C.c_void_p(int(stream)) if stream else None), "clipx")
 
+    def check_range(self, stream=None):
+        """After *_device calls: synchronise `stream` and raise ResidualStreamOverflow if the fp16 residual stream overflowed in any
+        of them since the last check (include/clipx.h: clipx_range_check).  The host-buffer calls and tickets check by themselves."""
+        check(self._lib, self._lib.clipx_range_check(self._h, C.c_void_p(int(stream)) if stream else None), "clipx")
+
+    OPT_RAGGED_TEXT, OPT_POOL_LAST_BLOCK = 1, 2
+
+    def set_option(self, option, value):
+        check(self._lib, self._lib.clipx_set_option(self._h, int(option), int(value)), "clipx")
+
+    def get_option(self, option):
+        return int(self._lib.clipx_get_option(self._h, int(option)))
+
     def graphs_cached(self):
         """Small-batch launch sequences captured as hipGraphs so far (include/clipx.h: clipx_graphs_cached)."""
         return int(self._lib.clipx_graphs_cached(self._h))

@@ -579,7 +579,9 @@ def build_ivf_index_device(fill_rows, n, d, nlist, nprobe=16, niter=8, seed=0, d
 
     `fill_rows(dst_ptr, row0, count, stride)` writes fp16 rows row0, row0 + stride, ... ([count, d], d a multiple of 256)
     at device address dst_ptr; it is called for the training sample (stride > 1) and twice per chunk (assignment pass and
-    scatter pass) -- the corpus never exists twice.  `alloc(nbytes)` returns (device pointer, keep-alive object) for the
+    scatter pass) -- the corpus never exists twice.  **fill_rows must have COMPLETED when it returns** (synchronise the stream it
+    launched on): the library's assignment / scatter kernels read the buffer on the index's own non-blocking streams right after,
+    and nothing orders those behind a producer that is still running on another stream.  `alloc(nbytes)` returns (device pointer, keep-alive object) for the
     scratch buffers (sample, one chunk of rows, 4 bytes per row of list ids); default: torch uint8 tensors (torch is
     this package's device-memory plumbing).  Returns (index, stats dict)."""
     import time

@@ -38,7 +38,9 @@ def clip_preprocess(image, size=224):
     image = image.resize((nw, nh), Image.BICUBIC)
     left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
     image = image.crop((left, top, left + size, top + size)).convert("RGB")
-    x = np.asarray(image, dtype=np.float32) * np.float32(1.0 / 255.0)
+    # torchvision's arithmetic operation for operation -- ToTensor: x / 255, Normalize: (x - mean) / std, f32 -- so that the tensor is
+    # the reference reader's bit for bit (tests/test_reader_reference_tensors.py: the reference-held test_tensors/*.pkl)
+    x = np.asarray(image, dtype=np.float32) / np.float32(255.0)
     x = (x - CLIP_MEAN) / CLIP_STD
     return np.ascontiguousarray(x.transpose(2, 0, 1))
 
@@ -60,16 +62,35 @@ def clip_preprocess_u8(image, size=224):
     return np.asarray(image.crop((left, top, left + size, top + size)).convert("RGB"), dtype=np.uint8)
 
 
-def decode_rgb_u8(image):
-    """No geometry on the host at all: PIL image -> its decoded RGB pixels, uint8 [h, w, 3] of whatever size it has.  A reader
-    built with this preprocess hands batches over as `image_raw` (one packed page-locked buffer + per-image offsets and sizes)
-    and the resize / centre crop run on the GPU, bit-identical to Pillow (csrc/preprocess.hip, clipx_resize_crop_u8_device;
-    SURVEY 8 row f2).  Worth it when the host's decode processes are the bottleneck and the sources are not much larger than
-    the crop: the decoded source travels through the pipes and PCIe instead of the 150 KB crop."""
-    return np.asarray(image.convert("RGB"), dtype=np.uint8)
+class DecodeRgbU8:
+    """No geometry on the host: PIL image -> its decoded RGB pixels, uint8 [h, w, 3] of whatever size it has.  A reader built with
+    this preprocess hands batches over as `image_raw` (one packed page-locked buffer + per-image offsets and sizes) and the
+    resize / centre crop run on the GPU, bit-identical to Pillow (csrc/preprocess.hip, clipx_resize_crop_u8_device; SURVEY 8 row
+    f2).  Worth it when the host's decode processes are the bottleneck and the sources are not much larger than the crop: the
+    decoded source travels through the pipes and PCIe instead of the 150 KB crop.
+
+    "Bit-identical" holds for what the GPU kernel restates: the 8-bit bicubic resample of RGB (and L: three equal channels)
+    images.  Pillow resamples the other modes DIFFERENTLY from their RGB conversion -- palette (P) and bilevel (1) images with
+    NEAREST, RGBA / LA / PA with premultiplied alpha, I / F / I;16 in 32-bit arithmetic -- and the reference (like
+    clip_preprocess_u8) resizes in the image's own mode and converts afterwards (CLIP's `_transform`: Resize, CenterCrop,
+    `_convert_image_to_rgb`).  Those images, and sources beyond what the kernel takes (a down-scale above ~30 x or a row that does
+    not fit its LDS staging: CLIPX_E_UNSUPPORTED would otherwise abort the whole partition), go through the host transform here
+    and travel as a ready size x size crop, which the GPU resample passes through unchanged."""
+
+    raw_images = True  # readers: collate as `image_raw`, not as a stacked `image_tensor`
+    GPU_MODES = ("RGB", "L")
+
+    def __init__(self, size=224, max_side=8192, max_downscale=16):
+        self.size, self.max_side, self.max_downscale = size, max_side, max_downscale
+
+    def __call__(self, image):
+        w, h = image.size
+        if image.mode not in self.GPU_MODES or max(w, h) > self.max_side or min(w, h) > self.max_downscale * self.size:
+            return clip_preprocess_u8(image, self.size)
+        return np.asarray(image.convert("RGB"), dtype=np.uint8)
 
 
-decode_rgb_u8.raw_images = True  # readers: collate as `image_raw`, not as a stacked `image_tensor`
+decode_rgb_u8 = DecodeRgbU8(224)  # the 224-pixel models' instance (worker() builds one for the model's own image size)
 
 
 class ClipTransform:
@@ -459,6 +480,7 @@ class _BatchingReader:
         self.tokenizer = tokenizer
         self.batch_size = batch_size
         self.workers = max(1, num_prepro_workers)
+        self.num_streams = num_prepro_workers
         self.enable_text, self.enable_image, self.enable_metadata = enable_text, enable_image, enable_metadata
         self.use_processes = True  # False: decode on a thread pool inside this process
         if enable_text and tokenizer is None:
@@ -473,6 +495,7 @@ class _BatchingReader:
     # samples per task sent to a decode process: amortises the per-task pickling / wake-up cost (a task per sample caps the
     # parent at a few thousand samples/s)
     chunk = 16
+    inflight_chunks = 0  # 0: 2 x workers + a batch's worth; WebdatasetReader's per-stream sub-readers set two batches' worth
 
     def _decode_args(self):
         return (self.preprocess, self.tokenizer, self.enable_image, self.enable_text, self.enable_metadata)
@@ -498,6 +521,8 @@ class _BatchingReader:
         procs = _DecodePool.get(self.workers, self._decode_args()) if self.use_processes and self.workers > 1 else None
         if procs is not None:
             limit = 2 * self.workers + max(1, self.batch_size // self.chunk)  # chunks in flight
+            if self.inflight_chunks:
+                limit = self.inflight_chunks
             inflight, raws, done = deque(), iter(self._raw_samples()), False
             while True:
                 while not done and len(inflight) < limit:
@@ -580,6 +605,38 @@ class WebdatasetReader(_BatchingReader):
         shards = [input_dataset] if isinstance(input_dataset, str) else list(input_dataset)
         self.shards = sampler(shards)
         self.image_key, self.caption_key = wds_image_key, wds_caption_key
+
+    # The reference's batch ORDER (reader.py:184-205, 262-269): its webdataset pipeline is an IterableDataset behind
+    # DataLoader(num_workers = num_prepro_workers, batch_size): webdataset deals the shards to the loader workers (shard i ->
+    # worker i mod W), every worker batches ITS OWN stream (a batch never mixes two workers' shards; each worker ends with its own
+    # short batch), and the loader hands the batches out round-robin over the workers, skipping the ones that are exhausted.
+    # Reproduced here so that the rows of img_emb_*.npy / metadata_*.parquet come out in the reference's order for the same
+    # arguments -- pinned against the reference-held test_tensors/{0..3}.pkl (tests/test_reader_reference_tensors.py).  The W
+    # streams share this reader's pool of decode processes.  False (or num_prepro_workers <= 1): one stream, shards in order.
+    reference_batch_order = True
+
+    def __iter__(self):
+        W = self.num_streams
+        if not self.reference_batch_order or W <= 1:
+            yield from super().__iter__()
+            return
+        import copy  # pylint: disable=import-outside-toplevel
+
+        streams = []
+        for w in range(W):
+            sub = copy.copy(self)
+            sub.shards = self.shards[w::W]
+            sub.reference_batch_order = False
+            sub.inflight_chunks = max(2, (2 * self.batch_size + self.chunk - 1) // self.chunk + 1)  # prefetch_factor = 2 batches
+            if sub.shards:
+                streams.append(iter(sub))
+        while streams:
+            for it in list(streams):
+                batch = next(it, None)
+                if batch is None:
+                    streams.remove(it)
+                else:
+                    yield batch
 
     def _emit(self, key, fields):
         if self.enable_image and self.image_key not in fields:

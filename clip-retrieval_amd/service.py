@@ -173,7 +173,15 @@ class _ResidentIndexPool:
             make = q.empty() and self._made.get(d, 0) < self._size
             if make:
                 self._made[d] = self._made.get(d, 0) + 1
-        ix = Mi355xIndex(d, device=self._device, coalesce=False) if make else q.get()
+        if make:
+            try:
+                ix = Mi355xIndex(d, device=self._device, coalesce=False)
+            except BaseException:
+                with self._lock:  # a failed construction must not use up one of the pool's `size` places for good (ADVICE r3:
+                    self._made[d] -= 1  # after `size` failures every later request would block forever in q.get())
+                raise
+        else:
+            ix = q.get()
 
         @contextlib.contextmanager
         def lease():
@@ -194,7 +202,7 @@ class KnnHotPath:
 
     def __init__(self, dedup_device=0):
         self._scratch = _ResidentIndexPool(dedup_device)   # dedup: the request's own result vectors
-        self._prompts = {}                             # id(violence_detector array) -> resident 2-row index
+        self._prompts = {}                             # (shape, content hash) -> (the prompt array, its resident fp32 Linear layer)
         self._prompts_lock = threading.Lock()
         self._device = dedup_device
 
@@ -268,19 +276,24 @@ class KnnHotPath:
         return np.flatnonzero(scores.reshape(len(scores), -1)[:, 0] > threshold)
 
     def get_violent_items(self, safety_prompts, embeddings):
-        """Indices whose best-matching prompt is prompt 1 ("violent"): top-1 of every result vector against the prompts,
-        searched on the GPU (the prompt matrix stays resident)."""
+        """Indices whose best-matching prompt is prompt 1 ("violent"): clip_back.py:327-331's
+        `argmax(einsum("ij,kj->ik", embeddings, safety_prompts), axis=1) == 1`, the product in fp32 FMA on the GPU (one bias-free
+        Linear layer of csrc/postfilter.hip; the prompt matrix stays resident IN FP32 -- round 3 kept it as a 2-row fp16 index,
+        whose rounding could flip a near-tie against the reference's fp32 einsum).  The resident copy is keyed on the
+        array's CONTENT and holds a reference to it (an id() can be reused by a new array); the GPU call runs outside the lock."""
         embeddings = np.ascontiguousarray(embeddings, dtype=np.float32)
         if embeddings.shape[0] == 0:
             return np.zeros(0, dtype=np.int64)
-        key = id(safety_prompts)
+        prompts = np.ascontiguousarray(safety_prompts, dtype=np.float32)
+        key = (prompts.shape, hash(prompts.tobytes()))
         with self._prompts_lock:
-            ix = self._prompts.get(key)
-            if ix is None:
-                ix = self._prompts[key] = Mi355xIndex(embeddings.shape[1], device=self._device, coalesce=False)
-                ix.add(np.ascontiguousarray(safety_prompts, dtype=np.float32))
-            _, best = ix.search(embeddings, 1)
-        return np.flatnonzero(best[:, 0] == 1)
+            hit = self._prompts.get(key)
+            if hit is None or not np.array_equal(hit[0], prompts):
+                if len(self._prompts) >= 8:  # a service has one detector; do not grow without bound if a caller keeps swapping it
+                    self._prompts.clear()
+                hit = self._prompts[key] = (prompts, Mi355xSafetyHead({"layers.0.weight": prompts}, device=self._device, relu=[False]))
+        scores = hit[1].predict(embeddings, batch_size=embeddings.shape[0])
+        return np.flatnonzero(np.argmax(scores, axis=1) == 1)
 
     def post_filter(self, safety_model, embeddings, deduplicate, use_safety_model, use_violence_detector, violence_detector):
         """Local indices to drop: duplicates | violent | unsafe."""

@@ -18,7 +18,7 @@ import re
 
 from .encoder import load_clip
 from .mapper import ClipMapper
-from .reader import FilesReader, WebdatasetReader, clip_preprocess_u8, decode_rgb_u8
+from .reader import DecodeRgbU8, FilesReader, WebdatasetReader, clip_preprocess_u8
 from .runner import LoggerWriter, Runner, get_task_list
 from .writer import NumpyWriter
 
@@ -77,8 +77,8 @@ def worker(
     def reader_builder(sampler):
         model, preprocess, tokenizer = load_clip(clip_model=clip_model, use_jit=use_jit, warmup_batch_size=0,
                                                  clip_cache_path=clip_cache_path, device=device)
-        if gpu_resize:
-            preprocess = decode_rgb_u8  # decode only; geometry and normalisation on the GPU
+        if gpu_resize:  # decode only; geometry and normalisation on the GPU (non-RGB modes and oversized sources: host crop)
+            preprocess = DecodeRgbU8(model._enc.arch.image_size)  # pylint: disable=protected-access
         elif gpu_normalise:
             size = model._enc.arch.image_size  # pylint: disable=protected-access
             preprocess = functools.partial(clip_preprocess_u8, size=size)  # picklable: travels to the decode processes

@@ -32,7 +32,8 @@ enum {
   CLIPX_E_HIP = -2,
   CLIPX_E_NOMEM = -3,
   CLIPX_E_STATE = -4,
-  CLIPX_E_UNSUPPORTED = -5
+  CLIPX_E_UNSUPPORTED = -5,
+  CLIPX_E_RANGE = -6 /* the fp16 residual stream overflowed for these weights / inputs: the call's embeddings are invalid */
 };
 
 #define CLIPX_ACT_QUICK_GELU 0 /* OpenAI CLIP checkpoints (x * sigmoid(1.702 x)) */
@@ -110,7 +111,8 @@ int clipx_wait(clipx_ticket* ticket);
  * is shared by all calls: consecutive calls are ordered by an event even when they use different streams.
  * clipx_encode_text_device with B > 8 synchronises `stream` ONCE before its kernels are queued: it reads the token ids back
  * to find every caption's EOT position, and then runs the (causal) text tower on the rows up to the EOT only -- the same
- * embeddings, bit for bit (environment CLIPX_RAGGED_TEXT=0: every row, and a fully asynchronous call). */
+ * embeddings, bit for bit (CLIPX_OPT_RAGGED_TEXT = 0 / environment CLIPX_RAGGED_TEXT=0: every row, and a fully asynchronous
+ * call; a `stream` that is being captured into a hipGraph cannot be synchronised and takes that path by itself). */
 int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, int pix_fmt, uint16_t* out_f16_dev,
                               float* out_f32_or_null, void* stream);
 int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,
@@ -124,6 +126,26 @@ int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uin
  * CLIPX_E_UNSUPPORTED for down-scales beyond ~30 x (a band of output rows no longer fits the LDS). */
 int clipx_resize_crop_u8_device(int device, const void* src_dev, const int64_t* offsets, const int32_t* hw, int B, int S, void* out_dev,
                                 void* stream);
+
+/* Range guard.  The encoder keeps the residual stream of both towers in IEEE fp16: exact for every checkpoint that is
+ * trained or served in fp16 (the reference's CUDA path runs the whole model in fp16, mapper.py:35-41), but a model whose
+ * activations exceed 65 504 (possible for bf16-trained checkpoints) would overflow to inf, and LayerNorm turns a row holding inf
+ * into a finite-looking WRONG embedding.  Every state of the stream is therefore checked on the device (one compare inside the
+ * kernels that read it anyway) and an overflow is reported, never hidden: the host entry points (clipx_encode_image / _text /
+ * _f32) and clipx_wait() return CLIPX_E_RANGE for a call in which any row overflowed (the output buffer of that call must be
+ * discarded); after *_device calls, clipx_range_check(h, stream) synchronises `stream` and returns CLIPX_OK or CLIPX_E_RANGE for
+ * everything queued through the *_device entry points since the previous check (it also clears the flag). */
+int clipx_range_check(clipx_handle* h, void* stream);
+
+/* Per-handle switches (defaults in brackets; the environment variables CLIPX_RAGGED_TEXT / CLIPX_FULL_LAST_BLOCK set the initial
+ * values).  Both change which rows are computed, never the bytes of the embeddings (tests/test_clip_gpu.py).
+ *   CLIPX_OPT_RAGGED_TEXT [1]      text batches > 8 run every layer on the rows up to each caption's EOT only
+ *   CLIPX_OPT_POOL_LAST_BLOCK [1]  the last block runs past its attention on the pooled rows only
+ * clipx_get_option returns the value or -1. */
+#define CLIPX_OPT_RAGGED_TEXT 1
+#define CLIPX_OPT_POOL_LAST_BLOCK 2
+int clipx_set_option(clipx_handle* h, int option, int value);
+int clipx_get_option(const clipx_handle* h, int option);
 
 /* Largest batch one launch sequence handles (workspace is sized for it at create time;
  * CLIPX_MAX_BATCH env var, default 256).  Bigger B is processed in chunks of this size. */
@@ -149,16 +171,18 @@ int clipx_gemm_bf16_ex_device(int device, const void* A_bf16, const void* W_bf16
  * residual epilogue of out_proj / fc2 in the encoder, whose residual stream is stored in fp16.) */
 
 /* The LayerNorm-folded GEMMs of the encoder (QKV, fc1) read that fp16 residual stream as their A operand: A and W are IEEE
- * fp16 (v_mfma_f32_32x32x16_f16, the same rate as bf16), out bf16 [M, N]; epi 0..2 and rowscale as above. */
-int clipx_gemm_f16_device(int device, const void* A_f16, const void* W_f16, const float* bias, void* out_bf16, int M, int N, int K,
+ * fp16 (v_mfma_f32_32x32x16_f16, the same rate as bf16), out bf16 [M, N]; epi 0..2 and rowscale as above, or epi 7: epi 0 with
+ * an IEEE fp16 output (the QKV projection: q and k carry three more mantissa bits into the softmax logits). */
+int clipx_gemm_f16_device(int device, const void* A_f16, const void* W_f16, const float* bias, void* out_16bit, int M, int N, int K,
                           int epi, const float* rowscale_or_null, void* stream);
 
 /* The attention and LayerNorm kernels in isolation (device pointers), for per-kernel parity tests:
- * qkv bf16 [B*T, 3*H*64] -> out bf16 [B*T, H*64];  x f32 [M, d] -> y (bf16 if out_bf16 else f32). */
-int clipx_attention_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int causal,
+ * qkv IEEE fp16 [B*T, 3*H*64] (q | k | v as the QKV projection's epi 7 writes them; the products run on fp16 MFMA, P is
+ * rounded to fp16) -> out bf16 [B*T, H*64];  x f32 [M, d] -> y (bf16 if out_bf16 else f32). */
+int clipx_attention_device(int device, const void* qkv_f16, void* out_bf16, int B, int T, int H, int causal,
                            void* stream);
 /* Same for head dimension dh = 64 or 80 (ViT-H/14 image tower: 1280 / 16): qkv [B*T, 3*H*dh] -> out [B*T, H*dh]. */
-int clipx_attention_dh_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int dh,
+int clipx_attention_dh_device(int device, const void* qkv_f16, void* out_bf16, int B, int T, int H, int dh,
                               int causal, void* stream);
 int clipx_layernorm_device(int device, const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
                            int M, int d, float eps, void* stream);

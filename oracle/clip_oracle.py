@@ -114,18 +114,19 @@ class HFClipOracle:
                     p.add_(torch.randn(p.shape, generator=g) * 0.05)
 
     @torch.no_grad()
-    def make_trained_like(self, seed: int = 0) -> None:
+    def make_trained_like(self, seed: int = 0, outliers=(300.0, -300.0), gain: float = 30.0) -> None:
         """Push the seeded random weights towards the statistics of TRAINED CLIP towers, which random init does not have and
-        which stress a bf16 operand path (missing #3): LayerNorm gains spread over two orders of magnitude with a
-        few large ones, LayerNorm biases of order 1, two 'massive activation' channels per tower (a constant of +-30..40 in the
-        residual stream from the first block on: 50-100 x the other channels), sharper attention (q, k scaled up) and a
-        negative fc1 bias.  No real checkpoint is available offline; this is the closest stand-in.  Call before export_blob()."""
+        which stress a reduced-precision operand path: LayerNorm gains spread over two orders of magnitude with 1 % of them
+        `gain` x larger, LayerNorm biases of order 1, 'massive activation' channels (a constant of `outliers[i]` in the residual
+        stream from the first block on -- published CLIP ViT-L/14 checkpoints carry two channels in the hundreds, 500 - 1000 x
+        the other channels; round 3 planted +-30 .. 40), sharper attention (q, k scaled up) and a negative
+        fc1 bias.  No real checkpoint is available offline; this is the closest stand-in.  Call before export_blob()."""
         g = torch.Generator().manual_seed(1000 + seed)
         for name, p in self.model.named_parameters():
             if ("layer_norm" in name or "layernorm" in name or "layrnorm" in name) and name.endswith("weight"):
                 p.mul_(torch.exp(torch.randn(p.shape, generator=g) * 0.5))
                 idx = torch.randperm(p.numel(), generator=g)[: max(1, p.numel() // 100)]
-                p.view(-1)[idx] *= 8.0
+                p.view(-1)[idx] *= gain
             elif ("layer_norm" in name or "layernorm" in name or "layrnorm" in name) and name.endswith("bias"):
                 p.add_(torch.randn(p.shape, generator=g) * 0.5)
             elif name.endswith("q_proj.weight") or name.endswith("k_proj.weight"):
@@ -133,9 +134,9 @@ class HFClipOracle:
             elif name.endswith("mlp.fc1.bias"):
                 p.sub_(0.5)
             elif name.endswith("encoder.layers.0.mlp.fc2.bias"):
-                c = torch.randperm(p.numel(), generator=g)[:2]
-                p[c[0]] += 40.0
-                p[c[1]] -= 30.0
+                c = torch.randperm(p.numel(), generator=g)[: len(outliers)]
+                for ci, v in zip(c, outliers):
+                    p[ci] += float(v)
 
     @torch.no_grad()
     def encode_image(self, pixel_values: torch.Tensor) -> torch.Tensor:
@@ -332,17 +333,93 @@ def mapper_semantics(features: torch.Tensor):
 
 
 # ----------------------------------------------------------------------------------------------
+# the acceptance gate of the encode half (tests/, bench.py)
+# ----------------------------------------------------------------------------------------------
+NORTH_STAR_BAR = 1.0 - 1e-3   # BASELINE.json north_star: cosine to the reference CPU encoder within 1e-3
+TIGHT_BAR = 1.0 - 1e-4        # what the kernels actually deliver is 1 - 4e-6 .. 1 - 3e-5; a gate at 1e-3 sits inside the
+                              # inter-sample spread of some inputs, this one does not
+CENTRED_BAR = 0.99
+
+
+def _unit(a):
+    a = np.asarray(a, dtype=np.float64)
+    return a / np.maximum(np.linalg.norm(a, axis=-1, keepdims=True), 1e-300)
+
+
+def parity_report(got, want_f32):
+    """Per-row evidence that `got` [B, d] (any float dtype) is the oracle's `want_f32` [B, d] ROW FOR ROW:
+      cos      raw cosine per row;
+      centred  cosine after subtracting the oracle's batch-mean embedding from both (embeddings of one model share a large
+               common component -- 0.7 .. 0.98 of the norm here -- which a raw cosine rewards whatever the row is); None for B = 1;
+      nearest  for every row of `got` the index of the oracle row it is closest to (must be its own index);
+      other    the largest cosine of a row of `got` to an oracle row that is NOT its own (how far a wrong row would be)."""
+    g, w = _unit(got), _unit(want_f32)
+    B = g.shape[0]
+    c = g @ w.T
+    rep = dict(cos=np.diag(c).copy(), nearest=c.argmax(axis=1), centred=None, other=None)
+    if B > 1:
+        mu = w.mean(axis=0, keepdims=True)
+        rep["centred"] = (_unit(g - mu) * _unit(w - mu)).sum(-1)
+        rep["other"] = (c - 2.0 * np.eye(B)).max(axis=1)
+    return rep
+
+
+def parity_gate(got, want_f32, what="", bar=TIGHT_BAR, centred_bar=CENTRED_BAR):
+    """Raises AssertionError unless every row passes: finite, raw cosine >= bar, centred cosine >= centred_bar, nearest oracle
+    row == own row.  A row-swapped, stale or input-independent output fails (tests/test_oracle.py::test_parity_gate_*)."""
+    rep = parity_report(got, want_f32)
+    assert np.isfinite(np.asarray(got, dtype=np.float64)).all(), f"{what}: non-finite values"
+    assert rep["cos"].min() >= bar, f"{what}: cosine {rep['cos'].min():.7f} < {bar} (rows {np.nonzero(rep['cos'] < bar)[0][:8]})"
+    B = len(rep["cos"])
+    assert (rep["nearest"] == np.arange(B)).all(), f"{what}: rows {np.nonzero(rep['nearest'] != np.arange(B))[0][:8]} are closer to another row's oracle embedding"
+    if rep["centred"] is not None:
+        assert rep["centred"].min() >= centred_bar, f"{what}: centred cosine {rep['centred'].min():.5f} < {centred_bar}"
+    return rep
+
+
+# ----------------------------------------------------------------------------------------------
 # synthetic inputs of SURVEY 8(d) config 2
 # ----------------------------------------------------------------------------------------------
-def synth_pixels_u8(B: int, size: int = 224, seed: int = 1) -> np.ndarray:
-    g = torch.Generator().manual_seed(seed)
-    return torch.randint(0, 256, (B, size, size, 3), generator=g, dtype=torch.uint8).numpy()
+def synth_pixels_u8(B, size=224, seed=1):
+    """Structured synthetic images (i.i.d. noise images all embed to the same point --
+    inter-sample oracle cosine 0.998 -- so a cosine gate could not tell one row from another).  Sample b depends on (seed, b)
+    only: a saturated background colour (a corner of the RGB cube, all eight distinct within each aligned group of eight
+    samples, pulled up to 15 % towards a random colour) with a gradient, a low-frequency sinusoid, 2 - 5 filled rectangles /
+    ellipses of random colours, mild per-sample noise.  Random-init CLIP towers are close to position-invariant colour
+    statistics, so the dominant colour is what separates embeddings: mean inter-sample cosine ~0.72, < 0.93 within a group
+    of eight (tests/test_oracle.py)."""
+    out = np.empty((B, size, size, 3), dtype=np.uint8)
+    yy, xx = np.meshgrid(np.arange(size, dtype=np.float32), np.arange(size, dtype=np.float32), indexing="ij")
+    u, v = xx / size, yy / size
+    for b in range(B):
+        r = np.random.default_rng([int(seed), b, 0x5EED])
+        corner = int(np.random.default_rng([int(seed), b // 8, 0xC0]).permutation(8)[b % 8])
+        c0 = np.asarray([corner & 1, (corner >> 1) & 1, (corner >> 2) & 1], dtype=np.float64) * 255.0
+        c0 = c0 + r.uniform(0, 0.15) * (r.uniform(0, 255, 3) - c0)
+        c1 = c0 + r.uniform(0.1, 0.3) * (r.uniform(0, 255, 3) - c0)
+        ang = r.uniform(0, 2 * np.pi)
+        t = (np.cos(ang) * (u - 0.5) + np.sin(ang) * (v - 0.5)) * 1.2 + 0.5
+        img = c0 + np.clip(t, 0, 1)[..., None] * (c1 - c0)
+        fx, fy, ph = r.uniform(0.5, 6), r.uniform(0.5, 6), r.uniform(0, 2 * np.pi)
+        img = img + (r.uniform(5, 30) * np.sin(2 * np.pi * (fx * u + fy * v) + ph))[..., None] * r.uniform(-1, 1, 3)
+        for _ in range(int(r.integers(2, 6))):
+            cx, cy = r.uniform(0, 1, 2)
+            hw, hh = r.uniform(0.04, 0.2, 2)
+            col = r.uniform(0, 255, 3)
+            if r.random() < 0.5:
+                m = (np.abs(u - cx) < hw) & (np.abs(v - cy) < hh)
+            else:
+                m = ((u - cx) / hw) ** 2 + ((v - cy) / hh) ** 2 < 1.0
+            img[m] = col
+        img = img + r.normal(0, r.uniform(1, 10), (size, size, 3))
+        out[b] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return out
 
 
 def normalise_u8_nhwc(u8: np.ndarray) -> np.ndarray:
     """u8 NHWC -> the reference's `image_tensor`: f32 NCHW, /255, CLIP mean/std."""
-    x = u8.astype(np.float32) * np.float32(1.0 / 255.0)
-    x = (x - np.asarray(CLIP_MEAN, np.float32)) * (np.float32(1.0) / np.asarray(CLIP_STD, np.float32))
+    x = u8.astype(np.float32) / np.float32(255.0)  # torchvision: ToTensor, then Normalize -- two f32 divisions
+    x = (x - np.asarray(CLIP_MEAN, np.float32)) / np.asarray(CLIP_STD, np.float32)
     return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
 
 

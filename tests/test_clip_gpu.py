@@ -9,7 +9,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-COS_BAR = 1.0 - 1e-3
+COS_BAR = 1.0 - 1e-3  # north_star; the encoder-vs-oracle tests below use oracle.parity_gate: raw cosine >= 1 - 1e-4, centred
+                      # cosine >= 0.99 and "the nearest oracle row is my own row" (a row-swapped output fails all three)
 
 
 def _cos(a, b):
@@ -92,12 +93,12 @@ def test_layernorm(lib, d):
                                               (2, 77, 8, 64, 1), (1, 1, 1, 64, 0), (2, 257, 16, 80, 0), (2, 77, 4, 80, 1),
                                               (1, 33, 2, 80, 0)])
 def test_attention(lib, B, T, H, dh, causal):
-    """softmax(q k^T / sqrt(dh) [+causal]) v per head; reference in fp32 on the same bf16 inputs.  Output is bf16 and
-    P is rounded to bf16 before the PV product: tol 1e-2 absolute on O(1) values.  dh = 80 is the ViT-H/14 image tower."""
+    """softmax(q k^T / sqrt(dh) [+causal]) v per head; reference in fp32 on the same IEEE fp16 inputs (round 4: q, k, v and P
+    are fp16 operands).  The output is bf16: tol 1e-2 absolute on O(1) values.  dh = 80 is the ViT-H/14 image tower."""
     from clip_retrieval_amd._lib import check
 
     g = torch.Generator().manual_seed(T * 31 + H)
-    qkv = (torch.randn(B * T, 3 * H * dh, generator=g)).to(torch.bfloat16).cuda()
+    qkv = (torch.randn(B * T, 3 * H * dh, generator=g)).to(torch.float16).cuda()
     qkv[:, : H * dh] *= 2.0  # sharper softmax
     out = torch.empty(B * T, H * dh, dtype=torch.bfloat16, device="cuda")
     if dh == 64:
@@ -136,7 +137,7 @@ def tiny(request):
 
 @pytest.mark.parametrize("B", [1, 2, 5])
 def test_encoder_parity_vs_oracle(tiny, B):
-    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, parity_gate, synth_pixels_u8, synth_tokens
 
     name, arch, oracle, enc = tiny
     u8 = synth_pixels_u8(B, seed=B)
@@ -147,14 +148,40 @@ def test_encoder_parity_vs_oracle(tiny, B):
     got_i = enc.encode_image(pix)
     got_t = enc.encode_text(ids)
     assert got_i.dtype == np.float16 and got_i.shape == (B, arch.embed_dim) and got_i.flags["C_CONTIGUOUS"]
-    ci, ct = _cos(got_i, want_i32), _cos(got_t, want_t32)
-    assert ci.min() >= COS_BAR, f"{name} image cos {ci}"
-    assert ct.min() >= COS_BAR, f"{name} text cos {ct}"
+    parity_gate(got_i, want_i32, f"{name} image")
+    parity_gate(got_t, want_t32, f"{name} text")
     assert np.allclose(np.linalg.norm(got_i.astype(np.float32), axis=1), 1, atol=2e-3)
     assert np.abs(got_i.astype(np.float32) - want_i16.astype(np.float32)).max() < 0.02
     # the raw-uint8 entry point normalises on the device and must land on the same embedding
     got_u8 = enc.encode_image(u8)
     assert _cos(got_u8, got_i).min() > 1 - 1e-4
+
+
+def test_parity_gate_rejects_swapped_stale_and_input_independent_rows(tiny):
+    """the old gate (raw cosine >= 0.999 on i.i.d.-noise images, whose oracle embeddings have cosine
+    0.998 with EACH OTHER) could not tell one row from another.  With the structured images and parity_gate, the HIP
+    encoder's own outputs fail as soon as two rows are exchanged, a row is stale, or the output ignores its input."""
+    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, parity_gate, parity_report, synth_pixels_u8, synth_tokens
+
+    name, arch, oracle, enc = tiny
+    B = 6
+    pix, ids = normalise_u8_nhwc(synth_pixels_u8(B, arch.image_size, seed=61)), synth_tokens(B, arch.ctx_len, arch.vocab, seed=62)
+    _, wi = mapper_semantics(oracle.encode_image(torch.from_numpy(pix)))
+    _, wt = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
+    gi, gt = enc.encode_image(pix), enc.encode_text(ids)
+    rep = parity_gate(gi, wi, f"{name} image")
+    parity_gate(gt, wt, f"{name} text")
+    assert rep["other"].max() < 0.95, f"the inputs must separate the rows: nearest wrong row at cosine {rep['other']}"
+    for got, want in ((gi, wi), (gt, wt)):
+        swapped = got.copy()
+        swapped[[1, 4]] = swapped[[4, 1]]
+        stale = got.copy()
+        stale[3] = stale[2]
+        const = np.repeat(got.astype(np.float32).mean(0, keepdims=True), B, 0)
+        for wrong in (swapped, stale, const, np.roll(got, 1, axis=0)):
+            with pytest.raises(AssertionError):
+                parity_gate(wrong, want, "negative")
+        assert (parity_report(swapped, want)["nearest"][[1, 4]] == [4, 1]).all()
 
 
 def test_device_path_and_fp16_rounding(tiny):
@@ -306,7 +333,7 @@ def test_mapper_vs_reference_clipmapper_golden(tiny):
     (tests/golden/make_golden_mapper.py): per-sample cosine >= 1 - 1e-3 (north_star bar), same shapes and dtype."""
     from clip_retrieval_amd.encoder import register_encoder
     from clip_retrieval_amd.mapper import ClipMapper
-    from oracle.clip_oracle import normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+    from oracle.clip_oracle import normalise_u8_nhwc, parity_gate, synth_pixels_u8, synth_tokens
 
     name, arch, oracle, enc = tiny
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_mapper_" + name.replace("/", "-") + ".npz"))
@@ -319,8 +346,7 @@ def test_mapper_vs_reference_clipmapper_golden(tiny):
              "text": ["b"] * B, "metadata": ["{}"] * B})
     for key in ("image_embs", "text_embs"):
         assert out[key].dtype == np.float16 and out[key].shape == g[key].shape
-        cos = _cos(out[key], g[key])
-        assert cos.min() >= COS_BAR, f"{name} {key}: cosine {cos}"
+        parity_gate(out[key], g[key].astype(np.float32), f"{name} {key} vs the reference ClipMapper's fp16 rows")
         assert np.abs(out[key].astype(np.float32) - g[key].astype(np.float32)).max() < 2e-2
 
 
@@ -329,7 +355,7 @@ def test_clip_mapper_drop_in(tiny):
     of 2 and 1, plus the value check the reference never had."""
     from clip_retrieval_amd.encoder import register_encoder
     from clip_retrieval_amd.mapper import ClipMapper
-    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+    from oracle.clip_oracle import mapper_semantics, normalise_u8_nhwc, parity_gate, synth_pixels_u8, synth_tokens
 
     name, arch, oracle, enc = tiny
     register_encoder("tiny-under-test", enc)
@@ -346,9 +372,9 @@ def test_clip_mapper_drop_in(tiny):
         assert out["text_embs"].shape[0] == B and out["text_embs"].dtype == np.float16
         assert out["image_filename"] == item["image_filename"] and out["text"] == item["text"]
         _, w32 = mapper_semantics(oracle.encode_image(pix))
-        assert _cos(out["image_embs"], w32).min() >= COS_BAR
+        parity_gate(out["image_embs"], w32, "mapper image")
         _, w32 = mapper_semantics(oracle.encode_text(ids))
-        assert _cos(out["text_embs"], w32).min() >= COS_BAR
+        parity_gate(out["text_embs"], w32, "mapper text")
     off = ClipMapper(True, False, False, False, "registered:tiny-under-test", True, "", warmup_batch_size=0)
     o = off({"image_tensor": pix, "image_filename": ["a"]})
     assert o["text_embs"] is None and o["metadata"] is None and o["image_embs"].shape == (1, arch.embed_dim)
@@ -359,7 +385,7 @@ def test_clip_mapper_drop_in(tiny):
 def test_full_depth_vit_l14_parity():
     """The BASELINE config's model at full depth (24 + 12 layers), small batch: the oracle needs ~1 s per image."""
     from clip_retrieval_amd.encoder import ClipEncoder
-    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, parity_gate, synth_pixels_u8, synth_tokens
 
     arch = ARCHS["ViT-L/14"]
     oracle = HFClipOracle(arch, seed=0)
@@ -368,17 +394,20 @@ def test_full_depth_vit_l14_parity():
     ids = synth_tokens(6, seed=2)
     _, wi = mapper_semantics(oracle.encode_image(torch.from_numpy(pix)))
     _, wt = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
-    ci, ct = _cos(enc.encode_image(pix), wi), _cos(enc.encode_text(ids), wt)
+    gi, gt = enc.encode_image(pix), enc.encode_text(ids)
     enc.close()
-    assert ci.min() >= COS_BAR, f"ViT-L/14 image cos {ci}"
-    assert ct.min() >= COS_BAR, f"ViT-L/14 text cos {ct}"
+    parity_gate(gi, wi, "ViT-L/14 image")
+    for wrong, want in ((gi[::-1], wi), (gt[::-1], wt), (np.repeat(gi[:1], len(gi), 0), wi)):  # swapped / stale rows must fail
+        with pytest.raises(AssertionError):
+            parity_gate(wrong, want, "negative")
+    parity_gate(gt, wt, "ViT-L/14 text")
 
 
 def test_full_depth_vit_h14_parity():
     """open_clip ViT-H/14 (BASELINE config 5's query encoder: erf GELU, 80-wide image heads, 32 + 24 layers) at FULL depth,
     B = 2 -- round 1 only compared the 2-layer tiny-H/14."""
     from clip_retrieval_amd.encoder import ClipEncoder
-    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, parity_gate, synth_pixels_u8, synth_tokens
 
     arch = ARCHS["ViT-H/14"]
     oracle = HFClipOracle(arch, seed=0)
@@ -387,33 +416,110 @@ def test_full_depth_vit_h14_parity():
     ids = synth_tokens(2, seed=4)
     _, wi = mapper_semantics(oracle.encode_image(torch.from_numpy(pix)))
     _, wt = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
-    ci, ct = _cos(enc.encode_image(pix), wi), _cos(enc.encode_text(ids), wt)
+    gi, gt = enc.encode_image(pix), enc.encode_text(ids)
     enc.close()
-    assert ci.min() >= COS_BAR, f"ViT-H/14 image cos {ci}"
-    assert ct.min() >= COS_BAR, f"ViT-H/14 text cos {ct}"
+    parity_gate(gi, wi, "ViT-H/14 image")
+    for wrong, want in ((gi[::-1], wi), (gt[::-1], wt), (np.repeat(gi[:1], len(gi), 0), wi)):  # swapped / stale rows must fail
+        with pytest.raises(AssertionError):
+            parity_gate(wrong, want, "negative")
+    parity_gate(gt, wt, "ViT-H/14 text")
 
 
-@pytest.mark.parametrize("name,B", [("tiny-L/14", 4), ("tiny-H/14", 3), ("ViT-L/14", 2)])
-def test_parity_with_trained_like_weight_statistics(name, B):
-    """Random init gives benign activations; trained CLIP does not (outlier channels, wide LayerNorm gains, peaked softmax).
-    The LayerNorm fold in particular multiplies the UN-normalised bf16 residual stream by mean-centred weights, so a row with
-    a large mean leans on cancellation.  Same acceptance bar as everywhere else, on weights pushed to those statistics
-    (oracle.make_trained_like; no real checkpoint exists offline), full depth for ViT-L/14."""
+@pytest.mark.parametrize("name,B,outliers", [("tiny-L/14", 4, (300.0, -300.0)), ("tiny-H/14", 3, (2000.0,)), ("tiny-H/14", 4, (300.0, -300.0)),
+                                             ("ViT-L/14", 2, (300.0, -300.0)), ("ViT-H/14", 2, (2000.0,))])
+def test_parity_with_trained_like_weight_statistics(name, B, outliers):
+    """Random init gives benign activations; trained CLIP does not (massive-activation channels, wide LayerNorm gains, peaked
+    softmax).  VERDICT r3 weak #4 asked for published magnitudes: two channels at +-300 (ViT-L/14), one at 2 000 (ViT-H/14, a
+    bf16-trained checkpoint), LayerNorm gains up to 30 x, FULL depth for both.  The LayerNorm fold multiplies the UN-normalised
+    fp16 stream by mean-centred fp16 weights, the residual adds round to fp16: both are exercised at those magnitudes here.
+    Bar: the north-star 1e-3 on the raw cosine, nearest-oracle-row == own row, centred cosine >= 0.9 (these weights push every
+    embedding onto a common direction: the closest WRONG row sits at 0.97 .. 0.995), and no range flag.
+    Round 4 made q, k, v IEEE fp16 for this test: with bf16 q / k the 30 x gains cost tiny-H/14 1 - cos = 2e-3
+    (tools/emulate_fp16_stream.py --exact qkv_bf16)."""
     from clip_retrieval_amd.encoder import ClipEncoder
-    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, synth_pixels_u8, synth_tokens
+    from oracle.clip_oracle import ARCHS, NORTH_STAR_BAR, HFClipOracle, mapper_semantics, normalise_u8_nhwc, parity_gate, synth_pixels_u8, synth_tokens
 
     arch = ARCHS[name]
     oracle = HFClipOracle(arch, seed=5)
-    oracle.make_trained_like(seed=5)
+    oracle.make_trained_like(seed=5, outliers=outliers, gain=30.0)
     enc = ClipEncoder(_product_arch(arch), oracle.export_blob(), 0)
     pix = normalise_u8_nhwc(synth_pixels_u8(B, arch.image_size, seed=11))
     ids = synth_tokens(B, arch.ctx_len, arch.vocab, seed=12)
     _, wi = mapper_semantics(oracle.encode_image(torch.from_numpy(pix)))
     _, wt = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
-    ci, ct = _cos(enc.encode_image(pix), wi), _cos(enc.encode_text(ids), wt)
+    gi, gt = enc.encode_image(pix), enc.encode_text(ids)  # a range overflow would raise ResidualStreamOverflow here
     enc.close()
-    assert ci.min() >= COS_BAR, f"{name} image cos {ci}"
-    assert ct.min() >= COS_BAR, f"{name} text cos {ct}"
+    ri = parity_gate(gi, wi, f"{name} image", bar=NORTH_STAR_BAR, centred_bar=0.9)
+    rt = parity_gate(gt, wt, f"{name} text", bar=NORTH_STAR_BAR, centred_bar=0.9)
+    print(f"{name} outliers {outliers}: image 1-cos {1 - ri['cos'].min():.2e} centred {ri['centred'].min():.4f}; text 1-cos {1 - rt['cos'].min():.2e}")
+    for wrong, want in ((gi[::-1], wi), (gt[::-1], wt)):
+        with pytest.raises(AssertionError):
+            parity_gate(wrong, want, "negative", bar=NORTH_STAR_BAR, centred_bar=0.9)
+
+
+@pytest.mark.parametrize("where", ["fc2_bias", "token_embedding", "ln_pre"])
+def test_fp16_stream_overflow_is_reported_never_hidden(where):
+    """The residual stream lives in IEEE fp16 (65 504).  A model that exceeds it must get CLIPX_E_RANGE, never a finite-looking wrong
+    embedding: LayerNorm of a row holding inf has rstd = 0, i.e. a perfectly finite output.  Weights are
+    planted so that the stream overflows (a 70 000 bias on the image tower's first MLP output / a 70 000 token embedding / a
+    ln_pre gain of 1e6) and EVERY way into the encoder is checked: the host calls, tickets + clipx_wait, the *_device calls +
+    clipx_range_check, the B = 1 hipGraph replays; the unaffected tower keeps working and the flag clears after it is read."""
+    import clip_retrieval_amd
+    from clip_retrieval_amd import ResidualStreamOverflow
+    from clip_retrieval_amd.encoder import ClipEncoder
+    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, parity_gate, synth_pixels_u8, synth_tokens
+
+    arch = ARCHS["tiny-L/14"]
+    oracle = HFClipOracle(arch, seed=0)
+    sd = oracle.model.state_dict()
+    with torch.no_grad():
+        if where == "fc2_bias":
+            sd["vision_model.encoder.layers.0.mlp.fc2.bias"][7] += 70000.0
+        elif where == "ln_pre":
+            sd["vision_model.pre_layrnorm.weight"][3] = 1.0e6
+        else:
+            sd["text_model.embeddings.token_embedding.weight"][:, 11] += 70000.0
+    bad_img, bad_txt = where != "token_embedding", where == "token_embedding"
+    enc = ClipEncoder(_product_arch(arch), oracle.export_blob(), 0)
+    for B in (1, 3, 12):  # 1, 3: replayed from hipGraphs after the second call; 12: plain launches, ragged text
+        pix = normalise_u8_nhwc(synth_pixels_u8(B, arch.image_size, seed=70 + B))
+        ids = synth_tokens(B, arch.ctx_len, arch.vocab, seed=80 + B)
+        for rep in range(3):
+            for bad, call, arg in ((bad_img, enc.encode_image, pix), (bad_txt, enc.encode_text, ids)):
+                if bad:
+                    with pytest.raises(ResidualStreamOverflow):
+                        call(arg)
+                else:
+                    call(arg)
+        # tickets
+        hi, ht = enc.submit_image(pix), enc.submit_text(ids)
+        for bad, h in ((bad_img, hi), (bad_txt, ht)):
+            if bad:
+                with pytest.raises(ResidualStreamOverflow):
+                    enc.collect(h)
+            else:
+                enc.collect(h)
+        # device entry points + clipx_range_check
+        dp, di = torch.from_numpy(pix).cuda(), torch.from_numpy(ids).cuda()
+        o = torch.empty(B, arch.embed_dim, dtype=torch.float16, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        enc.check_range(st)  # nothing queued through the device entry points yet: clean
+        for bad, fn in ((bad_img, lambda: enc.encode_image_device(dp.data_ptr(), B, 0, o.data_ptr(), None, st)),
+                        (bad_txt, lambda: enc.encode_text_device(di.data_ptr(), B, o.data_ptr(), None, st))):
+            fn()
+            if bad:
+                with pytest.raises(ResidualStreamOverflow):
+                    enc.check_range(st)
+            enc.check_range(st)  # read once, cleared
+    # the tower whose weights are sane is still right, row for row
+    pix = normalise_u8_nhwc(synth_pixels_u8(4, arch.image_size, seed=7))
+    ids = synth_tokens(4, arch.ctx_len, arch.vocab, seed=8)
+    if bad_img:
+        parity_gate(enc.encode_text(ids), mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))[1], "text tower beside an overflowing image tower")
+    else:
+        parity_gate(enc.encode_image(pix), mapper_semantics(oracle.encode_image(torch.from_numpy(pix)))[1], "image tower beside an overflowing text tower")
+    enc.close()
+    assert clip_retrieval_amd.load_library().clipx_last_error() is not None
 
 
 def test_load_clip_facade_query_path(tiny, tmp_path):
@@ -579,7 +685,8 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
     """Round 3: the residual stream lives in IEEE fp16.  (1) epi 6, out16 = fp16(f32(out16) + acc + bias) in place (bf16
     operands): against torch fp32 on the same operands to half an fp16 ulp + accumulation noise, and bit-identical between the
     persistent 256x256 kernel and the 128x128 kernel; (2) fp16 operands (clipx_gemm_f16_device, the LayerNorm-folded QKV / fc1):
-    out = act(acc * rowscale + bias) against torch fp32, bit-identical between the kernels."""
+    out = act(acc * rowscale + bias) against torch fp32 -- bf16 out, and fp16 out for epi 7 (round 4: the QKV projection) to fp16's
+    tolerance --, bit-identical between the kernels."""
     from clip_retrieval_amd._lib import check
 
     g = torch.Generator(device="cuda").manual_seed(M + 3 * N)
@@ -606,8 +713,8 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
             want_r = 1.0 / torch.sqrt(x.float().var(dim=1, unbiased=False) + 1e-5)
             assert torch.allclose(r_pass, want_r, rtol=1e-4, atol=0)
         ys = []
-        for epi in (0, 1, 2):
-            y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        for epi in (0, 1, 2, 7):  # 7 (round 4): epi 0 with an IEEE fp16 output -- the QKV projection
+            y = torch.empty(M, N, device="cuda", dtype=torch.float16 if epi == 7 else torch.bfloat16)
             check(lib, lib.clipx_gemm_f16_device(0, _ptr(Ah), _ptr(Wh), _ptr(bias), _ptr(y), M, N, K, epi, _ptr(rs), C.c_void_p(st)), "clipx")
             ys.append(y)
         torch.cuda.synchronize()
@@ -621,8 +728,9 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
     tol = 1e-3 + 1.2e-3 * want.abs()   # fp16: 2^-11 relative rounding + fp32 accumulation-order noise
     assert (err <= tol).all(), f"fp16 residual: max err {float(err.max()):.4g} at {(err > tol).nonzero()[:4].tolist()}"
     ref = (Ah.float() @ Wh.float().T) * rs[:, None] + bias
-    for epi, y in zip((0, 1, 2), outs[3][1:]):
-        w = ref if epi == 0 else (ref * torch.sigmoid(1.702 * ref) if epi == 1 else torch.nn.functional.gelu(ref))
+    for epi, y in zip((0, 1, 2, 7), outs[3][1:]):
+        w = ref if epi in (0, 7) else (ref * torch.sigmoid(1.702 * ref) if epi == 1 else torch.nn.functional.gelu(ref))
         e = (y.float() - w).abs()
-        t = 2e-3 + 4e-3 * w.abs()
+        t = (3e-4 + 6e-4 * w.abs()) if epi == 7 else (2e-3 + 4e-3 * w.abs())  # fp16: 2^-11 relative, bf16: 2^-8
+        assert y.dtype == (torch.float16 if epi == 7 else torch.bfloat16)
         assert (e <= t).all(), f"f16 operands epi {epi}: max err {float(e.max()):.4g}"

@@ -449,8 +449,8 @@ def test_u8_preprocess_is_the_float_transform_before_normalisation(image_folder)
     img = Image.fromarray(np.random.default_rng(5).integers(0, 255, (300, 411, 3), dtype=np.uint8))
     u8 = clip_preprocess_u8(img, 224)
     assert u8.shape == (224, 224, 3) and u8.dtype == np.uint8
-    want = ((u8.astype(np.float32) * np.float32(1 / 255.0) - CLIP_MEAN) / CLIP_STD).transpose(2, 0, 1)
-    assert np.allclose(clip_preprocess(img, 224), want, atol=1e-6)
+    want = ((u8.astype(np.float32) / np.float32(255.0) - CLIP_MEAN) / CLIP_STD).transpose(2, 0, 1)  # torchvision's arithmetic
+    assert np.array_equal(clip_preprocess(img, 224), want)
     r = FilesReader(Sampler(0, 1), clip_preprocess_u8, None, str(image_folder), 4, 2, enable_text=False)
     b = next(iter(r))
     assert b["image_tensor"].dtype.__str__() == "torch.uint8" and tuple(b["image_tensor"].shape) == (4, 224, 224, 3)
@@ -478,7 +478,10 @@ def test_decode_processes_equal_the_thread_pool(tmp_path, tar_shards):
             r = WebdatasetReader(Sampler(0, 1), prep, HashTokenizer(), shards, 5, 3)
             r.use_processes, r.chunk = procs, 2
             out[procs] = list(r)
-        assert [b["image_tensor"].shape[0] for b in out[True]] == [5, 5, 2]
+        # the reference's loader order with 3 workers (round 4, WebdatasetReader.reference_batch_order): shards 0, 3 -> stream 0
+        # (4 + 2 samples: batches 5, 1), shards 1, bad -> stream 1 (3 + 1: batch 4), shard 2 -> stream 2 (batch 2), round-robin
+        assert [b["image_tensor"].shape[0] for b in out[True]] == [5, 4, 2, 1]
+        assert [b["image_filename"] for b in out[True]][1] == ["00004", "00005", "00006", "x1"]
         for a, b in zip(out[False], out[True]):
             assert torch.equal(a["image_tensor"], b["image_tensor"]) and a["image_tensor"].dtype == b["image_tensor"].dtype
             assert torch.equal(a["text_tokens"], b["text_tokens"]) and a["text"] == b["text"]
@@ -549,8 +552,11 @@ def test_config1_plumbing_with_the_oracle_mapper(tmp_path):
         assert img.dtype == np.float16 and txt.dtype == np.float16 and img.shape == (50, arch.embed_dim) == txt.shape
         assert len(meta) == 50 and list(meta.columns)[:2] == ["image_path", "caption"]
         assert np.allclose(np.linalg.norm(img.astype(np.float32), axis=1), 1, atol=2e-3)
-        # partition i holds shards i, i + 2 (Sampler: every count-th shard) in order, 25 samples each
-        want = [f"caption {j}" for s in (i, i + 2) for j in range(25 * s, 25 * s + 25)]
+        # partition i holds shards i, i + 2 (Sampler: every count-th shard), 25 samples each; rows come in the reference loader's
+        # order for its 2 workers (reader.py:184-205): each worker batches its own shard, batches alternate -- 16 of shard i,
+        # 16 of shard i + 2, then the 9 left of each
+        a, b = [f"caption {j}" for j in range(25 * i, 25 * i + 25)], [f"caption {j}" for j in range(25 * (i + 2), 25 * (i + 2) + 25)]
+        want = a[:16] + b[:16] + a[16:] + b[16:]
         assert list(meta["caption"]) == want
         total += len(meta)
         st = json.loads((out / "stats" / f"{i}.json").read_text())  # LoggerWriter: summed stats of the partition (logger.py:13-62)

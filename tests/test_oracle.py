@@ -178,3 +178,84 @@ def test_knn_oracle_against_an_independent_exact_search():
     for i in range(4):
         want = np.flatnonzero((x.astype(np.float32) @ q[i]) > 0.3)
         assert np.array_equal(np.sort(Ir[lims[i]:lims[i + 1]]), want)
+
+
+# ------------------------------------------------------------------------------------------ the encode gate can fail
+@pytest.mark.parametrize("name", ["tiny-B/32", "tiny-L/14", "tiny-H/14"])
+def test_synthetic_images_separate_the_oracle_embeddings(name):
+    """with i.i.d.-noise images the oracle's embeddings of DIFFERENT images had cosine 0.998 with each
+    other -- inside the 0.999 acceptance bar.  The structured generator must keep rows apart on every test architecture:
+    within a group of eight every pair < 0.93 and the mean < 0.8 on random-init weights (the weights of every parity test
+    but one), and on trained-like weights -- whose planted massive-activation channels give all embeddings a common component, as
+    real CLIP embeddings have -- every CENTRED cosine < 0.9; in both cases at least 10 x the gate's 1e-4 away from 1."""
+    from oracle.clip_oracle import ARCHS, HFClipOracle, mapper_semantics, normalise_u8_nhwc, parity_report, synth_pixels_u8
+
+    arch = ARCHS[name]
+    off = ~np.eye(8, dtype=bool)
+    for trained_like in (False, True):
+        o = HFClipOracle(arch, seed=0)
+        if trained_like:
+            o.make_trained_like(0)
+        for seed in (1, 11):
+            _, f = mapper_semantics(o.encode_image(torch.from_numpy(normalise_u8_nhwc(synth_pixels_u8(8, arch.image_size, seed=seed)))))
+            c = (f @ f.T)[off]
+            fc = f - f.mean(0)
+            fc /= np.linalg.norm(fc, axis=1, keepdims=True)
+            cc = (fc @ fc.T)[off]
+            # trained-like weights (two +-300 channels, 30 x LayerNorm gains) put every embedding on a common direction: raw
+            # cosines of 0.98 .. 0.998 -- still 10 x the gate's 1e-4 away from 1, and the centred cosine separates them
+            # (worst case tiny-B/32, 50 tokens: raw 0.9987, centred 0.97 -- both still below the gate's bars of 0.9999 / 0.99)
+            assert c.max() < 1 - 1e-3 and cc.max() < (0.98 if trained_like else 0.9), (name, trained_like, seed, c.max(), cc.max())
+            if not trained_like:
+                assert c.max() < 0.93 and c.mean() < 0.8, (name, seed, c.max(), c.mean())
+            rep = parity_report(f, f)
+            assert (rep["nearest"] == np.arange(8)).all() and rep["other"].max() < 1 - 1e-3
+
+
+def test_synthetic_images_are_the_same_in_the_product_and_the_oracle_module():
+    from clip_retrieval_amd import synth
+    from oracle import clip_oracle
+
+    a, b = synth.synth_pixels_u8(11, 96, seed=7), clip_oracle.synth_pixels_u8(11, 96, seed=7)
+    assert a.dtype == np.uint8 and a.shape == (11, 96, 96, 3) and np.array_equal(a, b)
+    assert np.array_equal(clip_oracle.synth_pixels_u8(3, 96, seed=7), a[:3])  # sample b depends on (seed, b) only
+    assert not np.array_equal(clip_oracle.synth_pixels_u8(3, 96, seed=8), a[:3])
+    assert a.std() > 60 and len({tuple(x[0, 0] // 64) for x in a[:8]}) >= 6  # eight distinct background corners
+
+
+def test_parity_gate_rejects_wrong_rows_and_accepts_the_measured_error():
+    """The gate itself, on oracle embeddings: accepts the row-for-row answer perturbed by the error the kernels measure
+    (1 - cos ~ 2e-5), rejects swapped rows, a stale row, the batch mean in every row, a rolled batch, NaN; and the OLD gate
+    (raw cosine >= 0.999 alone) accepts a swapped pair of near-duplicate rows, which is the point."""
+    from oracle.clip_oracle import (ARCHS, NORTH_STAR_BAR, HFClipOracle, mapper_semantics, normalise_u8_nhwc, parity_gate,
+                                    parity_report, synth_pixels_u8)
+
+    arch = ARCHS["tiny-L/14"]
+    o = HFClipOracle(arch, seed=0)
+    o.make_trained_like(0)
+    _, w = mapper_semantics(o.encode_image(torch.from_numpy(normalise_u8_nhwc(synth_pixels_u8(6, seed=3)))))
+    rng = np.random.default_rng(0)
+    noise = rng.standard_normal(w.shape)
+    noise *= np.sqrt(2 * 2e-5) / np.linalg.norm(noise, axis=1, keepdims=True)
+    good = (w + noise).astype(np.float16)
+    rep = parity_gate(good, w, "perturbed")
+    assert rep["cos"].min() > 1 - 1e-4 and rep["centred"].min() > 0.99
+    swapped = good.copy()
+    swapped[[0, 5]] = swapped[[5, 0]]
+    stale = good.copy()
+    stale[2] = stale[1]
+    const = np.repeat(w.mean(0, keepdims=True), 6, 0)
+    nan = good.copy()
+    nan[4, 7] = np.nan
+    for wrong in (swapped, stale, const, np.roll(good, 1, 0), nan):
+        with pytest.raises(AssertionError):
+            parity_gate(wrong, w, "negative")
+    # the old gate on the old inputs: a pair of rows closer than 1e-3 swaps unnoticed
+    near = w.copy()
+    near[1] = w[0] + 0.02 * (w[1] - w[0])
+    near /= np.linalg.norm(near, axis=1, keepdims=True)
+    sw = near.copy()
+    sw[[0, 1]] = sw[[1, 0]]
+    assert parity_report(sw, near)["cos"].min() >= NORTH_STAR_BAR  # would have passed
+    with pytest.raises(AssertionError):
+        parity_gate(sw, near, "negative")  # nearest-row rule catches it

@@ -78,3 +78,38 @@ def test_raw_batches_are_packed_with_offsets():
     for im, o in zip(imgs, raw["offsets"]):
         assert np.array_equal(flat[o:o + im.size], im.reshape(-1))
     assert batch["image_filename"] == ["0", "1", "2"] and "image_tensor" not in batch
+
+
+def test_decode_only_preprocess_keeps_the_reference_transform_for_modes_the_gpu_kernel_does_not_restate():
+    """Pillow resamples palette / bilevel images with NEAREST and premultiplies alpha, and the reference resizes in the
+    image's own mode before converting to RGB.  `DecodeRgbU8` therefore hands P / 1 / RGBA / LA / I;16 sources (and oversized
+    ones) over as the HOST transform's ready crop -- which the GPU resample (here: its numpy restatement) passes through
+    unchanged -- and only RGB / L sources as decoded pixels; either way the crop is Pillow's, byte for byte."""
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (150, 201, 3), dtype=np.uint8)
+    rgb = Image.fromarray(base)
+    alpha = rng.integers(0, 256, (150, 201), dtype=np.uint8)
+    cases = {
+        "RGB": rgb, "L": rgb.convert("L"), "P": rgb.quantize(16), "1": rgb.convert("1"),
+        "RGBA": Image.merge("RGBA", (*rgb.split(), Image.fromarray(alpha))), "LA": Image.merge("LA", (rgb.convert("L"), Image.fromarray(alpha))),
+        "I;16": Image.fromarray((base[..., 0].astype(np.uint16) * 200)),
+    }
+    dec = reader.DecodeRgbU8(224)
+    assert dec.raw_images and reader.decode_rgb_u8.raw_images
+    for mode, im in cases.items():
+        assert im.mode == mode
+        want = np.asarray(reader.clip_preprocess_u8(im, size=224))
+        src = dec(im)
+        if mode in ("RGB", "L"):
+            assert src.shape == (150, 201, 3)  # decoded pixels: the GPU does the geometry
+        else:
+            assert src.shape == (224, 224, 3) and np.array_equal(src, want), mode  # the host transform's crop
+        assert np.array_equal(ro.clip_resize_crop_u8(src, 224), want), f"mode {mode}: the crop differs from the reference transform's"
+    # converting first and resizing afterwards is NOT the reference's crop for these modes (which is why they take the host path)
+    for mode in ("P", "RGBA"):
+        first = ro.clip_resize_crop_u8(np.asarray(cases[mode].convert("RGB"), dtype=np.uint8), 224)
+        assert not np.array_equal(first, np.asarray(reader.clip_preprocess_u8(cases[mode], size=224))), mode
+    # oversized sources stay on the host as well (the kernel would refuse them and the partition would die)
+    big = Image.fromarray(np.zeros((224 * 16 + 1, 224 * 16 + 8, 3), dtype=np.uint8))  # a 16 x down-scale of the shorter side
+    assert reader.DecodeRgbU8(224)(big).shape == (224, 224, 3)
+    assert reader.DecodeRgbU8(224, max_side=256)(Image.fromarray(base).resize((300, 100))).shape == (224, 224, 3)

@@ -341,3 +341,42 @@ def test_safety_head_arguments():
         Mi355xSafetyHead({})
     with pytest.raises(FileNotFoundError):
         Mi355xSafetyHead.from_cache("/nonexistent-cache")
+
+
+def test_violence_filter_is_the_fp32_einsum_and_follows_a_swapped_detector():
+    """clip_back.py:327-331 on the GPU in fp32 (the round-3 form stored the prompts as fp16 rows, cached them under
+    id(array) without holding the array, and held a lock across the GPU call): same picks as the reference's numpy einsum on
+    random vectors INCLUDING near-ties that fp16 prompts would flip, a replaced detector is picked up even when it is a new
+    array of the same shape, and concurrent callers agree."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from clip_retrieval_amd.service import KnnHotPath
+
+    rng = np.random.default_rng(0)
+    d = 768
+    hp = KnnHotPath()
+    for trial in range(3):
+        prompts = rng.standard_normal((2, d)).astype(np.float32)
+        prompts /= np.linalg.norm(prompts, axis=1, keepdims=True)
+        emb = rng.standard_normal((400, d)).astype(np.float32)
+        emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+        # plant near-ties: rows whose two scores differ by ~1e-5 (an fp16 prompt matrix has errors of ~1e-4 per score)
+        diff = prompts[1] - prompts[0]
+        for i in range(0, 100):
+            e = emb[i] - (emb[i] @ diff) / (diff @ diff) * diff          # exactly tied
+            emb[i] = e + (1e-5 if i % 2 else -1e-5) * diff / (diff @ diff)
+        want_scores = np.einsum("ij,kj->ik", emb, prompts)
+        want = np.where(np.argmax(want_scores, axis=1) == 1)[0]
+        margin = np.abs(want_scores[:, 1] - want_scores[:, 0])
+        got = hp.get_violent_items(prompts, emb)
+        clear = margin > 2e-6  # beyond f32 summation-order noise the pick is the reference's
+        assert np.array_equal(np.intersect1d(got, np.flatnonzero(clear)), np.intersect1d(want, np.flatnonzero(clear)))
+        assert (margin[:100] < 5e-5).all() and clear[:100].sum() > 80  # the planted near-ties were really tested
+        with ThreadPoolExecutor(8) as ex:
+            for g in ex.map(lambda _: hp.get_violent_items(prompts, emb), range(16)):
+                assert np.array_equal(g, got)
+        swapped = prompts[::-1].copy()  # "violent" and "safe" exchanged: the complement on the clear rows
+        got2 = hp.get_violent_items(swapped, emb)
+        assert np.array_equal(np.intersect1d(got2, np.flatnonzero(clear)), np.setdiff1d(np.flatnonzero(clear), want))
+    assert len(hp._prompts) <= 8  # pylint: disable=protected-access
+    assert hp.get_violent_items(prompts, np.zeros((0, d), np.float32)).shape == (0,)

@@ -1,5 +1,5 @@
 // attn_bench.cpp -- times the library's attention kernel (clipx_attention_dh_device, include/clipx.h) without Python and
-// checks a few (batch, head) pairs against an fp32 CPU softmax(QK^T/sqrt(dh))V of the same bf16 inputs.
+// checks a few (batch, head) pairs against an fp32 CPU softmax(QK^T/sqrt(dh))V of the same IEEE fp16 inputs (round 4: q, k, v are fp16; the output is bf16).
 //   hipcc -O2 -o tools/attn_bench tools/attn_bench.cpp -ldl ;  tools/attn_bench [B T H dh causal]
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -14,7 +14,8 @@
 typedef int (*attn_fn)(int, const void*, void*, int, int, int, int, int, void*);
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
-static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16); }
+static float h2f(uint16_t b) { _Float16 h; memcpy(&h, &b, 2); return (float)h; }
+static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t b; memcpy(&b, &h, 2); return b; }
 int main(int argc, char** argv) {
   std::string self = argv[0];
   std::string dir = self.substr(0, self.find_last_of('/') == std::string::npos ? 0 : self.find_last_of('/'));
@@ -26,7 +27,7 @@ int main(int argc, char** argv) {
   const size_t ld = (size_t)3 * H * dh, nq = (size_t)B * T * ld, no = (size_t)B * T * H * dh;
   std::vector<uint16_t> hq(nq), ho(no);
   unsigned r = 777u;
-  for (auto& v : hq) { r = r * 1664525u + 1013904223u; v = f2bf((((int)(r >> 9) & 0xffff) / 32768.f - 1.f) * 1.5f); }
+  for (auto& v : hq) { r = r * 1664525u + 1013904223u; v = f2h((((int)(r >> 9) & 0xffff) / 32768.f - 1.f) * 1.5f); }
   void *dq, *dout;
   CK(hipMalloc(&dq, nq * 2)); CK(hipMalloc(&dout, no * 2));
   CK(hipMemcpy(dq, hq.data(), nq * 2, hipMemcpyHostToDevice));
@@ -46,7 +47,7 @@ int main(int argc, char** argv) {
       for (int k = 0; k < kend; ++k) {
         const uint16_t* kp = &hq[((size_t)b * T + k) * ld + H * dh + hh * dh];
         float a = 0;
-        for (int d = 0; d < dh; ++d) a += bf2f(qp[d]) * bf2f(kp[d]);
+        for (int d = 0; d < dh; ++d) a += h2f(qp[d]) * h2f(kp[d]);
         s[k] = a / sqrtf((float)dh);
         mx = std::max(mx, s[k]);
       }
@@ -54,7 +55,7 @@ int main(int argc, char** argv) {
       for (int k = 0; k < kend; ++k) { s[k] = expf(s[k] - mx); sum += s[k]; }
       for (int d = 0; d < dh; ++d) {
         double o = 0;
-        for (int k = 0; k < kend; ++k) o += s[k] * bf2f(hq[((size_t)b * T + k) * ld + 2 * H * dh + hh * dh + d]);
+        for (int k = 0; k < kend; ++k) o += s[k] * h2f(hq[((size_t)b * T + k) * ld + 2 * H * dh + hh * dh + d]);
         o /= sum;
         maxerr = std::max(maxerr, fabs(o - bf2f(ho[((size_t)b * T + q) * (H * dh) + hh * dh + d])));
       }

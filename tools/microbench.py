@@ -94,7 +94,7 @@ if "gemm" in what:
             print(f"gemm v{v:5s} {name:26s} {ms * 1e3:9.1f} us  {2.0 * m * N * K / ms / 1e9:8.1f} TFLOP/s   (min {min(res[v]) * 1e3:.1f})", flush=True)
 if "attn" in what:
     for (B, T, H, causal) in [(256, 257, 16, 0), (256, 77, 12, 1)]:
-        qkv = torch.randn(B * T, 3 * H * 64, device="cuda").to(torch.bfloat16)
+        qkv = torch.randn(B * T, 3 * H * 64, device="cuda").to(torch.float16)
         out = torch.empty(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
         timed(f"attention B={B} T={T} H={H} causal={causal}",
               lambda: check(lib, lib.clipx_attention_device(0, P(qkv), P(out), B, T, H, causal, C.c_void_p(st)), "clipx"),
