@@ -892,7 +892,7 @@ static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const f
                      const float* rowscale, void* out16, void* stream, int f16 = 0) {
   if (!A_bf16 || !W_bf16 || !out || M <= 0 || N <= 0 || K <= 0) return fail(CLIPX_E_ARG, "bad gemm arguments");
   if (!((epi >= 0 && epi <= 3) || epi == EPI_BIAS_RESID_H16 || epi == EPI_BIAS_F16) || !bias) return fail(CLIPX_E_ARG, "epi must be 0..3, 6 or 7 and bias non-null");
-  if (f16 && epi > 2) return fail(CLIPX_E_ARG, "fp16 operands go with the bf16-output epilogues 0..2 only");
+  if (f16 && epi > 2 && epi != EPI_BIAS_F16) return fail(CLIPX_E_ARG, "fp16 operands go with the 16-bit-output epilogues 0..2 and 7 only");
   if (N % 128 || K % 64) return fail(CLIPX_E_UNSUPPORTED, "N must be a multiple of 128 and K of 64");
   HIPCHK(hipSetDevice(device));
   GemmArgs g{};
