@@ -312,6 +312,19 @@ class ShardedMi355xIndex(_FaissShaped):
         return int(self._lib.knnx_shards_ntotal(self._h))
 
     @property
+    def nprobe(self):
+        return getattr(self, "_nprobe", 1)
+
+    @nprobe.setter
+    def nprobe(self, v):
+        """IVF-Flat shards: faiss `extract_index_ivf(index).nprobe = v` on every shard (clip_back.py:357-369)."""
+        for g in range(self.nshards):
+            sh = C.c_void_p(self._lib.knnx_shards_get(self._h, g))
+            if self._lib.knnx_ivf_nlist(sh) > 0:
+                check(self._lib, self._lib.knnx_ivf_set_nprobe(sh, int(v)), "knnx")
+        self._nprobe = int(v)
+
+    @property
     def nshards(self):
         return int(self._lib.knnx_shards_count(self._h))
 
@@ -388,7 +401,8 @@ def embedding_files(folder):
 
 
 def load_index(path, device=0, row_range=None, enable_faiss_memory_mapping=False, devices=None):  # pylint: disable=unused-argument
-    """Build an HBM-resident flat index from a folder of fp16 `.npy` partitions.
+    """Build an HBM-resident flat index from a folder of fp16 `.npy` partitions -- or, when `path` is a folder written by
+    `save_index()` (it holds ivf_manifest.json), re-create that IVF-Flat index without training or assigning anything.
 
     Takes the place of clip_back.py:589-596 (`faiss.read_index`) for this index type; ids are the global
     row order of the concatenated partitions = the metadata row order (clip_back.py:401-417).
@@ -397,17 +411,10 @@ def load_index(path, device=0, row_range=None, enable_faiss_memory_mapping=False
     (`ShardedMi355xIndex`, the KnnService case).  `enable_faiss_memory_mapping` is accepted for call compatibility:
     rows are always resident in HBM; the files themselves are read through np.load(mmap_mode="r").
     """
-    files = embedding_files(path)
-    shapes = []
-    for f in files:
-        a = np.load(f, mmap_mode="r")
-        if a.ndim != 2:
-            raise ValueError(f"{f}: expected a 2-D embedding matrix")
-        shapes.append(a.shape)
-    d = shapes[0][1]
-    if any(s[1] != d for s in shapes):
-        raise ValueError("embedding files disagree on the dimension")
-    total = sum(s[0] for s in shapes)
+    if os.path.isfile(os.path.join(path, IVF_MANIFEST)):  # a built IVF-Flat index saved by save_index(): no k-means, no assignment
+        return _load_ivf_index(path, device=device, row_range=row_range, devices=devices)
+    src = FolderRows(path)
+    files, shapes, d, total = src.files, src.shapes, src.d, src.n
     lo, hi = (0, total) if row_range is None else row_range
     if devices is not None:
         if row_range is not None:
@@ -700,5 +707,198 @@ def build_ivf_index(x_f16, nlist, nprobe=16, niter=8, seed=0, device=0, id_base=
         check(lib, lib.knnx_ivf_add_assigned(index._h, rows.ctypes.data, rows.shape[0], ids.ctypes.data, ls.ctypes.data, pos.ctypes.data), "knnx")  # pylint: disable=protected-access
     check(lib, lib.knnx_ivf_end(index._h), "knnx")  # pylint: disable=protected-access
     index.nprobe = min(nprobe, nlist)
-    index.ivf_lists = lists  # kept for tests / recall measurement
+    index.ivf_lists = lists  # kept for tests / recall measurement, and for save_index(index, folder, embeddings_folder=...)
+    index.ivf_centroids, index.ivf_row_range = centroids, (int(id_base), int(id_base) + int(n))
     return index
+
+
+# ------------------------------------------------------------------------------------------------------------
+# IVF-Flat from disk and back ("img_emb_*.npy -> resident shards"; row a17: the reference builds once,
+# offline -- clip_index.py:12-66 -- and boots by reading the index file -- clip_back.py:589-596, 883-896)
+# ------------------------------------------------------------------------------------------------------------
+IVF_MANIFEST = "ivf_manifest.json"
+IVF_FORMAT = "clip-retrieval_amd ivf-flat v1"
+
+
+class FolderRows:
+    """The rows of one `clip inference` output folder (`img_emb_{zfill}.npy`, writer.py:67-75: NPY v1, C order, fp16 [n_i, d]) as
+    ONE virtual [n, d] matrix in partition order -- global row number = id = metadata row (clip_back.py:401-417) -- read through
+    np.load(mmap_mode="r"), never resident as a whole."""
+
+    def __init__(self, folder):
+        self.folder = folder
+        self.files = embedding_files(folder)
+        self.shapes = []
+        for f in self.files:
+            a = np.load(f, mmap_mode="r")
+            if a.ndim != 2:
+                raise ValueError(f"{f}: expected a 2-D embedding matrix")
+            self.shapes.append(tuple(int(v) for v in a.shape))
+        self.d = self.shapes[0][1]
+        if any(sh[1] != self.d for sh in self.shapes):
+            raise ValueError("embedding files disagree on the dimension")
+        self.starts = np.concatenate([[0], np.cumsum([sh[0] for sh in self.shapes])]).astype(np.int64)
+        self.n = int(self.starts[-1])
+
+    def rows(self, lo, hi):
+        """fp16 [hi - lo, d] (a copy), possibly spanning several files."""
+        lo, hi = int(lo), int(hi)
+        if not 0 <= lo <= hi <= self.n:
+            raise IndexError(f"rows [{lo}, {hi}) outside [0, {self.n})")
+        parts = []
+        f0 = int(np.searchsorted(self.starts, lo, side="right")) - 1
+        for fi in range(max(f0, 0), len(self.files)):
+            a0, a1 = max(lo, int(self.starts[fi])), min(hi, int(self.starts[fi + 1]))
+            if a1 > a0:
+                a = np.load(self.files[fi], mmap_mode="r")[a0 - int(self.starts[fi]):a1 - int(self.starts[fi])]
+                parts.append(np.asarray(a, dtype=np.float16))
+            if int(self.starts[fi + 1]) >= hi:
+                break
+        if not parts:
+            return np.zeros((0, self.d), dtype=np.float16)
+        return np.ascontiguousarray(parts[0]) if len(parts) == 1 else np.concatenate(parts)
+
+    def chunks(self, lo, hi, chunk):
+        for o in range(int(lo), int(hi), int(chunk)):
+            yield o, self.rows(o, min(o + chunk, hi))
+
+    def take(self, idx):
+        """fp16 rows at sorted global row numbers `idx` (the k-means training sample)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        out = np.empty((idx.size, self.d), dtype=np.float16)
+        fi = np.searchsorted(self.starts, idx, side="right") - 1
+        for f in np.unique(fi):
+            sel = np.flatnonzero(fi == f)
+            out[sel] = np.load(self.files[int(f)], mmap_mode="r")[idx[sel] - int(self.starts[int(f)])]
+        return out
+
+    def manifest(self):
+        return {"folder": os.path.abspath(self.folder), "files": [[os.path.basename(f), sh[0]] for f, sh in zip(self.files, self.shapes)],
+                "rows": self.n, "d": self.d}
+
+
+def _scatter_into_ivf(src, lo, hi, centroids, lists, nprobe, device, chunk):
+    """The second pass of an IVF build: rows [lo, hi) of `src` into a list-sorted arena on `device` (ids = global row numbers),
+    given every row's list id.  Streams the rows once; no training, no assignment."""
+    nlist, d = centroids.shape
+    sizes = np.bincount(lists, minlength=nlist).astype(np.int64)
+    if sizes.shape[0] != nlist:
+        raise ValueError("a list id is outside [0, nlist)")
+    index = Mi355xIndex(d, device=device, id_base=lo)
+    lib = index._lib  # pylint: disable=protected-access
+    cpad = np.ascontiguousarray(index._pad(np.asarray(centroids, dtype=np.float16)))  # pylint: disable=protected-access
+    check(lib, lib.knnx_ivf_begin(index._h, nlist, cpad.ctypes.data, sizes.ctypes.data), "knnx")  # pylint: disable=protected-access
+    cursor = np.zeros(nlist, dtype=np.int64)
+    for o, x in src.chunks(lo, hi, chunk):
+        rows = np.ascontiguousarray(index._pad(x))  # pylint: disable=protected-access
+        ls = np.ascontiguousarray(lists[o - lo:o - lo + rows.shape[0]], dtype=np.int32)
+        pos = _positions_in_lists(ls, cursor)
+        ids = np.arange(o, o + rows.shape[0], dtype=np.int64)
+        check(lib, lib.knnx_ivf_add_assigned(index._h, rows.ctypes.data, rows.shape[0], ids.ctypes.data, ls.ctypes.data, pos.ctypes.data), "knnx")  # pylint: disable=protected-access
+    check(lib, lib.knnx_ivf_end(index._h), "knnx")  # pylint: disable=protected-access
+    index.nprobe = min(int(nprobe), nlist)
+    index.ivf_lists, index.ivf_centroids, index.ivf_source, index.ivf_row_range = lists, np.asarray(centroids, dtype=np.float16), src, (int(lo), int(hi))
+    return index
+
+
+def build_ivf_index_from_folder(path, nlist, nprobe=16, niter=8, seed=0, device=0, row_range=None, centroids=None,
+                                max_points_per_centroid=256, chunk=1 << 20):
+    """`clip inference` output folder -> HBM-resident IVF-Flat index, streaming the `.npy` partitions (never the whole shard in
+    host memory; what `clip_index` / autofaiss do for the reference's index types, clip_index.py:12-66).
+      pass 0  a strided sample of <= nlist * max_points_per_centroid rows -> spherical k-means on the GPU (train_ivf_centroids);
+              `centroids=` skips it (all shards of a row-sharded index MUST share one set: train once, pass it to the others)
+      pass 1  every row through the MFMA assignment kernel (knnx_ivfb_assign): 4 bytes of list id per row stay on the host
+      pass 2  knnx_ivf_begin / add_assigned / end: the rows into the list-sorted, tile-padded arena
+    `row_range=(lo, hi)`: one shard of a row-sharded index (ids stay global row numbers).  The result can be `save_index()`ed."""
+    src = path if isinstance(path, FolderRows) else FolderRows(path)
+    lo, hi = (0, src.n) if row_range is None else (int(row_range[0]), int(row_range[1]))
+    if centroids is None:
+        take = min(src.n, int(nlist) * int(max_points_per_centroid))  # sample the WHOLE folder, so that every shard trains the same
+        idx = np.unique(np.linspace(0, src.n - 1, take).astype(np.int64))
+        centroids = train_ivf_centroids(src.take(idx), nlist, niter=niter, seed=seed, device=device, max_points_per_centroid=max_points_per_centroid)
+    centroids = np.asarray(centroids).astype(np.float16)
+    b = IvfBuilder(src.d, nlist, device)
+    b.set_centroids(centroids)
+    lists = np.empty(hi - lo, dtype=np.int32)
+    for o, x in src.chunks(lo, hi, chunk):
+        lists[o - lo:o - lo + x.shape[0]] = b.assign(x)
+    b.close()
+    return _scatter_into_ivf(src, lo, hi, centroids, lists, nprobe, device, chunk)
+
+
+def save_index(index, folder, embeddings_folder=None):
+    """Write a built IVF-Flat index (build_ivf_index_from_folder, or build_ivf_index given `embeddings_folder`) so that a service
+    boots WITHOUT k-means or assignment: `ivf_centroids.npy` (fp16 [nlist, d]), `ivf_lists.npy` (int32 list id of every row of the
+    shard: 4 bytes per row) and `ivf_manifest.json` (format, d, nlist, nprobe, row range, and the embeddings folder with the name
+    and row count of each partition file -- the rows themselves are not copied: the arena is rebuilt from them by one scatter
+    pass).  The counterpart of the reference's `<indices>/image.index` written by clip_index (clip_index.py:12-66), read back by
+    `load_index(folder)` in the place of clip_back.py:589-596."""
+    import json  # pylint: disable=import-outside-toplevel
+
+    lists, cent = getattr(index, "ivf_lists", None), getattr(index, "ivf_centroids", None)
+    src = getattr(index, "ivf_source", None)
+    if lists is None or cent is None:
+        raise ValueError("save_index takes an IVF-Flat index built by build_ivf_index_from_folder / build_ivf_index")
+    if src is None:
+        if embeddings_folder is None:
+            raise ValueError("this index was built from an in-memory array: name the embeddings folder its rows can be re-read from")
+        src = FolderRows(embeddings_folder)
+    lo, hi = getattr(index, "ivf_row_range", (0, src.n))
+    if hi - lo != lists.shape[0]:
+        raise ValueError("list ids and row range disagree")
+    os.makedirs(folder, exist_ok=True)
+    np.save(os.path.join(folder, "ivf_centroids.npy"), np.asarray(cent, dtype=np.float16))
+    np.save(os.path.join(folder, "ivf_lists.npy"), np.asarray(lists, dtype=np.int32))
+    man = {"format": IVF_FORMAT, "d": int(index.d), "nlist": int(cent.shape[0]), "nprobe": int(index.nprobe), "row_range": [int(lo), int(hi)],
+           "embeddings": src.manifest(), "embeddings_relative": os.path.relpath(os.path.abspath(src.folder), os.path.abspath(folder))}
+    tmp = os.path.join(folder, IVF_MANIFEST + ".part")
+    with open(tmp, "w", encoding="utf-8") as f:
+        json.dump(man, f, indent=1)
+    os.replace(tmp, os.path.join(folder, IVF_MANIFEST))  # the manifest appears last: a folder without it is not an index
+    return man
+
+
+def read_ivf_manifest(folder, embeddings_folder=None):
+    """(manifest dict, FolderRows of the embeddings it names) -- the embeddings are looked for at the recorded relative path
+    first (the index folder and the embeddings usually move together), then at the absolute one; their file names and row
+    counts must still be what they were when the index was built (ids are row numbers)."""
+    import json  # pylint: disable=import-outside-toplevel
+
+    with open(os.path.join(folder, IVF_MANIFEST), encoding="utf-8") as f:
+        man = json.load(f)
+    if man.get("format") != IVF_FORMAT:
+        raise ValueError(f"{folder}: unknown index format {man.get('format')!r}")
+    cands = [embeddings_folder] if embeddings_folder else [os.path.normpath(os.path.join(folder, man["embeddings_relative"])), man["embeddings"]["folder"]]
+    src = None
+    for c in cands:
+        if c and os.path.isdir(c) and glob.glob(os.path.join(c, "*.npy")):
+            src = FolderRows(c)
+            break
+    if src is None:
+        raise FileNotFoundError(f"{folder}: the embeddings this index was built from are not at {cands}")
+    if src.manifest()["files"] != man["embeddings"]["files"] or src.d != man["d"]:
+        raise ValueError(f"{src.folder}: the embedding files changed since the index was built (names / row counts / dimension)")
+    return man, src
+
+
+def _load_ivf_index(folder, device=0, row_range=None, devices=None, embeddings_folder=None, chunk=1 << 20):
+    man, src = read_ivf_manifest(folder, embeddings_folder)
+    cent = np.load(os.path.join(folder, "ivf_centroids.npy"))
+    lists = np.load(os.path.join(folder, "ivf_lists.npy"), mmap_mode="r")
+    slo, shi = man["row_range"]
+    if cent.shape != (man["nlist"], man["d"]) or lists.shape[0] != shi - slo:
+        raise ValueError(f"{folder}: sidecar files disagree with the manifest")
+    if devices is not None:
+        if row_range is not None:
+            raise ValueError("row_range and devices are mutually exclusive")
+        G = len(devices)
+        cuts = [slo + (shi - slo) * g // G for g in range(G + 1)]
+        shards = [_scatter_into_ivf(src, cuts[g], cuts[g + 1], cent, np.asarray(lists[cuts[g] - slo:cuts[g + 1] - slo]), man["nprobe"], devices[g], chunk)
+                  for g in range(G)]
+        sharded = ShardedMi355xIndex.from_shards(shards, cuts[:-1])
+        sharded.nprobe = man["nprobe"]
+        return sharded
+    lo, hi = (slo, shi) if row_range is None else (int(row_range[0]), int(row_range[1]))
+    if not slo <= lo <= hi <= shi:
+        raise ValueError(f"row_range {row_range} is outside the saved shard's rows [{slo}, {shi})")
+    return _scatter_into_ivf(src, lo, hi, cent, np.asarray(lists[lo - slo:hi - slo]), man["nprobe"], device, chunk)

@@ -608,3 +608,30 @@ def test_pipelined_runner_drops_in_flight_tickets_when_a_batch_fails(tmp_path, i
         r(0)
     assert not m.outstanding, f"tickets left in flight: {log}"
     assert any(k == "discard" for k, _ in log)
+
+
+def test_folder_rows_is_the_concatenation_of_the_partitions(tmp_path):
+    """knn.FolderRows (the row source of the streamed IVF build / load): any [lo, hi) of the virtual matrix, chunks across file
+    borders, sorted gathers, and the manifest that save_index records (file names + row counts: ids are row numbers)."""
+    from clip_retrieval_amd.knn import FolderRows
+
+    rng = np.random.default_rng(0)
+    parts = [rng.standard_normal((n, 16)).astype(np.float16) for n in (5, 0, 7, 3)]
+    for i, a in enumerate(parts):
+        np.save(tmp_path / f"img_emb_{i}.npy", a)
+    allr = np.concatenate(parts)
+    fr = FolderRows(str(tmp_path))
+    assert fr.n == 15 and fr.d == 16 and fr.starts.tolist() == [0, 5, 5, 12, 15]
+    for lo in range(16):
+        for hi in range(lo, 16):
+            got = fr.rows(lo, hi)
+            assert got.dtype == np.float16 and got.flags["C_CONTIGUOUS"] and np.array_equal(got, allr[lo:hi])
+    assert [(o, len(x)) for o, x in fr.chunks(2, 15, 4)] == [(2, 4), (6, 4), (10, 4), (14, 1)]
+    idx = np.array([0, 4, 5, 11, 12, 14])
+    assert np.array_equal(fr.take(idx), allr[idx])
+    assert fr.manifest()["files"] == [["img_emb_0.npy", 5], ["img_emb_1.npy", 0], ["img_emb_2.npy", 7], ["img_emb_3.npy", 3]]
+    with pytest.raises(IndexError):
+        fr.rows(3, 16)
+    np.save(tmp_path / "img_emb_4.npy", np.zeros((2, 8), np.float16))
+    with pytest.raises(ValueError):
+        FolderRows(str(tmp_path))

@@ -622,6 +622,102 @@ def test_load_index_from_numpy_writer_output(tmp_path):
     part.close()
 
 
+def test_ivf_index_from_a_folder_saved_and_loaded_back(tmp_path):
+    """Row f1 finished (VERDICT r3 missing #1; clip_index.py:12-66 builds once, clip_back.py:589-596 / 883-896 boots from the file):
+    a `clip inference` output folder (NumpyWriter's img_emb_*.npy, 70 k rows over five partitions incl. an empty one) is
+    streamed into an IVF-Flat index (sample -> k-means, assignment pass, scatter pass), saved (centroids + 4 bytes of list id per
+    row + manifest), and `load_index(folder)` re-creates it WITHOUT k-means or assignment: identical id lists and scores before /
+    after, equal to the numpy oracle on the same centroids and lists; `row_range=` (one shard) and `devices=[...]` (the in-process
+    sharded object) load from the same files; a changed embeddings folder is refused."""
+    import json
+    import os
+
+    from clip_retrieval_amd import knn
+    from clip_retrieval_amd.writer import NumpyWriter
+    from oracle.knn_oracle import IVFFlatOracle
+
+    d, nlist, nprobe = 512, 96, 12
+    sizes = (30_000, 0, 17_500, 1, 22_500)
+    emb = tmp_path / "embeddings"
+    parts = []
+    rng = np.random.default_rng(9)
+    centres = rng.standard_normal((200, d)).astype(np.float32)
+    for i, m in enumerate(sizes):
+        x = centres[rng.integers(0, 200, m)] + 0.7 * rng.standard_normal((m, d)).astype(np.float32)
+        x = (x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)).astype(np.float16)
+        parts.append(x)
+        w = NumpyWriter(partition_id=i, output_folder=str(emb), enable_text=False, enable_image=True, enable_metadata=False,
+                        output_partition_count=len(sizes))
+        if m:
+            w({"image_embs": x, "text_embs": None, "image_filename": [str(j) for j in range(m)], "text": None, "metadata": None})
+        w.flush()
+    x = np.concatenate(parts)
+    n = len(x)
+    folder = str(emb / "img_emb")
+    built = knn.build_ivf_index_from_folder(folder, nlist, nprobe=nprobe, niter=4, seed=1, chunk=8192)
+    assert built.ntotal == n and built.nlist == nlist and built.nprobe == nprobe
+    lists = built.ivf_lists
+    assert lists.shape == (n,) and lists.min() >= 0 and lists.max() < nlist and np.bincount(lists, minlength=nlist).min() > 0
+    q = _queries(40, d, seed=4, x=x)
+    ora = IVFFlatOracle(d, built.ivf_centroids, lists, x)
+    Do, Io = ora.search(q, 40, nprobe)
+    Db, Ib, Rb = built.search_and_reconstruct(q, 40)
+    _check(Db, Ib, Do, Io, "ivf from folder")
+    assert np.array_equal(Rb[Ib >= 0], x[Ib[Ib >= 0]].astype(np.float32))
+    # recall of the trained lists against the exact answer: the lists are real clusters, not a random partition
+    exact = np.argsort(-(q @ x.astype(np.float32).T), axis=1, kind="stable")[:, :10]
+    assert np.mean([len(set(exact[i]) & set(Ib[i])) / 10 for i in range(len(q))]) > 0.8
+
+    out = str(tmp_path / "indices" / "image.index")
+    man = knn.save_index(built, out)
+    assert sorted(os.listdir(out)) == ["ivf_centroids.npy", "ivf_lists.npy", "ivf_manifest.json"]
+    assert man["row_range"] == [0, n] and man["embeddings"]["files"] == [[f"img_emb_{i}.npy", m] for i, m in enumerate(sizes) if m]  # (an empty partition writes no file: writer.py:58-60)
+    assert os.path.getsize(os.path.join(out, "ivf_lists.npy")) == 128 + 4 * n  # 4 bytes per row
+    built.close()
+
+    loaded = knn.load_index(out)  # no training, no assignment: one scatter pass
+    assert loaded.ntotal == n and loaded.nlist == nlist and loaded.nprobe == nprobe
+    Dl, Il, Rl = loaded.search_and_reconstruct(q, 40)
+    assert np.array_equal(Il, Ib) and np.array_equal(Dl, Db) and np.array_equal(Rl, Rb), "the loaded index answers differently"
+    loaded.nprobe = nlist  # every list: the flat answer
+    D, I = loaded.search(q[:8], 10)
+    assert np.array_equal(I, exact[:8])
+    loaded.close()
+
+    lo, hi = 25_000, 52_000  # a shard spanning three partition files; ids stay global
+    shard = knn.load_index(out, row_range=(lo, hi))
+    Ds, Is = shard.search(q, 40)
+    Dso, Iso = IVFFlatOracle(d, np.load(os.path.join(out, "ivf_centroids.npy")), lists[lo:hi], x[lo:hi]).search(q, 40, nprobe)
+    _check(Ds, Is, Dso, np.where(Iso >= 0, Iso + lo, -1), "ivf shard from a saved index")
+    shard.close()
+
+    sharded = knn.load_index(out, devices=[0, 0, 0])  # three shards of one saved index (all on this GPU), merged top-k
+    assert sharded.ntotal == n and sharded.nprobe == nprobe
+    Dm, Im, Rm = sharded.search_and_reconstruct(q, 40)
+    _check(Dm, Im, Do, Io, "ivf sharded from a saved index")
+    assert np.array_equal(Rm[Im >= 0], x[Im[Im >= 0]].astype(np.float32))
+    sharded.nprobe = nlist
+    D, I = sharded.search(q[:8], 10)
+    assert np.array_equal(I, exact[:8])
+    sharded.close()
+
+    # a second shard trained on ITS OWN rows would have other centroids: shards share one set through `centroids=`
+    other = knn.build_ivf_index_from_folder(folder, nlist, nprobe=nprobe, row_range=(lo, hi), centroids=np.load(os.path.join(out, "ivf_centroids.npy")), chunk=8192)
+    assert np.array_equal(other.ivf_lists, lists[lo:hi])
+    man2 = knn.save_index(other, str(tmp_path / "indices" / "shard1"))
+    assert man2["row_range"] == [lo, hi]
+    other.close()
+    with pytest.raises(ValueError):
+        knn.load_index(str(tmp_path / "indices" / "shard1"), row_range=(0, 10))  # outside the saved shard
+
+    # ids are row numbers: an index must not be loaded over embeddings that changed
+    np.save(os.path.join(folder, "img_emb_3.npy"), x[:2])
+    with pytest.raises(ValueError):
+        knn.load_index(out)
+    with open(os.path.join(out, "ivf_manifest.json"), encoding="utf-8") as f:
+        assert json.load(f)["format"] == knn.IVF_FORMAT
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # IVF build on the device (assignment kernel, Lloyd update, streaming scatter) and nprobe > 64
 # ---------------------------------------------------------------------------------------------------------------
