@@ -332,7 +332,7 @@ extern "C" int knnx_shards_reconstruct(knnx_shards* s, const int64_t* ids, int64
 
 extern "C" int knnx_shards_search(knnx_shards* s, const float* q, int n, int k, float* D, int64_t* I, float* R) {
   if (!s || (n > 0 && (!q || !D || !I)) || n < 0 || k <= 0) return knnx_set_error(KNNX_E_ARG, "bad shards_search arguments");
-  if (k > KNNX_MAX_K) return knnx_set_error(KNNX_E_UNSUPPORTED, "k > 16384 is not implemented");
+  if (k > KNNX_MAX_K) return knnx_set_error(KNNX_E_UNSUPPORTED, "k > 131072 is not implemented");
   if (n == 0) return KNNX_OK;
   {
     std::lock_guard<std::mutex> lk(s->mu);

@@ -312,6 +312,11 @@ class ShardedMi355xIndex(_FaissShaped):
         return int(self._lib.knnx_shards_ntotal(self._h))
 
     @property
+    def nlist(self):
+        """Lists of the (shared) coarse quantiser when the shards are IVF-Flat, else 0."""
+        return int(self._lib.knnx_ivf_nlist(C.c_void_p(self._lib.knnx_shards_get(self._h, 0)))) if self.nshards else 0
+
+    @property
     def nprobe(self):
         return getattr(self, "_nprobe", 1)
 

@@ -204,6 +204,7 @@ class KnnHotPath:
         self._scratch = _ResidentIndexPool(dedup_device)   # dedup: the request's own result vectors
         self._prompts = {}                             # (shape, content hash) -> (the prompt array, its resident fp32 Linear layer)
         self._prompts_lock = threading.Lock()
+        self._nprobe_lock = threading.Lock()
         self._device = dedup_device
 
     # ------------------------------------------------------------------ clip_back.py:207-255
@@ -314,7 +315,23 @@ class KnnHotPath:
         if getattr(clip_resource, "metadata_is_ordered_by_ivf", False):
             raise NotImplementedError("metadata_is_ordered_by_ivf needs faiss' IVF id mapping; serve with reorder_metadata_by_ivf_index=False")
         index = clip_resource.image_index if modality == "image" else clip_resource.text_index
-        D, I, R = index.search_and_reconstruct(query, num_result_ids)
+        # clip_back.py:356-369: a request for >= 100 000 results widens the IVF probe to ceil(k / 3000) lists for the duration of the
+        # search (nprobe lists hold ~nprobe * N / nlist rows: fewer than k otherwise) and puts the old value back.  The reference does
+        # this on its IVF-reordered branch; here it applies to every IVF-Flat index.  nprobe is index-wide state, so such requests
+        # are serialised among themselves (the reference has the same race and no lock).
+        wide = num_result_ids >= 100000 and getattr(index, "nlist", 0) > 0
+        if wide:
+            import math  # pylint: disable=import-outside-toplevel
+
+            with self._nprobe_lock:
+                previous = index.nprobe
+                index.nprobe = min(index.nlist, max(previous, math.ceil(num_result_ids / 3000)))
+                try:
+                    D, I, R = index.search_and_reconstruct(query, num_result_ids)
+                finally:
+                    index.nprobe = previous
+        else:
+            D, I, R = index.search_and_reconstruct(query, num_result_ids)
         ids = I[0]
         n = int(np.argmax(ids == -1)) if (ids == -1).any() else len(ids)
         ids, dist = ids[:n], D[0][:n]

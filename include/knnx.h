@@ -35,7 +35,8 @@ enum {
 
 #define KNNX_METRIC_INNER_PRODUCT 0 /* faiss.METRIC_INNER_PRODUCT; the only metric clip_back uses */
 #define KNNX_MAX_K_FAST 64          /* k <= 64: single-scan LDS candidate queues               */
-#define KNNX_MAX_K 16384            /* 64 < k <= 16384: two-scan threshold select              */
+#define KNNX_MAX_K 131072           /* 64 < k <= 131072: one range scan above a sampled / extrapolated threshold, hits ranked on the
+                                     * host (the reference advertises K = 100 000: README.md:301, clip_back.py:358)        */
 
 /* faiss.IndexFlatIP(d) / faiss.read_index(...) (clip_back.py:589-596).  `device` is the HIP
  * ordinal.  d must be a multiple of 256 and <= 1024 (CLIP embedding widths 512/768/1024). */

@@ -231,6 +231,64 @@ def test_large_k_parity(k):
     _check(D, I, Do, Io, f"k={k}")
 
 
+def test_k_100000_over_a_million_rows():
+    """The reference advertises K = 100 000 (README.md:301; clip_back.py:358 special-cases num_result_ids >= 100000); round 3
+    refused k > 16 384 (VERDICT r3 missing #2).  Exact id lists against the numpy oracle at k = 100 000 over 1 M rows (the
+    density-extrapolated descent: N < 128 k), at the new limit 131 072 with the stored rows reconstructed, and k beyond it refused."""
+    from clip_retrieval_amd import HipLibraryError
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d, n = 256, 1_000_000
+    x = _data(n, d, 77)
+    ix, o = Mi355xIndex(d), FlatIPOracle(d)
+    for lo in range(0, n, 250_000):
+        ix.add(x[lo:lo + 250_000])
+    o.add(x)
+    q = _queries(2, d, 5, x)
+    for k in (100_000, 131_072):
+        D, I = ix.search(q, k)
+        Do, Io = o.search(q, k)
+        _check(D, I, Do, Io, f"k={k} over 1 M rows")
+        assert (np.diff(D, axis=1) <= 0).all()
+    D, I, R = ix.search_and_reconstruct(q[:1], 100_000)
+    assert R.shape == (1, 100_000, d) and np.array_equal(R[0, ::997], x[I[0, ::997]].astype(np.float32))
+    with pytest.raises(HipLibraryError):
+        ix.search(q, 131_073)
+    ix.close()
+
+
+def test_k_100000_takes_the_sampled_threshold_on_a_large_index():
+    """N >= 128 k: ONE range scan above the j-th best score of a strided sample (every 3 126-th tile at k = 100 000).  16 M x 256
+    synthetic rows, ids checked against chunked torch matmul + topk on the same bytes (independent arithmetic)."""
+    import torch
+
+    from clip_retrieval_amd.knn import Mi355xIndex
+
+    d, n, k = 256, 16_000_000, 100_000
+    X = torch.empty((n, d), dtype=torch.float16, device="cuda")  # the arena is a torch tensor the index borrows (as bench.py does)
+    ix = Mi355xIndex(d)
+    ix.attach_device_rows(X.data_ptr(), n)
+    ix.synth_fill(n, 21)
+    q = _queries(1, d, 8)
+    q = ix.reconstruct_batch(np.asarray([12345], dtype=np.int64)).astype(np.float32) * 0.7 + 0.3 * q
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    D, I = ix.search(q, k)
+    assert (I >= 0).all() and len(set(I[0].tolist())) == k and (np.diff(D[0]) <= 0).all() and I[0, 0] == 12345
+    qt = torch.from_numpy(q).cuda()
+    best_s, best_i = None, None
+    for lo in range(0, n, 2_000_000):
+        ts, ti = torch.topk((qt @ X[lo:lo + 2_000_000].float().T)[0], k)
+        ti = ti + lo
+        best_s, best_i = (ts, ti) if best_s is None else (torch.cat([best_s, ts]), torch.cat([best_i, ti]))
+        best_s, sel = torch.topk(best_s, k)
+        best_i = best_i[sel]
+    want_s, want_i = best_s.cpu().numpy(), best_i.cpu().numpy()
+    assert np.allclose(D[0], want_s, atol=2e-6)
+    assert len(set(I[0].tolist()) ^ set(want_i.tolist())) <= 4  # only exact-tie / 1e-7 swaps at the k-th boundary
+    ix.close()
+
+
 def test_synthetic_corpus_is_bit_identical_to_the_cpu_derivation():
     from clip_retrieval_amd.knn import Mi355xIndex
     from oracle.knn_oracle import synth_rows

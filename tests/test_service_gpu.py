@@ -380,3 +380,32 @@ def test_violence_filter_is_the_fp32_einsum_and_follows_a_swapped_detector():
         assert np.array_equal(np.intersect1d(got2, np.flatnonzero(clear)), np.setdiff1d(np.flatnonzero(clear), want))
     assert len(hp._prompts) <= 8  # pylint: disable=protected-access
     assert hp.get_violent_items(prompts, np.zeros((0, d), np.float32)).shape == (0,)
+
+
+def test_knn_search_for_100000_results_widens_the_ivf_probe_like_the_reference():
+    """clip_back.py:356-369: num_result_ids >= 100000 sets nprobe = ceil(k / 3000) for the search and restores it.  400 k rows in
+    64 lists at nprobe 2 reach ~12 k rows; the request must come back with 100 000 distinct ids, best first, and nprobe as before."""
+    from types import SimpleNamespace
+
+    from clip_retrieval_amd.knn import build_ivf_index
+    from clip_retrieval_amd.service import KnnHotPath
+
+    rng = np.random.default_rng(3)
+    d, n, nlist = 256, 400_000, 64
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
+    ix = build_ivf_index(x, nlist, nprobe=2, niter=2, seed=0)
+    res = SimpleNamespace(image_index=ix, text_index=ix, metadata_is_ordered_by_ivf=False, safety_model=None, violence_detector=None)
+    hp = KnnHotPath()
+    q = x[7:8].astype(np.float32)
+    dist, ids = hp.knn_search(q, "image", 3000, res, deduplicate=False, use_safety_model=False, use_violence_detector=False)
+    assert len(ids) == 3000 and ix.nprobe == 2
+    dist, ids = hp.knn_search(q, "image", 100_000, res, deduplicate=False, use_safety_model=False, use_violence_detector=False)
+    assert ix.nprobe == 2, "nprobe must be restored after the request"
+    assert len(ids) == 100_000 == len(set(int(i) for i in ids)) and ids[0] == 7 and all(a >= b for a, b in zip(dist, dist[1:]))
+    # the answer is the exact top-100 000 of the rows in the 34 probed lists
+    ix.nprobe = 34
+    D, I = ix.search(q, 100_000)
+    ix.nprobe = 2
+    assert np.array_equal(np.asarray(ids), I[0])
+    ix.close()
