@@ -11,6 +11,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -45,6 +47,18 @@ struct knnx_index {
   hipStream_t stream = nullptr;
   std::mutex mu;
 
+  // Request coalescer ("knnx_search is re-entrant; internally a batching queue"): concurrent single-query callers
+  // (the werkzeug request threads of clip_back.py:1018) queue here; one of them -- the leader -- serves everything that queued
+  // while the GPU was busy, up to one scan's worth with the same k, in ONE pass over HBM, then hands the lead on.
+  bool coalesce = true;
+  std::mutex co_mu;
+  std::condition_variable co_cv;
+  std::deque<struct CoReq*> co_q;
+  bool co_leader = false;
+  int64_t co_batches = 0, co_queries = 0, co_largest = 0;
+  std::vector<float> co_qbuf, co_Dbuf;
+  std::vector<int64_t> co_Ibuf;
+
   // per-scan scratch (sized for KNN_NQ_MAX queries, grid = n_cu workgroups, k <= KNNX_MAX_K_FAST)
   _Float16* qfrag = nullptr;
   float* q_dev = nullptr;  // [KNN_NQ, d]
@@ -64,8 +78,8 @@ struct knnx_index {
   size_t pin_bytes = 0;
   // device scratch of reconstruct / range_fetch, kept between calls (hipMalloc + hipFree per request cost more than a
   // small search: hipFree synchronises the device); grown on demand, released with the index.  Used under ix->mu only.
-  void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+  void* scratch[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // IVF-Flat state (knnx_ivf_set_lists): rows live list-sorted and tile-padded in `rows`; see knn_kernels.hip
   int ivf_nlist = 0, ivf_nprobe = 1;
@@ -302,7 +316,7 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->ivfb_lists);
   hipFree(ix->ivfb_pos);
   if (ix->pin) hipHostFree(ix->pin);
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 9; ++i)
     if (ix->scratch[i]) hipFree(ix->scratch[i]);
   for (auto& ev : ix->prof_events) {
     hipEventDestroy(ev.first);
@@ -785,10 +799,193 @@ static int search_fast_locked(knnx_index* ix, const float* q, int n, int k, floa
 
 static int search_large_k_locked(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I);
 
+// ---------------------------------------------------------------------------------------------
+// Request coalescer: single-query calls from many threads -> one scan per batch
+// ---------------------------------------------------------------------------------------------
+hipError_t knnx_launch_dedup_pairs(const float* rows, const int64_t* ids, int m, int k, int d, float thr, const unsigned char* want_or_null,
+                                   int32_t* pairs, int cap, int* npairs, hipStream_t st);  // postfilter.hip
+
+struct CoReq {
+  const float* q;     // [d]
+  int k;
+  float* D;           // [k]
+  int64_t* I;         // [k]
+  float* R;           // [k, d] or null
+  bool dedup;         // also report the request's duplicate links (knnx_search_dedup)
+  float thr;
+  int32_t* pairs;     // [2 * pairs_cap] (i, j), i < j
+  int pairs_cap;
+  int* n_pairs;
+  int rc = 0;
+  std::string err;
+  bool done = false;
+};
+
+constexpr int CO_PAIR_CAP = 512;  // links kept per request on the device (a request with more falls back to the range scan)
+
+// One batch: `b` holds m <= KNN_RQ_MAX requests with the same k.  Search (one scan), one gather of the m k result rows on the
+// device when a request wants them back or wants its dedup links, the link kernel for all of them at once, then every request's
+// slice into its own buffers.  Runs under ix->mu; the requests' threads sleep on ix->co_cv meanwhile.
+static int co_run_batch(knnx_index* ix, std::vector<CoReq*>& b) {
+  const int m = (int)b.size(), k = b[0]->k, d = ix->d;
+  ix->co_qbuf.resize((size_t)m * d);
+  ix->co_Dbuf.resize((size_t)m * k);
+  ix->co_Ibuf.resize((size_t)m * k);
+  for (int i = 0; i < m; ++i) memcpy(ix->co_qbuf.data() + (size_t)i * d, b[i]->q, (size_t)d * sizeof(float));
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (set_dev(ix)) return KNNX_E_HIP;
+  int r = search_fast_locked(ix, ix->co_qbuf.data(), m, k, ix->co_Dbuf.data(), ix->co_Ibuf.data());
+  if (r) return r;
+  bool any_r = false, any_dd = false;
+  for (CoReq* c : b) { any_r |= c->R != nullptr; any_dd |= c->dedup; }
+  if (any_r || any_dd) {
+    hipStream_t st = ix->stream;
+    const int64_t nrow = (int64_t)m * k;
+    int64_t* ids_dev = nullptr;
+    float* rows_dev = nullptr;
+    int32_t* pairs_dev = nullptr;
+    int* np_dev = nullptr;
+    unsigned char* want_dev = nullptr;
+    if ((r = ensure_scratch(ix, 0, (size_t)nrow * sizeof(int64_t), (void**)&ids_dev))) return r;
+    if ((r = ensure_scratch(ix, 1, (size_t)nrow * d * sizeof(float), (void**)&rows_dev))) return r;
+    size_t pin_need = (size_t)nrow * sizeof(int64_t);
+    if (any_dd) pin_need = std::max(pin_need, (size_t)m * ((size_t)CO_PAIR_CAP * 4 + 8));
+    if (any_r) pin_need = std::max(pin_need, std::min((size_t)nrow * d * sizeof(float), (size_t)32 << 20));
+    if ((r = ensure_pin(ix, pin_need))) return r;
+    memcpy(ix->pin, ix->co_Ibuf.data(), (size_t)nrow * sizeof(int64_t));
+    HIPCHK(hipMemcpyAsync(ids_dev, ix->pin, (size_t)nrow * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // the pinned buffer is reused below
+    hipError_t e = ix->ivf_nlist ? launch_gather_inv(ix->rows, d, ix->id_base, ix->ntotal, ix->ivf_inv, ids_dev, nrow, rows_dev, st)
+                                 : launch_gather(ix->rows, ix->ntotal, d, ix->id_base, ids_dev, nrow, rows_dev, st);
+    if (e != hipSuccess) return fail(KNNX_E_HIP, std::string("coalesced gather: ") + hipGetErrorString(e));
+    if (any_dd) {
+      if ((r = ensure_scratch(ix, 6, (size_t)m * CO_PAIR_CAP * sizeof(int32_t), (void**)&pairs_dev))) return r;
+      if ((r = ensure_scratch(ix, 7, (size_t)m * sizeof(int), (void**)&np_dev))) return r;
+      if ((r = ensure_scratch(ix, 8, (size_t)m, (void**)&want_dev))) return r;
+      unsigned char* want = (unsigned char*)ix->pin;
+      for (int i = 0; i < m; ++i) want[i] = b[i]->dedup ? 1 : 0;
+      HIPCHK(hipMemcpyAsync(want_dev, want, (size_t)m, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemsetAsync(np_dev, 0, (size_t)m * sizeof(int), st));
+      HIPCHK(hipStreamSynchronize(st));
+      // one threshold per batch: requests with another threshold run in their own launch (a service has one: 0.94)
+      std::vector<float> thrs;
+      for (CoReq* c : b)
+        if (c->dedup && std::find(thrs.begin(), thrs.end(), c->thr) == thrs.end()) thrs.push_back(c->thr);
+      for (float t : thrs) {
+        for (int i = 0; i < m; ++i) want[i] = (b[i]->dedup && b[i]->thr == t) ? 1 : 0;
+        if (thrs.size() > 1) {
+          HIPCHK(hipMemcpyAsync(want_dev, want, (size_t)m, hipMemcpyHostToDevice, st));
+          HIPCHK(hipStreamSynchronize(st));
+        }
+        e = knnx_launch_dedup_pairs(rows_dev, ids_dev, m, k, d, t, want_dev, pairs_dev, CO_PAIR_CAP, np_dev, st);
+        if (e != hipSuccess) return fail(KNNX_E_HIP, std::string("dedup links: ") + hipGetErrorString(e));
+      }
+      int* np_h = (int*)ix->pin;
+      int32_t* pairs_h = (int32_t*)((char*)ix->pin + (size_t)m * 8);
+      HIPCHK(hipMemcpyAsync(np_h, np_dev, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(pairs_h, pairs_dev, (size_t)m * CO_PAIR_CAP * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      for (int i = 0; i < m; ++i) {
+        CoReq* c = b[i];
+        if (!c->dedup) continue;
+        const int n = np_h[i];
+        *c->n_pairs = n;  // may exceed pairs_cap / CO_PAIR_CAP: the caller sees that and takes the general path
+        const int keep = std::min(n, std::min(c->pairs_cap, CO_PAIR_CAP));
+        // the device appends in completion order: sort so that the answer does not depend on scheduling
+        std::vector<int32_t> ps(pairs_h + (size_t)i * CO_PAIR_CAP, pairs_h + (size_t)i * CO_PAIR_CAP + std::min(n, CO_PAIR_CAP));
+        std::sort(ps.begin(), ps.end());
+        for (int j = 0; j < keep; ++j) { c->pairs[2 * j] = ps[j] >> 16; c->pairs[2 * j + 1] = ps[j] & 0xffff; }
+      }
+    }
+    if (any_r) {
+      const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(ix->pin_bytes / ((size_t)d * sizeof(float))));
+      for (int i = 0; i < m; ++i) {
+        if (!b[i]->R) continue;
+        for (int64_t o = 0; o < k; o += chunk_rows) {
+          const int64_t n = std::min<int64_t>(chunk_rows, k - o);
+          HIPCHK(hipMemcpyAsync(ix->pin, rows_dev + ((size_t)i * k + o) * d, (size_t)n * d * sizeof(float), hipMemcpyDeviceToHost, st));
+          HIPCHK(hipStreamSynchronize(st));
+          memcpy(b[i]->R + (size_t)o * d, ix->pin, (size_t)n * d * sizeof(float));
+        }
+      }
+    }
+  }
+  for (int i = 0; i < m; ++i) {
+    memcpy(b[i]->D, ix->co_Dbuf.data() + (size_t)i * k, (size_t)k * sizeof(float));
+    memcpy(b[i]->I, ix->co_Ibuf.data() + (size_t)i * k, (size_t)k * sizeof(int64_t));
+  }
+  return KNNX_OK;
+}
+
+// Called by every single-query request.  The first thread to find no leader leads: it serves batches (its own request is in
+// the first one) until its request is done, then gives the lead away -- a waiting thread picks it up -- so no caller works for
+// the others longer than one batch.
+static int co_submit(knnx_index* ix, CoReq& me) {
+  std::unique_lock<std::mutex> lk(ix->co_mu);
+  ix->co_q.push_back(&me);
+  for (;;) {
+    if (me.done) break;
+    if (ix->co_leader) {
+      ix->co_cv.wait(lk);
+      continue;
+    }
+    ix->co_leader = true;
+    std::vector<CoReq*> batch;
+    const int k0 = ix->co_q.front()->k;
+    for (auto it = ix->co_q.begin(); it != ix->co_q.end() && (int)batch.size() < KNN_RQ_MAX;) {
+      if ((*it)->k == k0) { batch.push_back(*it); it = ix->co_q.erase(it); } else ++it;
+    }
+    lk.unlock();
+    const int r = co_run_batch(ix, batch);
+    const std::string msg = r ? std::string(g_err) : std::string();
+    lk.lock();
+    ix->co_batches++;
+    ix->co_queries += (int64_t)batch.size();
+    ix->co_largest = std::max<int64_t>(ix->co_largest, (int64_t)batch.size());
+    for (CoReq* c : batch) { c->rc = r; c->err = msg; c->done = true; }
+    ix->co_leader = false;
+    ix->co_cv.notify_all();
+  }
+  lk.unlock();
+  if (me.rc) g_err = me.err;  // the message is thread-local: hand the leader's to this thread
+  return me.rc;
+}
+
+extern "C" int knnx_set_coalesce(knnx_index* ix, int on) {
+  if (!ix) return fail(KNNX_E_ARG, "index is null");
+  std::lock_guard<std::mutex> lk(ix->co_mu);
+  ix->coalesce = on != 0;
+  return KNNX_OK;
+}
+
+extern "C" int knnx_coalesce_stats(knnx_index* ix, int64_t* batches, int64_t* queries, int64_t* largest_batch) {
+  if (!ix) return fail(KNNX_E_ARG, "index is null");
+  std::lock_guard<std::mutex> lk(ix->co_mu);
+  if (batches) *batches = ix->co_batches;
+  if (queries) *queries = ix->co_queries;
+  if (largest_batch) *largest_batch = ix->co_largest;
+  return KNNX_OK;
+}
+
+extern "C" int knnx_search_dedup(knnx_index* ix, const float* q, int k, float* D, int64_t* I, float* R_or_null, float dedup_thr,
+                                 int32_t* pairs, int pairs_cap, int* n_pairs) {
+  if (!ix || !q || !D || !I || k <= 0 || !pairs || pairs_cap < 0 || !n_pairs) return fail(KNNX_E_ARG, "bad search_dedup arguments");
+  if (k > KNNX_MAX_K_FAST) return fail(KNNX_E_UNSUPPORTED, "search_dedup serves k <= 64 (larger answers: knnx_search + knnx_range_search_once)");
+  CoReq me{q, k, D, I, R_or_null, true, dedup_thr, pairs, pairs_cap, n_pairs};
+  *n_pairs = 0;
+  if (ix->coalesce) return co_submit(ix, me);
+  std::vector<CoReq*> one{&me};
+  return co_run_batch(ix, one);
+}
+
 extern "C" int knnx_search(knnx_index* ix, const float* q, int n, int k, float* D, int64_t* I, float* R) {
   if (!ix || (n > 0 && (!q || !D || !I)) || n < 0 || k <= 0) return fail(KNNX_E_ARG, "bad search arguments");
   if (k > KNNX_MAX_K) return fail(KNNX_E_UNSUPPORTED, "k > 131072 is not implemented");
   if (n == 0) return KNNX_OK;
+  if (n == 1 && k <= KNNX_MAX_K_FAST && ix->coalesce) {  // concurrent single-query callers share one scan
+    CoReq me{q, k, D, I, R, false, 0.f, nullptr, 0, nullptr};
+    return co_submit(ix, me);
+  }
   {
     std::lock_guard<std::mutex> lk(ix->mu);
     if (set_dev(ix)) return KNNX_E_HIP;

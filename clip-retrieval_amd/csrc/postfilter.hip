@@ -201,3 +201,58 @@ extern "C" int knnx_mlp_forward(knnx_mlp* m, const float* x_host, int n, float* 
   MLPCHK(hipStreamSynchronize(m->stream));
   return KNNX_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Dedup links of a batch of requests (clip_back.py:290-309, fused into the coalesced search of knnx_api.hip).
+// The reference, per request: faiss.IndexFlatIP over the k normalised result vectors, range_search(same vectors, 0.94), connected
+// components.  Here the product: for request b (one workgroup), rows = its k reconstructed f32 vectors; sim(i, j) =
+// dot(r_i, r_j) / (|r_i| |r_j|) in f32 (a wave per pair, lanes over d, fixed shuffle tree), every pair i < j with sim > thr is
+// appended to the request's pair list.  k <= 64, so at most 2 016 pairs are examined per request: ~1.6 MFLOP at d = 1024.
+// ids < 0 (the -1 padding of a short answer) take no part.  npairs counts every link, also past `cap` (the caller then
+// falls back to the range scan for that request).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void dedup_pairs_kernel(const float* __restrict__ rows, const int64_t* __restrict__ ids, int k, int d,
+                                                          float thr, const unsigned char* __restrict__ want, int32_t* __restrict__ pairs,
+                                                          int cap, int* __restrict__ npairs) {
+  const int b = blockIdx.x;
+  if (want && !want[b]) return;
+  __shared__ float inv_norm[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* R = rows + (size_t)b * k * d;
+  for (int i = w; i < k; i += 4) {
+    float s = 0.f;
+    if (ids[(size_t)b * k + i] >= 0)
+      for (int c = lane; c < d; c += 64) { const float v = R[(size_t)i * d + c]; s = __builtin_fmaf(v, v, s); }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) inv_norm[i] = s > 0.f ? 1.f / sqrtf(s) : 0.f;  // a zero vector keeps norm 1 in the reference: its products are 0 either way
+  }
+  __syncthreads();
+  const int np = k * (k - 1) / 2;
+  for (int p = w; p < np; p += 4) {
+    // pair index -> (i, j), i < j, row-major over the strict upper triangle
+    int i = 0, rem = p;
+    while (rem >= k - 1 - i) { rem -= k - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    const float ni = inv_norm[i], nj = inv_norm[j];
+    if (ni == 0.f || nj == 0.f) continue;  // padding / zero rows (wave-uniform)
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s = __builtin_fmaf(R[(size_t)i * d + c] * ni, R[(size_t)j * d + c] * nj, s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0 && s > thr) {
+      const int at = atomicAdd(npairs + b, 1);
+      if (at < cap) pairs[(size_t)b * cap + at] = (i << 16) | j;
+    }
+  }
+}
+}  // namespace
+
+// rows f32 [m, k, d] and ids [m, k] on the device; pairs [m, cap] (i << 16 | j), npairs [m] (zeroed by the caller)
+hipError_t knnx_launch_dedup_pairs(const float* rows, const int64_t* ids, int m, int k, int d, float thr, const unsigned char* want_or_null,
+                                   int32_t* pairs, int cap, int* npairs, hipStream_t st) {
+  if (m <= 0) return hipSuccess;
+  if (k < 1 || k > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dedup_pairs_kernel, dim3(m), dim3(256), 0, st, rows, ids, k, d, thr, want_or_null, pairs, cap, npairs);
+  return hipGetLastError();
+}

@@ -132,7 +132,10 @@ class Mi355xIndex(_FaissShaped):
         self.is_trained = True
         if id_base:
             check(self._lib, self._lib.knnx_set_id_base(self._h, int(id_base)), "knnx")
-        self._init_queue(coalesce)
+        # concurrent single-query callers are coalesced INSIDE the library (knnx.h: knnx_set_coalesce; round 4 -- round 3 did it
+        # here with a Python condition variable, and the GIL hand-offs capped a served index at 6.5 k requests/s)
+        self._init_queue(False)
+        check(self._lib, self._lib.knnx_set_coalesce(self._h, 1 if coalesce else 0), "knnx")
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -227,6 +230,34 @@ class Mi355xIndex(_FaissShaped):
         out = np.empty((keys.shape[0], self._dpad), dtype=np.float32)
         check(self._lib, self._lib.knnx_reconstruct(self._h, keys.ctypes.data, keys.shape[0], out.ctypes.data), "knnx")
         return np.ascontiguousarray(out[:, : self.d])
+
+    DEDUP_PAIR_CAP = 512
+
+    def search_dedup(self, x, k, threshold=0.94, want_r=False):
+        """One request of KnnService.knn_search with its dedup fused (knnx.h: knnx_search_dedup; clip_back.py:362 + :290-309):
+        x float32 [1, d], k <= 64 -> (D [1, k], I [1, k], R [1, k, d] or None, links int32 [n_links, 2] of result ranks i < j
+        whose normalised stored vectors have inner product > threshold, or None when there were more links than the device
+        keeps -- take the general path then).  Concurrent callers share one scan, one gather and one link launch."""
+        q = np.ascontiguousarray(self._pad(_as_queries(x, self.d)))
+        if q.shape[0] != 1 or not 0 < k <= 64:
+            raise AssertionError("search_dedup serves one query and k <= 64")
+        k = int(k)
+        D = np.empty((1, k), dtype=np.float32)
+        I = np.empty((1, k), dtype=np.int64)
+        R = np.empty((1, k, self._dpad), dtype=np.float32) if want_r else None
+        pairs = np.empty((self.DEDUP_PAIR_CAP, 2), dtype=np.int32)
+        n = C.c_int(0)
+        check(self._lib, self._lib.knnx_search_dedup(self._h, q.ctypes.data, k, D.ctypes.data, I.ctypes.data, R.ctypes.data if want_r else None,
+                                                     C.c_float(threshold), pairs.ctypes.data, self.DEDUP_PAIR_CAP, C.byref(n)), "knnx")
+        if want_r and self._dpad != self.d:
+            R = np.ascontiguousarray(R[:, :, : self.d])
+        return D, I, R, (pairs[: n.value].copy() if n.value <= self.DEDUP_PAIR_CAP else None)
+
+    def coalesce_stats(self):
+        """(batches served, queries in them, largest batch) of the library's request coalescer."""
+        b, q, m = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self._lib, self._lib.knnx_coalesce_stats(self._h, C.byref(b), C.byref(q), C.byref(m)), "knnx")
+        return int(b.value), int(q.value), int(m.value)
 
     def range_search(self, x, thresh):
         q = np.ascontiguousarray(self._pad(_as_queries(x, self.d)))

@@ -267,6 +267,26 @@ class KnnHotPath:
         np.minimum.at(first, label, np.arange(n))
         return np.flatnonzero(first[label] != np.arange(n)).tolist()
 
+    @staticmethod
+    def non_uniques_from_pairs(pairs, n):
+        """Links (i, j) between result ranks -> every rank that is not the smallest of its connected group (the reference keeps
+        g[0] of every component, and its components start from the smallest unseen node: clip_back.py:270-288, 303-307)."""
+        if len(pairs) == 0:
+            return []
+        parent = list(range(n))
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+
+        for i, j in pairs:
+            a, b = find(int(i)), find(int(j))
+            if a != b:
+                parent[max(a, b)] = min(a, b)  # the root of a group is its smallest member
+        return [i for i in range(n) if find(i) != i]
+
     connected_components_dedup = get_non_uniques
 
     # ------------------------------------------------------------------ clip_back.py:315-341
@@ -320,6 +340,11 @@ class KnnHotPath:
         # this on its IVF-reordered branch; here it applies to every IVF-Flat index.  nprobe is index-wide state, so such requests
         # are serialised among themselves (the reference has the same race and no lock).
         wide = num_result_ids >= 100000 and getattr(index, "nlist", 0) > 0
+        safety_model = getattr(clip_resource, "safety_model", None)
+        violence_detector = getattr(clip_resource, "violence_detector", None)
+        need_vectors = (use_safety_model and safety_model is not None) or (use_violence_detector and violence_detector is not None)
+        query = np.asarray(query)
+        links = None
         if wide:
             import math  # pylint: disable=import-outside-toplevel
 
@@ -330,14 +355,32 @@ class KnnHotPath:
                     D, I, R = index.search_and_reconstruct(query, num_result_ids)
                 finally:
                     index.nprobe = previous
-        else:
+        elif deduplicate and num_result_ids <= 64 and query.shape[0] == 1 and hasattr(index, "search_dedup"):
+            # the request's dedup fused into the coalesced search (knnx_search_dedup): the k result rows are gathered once on the
+            # device for every request of the batch, the links of all of them come from one launch, and the rows only travel to
+            # the host when another filter needs them
+            D, I, R, links = index.search_dedup(query, num_result_ids, 0.94, want_r=need_vectors)
+            if links is None and R is None:  # more links than the device keeps: the general path below
+                R = index.reconstruct_batch(I[0])[None]
+        elif deduplicate or need_vectors:
             D, I, R = index.search_and_reconstruct(query, num_result_ids)
+        else:
+            D, I = index.search(query, num_result_ids)  # no filter looks at the vectors: they stay in HBM
+            R = None
         ids = I[0]
         n = int(np.argmax(ids == -1)) if (ids == -1).any() else len(ids)
         ids, dist = ids[:n], D[0][:n]
         keep = np.ones(n, dtype=bool)
-        drop = self.post_filter(getattr(clip_resource, "safety_model", None), normalized(R[0][:n]), deduplicate, use_safety_model,
-                                use_violence_detector, getattr(clip_resource, "violence_detector", None))
+        drop = set()
+        emb = normalized(R[0][:n]) if R is not None else None
+        if deduplicate:
+            if links is not None:
+                links = links[(links[:, 0] < n) & (links[:, 1] < n)]
+                drop.update(self.non_uniques_from_pairs(links, n))
+            else:
+                drop.update(self.get_non_uniques(emb))
+        if need_vectors:
+            drop.update(self.post_filter(safety_model, emb, False, use_safety_model, use_violence_detector, violence_detector))
         if drop:
             keep &= ~np.isin(ids, ids[np.fromiter(drop, dtype=np.int64)])  # an id the filter dropped goes everywhere it occurs
         _, first = np.unique(ids, return_index=True)                       # an id is reported once, at its best rank

@@ -205,6 +205,27 @@ int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed);
 int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed,
                            int kind, int64_t n_clusters, void* stream);
 
+/* ---- request coalescing ("knnx_search is re-entrant; internally a batching queue") ---------------------------
+ * The service calls the index from concurrent request threads with ONE query each (clip_back.py:1018 -> :362).  With coalescing
+ * on (the default), knnx_search calls with n == 1 and k <= 64 that arrive while the GPU is busy wait in a queue inside the
+ * library; the first caller to find no leader serves everything queued with the same k -- up to one scan's worth, 256 queries --
+ * in ONE pass over HBM (one batched gather for the callers that want R), hands each caller its slice and passes the lead on.
+ * Results are those of the uncoalesced call, row for row (a query's answer does not depend on its batch).  Calls with n > 1 or
+ * k > 64 are served directly.  knnx_set_coalesce(ix, 0) turns the queue off; knnx_coalesce_stats: batches served, queries in
+ * them, the largest batch so far (any pointer may be NULL). */
+int knnx_set_coalesce(knnx_index* ix, int on);
+int knnx_coalesce_stats(knnx_index* ix, int64_t* batches, int64_t* queries, int64_t* largest_batch);
+
+/* One request of KnnService.knn_search with its dedup fused (clip_back.py:362 + :290-309): the top-k (k <= 64) of ONE query, and
+ * the links of the reference's `get_non_uniques` -- every pair of result ranks (i < j) whose stored vectors, L2-normalised in
+ * f32 as `normalized()` does (clip_back.py:194-197, :378), have inner product > dedup_thr (the reference: 0.94, strict).  The
+ * k result rows are gathered ONCE on the device for the whole coalesced batch and the links of all its requests come from one
+ * launch; they need not travel to the host (R_or_null = NULL).  pairs: int32 [2 * pairs_cap] = (i0, j0, i1, j1, ...), sorted;
+ * *n_pairs = number of links found -- when it exceeds pairs_cap (or 512) only the first are stored and the caller should take
+ * the general path (knnx_reconstruct + knnx_range_search_once).  Connected components over the links are the caller's. */
+int knnx_search_dedup(knnx_index* ix, const float* q, int k, float* D, int64_t* I, float* R_or_null, float dedup_thr,
+                      int32_t* pairs, int pairs_cap, int* n_pairs);
+
 /* ---- post filter: the safety head on the GPU --------------------------------------------------------
  * Replaces `safety_model.predict(embeddings, batch_size)` of clip_retrieval/clip_back.py:315-325 for a model that is a stack
  * of fp32 Linear layers with ReLU between them -- the H14 detector of clip_retrieval/h14_nsfw_model.py:16-34
