@@ -368,8 +368,15 @@ class KnnHotPath:
             D, I = index.search(query, num_result_ids)  # no filter looks at the vectors: they stay in HBM
             R = None
         ids = I[0]
-        n = int(np.argmax(ids == -1)) if (ids == -1).any() else len(ids)
+        ids_l = ids.tolist() if len(ids) <= 4096 else None  # small answers (the client default is 40): plain Python beats numpy calls
+        if ids_l is not None:
+            n = ids_l.index(-1) if ids_l[-1] == -1 else len(ids_l)
+        else:
+            n = int(np.argmax(ids == -1)) if (ids == -1).any() else len(ids)
         ids, dist = ids[:n], D[0][:n]
+        if (ids_l is not None and not need_vectors and (not deduplicate or (links is not None and len(links) == 0))
+                and len(set(ids_l[:n])) == n):
+            return list(dist), list(ids)  # nothing to drop, every id once: the answer as it is (numpy scalars, like the reference's lists)
         keep = np.ones(n, dtype=bool)
         drop = set()
         emb = normalized(R[0][:n]) if R is not None else None

@@ -249,8 +249,12 @@ def test_k_100000_over_a_million_rows():
     for k in (100_000, 131_072):
         D, I = ix.search(q, k)
         Do, Io = o.search(q, k)
-        _check(D, I, Do, Io, f"k={k} over 1 M rows")
+        # 100 k of 1 M rows: neighbouring scores are ~1e-6 apart, so the numpy oracle's f32 summation order swaps a few per cent of
+        # adjacent POSITIONS; the id sets (beyond 2e-6 ties), the scores (1e-5) and the order of ours are held exactly
+        _check(D, I, Do, Io, f"k={k} over 1 M rows", min_exact=0.9)
         assert (np.diff(D, axis=1) <= 0).all()
+        moved = I != Io
+        assert np.abs(D[moved] - Do[moved]).max() < 2e-6  # every position that differs is such a near-tie
     D, I, R = ix.search_and_reconstruct(q[:1], 100_000)
     assert R.shape == (1, 100_000, d) and np.array_equal(R[0, ::997], x[I[0, ::997]].astype(np.float32))
     with pytest.raises(HipLibraryError):
