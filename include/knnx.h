@@ -210,7 +210,8 @@ int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t
  * on (the default), knnx_search calls with n == 1 and k <= 64 that arrive while the GPU is busy wait in a queue inside the
  * library; the first caller to find no leader serves everything queued with the same k -- up to one scan's worth, 256 queries --
  * in ONE pass over HBM (one batched gather for the callers that want R), hands each caller its slice and passes the lead on.
- * Results are those of the uncoalesced call, row for row (a query's answer does not depend on its batch).  Calls with n > 1 or
+ * Results are those of the uncoalesced call: the same ids, scores equal to f32 summation order (the scan kernel that serves a
+ * query depends on how many queries share its pass).  Calls with n > 1 or
  * k > 64 are served directly.  knnx_set_coalesce(ix, 0) turns the queue off; knnx_coalesce_stats: batches served, queries in
  * them, the largest batch so far (any pointer may be NULL). */
 int knnx_set_coalesce(knnx_index* ix, int on);

