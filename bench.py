@@ -139,7 +139,8 @@ def main():
         if img:
             enc.encode_image_device(pix.data_ptr(), B, 0, out_i.data_ptr(), o32_i.data_ptr(), stream)
         if txt:
-            enc.encode_text_device(ids.data_ptr(), B, out_t.data_ptr(), o32_t.data_ptr(), stream)
+            # the tokens exist on the host too (the reference's batch holds them there, mapper.py:63-65): no read-back in the timed region
+            enc.encode_text_device(ids.data_ptr(), B, out_t.data_ptr(), o32_t.data_ptr(), stream, ids_host=ids_host)
 
     for _ in range(args.warmup):
         step()

@@ -116,6 +116,7 @@ SIGNATURES = {
     "clipx_wait": (C.c_int, [_P]),
     "clipx_encode_image_device": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "clipx_encode_text_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "clipx_encode_text_device_ids": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
     "clipx_resize_crop_u8_device": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "clipx_range_check": (C.c_int, [_P, _P]),
     "clipx_set_option": (C.c_int, [_P, C.c_int, C.c_int]),

@@ -685,8 +685,22 @@ extern "C" int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev
   return CLIPX_OK;
 }
 
+static int encode_text_device_impl(clipx_handle* h, const int32_t* ids_dev, const int32_t* ids_host_or_null, int B, uint16_t* out_f16_dev,
+                                   float* out_f32_or_null, void* stream);
+
 extern "C" int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,
                                         float* out_f32_or_null, void* stream) {
+  return encode_text_device_impl(h, ids_dev, nullptr, B, out_f16_dev, out_f32_or_null, stream);
+}
+
+extern "C" int clipx_encode_text_device_ids(clipx_handle* h, const int32_t* ids_dev, const int32_t* ids_host, int B, uint16_t* out_f16_dev,
+                                            float* out_f32_or_null, void* stream) {
+  if (!ids_host) return fail(CLIPX_E_ARG, "ids_host is null (use clipx_encode_text_device)");
+  return encode_text_device_impl(h, ids_dev, ids_host, B, out_f16_dev, out_f32_or_null, stream);
+}
+
+static int encode_text_device_impl(clipx_handle* h, const int32_t* ids_dev, const int32_t* ids_host_or_null, int B, uint16_t* out_f16_dev,
+                                   float* out_f32_or_null, void* stream) {
   if (!h || !ids_dev || !out_f16_dev || B < 0) return fail(CLIPX_E_ARG, "bad encode_text arguments");
   std::lock_guard<std::mutex> lk(h->mu);
   HIPCHK(hipSetDevice(h->device));
@@ -697,8 +711,11 @@ extern "C" int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev,
   if (ws_acquire(h, st)) return CLIPX_E_HIP;
   for (int o = 0; o < B; o += h->max_batch) {
     const int nb = std::min(h->max_batch, B - o);
+    // the caller's host copy of the ids (the reader tokenised them there): the ragged row map is built without reading them back
+    h->text_ids_host = ids_host_or_null ? ids_host_or_null + (size_t)o * h->desc.ctx_len : nullptr;
     int r = text_chunk(h, st, ids_dev + (size_t)o * h->desc.ctx_len, nb, out_f16_dev + (size_t)o * E,
                        out_f32_or_null ? out_f32_or_null + (size_t)o * E : nullptr);
+    h->text_ids_host = nullptr;
     if (r) return r;
   }
   if (ws_release(h, st)) return CLIPX_E_HIP;

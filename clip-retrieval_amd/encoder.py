@@ -350,10 +350,19 @@ class ClipEncoder:
             self._h, C.c_void_p(int(pix_ptr)), int(B), int(fmt), C.c_void_p(int(out_f16_ptr)),
             C.c_void_p(int(out_f32_ptr)) if out_f32_ptr else None, C.c_void_p(int(stream)) if stream else None), "clipx")
 
-    def encode_text_device(self, ids_ptr, B, out_f16_ptr, out_f32_ptr=None, stream=None):
-        check(self._lib, self._lib.clipx_encode_text_device(
-            self._h, C.c_void_p(int(ids_ptr)), int(B), C.c_void_p(int(out_f16_ptr)),
-            C.c_void_p(int(out_f32_ptr)) if out_f32_ptr else None, C.c_void_p(int(stream)) if stream else None), "clipx")
+    def encode_text_device(self, ids_ptr, B, out_f16_ptr, out_f32_ptr=None, stream=None, ids_host=None):
+        """ids_host: the same ids as a C-contiguous int32 numpy array [B, ctx_len] when the caller has them on the host (the
+        reference's batch does): the ragged text tower then needs no read-back and the call stays asynchronous."""
+        o32 = C.c_void_p(int(out_f32_ptr)) if out_f32_ptr else None
+        st = C.c_void_p(int(stream)) if stream else None
+        if ids_host is not None:
+            ids_host = np.ascontiguousarray(ids_host, dtype=np.int32)
+            if ids_host.shape != (int(B), self.arch.ctx_len):
+                raise ValueError(f"ids_host must be [{B}, {self.arch.ctx_len}]")
+            check(self._lib, self._lib.clipx_encode_text_device_ids(self._h, C.c_void_p(int(ids_ptr)), ids_host.ctypes.data, int(B),
+                                                                    C.c_void_p(int(out_f16_ptr)), o32, st), "clipx")
+            return
+        check(self._lib, self._lib.clipx_encode_text_device(self._h, C.c_void_p(int(ids_ptr)), int(B), C.c_void_p(int(out_f16_ptr)), o32, st), "clipx")
 
     def check_range(self, stream=None):
         """After *_device calls: synchronise `stream` and raise ResidualStreamOverflow if the fp16 residual stream overflowed in any

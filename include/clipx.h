@@ -117,6 +117,12 @@ int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, in
                               float* out_f32_or_null, void* stream);
 int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,
                              float* out_f32_or_null, void* stream);
+/* The same for a caller that ALSO holds the ids on the host -- the reference's batch does: item["text_tokens"] is a CPU tensor the
+ * reader tokenised (reader.py:163-170, mapper.py:63-65), uploaded by the caller for its own double-buffering.  ids_host [B, ctx_len]
+ * must equal ids_dev and stay valid for the duration of the call; the EOT positions are taken from it, so nothing is read back and
+ * the call never synchronises `stream`. */
+int clipx_encode_text_device_ids(clipx_handle* h, const int32_t* ids_dev, const int32_t* ids_host, int B, uint16_t* out_f16_dev,
+                                 float* out_f32_or_null, void* stream);
 
 /* The geometric half of the reference's image transform on the GPU (reader.py:83,87 `self.image_transform(image)` = CLIP's
  * Resize(S, BICUBIC) + CenterCrop(S) on a PIL image), bit-identical to Pillow's 8-bit bicubic resample: B decoded RGB images of

@@ -279,6 +279,25 @@ def test_ragged_text_tower_equals_the_rectangular_one(tiny):
         enc.encode_text_device(dev_ids.data_ptr(), B, o16.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(o16.cpu().numpy().view(np.uint16), b.view(np.uint16)), f"{name} B={B}: ragged != rectangular (device ids)"
+        # device ids + the caller's host copy (clipx_encode_text_device_ids): no read-back, so the call also works on a stream that
+        # is being captured into a hipGraph -- where the plain device entry falls back to the rectangular tower by itself
+        o16.zero_()
+        enc.encode_text_device(dev_ids.data_ptr(), B, o16.data_ptr(), None, torch.cuda.current_stream().cuda_stream, ids_host=ids)
+        torch.cuda.synchronize()
+        assert np.array_equal(o16.cpu().numpy().view(np.uint16), b.view(np.uint16)), f"{name} B={B}: ragged != rectangular (device + host ids)"
+        for hint in (None, ids):
+            side = torch.cuda.Stream()
+            o2 = torch.empty_like(o16)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                enc.encode_text_device(dev_ids.data_ptr(), B, o2.data_ptr(), None, side.cuda_stream, ids_host=hint)  # warm-up outside the capture
+                side.synchronize()
+                o2.zero_()
+                with torch.cuda.graph(g, stream=side):
+                    enc.encode_text_device(dev_ids.data_ptr(), B, o2.data_ptr(), None, side.cuda_stream, ids_host=hint)
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(o2.cpu().numpy().view(np.uint16), b.view(np.uint16)), f"{name} B={B}: captured call (hint={'host ids' if hint is not None else 'none'})"
         _, want = mapper_semantics(oracle.encode_text(torch.from_numpy(ids)))
         assert _cos(a, want).min() >= COS_BAR
     rect.close()
