@@ -649,11 +649,20 @@ static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_d
   return 0;
 }
 
+static bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return cs != hipStreamCaptureStatusNone;
+}
+// A caller that captures `st` into its own hipGraph: the workspace event must not be recorded inside the capture (an event
+// recorded there cannot be waited for by a later, non-captured call).  The captured launches are ordered by the graph itself;
+// the caller must not replay it concurrently with other calls on this handle (clipx.h).
 static int ws_acquire(clipx_handle* h, hipStream_t st) {
-  if (h->ev_ws_valid) HIPCHK(hipStreamWaitEvent(st, h->ev_ws, 0));
+  if (h->ev_ws_valid && !stream_is_capturing(st)) HIPCHK(hipStreamWaitEvent(st, h->ev_ws, 0));
   return 0;
 }
 static int ws_release(clipx_handle* h, hipStream_t st) {
+  if (stream_is_capturing(st)) return 0;
   HIPCHK(hipEventRecord(h->ev_ws, st));
   h->ev_ws_valid = true;
   return 0;

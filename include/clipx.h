@@ -112,7 +112,9 @@ int clipx_wait(clipx_ticket* ticket);
  * clipx_encode_text_device with B > 8 synchronises `stream` ONCE before its kernels are queued: it reads the token ids back
  * to find every caption's EOT position, and then runs the (causal) text tower on the rows up to the EOT only -- the same
  * embeddings, bit for bit (CLIPX_OPT_RAGGED_TEXT = 0 / environment CLIPX_RAGGED_TEXT=0: every row, and a fully asynchronous
- * call; a `stream` that is being captured into a hipGraph cannot be synchronised and takes that path by itself). */
+ * call; a `stream` that is being captured into a hipGraph cannot be synchronised and takes that path by itself).  Capturing
+ * these calls into a caller's own hipGraph is allowed for B > 8 (smaller batches replay the library's own graphs); the replays
+ * share the handle's activation workspace, so they must not run concurrently with other calls on the handle. */
 int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, int pix_fmt, uint16_t* out_f16_dev,
                               float* out_f32_or_null, void* stream);
 int clipx_encode_text_device(clipx_handle* h, const int32_t* ids_dev, int B, uint16_t* out_f16_dev,
