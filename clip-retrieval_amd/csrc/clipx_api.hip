@@ -552,6 +552,7 @@ static int run_graphed(clipx_handle* h, hipStream_t st, const clipx_handle::Grap
 static int vision_chunk_body(clipx_handle* h, hipStream_t st, const void* pix_dev, int B, int fmt, uint16_t* out_f16,
                              float* out_f32);
 static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_dev, int B, uint16_t* out_f16, float* out_f32);
+static bool stream_is_capturing(hipStream_t st);
 
 // one chunk (B <= max_batch), everything on the device, asynchronous on `st`
 static int vision_chunk(clipx_handle* h, hipStream_t st, const void* pix_dev, int B, int fmt, uint16_t* out_f16,
@@ -624,11 +625,10 @@ static int text_chunk_body(clipx_handle* h, hipStream_t st, const int32_t* ids_d
   Ragged rgv{};
   const Ragged* rg = nullptr;
   bool ragged = h->ragged_text && h->pool_last_block && B > GRAPH_MAX_B && X.T <= 128 && X.width / X.heads == 64;
-  if (ragged && !h->text_ids_host) {  // device-resident ids need one synchronisation: impossible on a capturing stream
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-    if (cs != hipStreamCaptureStatusNone) ragged = false;
-  }
+  // A stream that is being captured into a hipGraph: the read-back of device-resident ids needs a synchronisation,
+  // and even with the caller's host ids the row map is per-call host data uploaded from a ring slot that later calls overwrite --
+  // a replayed graph would upload whatever the slot holds then.  Captured calls run the rectangular tower (same bytes out).
+  if (ragged && stream_is_capturing(st)) ragged = false;
   if (ragged) {
     const int32_t* ids_host = h->text_ids_host;
     if (!ids_host) {  // device-resident ids: one synchronisation of `st` to read them (CLIPX_RAGGED_TEXT=0 keeps the call asynchronous)

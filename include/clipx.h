@@ -112,7 +112,7 @@ int clipx_wait(clipx_ticket* ticket);
  * clipx_encode_text_device with B > 8 synchronises `stream` ONCE before its kernels are queued: it reads the token ids back
  * to find every caption's EOT position, and then runs the (causal) text tower on the rows up to the EOT only -- the same
  * embeddings, bit for bit (CLIPX_OPT_RAGGED_TEXT = 0 / environment CLIPX_RAGGED_TEXT=0: every row, and a fully asynchronous
- * call; a `stream` that is being captured into a hipGraph cannot be synchronised and takes that path by itself).  Capturing
+ * call; a call on a `stream` that is being captured into a hipGraph takes that path by itself, with or without host ids).  Capturing
  * these calls into a caller's own hipGraph is allowed for B > 8 (smaller batches replay the library's own graphs); the replays
  * share the handle's activation workspace, so they must not run concurrently with other calls on the handle. */
 int clipx_encode_image_device(clipx_handle* h, const void* pixels_dev, int B, int pix_fmt, uint16_t* out_f16_dev,
