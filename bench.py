@@ -64,6 +64,7 @@ def main():
                     help="torch threads of the CPU baseline (all 256 cores of the GPU box oversubscribe torch's CPU GEMMs: 0.07 samples/s)")
     ap.add_argument("--parity-rows", type=int, default=64, help="rows of the timed batch the CPU oracle checks (and is timed on); all rows are checked for finite / unit norm")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: the line is marked parity=null")
+    ap.add_argument("--no-ab", action="store_true", help="profiling runs only: skip the rectangular-text A/B (its extra steps would enter the per-step counter averages)")
     ap.add_argument("--ivf", action="store_true", help="also run BASELINE config 5's per-GPU shard (tools/config5.py: IVF-Flat 125 M x 1024, "
                     "nlist 65 536, built on the device, served) and embed its object as `ivf` (adds ~3 minutes)")
     ap.add_argument("--ivf-rows", type=int, default=125_000_000)
@@ -199,7 +200,7 @@ def main():
     tok_len = (ids_host.argmax(axis=1) + 1).astype(np.int64)
     extras["text_rows"] = {"tokens_incl_sot_eot": {"min": int(tok_len.min()), "mean": round(float(tok_len.mean()), 2), "max": int(tok_len.max())},
                            "rows_run": int(tok_len.sum()), "rows_rectangular": int(B * arch.ctx_len)}
-    if enc.get_option(enc.OPT_RAGGED_TEXT) == 1:
+    if enc.get_option(enc.OPT_RAGGED_TEXT) == 1 and not args.no_ab:
         enc.set_option(enc.OPT_RAGGED_TEXT, 0)
         step()
         barrier()

@@ -14,7 +14,8 @@ What it does (reference call sites clip_back.py:343-369 knn_
   4. recall   recall@40 of nprobe 16 / 64 / 256 against it, bytes actually scanned (work-list tiles) vs the model
               (nprobe / nlist) * N * d * 2, scan GB/s from hipEvents around the scan kernel;
   5. served   T client threads issuing n = 1 requests through service.KnnHotPath.knn_search (search_and_reconstruct + the
-              reference's result handling; concurrent callers are coalesced into one scan by the index object): QPS, p50 / p99.
+              reference's result handling; concurrent callers are coalesced into one scan INSIDE the library -- knnx_set_coalesce, round 4 --
+              and the +dedup leg runs knnx_search_dedup: the links of every request of a batch in one launch): QPS, p50 / p99.
 Prints human-readable lines and ONE final JSON line (prefix "CONFIG5 "); bench.py --ivf embeds that object.
 """
 import argparse
@@ -142,6 +143,14 @@ def run(rows=125_000_000, d=1024, nlist=65536, clusters=0, nprobes=(16, 64, 256)
                "served": []}
         log(f"nprobe {npb:4d}: recall@{k} {rec:.4f} (planted top-1 {top1:.4f}); B=32 {n_queries / el:9.1f} QPS, scan {ms / max(nl, 1):.3f} ms, "
             f"{gbs:.0f} GB/s; n=1 {lat1 * 1e3:.3f} ms, {tiles1 * 32 * d * 2 / 64 / 1e6:.1f} MB scanned vs model {model1 / 1e6:.1f} MB")
+        # one call of 256 queries (bench.py --ivf row at B = 256): the IVF scan serves them 32 per pass
+        ix.search(q[:256], k)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ix.search(q[:256], k)
+        el256 = (time.perf_counter() - t1) / 3
+        row["batch256"] = {"qps": round(256 / el256, 1), "ms_per_batch": round(el256 * 1e3, 3), "passes": 8}
+        log(f"    B=256: {256 / el256:9.1f} QPS, {el256 * 1e3:.3f} ms per batch (8 passes of 32 queries)")
         legs = [(T, False) for T in threads]
         if dedup_leg:
             legs.append((threads[-1], True))
@@ -173,6 +182,9 @@ def run(rows=125_000_000, d=1024, nlist=65536, clusters=0, nprobes=(16, 64, 256)
             al = np.sort(np.concatenate([np.asarray(x) for x in lats]))
             srow = {"threads": T, "deduplicate": dedup, "qps": round(len(al) / el2, 1), "p50_ms": round(float(al[len(al) // 2]) * 1e3, 3),
                     "p99_ms": round(float(al[min(len(al) - 1, int(len(al) * 0.99))]) * 1e3, 3), "requests": int(len(al))}
+            if hasattr(ix, "coalesce_stats"):
+                cb, cq, cm = ix.coalesce_stats()
+                srow["coalescer"] = {"batches_total": cb, "queries_total": cq, "largest_batch": cm}
             row["served"].append(srow)
             log(f"    served n=1 x {T:3d} threads{' +dedup' if dedup else '       '}: {srow['qps']:9.1f} QPS, p50 {srow['p50_ms']:.3f} ms, "
                 f"p99 {srow['p99_ms']:.3f} ms ({srow['requests']} requests through KnnHotPath.knn_search)")
