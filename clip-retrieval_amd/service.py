@@ -7,12 +7,15 @@
   map_to_metadata(:401-417)  metadata_provider.get(ids, cols) -> one record per result
 `KnnHotPath` offers those four entry points with the reference's names, arguments and return values, so a maintainer binds them
 onto KnnService.  The arithmetic is re-designed for the GPU rather than retyped:
-  * dedup      one range scan of the resident GPU index over the result vectors -> CSR adjacency -> connected components by
-               scipy.sparse.csgraph; a component keeps its best-ranked member (the reference's own DFS keeps the first node it
-               visits, which is the smallest local index = the best rank);
-  * violence   argmax over the two prompt embeddings = a top-1 search of the result vectors against a resident 2-row GPU index
-               (ties -> the smaller id, like np.argmax);
-  * metadata   ONE batched Arrow `take` per request instead of a concat of 1-row slices per id (README.md:432: 41.5 ms).
+  * dedup      k <= 64 (the client default is 40): fused into the coalesced search -- the result rows of every request of a batch are
+               gathered once on the device and the links (normalised rows, inner product > 0.94, f32) of all of them come from one
+               launch (knnx_search_dedup); larger k: one range scan of a resident GPU index over the result vectors -> CSR adjacency.
+               Connected components on the host; a component keeps its best-ranked member (the reference's own DFS keeps the first
+               node it visits, which is the smallest local index = the best rank);
+  * violence   clip_back.py:327-331's einsum + argmax over the two prompt embeddings, the product in fp32 FMA on the GPU (the prompts
+               as one resident bias-free Linear layer), argmax on the host (ties -> the smaller index, like np.argmax);
+  * metadata   ids grouped by Arrow record batch, ONE `RecordBatch.take` per touched batch instead of a concat of 1-row slices per
+               id (README.md:432: 41.5 ms); a single `Table.take` over chunked string columns measured 75 x slower (DESIGN 5b);
   * safety     the H14 detector (h14_nsfw_model.py:16-34: seven fp32 Linear layers, ReLU between) runs on the GPU behind the
                reference's `.predict(embeddings, batch_size)` (`Mi355xSafetyHead`, csrc/postfilter.hip); any other object with
                `.predict` (the autokeras L/14 model) is called as the reference calls it.
