@@ -893,6 +893,18 @@ def test_ivf_index_from_a_folder_saved_and_loaded_back(tmp_path):
     with pytest.raises(ValueError):
         knn.load_index(str(tmp_path / "indices" / "shard1"), row_range=(0, 10))  # outside the saved shard
 
+    # an index built from an in-memory array (build_ivf_index) is saved by naming the folder its rows can be re-read from
+    mem = knn.build_ivf_index(x, nlist, nprobe=nprobe, centroids=np.load(os.path.join(out, "ivf_centroids.npy")))
+    with pytest.raises(ValueError):
+        knn.save_index(mem, str(tmp_path / "indices" / "from_memory"))
+    knn.save_index(mem, str(tmp_path / "indices" / "from_memory"), embeddings_folder=folder)
+    Dm2, Im2 = mem.search(q, 40)
+    mem.close()
+    again = knn.load_index(str(tmp_path / "indices" / "from_memory"))
+    Da, Ia = again.search(q, 40)
+    assert np.array_equal(Ia, Im2) and np.array_equal(Da, Dm2) and np.array_equal(Ia, Ib)
+    again.close()
+
     # ids are row numbers: an index must not be loaded over embeddings that changed
     np.save(os.path.join(folder, "img_emb_3.npy"), x[:2])
     with pytest.raises(ValueError):
