@@ -474,6 +474,65 @@ class _DecodePool:
         cls._pools.clear()
 
 
+class _DecodedStream:
+    """Iterator over a reader's decoded samples (see _BatchingReader._decoded)."""
+
+    def __init__(self, reader):
+        from collections import deque  # pylint: disable=import-outside-toplevel
+
+        r = self.r = reader
+        self.procs = _DecodePool.get(r.workers, r._decode_args()) if r.use_processes and r.workers > 1 else None  # pylint: disable=protected-access
+        self.raws = iter(r._raw_samples())  # pylint: disable=protected-access
+        self.inflight, self.ready, self.done = deque(), deque(), False
+        if self.procs is not None:
+            self.limit = r.inflight_chunks or (2 * r.workers + max(1, r.batch_size // r.chunk))  # chunks in flight
+            self.pool = None
+        else:
+            self.limit = max(2 * r.workers, 2) + r.batch_size  # samples in flight
+            self.pool = ThreadPoolExecutor(r.workers)
+
+    def prime(self, cap=None):
+        """Submit work until the window (or `cap` entries of it) is full; never blocks on a result."""
+        r = self.r
+        limit = self.limit if cap is None else min(self.limit, cap)
+        while not self.done and len(self.inflight) < limit:
+            if self.procs is not None:
+                part = []
+                for raw in self.raws:
+                    part.append(raw)
+                    if len(part) == r.chunk:
+                        break
+                if len(part) < r.chunk:
+                    self.done = True
+                if part:
+                    self.inflight.append(self.procs.submit(part))
+            else:
+                raw = next(self.raws, None)
+                if raw is None:
+                    self.done = True
+                    break
+                self.inflight.append(self.pool.submit(r._decode, raw))  # pylint: disable=protected-access
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        while not self.ready:
+            self.prime()
+            if not self.inflight:
+                if self.pool is not None:
+                    self.pool.shutdown(wait=False)
+                    self.pool = None
+                raise StopIteration
+            res = self.inflight.popleft().result()
+            if self.procs is not None:
+                self.ready.extend(res)
+            else:
+                self.ready.append(res)
+            self.prime()  # refill the window behind the chunk that just left it, before the caller goes away with the sample
+        return self.ready.popleft()
+
+
 class _BatchingReader:
     def __init__(self, preprocess, tokenizer, batch_size, num_prepro_workers, enable_text, enable_image, enable_metadata):
         self.preprocess = preprocess or clip_preprocess
@@ -515,48 +574,14 @@ class _BatchingReader:
     def _decoded(self):
         """Decoded samples in input order with a BOUNDED number of samples in flight (the reference's DataLoader holds at
         most prefetch_factor * workers batches): raw bytes are only read when a slot is free, so a 10 k-member shard is
-        never resident at once (`Executor.map` would submit -- i.e. read and decode -- the whole partition up front)."""
-        from collections import deque  # pylint: disable=import-outside-toplevel
+        never resident at once (`Executor.map` would submit -- i.e. read and decode -- the whole partition up front).
+        Returns an iterator with a `prime()` method: submit the first window of work WITHOUT waiting for any of it (the
+        multi-stream WebdatasetReader primes all its streams before it pulls the first batch)."""
+        return _DecodedStream(self)
 
-        procs = _DecodePool.get(self.workers, self._decode_args()) if self.use_processes and self.workers > 1 else None
-        if procs is not None:
-            limit = 2 * self.workers + max(1, self.batch_size // self.chunk)  # chunks in flight
-            if self.inflight_chunks:
-                limit = self.inflight_chunks
-            inflight, raws, done = deque(), iter(self._raw_samples()), False
-            while True:
-                while not done and len(inflight) < limit:
-                    part = []
-                    for raw in raws:
-                        part.append(raw)
-                        if len(part) == self.chunk:
-                            break
-                    if len(part) < self.chunk:
-                        done = True
-                    if part:
-                        inflight.append(procs.submit(part))
-                if not inflight:
-                    return
-                yield from inflight.popleft().result()
-        limit = max(2 * self.workers, 2) + self.batch_size
-        with ThreadPoolExecutor(self.workers) as pool:
-            inflight = deque()
-            raws = iter(self._raw_samples())
-            done = False
-            while True:
-                while not done and len(inflight) < limit:
-                    raw = next(raws, None)
-                    if raw is None:
-                        done = True
-                        break
-                    inflight.append(pool.submit(self._decode, raw))
-                if not inflight:
-                    return
-                yield inflight.popleft().result()
-
-    def __iter__(self):
+    def _batches(self, stream):
         pending, taken = [], 0
-        for decoded in self._decoded():
+        for decoded in stream:
             taken += 1
             if decoded is not None:
                 pending.append(decoded)
@@ -567,6 +592,9 @@ class _BatchingReader:
                 pending, taken = [], 0
         if pending:
             yield _collate(pending, self.enable_image, self.enable_text, self.enable_metadata, self.pin)
+
+    def __iter__(self):
+        return self._batches(self._decoded())
 
 
 class FilesReader(_BatchingReader):
@@ -622,14 +650,27 @@ class WebdatasetReader(_BatchingReader):
             return
         import copy  # pylint: disable=import-outside-toplevel
 
-        streams = []
+        streams, decoded = [], []
         for w in range(W):
             sub = copy.copy(self)
             sub.shards = self.shards[w::W]
             sub.reference_batch_order = False
-            sub.inflight_chunks = max(2, (2 * self.batch_size + self.chunk - 1) // self.chunk + 1)  # prefetch_factor = 2 batches
+            # one batch's worth (+ 1 chunk) in flight per stream: it is submitted when the stream's previous batch is handed out and
+            # has a whole round of the other streams' batches to get decoded.  (Two batches' worth -- the reference's
+            # prefetch_factor -- kept 4 k decoded samples alive across 8 streams: the parent's copies ran out of cache, -3 .. -7 %)
+            sub.inflight_chunks = max(2, (self.batch_size + self.chunk - 1) // self.chunk + 1)
             if sub.shards:
-                streams.append(iter(sub))
+                d = sub._decoded()
+                decoded.append(d)
+                streams.append(sub._batches(d))
+        # every stream's first window goes to the decode processes before the first batch is waited for -- one batch's worth per
+        # stream first (the order the batches will be asked for), then the rest: without this the W first batches were decoded one
+        # after the other (-14 % on a 16 k-sample partition, profiles/r04e_pipeline_vitl14*.log)
+        first = (self.batch_size + self.chunk - 1) // self.chunk
+        for d in decoded:
+            d.prime(first)
+        for d in decoded:
+            d.prime()
         while streams:
             for it in list(streams):
                 batch = next(it, None)

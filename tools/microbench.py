@@ -311,6 +311,11 @@ if "pipeline" in what:
         f.write("#version: 0.2\nt h\nth e</w>\no f</w>\np h\n")
     os.environ["CLIP_BPE_PATH"] = bpe
     pipe_model = os.environ.get("MB_PIPE_MODEL", "ViT-L/14")
+    if os.environ.get("MB_PIPE_ONE_STREAM"):  # A/B: shards in order through one stream instead of the reference loader's per-worker batching
+        from clip_retrieval_amd.reader import WebdatasetReader as _W
+
+        _W.reference_batch_order = False
+        print("pipeline: WebdatasetReader.reference_batch_order = False")
     for workers, gpu_resize in ((8, False), (32, False), (8, True), (32, True)):
         out = os.path.join(tmp, f"out{workers}{'r' if gpu_resize else ''}")
         args = dict(input_dataset=shards, output_folder=out, output_partition_count=2, input_format="webdataset", batch_size=256,
