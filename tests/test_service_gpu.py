@@ -215,7 +215,13 @@ def test_worker_on_the_gpu_over_tar_shards(tiny_checkpoints, tmp_path):
                 gy, gx = np.linspace(0, 255, hh, dtype=np.float32), np.linspace(0, 255, ww, dtype=np.float32)
                 img = (gx[None, :, None] * 0.5 + gy[:, None, None] * 0.5 + rng.normal(0, 8, (hh, ww, 3))).clip(0, 255).astype(np.uint8)
                 buf = io.BytesIO()
-                Image.fromarray(img).save(buf, format="JPEG", quality=92)
+                if k % 9 == 7:    # a palette image (Pillow resamples mode P with NEAREST) and
+                    Image.fromarray(img).quantize(32).save(buf, format="PNG")
+                elif k % 9 == 8:  # an image with an alpha channel (premultiplied resampling): ADVICE r3 -- the reference resizes in the
+                    a = np.linspace(0, 255, hh * ww, dtype=np.float32).reshape(hh, ww).astype(np.uint8)  # image's own mode, THEN converts
+                    Image.merge("RGBA", (*Image.fromarray(img).split(), Image.fromarray(a))).save(buf, format="PNG")
+                else:
+                    Image.fromarray(img).save(buf, format="JPEG", quality=92)
                 jpegs.append(buf.getvalue())
                 for ext, data in (("jpg", buf.getvalue()), ("txt", ("a photo of a cat" if k % 2 else "the dog").encode())):
                     ti = tarfile.TarInfo(f"{k:06d}.{ext}")
@@ -240,8 +246,9 @@ def test_worker_on_the_gpu_over_tar_shards(tiny_checkpoints, tmp_path):
         _, wt = mapper_semantics(oracle.encode_text(tok(list(meta["caption"]))))
         assert _cos(img, wi).min() >= COS_BAR and _cos(txt, wt).min() >= COS_BAR
         assert json.loads((out / "stats" / f"{i}.json").read_text())["sample_count"] == 9
-    # the same job with the resize + centre crop on the GPU as well (row f2): the decode processes hand over the decoded sources;
-    # the kernel is bit-identical to Pillow, so every written embedding must be the SAME BYTES as above
+    # the same job with the resize + centre crop on the GPU as well (row f2): the decode processes hand over the decoded sources
+    # (the palette and RGBA members: the host transform's ready crop, reader.DecodeRgbU8); the kernel is bit-identical to Pillow, so
+    # every written embedding must be the SAME BYTES as above
     out2 = tmp_path / "out_gpu_resize"
     worker(tasks=[0, 1], input_dataset=shards, output_folder=str(out2), output_partition_count=2, input_format="webdataset",
            batch_size=4, num_prepro_workers=2, enable_text=True, enable_image=True, enable_metadata=False, clip_model="tiny-test",
