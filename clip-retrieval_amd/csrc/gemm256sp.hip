@@ -526,7 +526,10 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
             const char* base = yb + (size_t)(mt * 4 + i) * rstep;
             // s_nop 4: the base SGPR may come straight from a v_readlane; s_nop 1: store-data hazard (hipcc cannot see that
             // this is a store and may rewrite q right behind it)
-            if (DBG != 6) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(q[i]), "s"(base) : "memory");
+            if (DBG == 31) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(q[i]), "s"(base) : "memory");  // ablation: streaming stores
+            else if (DBG == 32) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1 nt\n\ts_nop 1" ::"v"(voff), "v"(q[i]), "s"(base) : "memory");
+            else if (DBG == 33) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(q[i]), "s"(base) : "memory");
+            else if (DBG != 6) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(q[i]), "s"(base) : "memory");
             else asm volatile("" ::"v"(q[i]));
           }
         }
@@ -812,6 +815,9 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 21) return launch_sp_epi<EPI_BIAS_BF16, 21>(g, grid, st);
     if (d == 22) return launch_sp_epi<EPI_BIAS_BF16, 22>(g, grid, st);
     if (d == 24) return launch_sp_epi<EPI_BIAS_BF16, 24>(g, grid, st);
+    if (d == 31) return launch_sp_epi<EPI_BIAS_BF16, 31>(g, grid, st);  // store cache policies: nt / sc1 nt / sc0 sc1 (correct results)
+    if (d == 32) return launch_sp_epi<EPI_BIAS_BF16, 32>(g, grid, st);
+    if (d == 33) return launch_sp_epi<EPI_BIAS_BF16, 33>(g, grid, st);
   }
   if (g.epi == EPI_BIAS_RESID_F32) {
     const char* dbg = getenv("CLIPX_GEMM_DBG");

@@ -70,6 +70,99 @@ def test_dedup_groups_from_range_search_links():
         assert set(KnnHotPath.non_uniques_from_links(lims, nbr, n)) == _reference_non_uniques(nb)
 
 
+def test_dedup_groups_from_pair_links_and_the_request_tail_without_a_gpu():
+    """Round 4: (1) `non_uniques_from_pairs` (the links knnx_search_dedup reports: pairs i < j) against the reference's DFS on random
+    link structures; (2) `KnnHotPath.knn_search`'s result handling on a FAKE index (no GPU): the plain-Python fast path (nothing
+    dropped, ids distinct), the -1 truncation, duplicate ids reported once at their best rank, the fused-dedup drop set, and the
+    safety / violence filters must give what the reference's loop gives (clip_back.py:371-399 restated below)."""
+    from types import SimpleNamespace
+
+    from clip_retrieval_amd.service import KnnHotPath, normalized
+
+    rng = np.random.default_rng(1)
+    for n in (2, 7, 40, 64):
+        for dens in (0.0, 0.5 / n, 2.0 / n):
+            a = np.triu(rng.random((n, n)) < dens, 1)
+            pairs = np.argwhere(a).astype(np.int32)
+            nb = {i: sorted(set([i] + np.flatnonzero(a[i] | a[:, i]).tolist())) for i in range(n)}
+            assert set(KnnHotPath.non_uniques_from_pairs(pairs, n)) == _reference_non_uniques(nb), (n, dens)
+
+    def reference_tail(D, I, to_remove_local):
+        results = I[0]
+        nb = np.where(results == -1)[0]
+        n = nb[0] if len(nb) else len(results)
+        ri, rd = results[:n], D[0][:n]
+        removed = set(ri[j] for j in to_remove_local if j < n)
+        out_i, out_d = [], []
+        for ind, dist in zip(ri, rd):
+            if ind not in removed:
+                removed.add(ind)
+                out_i.append(ind)
+                out_d.append(dist)
+        return out_d, out_i
+
+    class FakeIndex:
+        d = 8
+
+        def __init__(self, D, I, links):
+            self.D, self.I, self.links = D, I, links
+            self.R = rng.standard_normal((1, I.shape[1], 8)).astype(np.float32)
+            self.calls = []
+
+        def search(self, q, k):
+            self.calls.append("search")
+            return self.D.copy(), self.I.copy()
+
+        def search_and_reconstruct(self, q, k):
+            self.calls.append("search_and_reconstruct")
+            return self.D.copy(), self.I.copy(), self.R.copy()
+
+        def search_dedup(self, q, k, thr, want_r=False):
+            self.calls.append("search_dedup" + ("+R" if want_r else ""))
+            return self.D.copy(), self.I.copy(), (self.R.copy() if want_r else None), self.links.copy()
+
+    class Safety:  # flags result rank 1
+        def predict(self, emb, batch_size=None):
+            y = np.zeros((emb.shape[0], 1), np.float32)
+            y[1] = 1.0
+            return y
+
+    hp = KnnHotPath.__new__(KnnHotPath)
+    import threading
+
+    hp._nprobe_lock = threading.Lock()  # pylint: disable=protected-access
+    q = np.zeros((1, 8), np.float32)
+    k = 12
+    D = np.sort(rng.random((1, k)).astype(np.float32))[:, ::-1].copy()
+    cases = {
+        "distinct": np.arange(100, 100 + k, dtype=np.int64)[None],
+        "short": np.r_[np.arange(5, 12), -np.ones(5)].astype(np.int64)[None],
+        "repeated ids": np.asarray([[4, 9, 4, 7, 9, 1, 2, 3, 5, 6, 8, 4]], dtype=np.int64),
+    }
+    for name, I in cases.items():
+        for links in (np.zeros((0, 2), np.int32), np.asarray([[0, 3], [3, 6], [2, 5]], np.int32)):
+            ix = FakeIndex(D, I, links)
+            res = SimpleNamespace(image_index=ix, text_index=ix, metadata_is_ordered_by_ivf=False, safety_model=None, violence_detector=None)
+            n = int(np.argmax(I[0] == -1)) if (I[0] == -1).any() else k
+            d0, i0 = hp.knn_search(q, "image", k, res, False, False, False)
+            assert ix.calls == ["search"], "no filter reads the vectors: they must not be fetched"
+            rd, ri = reference_tail(D, I, [])
+            assert [int(v) for v in i0] == [int(v) for v in ri] and np.array_equal(np.asarray(d0), np.asarray(rd)), name
+            ix.calls.clear()
+            d1, i1 = hp.knn_search(q, "image", k, res, True, False, False)
+            assert ix.calls == ["search_dedup"]
+            drop = KnnHotPath.non_uniques_from_pairs(links[(links[:, 0] < n) & (links[:, 1] < n)], n)
+            rd, ri = reference_tail(D, I, drop)
+            assert [int(v) for v in i1] == [int(v) for v in ri] and np.array_equal(np.asarray(d1), np.asarray(rd)), (name, len(links))
+            ix.calls.clear()
+            res.safety_model = Safety()
+            d2, i2 = hp.knn_search(q, "image", k, res, True, True, False)
+            assert ix.calls == ["search_dedup+R"]
+            rd, ri = reference_tail(D, I, sorted(set(drop) | ({1} if n > 1 else set())))
+            assert [int(v) for v in i2] == [int(v) for v in ri], (name, "safety")
+            assert all(hasattr(v, "item") for v in i2) and all(hasattr(v, "item") for v in d2)  # numpy scalars, like the reference's lists
+
+
 def test_map_to_metadata_and_embedding_query(tmp_path):
     """map_to_metadata (clip_back.py:401-417): metadata for the first num_images ids only, id / similarity always, bytes
     decoded; compute_query's embedding branch with the aesthetic shift (clip_back.py:247-255)."""
