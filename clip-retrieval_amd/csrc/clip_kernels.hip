@@ -40,7 +40,7 @@ constexpr int G_GROUP_M = 8;
 // barrier per K-tile, software-pipelined fragment reads.  The launches this kernel serves have few workgroups (the peeled
 // 257th m-tile of ViT-L/14: 16..64 workgroups; B = 1 queries), so nothing else runs on the CU to hide DMA or LDS latency.
 template <int EPI, bool GLDS, bool DEEP = false, bool F16 = false>  // F16: operands are IEEE fp16 (bits travel as "bf16" pointers)
-__global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+__global__ __launch_bounds__(256, (DEEP && !CLIPX_MFMA16) ? 1 : 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp,
                                                           const float* __restrict__ table, int T, int M, int N,
                                                           int K, int row0, const float* __restrict__ rowscale,
@@ -84,14 +84,31 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
   int foff[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) foff[kk] = l31 * 128 + (((2 * kk + hb) ^ ((l31 >> 1) & 7)) << 4);
+  // 16x16x32 form (CLIPX_MFMA16, gemm_common.h): row l15 of a 16-row half-block (+ 2 KiB per half), k-chunk 4 s + q4 of slab s
+  const int l15 = lane & 15, q4 = lane >> 4;
+  int foff16[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) foff16[sl] = l15 * 128 + (((4 * sl + q4) ^ ((l15 >> 1) & 7)) << 4);
 
+#if CLIPX_MFMA16
+  f32x4 acc[2][2][4];  // [weight block i][activation block j][quad g]: one 16 x 16 MFMA block each (gemm_common.h)
+#define G_ACC(i, j, g, e) acc[i][j][g][e]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[i][j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
   f32x16 acc[2][2];
+#define G_ACC(i, j, g, e) acc[i][j][4 * (g) + (e)]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#endif
 
   const int nk = kz > 0 ? kz : K / G_BK;
   const int t0 = kz > 0 ? (int)blockIdx.y * kz : 0;  // first K-tile of this workgroup
@@ -100,6 +117,25 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
   auto compute = [&](int buf) {
     const unsigned char* sW = smem + buf * G_STAGE_BYTES + (wn * 64) * 128;
     const unsigned char* sA = smem + buf * G_STAGE_BYTES + G_TN * G_BK * 2 + (wm * 64) * 128;
+#if CLIPX_MFMA16
+    {
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        frag_t wf[2][2], af[2][2];  // [32-row block][16-row half]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            wf[i][hf] = *reinterpret_cast<const frag_t*>(sW + (i * 32 + hf * 16) * 128 + foff16[sl]);
+            af[i][hf] = *reinterpret_cast<const frag_t*>(sA + (i * 32 + hf * 16) * 128 + foff16[sl]);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mfma_block16<F16>(acc[i][j], wf[i][0], wf[i][1], af[j][0], af[j][1]);
+      }
+    }
+#else
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 wf[2], af[2];
@@ -113,6 +149,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
         for (int j = 0; j < 2; ++j)
           acc[i][j] = mfma_32x32x16<F16>(__builtin_bit_cast(frag_t, wf[i]), __builtin_bit_cast(frag_t, af[j]), acc[i][j]);
     }
+#endif
   };
 
   if (GLDS) {
@@ -151,6 +188,38 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
       }
       i32x4 F0[4], F1[4];  // [0..1] W fragments (i), [2..3] A fragments (j)
 #define D_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#if CLIPX_MFMA16
+      // 16x16x32 form: a K-tile is four units u = 2 * slab + (activation half): unit (sl, ha) multiplies the slab's four weight
+      // fragments Wd[sl][2 i + j2] with the two activation fragments Ad[u & 1][j] of half ha -- 8 MFMAs of 16 cycles, the 128
+      // matrix-pipe cycles of a 32x32x16 k-step; F0 / F1 are not used
+      (void)F0; (void)F1;
+      unsigned fW16[2], fA16[2];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        fW16[sl] = lds0 + (wn * 64) * 128 + foff16[sl];
+        fA16[sl] = lds0 + G_TN * G_BK * 2 + (wm * 64) * 128 + foff16[sl];
+      }
+      i32x4 Wd[2][4], Ad[2][2];
+#define D_READ_W(sl, so)                                 \
+  D_DSREAD(Wd[sl][0], fW16[sl] + (so), 0);               \
+  D_DSREAD(Wd[sl][1], fW16[sl] + (so), 2048);            \
+  D_DSREAD(Wd[sl][2], fW16[sl] + (so), 4096);            \
+  D_DSREAD(Wd[sl][3], fW16[sl] + (so), 6144);
+#define D_READ_A(u, so)                                                \
+  D_DSREAD(Ad[(u) & 1][0], fA16[(u) >> 1] + (so), ((u) & 1) * 2048);     \
+  D_DSREAD(Ad[(u) & 1][1], fA16[(u) >> 1] + (so), 4096 + ((u) & 1) * 2048);
+#define D_READ_U0(so) D_READ_W(0, so) D_READ_A(0, so) __builtin_amdgcn_sched_barrier(0);
+#define D_READ_U1(so) D_READ_A(1, so) __builtin_amdgcn_sched_barrier(0);
+#define D_READ_U2(so) D_READ_W(1, so) D_READ_A(2, so) __builtin_amdgcn_sched_barrier(0);
+#define D_READ_U3(so) D_READ_A(3, so) __builtin_amdgcn_sched_barrier(0);
+#define D_WAIT_N(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); __builtin_amdgcn_sched_barrier(0);
+#define D_MFMA_U(u)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+      _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2)                                                               \
+          acc[i][j][2 * ((u) & 1) + j2] =                                                                            \
+              mfma_16x16x32<F16>(Wd[(u) >> 1][2 * i + j2], Ad[(u) & 1][j], acc[i][j][2 * ((u) & 1) + j2]);           \
+  __builtin_amdgcn_sched_barrier(0);
+#else
 #define D_READ(F, so, kk)                          \
   D_DSREAD(F[0], fW[kk] + (so), 0);                \
   D_DSREAD(F[1], fW[kk] + (so), 4096);             \
@@ -162,6 +231,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =            \
       mfma_32x32x16<F16>(F[i], F[2 + j], acc[i][j]);                                                                   \
   __builtin_amdgcn_sched_barrier(0);
+#endif
       // one DMA: M0 = LDS address of the piece (SGPR), 32-bit lane offset, SGPR base of the K-tile
 #define D_DMA(off, base, dst)                                                                                         \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory")
@@ -185,6 +255,18 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+#if CLIPX_MFMA16
+      D_READ_U0(0u)
+      unsigned so = 0;  // byte offset of the current ring slot
+#define D_KT_HEAD()                                   \
+  D_READ_U1(so) D_WAIT_N(2) D_MFMA_U(0)                \
+  D_READ_U2(so) D_WAIT_N(6) D_MFMA_U(1)                \
+  D_READ_U3(so) D_WAIT_N(2) D_MFMA_U(2)                \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+  __builtin_amdgcn_sched_barrier(0);
+#define D_READ_FIRST(so_) D_READ_U0(so_)
+#define D_MFMA_LAST() D_MFMA_U(3)
+#else
       D_READ(F0, 0u, 0)
       unsigned so = 0;  // byte offset of the current ring slot
 #define D_KT_HEAD()                                   \
@@ -193,6 +275,9 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
   D_READ(F1, so, 3) D_WAIT_PREV() D_MFMA(F0)           \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
   __builtin_amdgcn_sched_barrier(0);
+#define D_READ_FIRST(so_) D_READ(F0, so_, 0)
+#define D_MFMA_LAST() D_MFMA(F1)
+#endif
 #define D_SYNC(vm)                                           \
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(vm) : "memory");  \
   __builtin_amdgcn_sched_barrier(0);                         \
@@ -205,8 +290,8 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
         D_SYNC(16)
         stage(t + 4, t & 3);
         so = (so + G_STAGE_BYTES) & (4 * G_STAGE_BYTES - 1);
-        D_READ(F0, so, 0)
-        D_MFMA(F1)
+        D_READ_FIRST(so)
+        D_MFMA_LAST()
       }
       // the last (up to) four K-tiles: nothing left to stage
       for (; t < nk; ++t) {
@@ -214,13 +299,12 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
         D_KT_HEAD()
         if (rem >= 3) { D_SYNC(16) } else if (rem == 2) { D_SYNC(8) } else { D_SYNC(0) }
         so = (so + G_STAGE_BYTES) & (4 * G_STAGE_BYTES - 1);
-        if (rem > 0) { D_READ(F0, so, 0) }
-        D_MFMA(F1)
+        if (rem > 0) { D_READ_FIRST(so) }
+        D_MFMA_LAST()
       }
 #undef D_DSREAD
-#undef D_READ
-#undef D_WAIT_PREV
-#undef D_MFMA
+#undef D_READ_FIRST
+#undef D_MFMA_LAST
 #undef D_DMA
 #undef D_KT_HEAD
 #undef D_SYNC
@@ -275,17 +359,17 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_bf16_kernel(const bf16
 #undef G_STORE
   }
 
-  // ---- epilogue: lane (m = l31, n = (r&3) + 8*(r>>2) + 4*hb) of each 32x32 sub-tile
+  // ---- epilogue: quad g of each 32x32 sub-tile = four consecutive n of one m (gemm_common.h: quad_m / quad_n)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int m = m0 + wm * 64 + j * 32 + l31;
-    if (m >= M) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * hb;
-        const float4 v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        const int m = m0 + wm * 64 + j * 32 + quad_m(g, lane);
+        if (m >= M) continue;
+        const int n = n0 + wn * 64 + i * 32 + quad_n(g, lane);
+        const float4 v = make_float4(G_ACC(i, j, g, 0), G_ACC(i, j, g, 1), G_ACC(i, j, g, 2), G_ACC(i, j, g, 3));
         gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, row0, rowscale, out16);
       }
     }

@@ -83,9 +83,18 @@ __device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const b
   const int rb = strip & 7, cg = strip >> 3;
   const int tm = tail_m0 + rb * 32, tn = cg * NB * 32;
   const int l31 = lane & 31, hb = lane >> 5;
+#if CLIPX_MFMA16
+  // 16x16x32 form: a stage (128 k) is 4 slabs x 2 row halves = 8 pieces of 1 KiB per 32-row operand; piece p = 2 * slab + half is a
+  // fragment as the MFMA wants it: lane (l15, q4) holds row 16 * half + l15, k = 32 * slab + 8 * q4 .. + 8.  Wave w fetches piece w.
+  const unsigned voff = (unsigned)(((lane & 15) * K + 8 * (lane >> 4)) * 2);
+  const char* baseA = reinterpret_cast<const char*>(A) + ((size_t)tm + 16 * (w & 1)) * K * 2 + (w >> 1) * 64;
+  const char* baseW = reinterpret_cast<const char*>(W) + ((size_t)tn + 16 * (w & 1)) * K * 2 + (w >> 1) * 64;
+  (void)l31; (void)hb;
+#else
   const unsigned voff = (unsigned)((l31 * K + 8 * hb) * 2);  // row l31 of the operand, 16 B of the k-step
   const char* baseA = reinterpret_cast<const char*>(A) + (size_t)tm * K * 2 + w * 32;  // + w * 32: this wave's k-step in a stage
   const char* baseW = reinterpret_cast<const char*>(W) + (size_t)tn * K * 2 + w * 32;
+#endif
   const int nch = K >> 7;
 #define T_DMA(off, base, dst) \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory")
@@ -99,9 +108,17 @@ __device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const b
   };
 #pragma unroll
   for (int c = 0; c < R - 1; ++c) issue(c, c);
+#if CLIPX_MFMA16
+  f32x4 acc[4];  // the four 16 x 16 quads of the wave's 32 x 32 block
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define T_ACC(g, e) acc[g][e]
+#else
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#define T_ACC(g, e) acc[4 * (g) + (e)]
+#endif
   int slot = 0;
   for (int c = 0; c < nch; ++c) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NOP) : "memory");  // this wave's share of stage c has landed
@@ -111,12 +128,23 @@ __device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const b
     issue(c + R - 1, slot == 0 ? R - 1 : slot - 1);
     if (w < NB) {
       const unsigned char* st = smem + slot * SB + lane * 16;
+#if CLIPX_MFMA16
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const frag_t af0 = *reinterpret_cast<const frag_t*>(st + (2 * sl) * 1024);
+        const frag_t af1 = *reinterpret_cast<const frag_t*>(st + (2 * sl + 1) * 1024);
+        const frag_t wf0 = *reinterpret_cast<const frag_t*>(st + (1 + w) * 8192 + (2 * sl) * 1024);
+        const frag_t wf1 = *reinterpret_cast<const frag_t*>(st + (1 + w) * 8192 + (2 * sl + 1) * 1024);
+        mfma_block16<F16>(acc, wf0, wf1, af0, af1);
+      }
+#else
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const frag_t af = *reinterpret_cast<const frag_t*>(st + ks * 1024);
         const frag_t wf = *reinterpret_cast<const frag_t*>(st + (1 + w) * 8192 + ks * 1024);
         acc = mfma_32x32x16<F16>(wf, af, acc);
       }
+#endif
     }
     slot = slot + 1 == R ? 0 : slot + 1;
   }
@@ -124,14 +152,15 @@ __device__ __forceinline__ void gemm256_tail(const bf16* __restrict__ A, const b
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail reloads still in flight
   S_FENCE();
   if (w < NB) {
-    const int m = tm + l31;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int n = tn + w * 32 + 8 * g + 4 * hb;
-      const float4 v = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+      const int m = tm + quad_m(g, lane);
+      const int n = tn + w * 32 + quad_n(g, lane);
+      const float4 v = make_float4(T_ACC(g, 0), T_ACC(g, 1), T_ACC(g, 2), T_ACC(g, 3));
       gemm_store_quad<EPI>(v, m, n, N, bias, outp, table, T, 0, rowscale, out16);
     }
   }
+#undef T_ACC
 }
 
 // DBG (ablation, EPI_BIAS_BF16 only; garbage results): 1 = no staging, 3 = no staging and no ds_reads,
@@ -261,17 +290,95 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     fN[kk] = lds0 + S_NBASE + (wc * 64 + l31) * 128 + xk;   // + buf*S_OPB + ni*4096
   }
 
+  // 16x16x32 form (CLIPX_MFMA16): row l15 of a 16-row half-block (+ 2 KiB per half, + 4 KiB per 32-row block), k-chunk 4 sl + q4 of
+  // the 32-deep slab sl; (row >> 1) & 7 of the swizzle only depends on l15 (the block bases are multiples of 16 rows)
+  const int l15 = lane & 15, q4 = lane >> 4;
+  unsigned fM16[2], fN16[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int xk = ((4 * sl + q4) ^ ((l15 >> 1) & 7)) << 4;
+    fM16[sl] = lds0 + (wr * 128 + l15) * 128 + xk;            // + buf*S_OPB + mi*4096 + h2*2048
+    fN16[sl] = lds0 + S_NBASE + (wc * 64 + l15) * 128 + xk;   // + buf*S_OPB + ni*4096 + j2*2048
+  }
+  // accumulators of the wave's 128 x 64 tile: 32 x 32 blocks (mt, nt), quad g of a block, element e of a quad (gemm_common.h)
+#if CLIPX_MFMA16
+  f32x4 acc[8][4];  // [2 mt + m-half][2 nt + n-half]: one 16 x 16 MFMA block each
+#define ACC(mt, nt, g, e) acc[2 * (mt) + ((g) >> 1)][2 * (nt) + ((g) & 1)][e]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
   f32x16 acc[4][2];
+#define ACC(mt, nt, g, e) acc[mt][nt][4 * (g) + (e)]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#endif
 
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define S_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#if CLIPX_MFMA16
+  // A 64-deep K-tile is eight units u = 4 * slab + mi: unit (sl, mi) multiplies the slab's four weight fragments Nd[sl][2 ni + j2]
+  // (16 rows x 32 k each) with the two activation fragments Md[u & 1][h2] of the 32-row block mi: 8 v_mfma_f32_16x16x32 = 128
+  // matrix-pipe cycles.  The fragments of unit u + 1 are read while unit u multiplies: 2 reads (the next block's activations), or
+  // 6 (+ the next slab's weights).  48 fragment registers, as the 32x32x16 loop had: with 16-MFMA units (64 registers) hipcc
+  // spilled around the tile boundaries.  Fragments are held as 4 x b32 so that each stays one 128-bit register tuple.
+  i32x4 Nd[2][4], Md[2][2];
+  if (DBG_NO_READ) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Nd[0][i] = Nd[1][i] = i32x4{0, 0, 0, 0};
+      asm volatile("" : "+v"(Nd[0][i]), "+v"(Nd[1][i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      Md[0][i] = Md[1][i] = i32x4{0, 0, 0, 0};
+      asm volatile("" : "+v"(Md[0][i]), "+v"(Md[1][i]));
+    }
+  }
+#define S_READ_N(sl, buf)                                              \
+  S_DSREAD(Nd[sl][0], fN16[sl], (buf) * S_OPB);                        \
+  S_DSREAD(Nd[sl][1], fN16[sl], (buf) * S_OPB + 2048);                 \
+  S_DSREAD(Nd[sl][2], fN16[sl], (buf) * S_OPB + 4096);                 \
+  S_DSREAD(Nd[sl][3], fN16[sl], (buf) * S_OPB + 6144);
+#define S_READ_M(u, buf)                                                                     \
+  S_DSREAD(Md[(u) & 1][0], fM16[(u) >> 2], (buf) * S_OPB + ((u) & 3) * 4096);                  \
+  S_DSREAD(Md[(u) & 1][1], fM16[(u) >> 2], (buf) * S_OPB + ((u) & 3) * 4096 + 2048);
+// unit u of the K-tile in buffer `buf`: u = 0 / 4 also bring the slab's weight fragments
+#define S_READ_U(u, buf)                                                 \
+  if (!DBG_NO_READ) {                                                    \
+    if (((u) & 3) == 0) { S_READ_N((u) >> 2, buf) }                      \
+    S_READ_M(u, buf)                                                     \
+  }                                                                      \
+  S_FENCE();
+#define S_WAIT_N(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); S_FENCE();
+#define S_MFMA_U(u)                                                                                                            \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2)                            \
+      _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2)                                                                         \
+          acc[2 * ((u) & 3) + h2][2 * ni + j2] =                                                                               \
+              mfma_16x16x32<F16>(Nd[(u) >> 2][2 * ni + j2], Md[(u) & 1][h2], acc[2 * ((u) & 3) + h2][2 * ni + j2]);            \
+  S_FENCE();
+  // One K-tile = S_KT_HEAD (units 0..6 and the LDS drain), a vmcnt wait + barrier, the stage of a later K-tile into the buffer just
+  // released, then S_KT_TAIL (pre-read of the next K-tile's first unit + unit 7's MFMAs).
+#define S_KT_HEAD(buf)                                       \
+  S_READ_U(1, buf) S_WAIT_N(2) S_MFMA_U(0)                   \
+  S_READ_U(2, buf) S_WAIT_N(2) S_MFMA_U(1)                   \
+  S_READ_U(3, buf) S_WAIT_N(2) S_MFMA_U(2)                   \
+  S_READ_U(4, buf) S_WAIT_N(6) S_MFMA_U(3)                   \
+  S_READ_U(5, buf) S_WAIT_N(2) S_MFMA_U(4)                   \
+  S_READ_U(6, buf) S_WAIT_N(2) S_MFMA_U(5)                   \
+  S_READ_U(7, buf) S_WAIT_N(2) S_MFMA_U(6)                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+  S_FENCE();
+#define S_READ_FIRST(buf) S_READ_U(0, buf)
+#define S_MFMA_LAST() S_MFMA_U(7)
+#else
   // [0..3] M fragments (mi), [4..5] N fragments (ni) of one k-step; held as 4 x b32 so that hipcc keeps each
   // fragment one 128-bit register tuple across the loop back-edge (as 8 x bf16 it re-packs them with v_perm_b32)
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
   i32x4 F0[6], F1[6];
   if (DBG_NO_READ) {
 #pragma unroll
@@ -280,8 +387,6 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
       asm volatile("" : "+v"(F0[i]), "+v"(F1[i]));
     }
   }
-
-#define S_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define S_READ(F, buf, kk)                                                                 \
   if (!DBG_NO_READ) {                                                                      \
     S_DSREAD(F[4], fN[kk], (buf) * S_OPB);                                                 \
@@ -307,14 +412,17 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   S_READ(F1, buf, 3) S_WAIT_PREV() S_MFMA(F0)                \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
   S_FENCE();
+#define S_READ_FIRST(buf) S_READ(F0, buf, 0)
+#define S_MFMA_LAST() S_MFMA(F1)
+#endif
 #define S_KT_SYNC(vm)                                        \
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(vm) : "memory");  \
   S_FENCE();                                                 \
   __builtin_amdgcn_s_barrier();                              \
   S_FENCE();
 #define S_KT_TAIL(buf, preread)                              \
-  if (preread) { S_READ(F0, (buf) ^ 1, 0) }                  \
-  S_MFMA(F1)
+  if (preread) { S_READ_FIRST((buf) ^ 1) }                   \
+  S_MFMA_LAST()
 // the stage of a K-tile goes behind k-step 3's MFMAs so that its 8 DMA issues overlap with their execution (measured:
 // the same as staging right behind the barrier, 2835 vs 2845 cycles per steady K-tile)
 #define S_KT_END(buf, preread, stage_stmt)                   \
@@ -338,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
   S_FENCE();
   __builtin_amdgcn_s_barrier();
   S_FENCE();
-  S_READ(F0, 0, 0)
+  S_READ_FIRST(0)
 
   // bias of the current tile: one LDS-DMA per wave at the tile's last K-tile drops the wave's 64 bias floats into
   // its (then idle) epilogue scratch, AHEAD of the next tile's K-tile-1 stage, so the epilogue neither queues
@@ -450,6 +558,23 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
     // ---- epilogue of this output tile, transposed through the wave's LDS scratch (the next tile's K-tile 0 has landed,
     // its K-tile 1 is in flight; the bias landed in the scratch before the last K-tile's sync)
     S_FENCE();
+    // Where quad g (four consecutive columns of one row, gemm_common.h) of the 32 x 32 block (mt, nt) sits in the wave's transposition
+    // scratch -- rows of 128 B, one 32-row pass at a time -- and which bias / row-scale entries it needs, for both MFMA forms:
+#if CLIPX_MFMA16
+#define Q_ROW(g) (16 * ((g) >> 1) + l15)                        // row inside the 32-row pass
+#define Q_CH16(nt, g) (4 * (nt) + 2 * ((g) & 1) + (q4 >> 1))    // 16-B chunk of eight 16-bit outputs (64 columns = 8 chunks)
+#define Q_HALF(g) (q4 & 1)                                      // 8-B half of that chunk
+#define Q_CH32(g) (4 * ((g) & 1) + q4)                          // 16-B chunk of four f32 outputs inside the 32-column block
+#define Q_NCOL(nt, g) ((nt) * 32 + 16 * ((g) & 1) + 4 * q4)     // first column of the quad inside the wave's 64 columns
+#else
+#define Q_ROW(g) l31
+#define Q_CH16(nt, g) (4 * (nt) + (g))
+#define Q_HALF(g) hb
+#define Q_CH32(g) (2 * (g) + hb)
+#define Q_NCOL(nt, g) ((nt) * 32 + 8 * (g) + 4 * hb)
+#endif
+#define Q_POS16(nt, g) (Q_ROW(g) * 128 + ((Q_CH16(nt, g) ^ (Q_ROW(g) & 7)) << 4) + Q_HALF(g) * 8)
+#define Q_POS32(g) (Q_ROW(g) * 128 + ((Q_CH32(g) ^ (Q_ROW(g) & 7)) << 4))
     if (DBG != 5) {
       unsigned char* scr = smem + S_SCRATCH + w * 4096;
       if (OUT_BF16) {
@@ -461,10 +586,12 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + (nt * 32 + 8 * g + 4 * hb) * 4);
-        float rr[4];  // row scales of the lane's rows 32 mt + l31
+          for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + Q_NCOL(nt, g) * 4);
+        float rr[4][2];  // row scales of the lane's rows 32 mt + Q_ROW(g): one per row half (g >> 1) in the 16x16x32 form
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) rr[mt] = *reinterpret_cast<const float*>(scr + 1024 + (mt * 32 + l31) * 4);
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) rr[mt][hh] = *reinterpret_cast<const float*>(scr + 1024 + (mt * 32 + Q_ROW(2 * hh)) * 4);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -478,11 +605,11 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
               if (EPI == EPI_BIAS_QGELU_BF16) {
                 // two elements per VALU instruction for everything but the two transcendentals (v_pk_fma_f32, v_pk_mul_f32,
                 // v_pk_add_f32): each packed lane is the IEEE operation of gemm_common.h's quick_gelu, so the bits do not change
-                const f32x2_t r2 = {rr[mt], rr[mt]}, kk = {-1.702f * 1.4426950408889634f, -1.702f * 1.4426950408889634f};
+                const f32x2_t r2 = {rr[mt][g >> 1], rr[mt][g >> 1]}, kk = {-1.702f * 1.4426950408889634f, -1.702f * 1.4426950408889634f};
                 const f32x2_t one = {1.f, 1.f};
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
-                  const f32x2_t a2 = {acc[mt][nt][4 * g + e], acc[mt][nt][4 * g + e + 1]};
+                  const f32x2_t a2 = {ACC(mt, nt, g, e), ACC(mt, nt, g, e + 1)};
                   const f32x2_t b2 = {e == 0 ? bq.x : bq.z, e == 0 ? bq.y : bq.w};
                   const f32x2_t x2 = __builtin_elementwise_fma(a2, r2, b2);
                   const f32x2_t t2 = x2 * kk;
@@ -493,10 +620,10 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                 }
               } else {
                 // one fma per element, like gemm_store_quad (gemm_common.h): bit-identical rows from both kernels
-                v[0] = __builtin_fmaf(acc[mt][nt][4 * g + 0], rr[mt], bq.x);
-                v[1] = __builtin_fmaf(acc[mt][nt][4 * g + 1], rr[mt], bq.y);
-                v[2] = __builtin_fmaf(acc[mt][nt][4 * g + 2], rr[mt], bq.z);
-                v[3] = __builtin_fmaf(acc[mt][nt][4 * g + 3], rr[mt], bq.w);
+                v[0] = __builtin_fmaf(ACC(mt, nt, g, 0), rr[mt][g >> 1], bq.x);
+                v[1] = __builtin_fmaf(ACC(mt, nt, g, 1), rr[mt][g >> 1], bq.y);
+                v[2] = __builtin_fmaf(ACC(mt, nt, g, 2), rr[mt][g >> 1], bq.z);
+                v[3] = __builtin_fmaf(ACC(mt, nt, g, 3), rr[mt][g >> 1], bq.w);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                   if (EPI == EPI_BIAS_GELU_BF16) v[e] = gelu_erf(v[e]);
@@ -505,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
               // and assemble the pairs with v_perm / v_alignbit: 9 VALU per quad instead of 4)
               uint2 o;
               if (EPI == EPI_BIAS_F16) {  // v_cvt_pk_f16_f32: IEEE fp16, round to nearest even (the same bits as gemm_store_quad)
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));  // never v_fma_mix*_f16 (see gemm_store_quad)
                 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
                 o.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, f16x2_t));
                 o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, f16x2_t));
@@ -513,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
                 o.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t));
               }
               // row l31 = [8 chunks of 16 B]; chunk (4nt + g) holds columns 32nt + 8g .. +8, half hb
-              *reinterpret_cast<uint2*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8) = o;
+              *reinterpret_cast<uint2*>(scr + Q_POS16(nt, g)) = o;
             }
           u32x4 q[4];
 #pragma unroll
@@ -578,10 +706,10 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
           S_FENCE();
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2],
-                                         acc[mt][nt][4 * g + 3]);
+            const float4 v = make_float4(ACC(mt, nt, g, 0), ACC(mt, nt, g, 1), ACC(mt, nt, g, 2),
+                                         ACC(mt, nt, g, 3));
             // columns 8g + 4hb .. +4 = 16-B chunk 2g + hb of row l31
-            *reinterpret_cast<float4*>(scr + l31 * 128 + (((2 * g + hb) ^ (l31 & 7)) << 4)) = v;
+            *reinterpret_cast<float4*>(scr + Q_POS32(g)) = v;
           }
           float4 q[4];
 #pragma unroll
@@ -644,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + (nt * 32 + 8 * g + 4 * hb) * 4);
+          for (int g = 0; g < 4; ++g) b4[nt][g] = *reinterpret_cast<const float4*>(scr + Q_NCOL(nt, g) * 4);
         S_FENCE();  // hipcc waits vmcnt(0) for the bias DMA before these LDS reads: keep the x loads behind that wait
         u32x4 ext[2][4];
 #define S_LD_X16(set, mt_)                                                                                      \
@@ -668,7 +796,7 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)  // row l31, columns 32 nt + 8 g + 4 hb .. + 4: chunk (4 nt + g), half hb
-              xo[nt][g] = *reinterpret_cast<const uint2*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8);
+              xo[nt][g] = *reinterpret_cast<const uint2*>(scr + Q_POS16(nt, g));
           S_FENCE();
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
@@ -677,17 +805,17 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
               const f16x4 xh = __builtin_bit_cast(f16x4, xo[nt][g]);
               const float4 bq = b4[nt][g];
               f16x4 o;
-              o[0] = (_Float16)((float)xh[0] + (acc[mt][nt][4 * g + 0] + bq.x));
-              o[1] = (_Float16)((float)xh[1] + (acc[mt][nt][4 * g + 1] + bq.y));
-              o[2] = (_Float16)((float)xh[2] + (acc[mt][nt][4 * g + 2] + bq.z));
-              o[3] = (_Float16)((float)xh[3] + (acc[mt][nt][4 * g + 3] + bq.w));
+              o[0] = (_Float16)((float)xh[0] + (ACC(mt, nt, g, 0) + bq.x));
+              o[1] = (_Float16)((float)xh[1] + (ACC(mt, nt, g, 1) + bq.y));
+              o[2] = (_Float16)((float)xh[2] + (ACC(mt, nt, g, 2) + bq.z));
+              o[3] = (_Float16)((float)xh[3] + (ACC(mt, nt, g, 3) + bq.w));
               xo[nt][g] = __builtin_bit_cast(uint2, o);
             }
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<uint2*>(scr + l31 * 128 + (((4 * nt + g) ^ (l31 & 7)) << 4) + hb * 8) = xo[nt][g];
+              *reinterpret_cast<uint2*>(scr + Q_POS16(nt, g)) = xo[nt][g];
           S_FENCE();
           u32x4 q[4];
 #pragma unroll
@@ -720,9 +848,9 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const float4 v = make_float4(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2],
-                                           acc[mt][nt][4 * g + 3]);
-              *reinterpret_cast<float4*>(scr + l31 * 128 + (((2 * g + hb) ^ (l31 & 7)) << 4)) = v;
+              const float4 v = make_float4(ACC(mt, nt, g, 0), ACC(mt, nt, g, 1), ACC(mt, nt, g, 2),
+                                           ACC(mt, nt, g, 3));
+              *reinterpret_cast<float4*>(scr + Q_POS32(g)) = v;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -737,17 +865,19 @@ __global__ __launch_bounds__(512, 2) void gemm256sp_kernel(const bf16* __restric
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(acc[mt][nt]));
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(ACC(mt, nt, g, 0)), "v"(ACC(mt, nt, g, 1)), "v"(ACC(mt, nt, g, 2)), "v"(ACC(mt, nt, g, 3)));
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) ACC(mt, nt, r >> 2, r & 3) = 0.f;
     if (DBG_TIMER) { S_STAMP(0) ph[6] += 1; }
     if (!have_next) break;
-    S_READ(F0, 0, 0)  // first fragment set of the next tile (its K-tile 0 landed before the barrier of this tile's last K-tile);
+    S_READ_FIRST(0)  // first fragment set of the next tile (its K-tile 0 landed before the barrier of this tile's last K-tile);
                       // asking for it earlier, inside the epilogue, does not help: hipcc sinks the block behind the last store
     first = true;
     m0 = nm0;

@@ -10,6 +10,7 @@ namespace clipx {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef int frag_t __attribute__((ext_vector_type(4)));  // one MFMA operand fragment: 8 x 16-bit values, type-agnostic
@@ -20,6 +21,44 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(frag_t a, frag_t b, f32x16 c) {
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// ---- MFMA shape (round 4).  CLIPX_MFMA16 = 1: every GEMM kernel of this library multiplies with v_mfma_f32_16x16x32 (16 x 16
+// output blocks, 32-deep k-slabs) instead of v_mfma_f32_32x32x16.  Same flops per matrix-pipe cycle, same LDS bytes per flop -- but on
+// this power-managed part the 16x16x32 form sustains ~10 % more TFLOP/s: +13 % on register-only loops, +9 % on this library's GEMM
+// skeleton (fragment reads + LDS-DMA + barrier; tools/mfma_power_probe.hip, tools/mfma_probe2.hip, profiles/r04i_*, r04j_*): a quarter
+// of the accumulator registers are read and written per instruction for half the flops.  It is also the instruction the vendor's
+// assembly kernel uses.  All kernels switch together: an output element is the sum of its k-slabs in ascending order of
+// 32, whichever kernel computes it, so rows stay bit-identical across kernels, batch chunkings and the ragged tail.
+//
+// Accumulator layout.  A 32 x 32 output block (32 weight rows n x 32 activation rows m, the weights being the MFMA A operand) is 16
+// registers per lane in both forms (one f32x16, or four f32x4 quads):
+//   32x32x16  lane (l31 = lane & 31, hb = lane >> 5):  quad g = 0..3 -> m = l31,           n = 8 g + 4 hb + e
+//   16x16x32  lane (l15 = lane & 15, q4 = lane >> 4):  quad g = 0..3 -> m = 16 (g >> 1) + l15, n = 16 (g & 1) + 4 q4 + e     (e = 0..3)
+// i.e. quad g of the 16x16x32 form is the 16 x 16 sub-block (m-half g >> 1, n-half g & 1).  Fragments: one 16-B LDS read per lane in
+// both forms -- 32x32x16: row l31, k-chunk 2 kk + hb of the 16-deep step kk; 16x16x32: row l15 (+ 16 per half), k-chunk 4 s + q4 of
+// the 32-deep slab s.
+#ifndef CLIPX_MFMA16
+#define CLIPX_MFMA16 1
+#endif
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16x16x32(frag_t a, frag_t b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// In the 16x16x32 form the four quads of a 32 x 32 block are four separate f32x4 variables (each MFMA then accumulates in place;
+// packed into one f32x16 with shuffles the register allocator let the accumulators wander and spilled around tile boundaries).
+// one 32 x 32 block over one 32-deep k-slab: wf[j2] = weight rows 16 j2 .. + 16, af[h2] = activation rows 16 h2 .. + 16
+template <bool F16>
+__device__ __forceinline__ void mfma_block16(f32x4 (&q)[4], frag_t wf0, frag_t wf1, frag_t af0, frag_t af1) {
+  q[0] = mfma_16x16x32<F16>(wf0, af0, q[0]);
+  q[1] = mfma_16x16x32<F16>(wf1, af0, q[1]);
+  q[2] = mfma_16x16x32<F16>(wf0, af1, q[2]);
+  q[3] = mfma_16x16x32<F16>(wf1, af1, q[3]);
+}
+// the (m, n) of quad g inside its 32 x 32 block for this lane (n = first of four consecutive columns)
+__device__ __forceinline__ int quad_m(int g, int lane) { return CLIPX_MFMA16 ? 16 * (g >> 1) + (lane & 15) : (lane & 31); }
+__device__ __forceinline__ int quad_n(int g, int lane) { return CLIPX_MFMA16 ? 16 * (g & 1) + 4 * (lane >> 4) : 8 * g + 4 * (lane >> 5); }
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -72,6 +111,10 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
   if (EPI == EPI_BIAS_QGELU_BF16) { v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w); }
   if (EPI == EPI_BIAS_GELU_BF16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
   if (EPI == EPI_BIAS_F16) {
+    // the fma above and this conversion stay two instructions (f32 result, then round to fp16): left alone, hipcc may merge them into
+    // v_fma_mix{lo,hi}_f16 -- one rounding instead of two -- in one inlined copy and not in another, and a row would then depend on
+    // the kernel that produced it (seen in round 4: 1 ulp on ~2e-5 of the outputs of the 32-row tail strips)
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     f16x4 o;
     o[0] = (_Float16)v.x; o[1] = (_Float16)v.y; o[2] = (_Float16)v.z; o[3] = (_Float16)v.w;
     *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(outp) + (size_t)m * N + n) = o;
