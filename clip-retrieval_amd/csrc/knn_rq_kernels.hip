@@ -39,8 +39,24 @@
 
 namespace knnx {
 
+// KNNX_MFMA16 (default 1, round 4): the scan and the assignment kernel multiply with v_mfma_f32_16x16x32_f16 instead of
+// v_mfma_f32_32x32x16_f16 -- on this power-managed part the 16 x 16 x 32 shape sustains more TFLOP/s (the same switch as
+// the encoder's GEMMs, CLIPX_MFMA16; -DCLIPX_MFMA16=0 / -DKNNX_MFMA16=0 builds the previous kernels for the A/B).  What changes is
+// the fragment shape, nothing else: a 1-KiB LDS piece is (16 rows x 32 columns) -- lane (r = l & 15, q4 = l >> 4) holds row r,
+// columns 8 q4 .. + 8 of the 32-column slab -- instead of (32 rows x 16 columns); a 32-row tile is still d / 16 pieces, piece
+// p = 2 * slab + (row half); a wave's queries are blocks of 16 (lane: query l & 15, the same columns); a 16 x 16 result block gives
+// lane (query l & 15) the rows 4 q4 .. + 4 of its half.
+#ifndef KNNX_MFMA16
+#ifdef CLIPX_MFMA16
+#define KNNX_MFMA16 CLIPX_MFMA16
+#else
+#define KNNX_MFMA16 1
+#endif
+#endif
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int rq_enc_f(float f) {
@@ -58,18 +74,27 @@ __device__ __forceinline__ float rq_dec_f(int e) { return __int_as_float(e >= 0 
 __global__ void knn_rq_prep_kernel(const float* __restrict__ q, int nq, int d, int nblk, _Float16* __restrict__ qfrag,
                                    const float* __restrict__ samp, int kw, int J, float slack, float* __restrict__ thr,
                                    unsigned* __restrict__ cnt, unsigned* __restrict__ lost) {
-  const int s = blockIdx.x, b = blockIdx.y;  // k-step, query block
+  const int s = blockIdx.x, b = blockIdx.y;  // k-step (KNNX_MFMA16: 32-column slab), query block (KNNX_MFMA16: of 16)
   const int lane = threadIdx.x;
+#if KNNX_MFMA16
+  // qfrag [nblk16][d / 32][64 lanes][8 halves]: lane (n = l & 15, q4 = l >> 4) holds q_n[32 s + 8 q4 + j]
+  const int n = 16 * b + (lane & 15), h = lane >> 4;
+  constexpr int QB = 16, KW = 32;
+#else
   const int n = 32 * b + (lane & 31), h = lane >> 5;
+  constexpr int QB = 32, KW = 16;
+#endif
   half8 hi;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) hi[j] = (n < nq) ? (_Float16)q[(size_t)n * d + 16 * s + 8 * h + j] : (_Float16)0.f;
+  for (int j = 0; j < 8; ++j) hi[j] = (n < nq) ? (_Float16)q[(size_t)n * d + KW * s + 8 * h + j] : (_Float16)0.f;
   reinterpret_cast<half8*>(qfrag)[((size_t)b * gridDim.x + s) * 64 + lane] = hi;
-  if (s == 0 && lane < 32) {
+  if (s == 0 && lane < QB) {
     float t = INFINITY;
     if (n < nq) {
       const float v = samp[(size_t)n * kw + (J - 1)];
-      t = v > -FLT_MAX ? v - slack : -INFINITY;
+      // (KNNX_MFMA16: the sample scan accumulates 16 products per MFMA, this scan 32 -- the same exact products in another f32
+      // summation order; a relative 1e-5 keeps the sample rows themselves above their own threshold)
+      t = v > -FLT_MAX ? v - slack - (KNNX_MFMA16 ? 1e-5f * fabsf(v) : 0.f) : -INFINITY;
     }
     thr[n] = t;
     cnt[n] = 0u;
@@ -92,25 +117,56 @@ struct RqTile {
   const char* base;  // tile + this wave's offset
   unsigned m0b;      // LDS address of the slot + this wave's offset
   unsigned vo;       // per-lane byte offset (row, half)
+  unsigned vo1;      // KNNX_MFMA16: the same for the pieces of the tile's second row half (rows 16 .. 31)
 };
+// per-lane source offsets of a fragment-shaped DMA: [0] ordinary tiles, [1] the (possibly ragged) last tile, whose rows >= N re-read
+// row N - 1 (never admitted by the filter).  32x32x16: lane (row = l & 31, h = l >> 5) fetches 16 B of row `row` at column 8 h of
+// the k-step.  KNNX_MFMA16: lane (r = l & 15, q4 = l >> 4) fetches 16 B of row 16 * half + r at column 8 q4 of the slab.
+struct RqLaneOff {
+  unsigned v[2], v1[2];
+};
+__device__ __forceinline__ RqLaneOff rq_lane_offsets(int lane, int D, int lrow /* last valid row inside the last tile */) {
+  RqLaneOff o;
+#if KNNX_MFMA16
+  const int r = lane & 15, q4 = lane >> 4;
+  o.v[0] = (unsigned)(r * D * 2 + q4 * 16);
+  o.v1[0] = (unsigned)((16 + r) * D * 2 + q4 * 16);
+  o.v[1] = (unsigned)((r < lrow ? r : lrow) * D * 2 + q4 * 16);
+  o.v1[1] = (unsigned)((16 + r < lrow ? 16 + r : lrow) * D * 2 + q4 * 16);
+#else
+  const int row = lane & 31, hb = lane >> 5;
+  o.v[0] = o.v1[0] = (unsigned)(row * D * 2 + hb * 16);
+  o.v[1] = o.v1[1] = (unsigned)((row < lrow ? row : lrow) * D * 2 + hb * 16);
+#endif
+  return o;
+}
 template <int KS, int NW>
-__device__ __forceinline__ RqTile rq_tile(const _Float16* __restrict__ X, int64_t t, int64_t ntile, int64_t last, unsigned voff,
-                                          unsigned voff_last, unsigned lds_base, int slot, int w) {
+__device__ __forceinline__ RqTile rq_tile(const _Float16* __restrict__ X, int64_t t, int64_t ntile, int64_t last, const RqLaneOff& lo,
+                                          unsigned lds_base, int slot, int w) {
   constexpr int TILE_BYTES = KS * 1024, DPW = KS / NW;
   const int64_t tt = t < ntile ? t : last;
   RqTile r;
-  r.vo = tt == last ? voff_last : voff;
+  r.vo = tt == last ? lo.v[1] : lo.v[0];
+  r.vo1 = tt == last ? lo.v1[1] : lo.v1[0];
+  // the wave's DPW pieces: 32x32x16 -- k-steps w DPW .. (32 B each); KNNX_MFMA16 -- slabs w DPW / 2 .. (64 B each), both halves
   r.base = reinterpret_cast<const char*>(X) + (size_t)tt * TILE_BYTES + w * (DPW * 32);
   r.m0b = lds_base + slot * TILE_BYTES + w * (DPW * 1024);
   return r;
 }
-#define RQ_TILE(t_, slot_) rq_tile<KS, NW>(X, (t_), ntile, last, voff, voff_last, lds_base, (slot_), w)
+#define RQ_TILE(t_, slot_) rq_tile<KS, NW>(X, (t_), ntile, last, lane_off, lds_base, (slot_), w)
 template <int NW, int IDX>
 __device__ __forceinline__ void rq_issue_one(const RqTile& r) {
+#if KNNX_MFMA16
+  const char* p = r.base + (IDX >> 1) * 64;  // piece IDX of the wave = slab IDX >> 1, row half IDX & 1
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((IDX & 1) ? r.vo1 : r.vo), "s"(p), "s"(r.m0b),
+               "n"(IDX * 1024)
+               : "memory", "scc");
+#else
   constexpr int KOFF = IDX;  // k-step minus the wave's first one
   const char* p = r.base + KOFF * 32;
   asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(r.vo), "s"(p), "s"(r.m0b), "n"(KOFF * 1024)
                : "memory", "scc");
+#endif
 }
 template <int NW, int DPW, int IDX = 0>
 __device__ __forceinline__ void rq_issue_all(const RqTile& r) {
@@ -132,16 +188,32 @@ template <int N>
 __device__ __forceinline__ void rq_wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
+#if KNNX_MFMA16
+// piece S = 2 * slab + half: one LDS read feeds the 2 * QBW MFMAs of the wave's 16-query blocks against that half of the slab
+#define RQ_NQB(QBW) (2 * (QBW))
+#define RQ_NSL(KS) ((KS) / 2)
+typedef float4v rq_acc_t[2];  // [row half] of one 16-query block
+#else
+#define RQ_NQB(QBW) (QBW)
+#define RQ_NSL(KS) (KS)
+typedef float16v rq_acc_t;
+#endif
 template <int KS, int QBW, int NW, int DPW, int S>
-__device__ __forceinline__ void rq_ksteps(unsigned xa, i32x4 (&A)[4], float16v (&acc)[QBW], const half8 (&Q)[QBW][KS],
-                                          const RqTile& refill) {
+__device__ __forceinline__ void rq_ksteps(unsigned xa, i32x4 (&A)[4], rq_acc_t (&acc)[RQ_NQB(QBW)],
+                                          const half8 (&Q)[RQ_NQB(QBW)][RQ_NSL(KS)], const RqTile& refill) {
   if constexpr (S < KS) {
     if constexpr (S + 3 < KS) rq_dsread<(S + 3) * 1024>(A[(S + 3) & 3], xa);
     rq_wait_lgkm<(KS - 1 - S < 3 ? KS - 1 - S : 3)>();  // reads issued after the one this step needs may stay in flight
     __builtin_amdgcn_sched_barrier(0);
+#if KNNX_MFMA16
+#pragma unroll
+    for (int b = 0; b < 2 * QBW; ++b)
+      acc[b][S & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, A[S & 3]), Q[b][S >> 1], acc[b][S & 1], 0, 0, 0);
+#else
 #pragma unroll
     for (int b = 0; b < QBW; ++b)
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A[S & 3]), Q[b][S], acc[b], 0, 0, 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // DMA piece S / (KS / DPW) of the refill behind this step's MFMAs: the DPW pieces are spread over the tile so that
     // their issue time overlaps with MFMAs already queued instead of holding all waves at the top of the tile
@@ -170,31 +242,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qcol = lane & 31, hb = lane >> 5;
+  // query blocks of QBS queries, NQB per wave, NSL fragments each; lane = (query column qcol, hb) -- hb is the row-group index of
+  // the lane inside a result block: 32x32x16: rows 4 hb + 8 i + e (hb < 2), KNNX_MFMA16: rows 4 hb + e of a 16-row half (hb < 4)
+  constexpr int NQB = RQ_NQB(QBW), NSL = RQ_NSL(KS), QBS = KNNX_MFMA16 ? 16 : 32;
+  const int qcol = lane & (QBS - 1), hb = lane / QBS;
   float* st_s = reinterpret_cast<float*>(stage + w * RQ_STAGE * 12);
   uint32_t* st_r = reinterpret_cast<uint32_t*>(st_s + RQ_STAGE);
   uint32_t* st_q = st_r + RQ_STAGE;
 
   // ---- this wave's queries: B fragments for the whole kernel, and the thresholds of this lane's query columns
-  half8 Q[QBW][KS];
-  float tq[QBW];
+  half8 Q[NQB][NSL];
+  float tq[NQB];
 #pragma unroll
-  for (int b = 0; b < QBW; ++b) {
-    const int blk = w * QBW + b;
-    const half8* src = reinterpret_cast<const half8*>(qfrag) + (size_t)blk * KS * 64 + lane;
+  for (int b = 0; b < NQB; ++b) {
+    const int blk = w * NQB + b;
+    const half8* src = reinterpret_cast<const half8*>(qfrag) + (size_t)blk * NSL * 64 + lane;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) Q[b][s] = src[s * 64];
-    tq[b] = thr[blk * 32 + qcol];
+    for (int s = 0; s < NSL; ++s) Q[b][s] = src[s * 64];
+    tq[b] = thr[blk * QBS + qcol];
   }
   // every fragment is "used" here once, so hipcc waits for these loads HERE: otherwise it counts them down at their first
   // uses inside the tile loop, and the last of those waits (vmcnt(0)) would drain the DMA ring on every tile
 #pragma unroll
-  for (int b = 0; b < QBW; ++b) {
+  for (int b = 0; b < NQB; ++b) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      // the second block lives in accumulation registers for good (MFMA reads B operands from either file; without the
+    for (int s = 0; s < NSL; ++s) {
+      // the second 32 queries live in accumulation registers for good (MFMA reads B operands from either file; without the
       // constraint hipcc "spills" them to AGPRs and copies 4 registers back before every MFMA)
-      if (b == 0) asm volatile("" : "+v"(Q[b][s]));
+      if (b < NQB / QBW) asm volatile("" : "+v"(Q[b][s]));
       else asm volatile("" : "+a"(Q[b][s]));
     }
     asm volatile("" : "+v"(tq[b]));
@@ -202,12 +277,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
 
   const int64_t ntile = (N + 31) >> 5;
   const int64_t last = ntile - 1;
-  // lane offset of a fragment-shaped DMA: lane (row = l & 31, h = l >> 5) fetches 16 B of row `row` at column 8 h of the
-  // k-step; the k-step (32 B) and the tile are added to the SGPR base.  The last tile may be ragged: rows >= N re-read
-  // row N - 1 (never admitted by the filter).
-  const unsigned voff = (unsigned)(qcol * D * 2 + hb * 16);
-  const int lrow = (int)(N - 1 - last * 32);  // last valid row inside the last tile
-  const unsigned voff_last = (unsigned)((qcol < lrow ? qcol : lrow) * D * 2 + hb * 16);
+  // lane offsets of the fragment-shaped DMAs (rq_lane_offsets); the piece and the tile are added to the SGPR base
+  const RqLaneOff lane_off = rq_lane_offsets(lane, D, (int)(N - 1 - last * 32));
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
   // (helpers above instead of a lambda: a lambda capturing by reference makes hipcc keep the closure in scratch memory;
@@ -231,12 +302,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
     // cycles each) overlaps with MFMAs already queued instead of holding all waves at the top of the tile.
     const RqTile refill = RQ_TILE(t + (int64_t)(NSLOT - 1) * gstride, slot == 0 ? NSLOT - 1 : slot - 1);
 
-    float16v acc[QBW];
+    rq_acc_t acc[NQB];
+#if KNNX_MFMA16
+#pragma unroll
+    for (int b = 0; b < NQB; ++b) acc[b][0] = acc[b][1] = float4v{0.f, 0.f, 0.f, 0.f};
+#else
 #pragma unroll
     for (int b = 0; b < QBW; ++b) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     }
+#endif
     // the k-loop: rq_ksteps<...> above (A fragments through a 4-deep register ring, the refill DMAs spread over the steps)
     const unsigned xa = lds_base + slot * TILE_BYTES + lane * 16;
     i32x4 A[4];
@@ -252,6 +328,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
     // runs with the matrix pipe idle.  (hipcc keeps the accumulators in AGPRs -- forcing them into VGPRs only adds copies --
     // so every value still costs one v_accvgpr_read.)
     bool any = false;
+#if KNNX_MFMA16
+    // RQ_SCORE(b, r): the lane's r-th score of block b, r = 4 * half + e -> row row0 + 16 * half + e
+#define RQ_SCORE(b, r) acc[b][(r) >> 2][(r) & 3]
+#define RQ_ROWOFF(r) (16 * ((r) >> 2) + ((r) & 3))
+    constexpr int NSC = 8;
+#pragma unroll
+    for (int b = 0; b < NQB; ++b) {
+      const float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[b][0][0], acc[b][0][1]), acc[b][0][2]);
+      const float m1 = __builtin_fmaxf(__builtin_fmaxf(acc[b][0][3], acc[b][1][0]), acc[b][1][1]);
+      const float m2 = __builtin_fmaxf(acc[b][1][2], acc[b][1][3]);
+      any |= __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2) >= tq[b];
+    }
+#else
+#define RQ_SCORE(b, r) acc[b][r]
+#define RQ_ROWOFF(r) (((r) & 3) + 8 * ((r) >> 2))
+    constexpr int NSC = 16;
 #pragma unroll
     for (int b = 0; b < QBW; ++b) {
       float m0 = __builtin_fmaxf(__builtin_fmaxf(acc[b][0], acc[b][1]), acc[b][2]);
@@ -263,21 +355,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
       m3 = __builtin_fmaxf(__builtin_fmaxf(m3, m4), acc[b][15]);
       any |= __builtin_fmaxf(m0, m3) >= tq[b];
     }
+#endif
     if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // a hit somewhere in the wave: ~1 tile step in 8
       bool vmem = false;
 #pragma unroll
-      for (int b = 0; b < QBW; ++b) {
+      for (int b = 0; b < NQB; ++b) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-          const bool hit = acc[b][r] >= tq[b] && row < N;
+        for (int r = 0; r < NSC; ++r) {
+          const int64_t row = row0 + RQ_ROWOFF(r);
+          const bool hit = RQ_SCORE(b, r) >= tq[b] && row < N;
           const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
           if (m != 0ull) {
             const int pos = nst + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            const unsigned qq = (unsigned)((w * QBW + b) * 32 + qcol);
+            const unsigned qq = (unsigned)((w * NQB + b) * QBS + qcol);
             if (hit) {
               if (pos < RQ_STAGE) {
-                st_s[pos] = acc[b][r];
+                st_s[pos] = RQ_SCORE(b, r);
                 st_r[pos] = (uint32_t)row;
                 st_q[pos] = qq;
               } else {
@@ -339,43 +432,57 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_assign_kernel(const _Floa
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qcol = lane & 31, hb = lane >> 5;
+  constexpr int NQB = RQ_NQB(1), NSL = RQ_NSL(KS), QBS = KNNX_MFMA16 ? 16 : 32;
+  const int qcol = lane & (QBS - 1), hb = lane / QBS;
   const _Float16* X = C;  // the streamed operand (RQ_TILE below)
   const int64_t N = nlist;
 
   // this wave's 32 points as B fragments: lane (qcol, hb) holds point[16 s + 8 hb .. + 8] of every k-step s
-  const int64_t pidx = (int64_t)blockIdx.x * (NW * 32) + w * 32 + qcol;
-  const int64_t prow = pidx < n ? pidx : n - 1;
-  half8 Q[1][KS];
-  {
+  // (KNNX_MFMA16: two blocks of 16 points, point[32 s + 8 hb .. + 8] of every slab s)
+  int64_t pidx[NQB];
+  half8 Q[NQB][NSL];
+#pragma unroll
+  for (int b = 0; b < NQB; ++b) {
+    pidx[b] = (int64_t)blockIdx.x * (NW * 32) + w * 32 + b * QBS + qcol;
+    const int64_t prow = pidx[b] < n ? pidx[b] : n - 1;
     const half8* src = reinterpret_cast<const half8*>(P + (size_t)prow * D) + hb;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) Q[0][s] = src[2 * s];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(Q[0][s]));  // all landed before the DMA ring starts (see the scan)
+    for (int s = 0; s < NSL; ++s) Q[b][s] = src[(KNNX_MFMA16 ? 4 : 2) * s];
   }
+#pragma unroll
+  for (int b = 0; b < NQB; ++b)
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) asm volatile("" : "+v"(Q[b][s]));  // all landed before the DMA ring starts (see the scan)
 
   const int64_t ntile = (N + 31) >> 5;
   const int64_t last = ntile - 1;
-  const unsigned voff = (unsigned)(qcol * D * 2 + hb * 16);
-  const int lrow = (int)(N - 1 - last * 32);
-  const unsigned voff_last = (unsigned)((qcol < lrow ? qcol : lrow) * D * 2 + hb * 16);
+  const RqLaneOff lane_off = rq_lane_offsets(lane, D, (int)(N - 1 - last * 32));
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
 #pragma unroll
   for (int i = 0; i < NSLOT - 1; ++i) rq_issue_all<NW, DPW>(RQ_TILE((int64_t)i, i));
 
-  float best = -INFINITY;
-  int brow = 0;
+  float best[NQB];
+  int brow[NQB];
+#pragma unroll
+  for (int b = 0; b < NQB; ++b) {
+    best[b] = -INFINITY;
+    brow[b] = 0;
+  }
   int slot = 0;
   for (int64_t t = 0; t < ntile; ++t) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NSLOT - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const RqTile refill = RQ_TILE(t + (NSLOT - 1), slot == 0 ? NSLOT - 1 : slot - 1);
-    float16v acc[1];
+    rq_acc_t acc[NQB];
+#if KNNX_MFMA16
+#pragma unroll
+    for (int b = 0; b < NQB; ++b) acc[b][0] = acc[b][1] = float4v{0.f, 0.f, 0.f, 0.f};
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+#endif
     const unsigned xa = lds_base + slot * TILE_BYTES + lane * 16;
     i32x4 A[4];
     rq_dsread<0>(A[0], xa);
@@ -388,21 +495,36 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_assign_kernel(const _Floa
     const int row0 = (int)(t * 32) + 4 * hb;
     const bool ragged = t == last && (N & 31) != 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2);
-      const bool take = acc[0][r] > best && (!ragged || row < (int)N);
-      best = take ? acc[0][r] : best;
-      brow = take ? row : brow;
+    for (int b = 0; b < NQB; ++b) {
+#pragma unroll
+      for (int r = 0; r < (KNNX_MFMA16 ? 8 : 16); ++r) {
+        const int row = row0 + RQ_ROWOFF(r);
+        const float sc = RQ_SCORE(b, r);
+        const bool take = sc > best[b] && (!ragged || row < (int)N);
+        best[b] = take ? sc : best[b];
+        brow[b] = take ? row : brow[b];
+      }
     }
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail reloads still in flight
-  // the two half-waves of a point saw different rows of every tile
-  const float ob = __shfl_xor(best, 32);
-  const int orow = __shfl_xor(brow, 32);
-  if (ob > best || (ob == best && orow < brow)) brow = orow;
-  if (hb == 0 && pidx < n) out[pidx] = brow;
+  // the lane groups of a point (2 half-waves; KNNX_MFMA16: 4 quarter-waves) saw different rows of every tile
+#pragma unroll
+  for (int b = 0; b < NQB; ++b) {
+#pragma unroll
+    for (int o = 32; o >= QBS; o >>= 1) {
+      const float ob = __shfl_xor(best[b], o);
+      const int orow = __shfl_xor(brow[b], o);
+      if (ob > best[b] || (ob == best[b] && orow < brow[b])) {
+        best[b] = ob;
+        brow[b] = orow;
+      }
+    }
+    if (hb == 0 && pidx[b] < n) out[pidx[b]] = brow[b];
+  }
 }
+#undef RQ_SCORE
+#undef RQ_ROWOFF
 
 template <int KS, int NW, int NSLOT>
 static hipError_t launch_assign_cfg(const _Float16* C, int64_t nlist, const _Float16* P, int64_t n, int32_t* out, hipStream_t st) {
@@ -529,8 +651,8 @@ int rq_queries_per_pass(int d) { return d == 1024 ? 128 : (d == 512 || d == 768 
 
 hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, const float* samp, int kw, int J, float slack,
                           float* thr, unsigned* cnt, unsigned* lost, hipStream_t st) {
-  const int nblk = rq_queries_per_pass(d) / 32;
-  hipLaunchKernelGGL(knn_rq_prep_kernel, dim3(d / 16, nblk), dim3(64), 0, st, q_dev, nq, d, nblk, qfrag, samp, kw, J, slack, thr, cnt, lost);
+  const int nblk = rq_queries_per_pass(d) / (KNNX_MFMA16 ? 16 : 32);
+  hipLaunchKernelGGL(knn_rq_prep_kernel, dim3(d / (KNNX_MFMA16 ? 32 : 16), nblk), dim3(64), 0, st, q_dev, nq, d, nblk, qfrag, samp, kw, J, slack, thr, cnt, lost);
   return hipGetLastError();
 }
 
