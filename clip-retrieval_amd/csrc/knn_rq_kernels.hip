@@ -33,6 +33,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <float.h>
 #include <algorithm>
 #include "knn_kernels.h"
@@ -675,6 +676,13 @@ hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, int nq, const _Fl
   // configuration, whose upper four waves would multiply padding
   if (nq <= 128 && d == 768) return launch_rq_scan_cfg<48, 1, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
   if (nq <= 128 && d == 512) return launch_rq_scan_cfg<32, 1, 4, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+#ifdef CLIPX_ABLATE
+  {  // tools build only (A/B on one box): KNNX_RQ_4X64=1 -> 4 waves x 64 queries at d = 768 (half the LDS reads, one wave per SIMD):
+     // 38.3 ms per pass against 36.4 - 36.8 for 8 x 32 on the 16x16x32 kernels (profiles/r04p_rq_8x32_vs_4x64.log)
+    static const int w4 = getenv("KNNX_RQ_4X64") ? atoi(getenv("KNNX_RQ_4X64")) : 0;
+    if (w4 && d == 768) return launch_rq_scan_cfg<48, 2, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+  }
+#endif
   switch (d) {
     case 512: return launch_rq_scan_cfg<32, 1, 8, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
     // d = 768: 8 waves x 32 queries, two waves per SIMD: a wave's LDS-DMA issue (~100 cycles per instruction during which it
