@@ -841,6 +841,9 @@ __device__ __forceinline__ unsigned attn_pack_p(float p0, float p1) {  // one v_
 }
 
 __device__ long long g_attn_phase[8192 * 4];
+#ifdef CLIPX_ABLATE
+__device__ int g_attn_pk_timer = 0;  // set by launch_attention_pk9 from CLIPX_ATTN_PK_TIMER (tools build)
+#endif
 template <int DH, int NKB, int NW, int QPW, bool CAUSAL, bool RECOMP, bool TIMER = false>
 __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int Tin,
                                                               int H, float scale_log2e, int dbg, int q_blocks,
@@ -1091,10 +1094,17 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 // S phase is over and V at the top of its own pair: every wave issues 24 DMAs per pair -- 212 us.
 // profiles/r03_rejected/attention_persistent_3wave_split_dma.patch)
 // =============================================================================================
+#ifndef CLIPX_ATTN_SPIPE
+#define CLIPX_ATTN_SPIPE 1
+#endif
+#ifndef CLIPX_ATTN_ROLES
+#define CLIPX_ATTN_ROLES 1
+#endif
 template <int NKB>
 __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T, int H,
                                                             int nheads, float scale_log2e, int q_blocks) {
-  constexpr int DH = 64, KS = 4, NW = 6, NDW = 3, QPW = (NKB + NW - 1) / NW, TP = NKB * 32, KROW = 128, NB = 2;
+  constexpr int DH = 64, KS = 4, NW = 6, NDW = CLIPX_ATTN_ROLES ? 2 : 3, QPW = (NKB + NW - 1) / NW, TP = NKB * 32, KROW = 128, NB = 2;
+  static_assert(!CLIPX_ATTN_ROLES || NKB == 9, "the role table below is the one of 9 query blocks");
   constexpr int KBYTES = TP * KROW, VHALF = TP * 64, BUF = KBYTES + 2 * VHALF;
   constexpr int KDMA = TP * 8 / 64 / NDW, VDMA = 2 * TP * 4 / 64 / NDW;
   static_assert(TP * 8 % (64 * NDW) == 0, "the DMA pieces must divide evenly among the issuing waves");
@@ -1106,13 +1116,44 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
   const int hb = lane >> 5, l31 = lane & 31;
   const int ld = 3 * H * DH;  // qkv row stride (elements)
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+#ifdef CLIPX_ABLATE
+  // tools build, CLIPX_ATTN_PK_TIMER=1 (tools/attn_bench): shader cycles per wave in [0] the wait + barrier at the top of a pair,
+  // [1] the DMA issue, [2] the S phases, [3] exp + P V + output of its blocks -> g_attn_phase[(workgroup * 6 + wave) * 4 + i]
+  const bool timer = g_attn_pk_timer != 0;
+  long long tph[4] = {0, 0, 0, 0};
+  long long tst = timer ? (long long)__builtin_readcyclecounter() : 0;
+#define P_STAMP(i) if (timer) { const long long n_ = (long long)__builtin_readcyclecounter(); tph[i] += n_ - tst; tst = n_; }
+#else
+#define P_STAMP(i)
+#endif
+
+  // ---- who does what (CLIPX_ATTN_ROLES, round 4).  Waves w and w + 4 share a SIMD (0 & 4, 1 & 5); waves 2 and 3 have theirs alone.
+  // The phase timer (tools build, profiles/r04t_attention_phases.log) showed the original dealing -- blocks w and w + 6, the DMAs
+  // on waves 3 - 5 -- as 3 blocks + a DMA share on each shared SIMD (saturated: a block costs 7.7 - 12 k cycles there against 6.8 k
+  // alone), 2 blocks on wave 2's and 1 block + a DMA share on wave 3's (idle half of the pair).  New dealing: the lone waves take
+  // two blocks each (2: 2, 7; 3: 3, 8), wave 0 two (0, 6) beside wave 4's one, and waves 1 and 5 one block each plus all the DMAs.
+  auto blk_of = [&](int qi) -> int {  // query block qi of this wave (-1: none)
+#if CLIPX_ATTN_ROLES
+    if (qi == 0) return w;
+    return w == 0 ? 6 : (w == 2 ? 7 : (w == 3 ? 8 : -1));
+#else
+    return qi * NW + w < NKB ? qi * NW + w : -1;
+#endif
+  };
+#if CLIPX_ATTN_ROLES
+  const bool dma_wave = w == 1 || w == 5;
+  const int dma_idx = w == 1 ? 0 : 1;
+#else
+  const bool dma_wave = w >= NW - NDW;
+  const int dma_idx = w - (NW - NDW);
+#endif
 
   // ---- DMA of one pair into LDS half `buf`, by waves NW - NDW .. NW - 1.  Per-lane source offsets (bytes from the pair's q
   // base) are recomputed per piece -- a handful of VALU on waves that have the time.  The lane id goes through an opaque asm per
   // call: the offsets are loop-invariant, and hoisted out of the pair loop they would occupy 24 registers for the whole kernel.
   auto issue = [&](int hd, int buf) {
-    if (w < NW - NDW) return;  // wave-uniform
-    const int ww = w - (NW - NDW);
+    if (!dma_wave) return;  // wave-uniform
+    const int ww = dma_idx;
     const int b = hd / H, h = hd - b * H;
     const char* base = reinterpret_cast<const char*>(qkv + (size_t)b * T * ld + h * DH);
     int lane_v = lane;
@@ -1144,11 +1185,16 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
   auto load_q = [&](int hd, int qi) {
     const int b = hd / H, h = hd - b * H;
     const bf16* qbase = qkv + (size_t)b * T * ld + h * DH;
-    const int qpos = (qi * NW + w) * 32 + l31;
+    // (the lane id goes through an opaque asm per call, as in issue(): hoisted out of the pair loop the per-lane row offsets are
+    // 64-bit values that live -- or, once the hand-pipelined phases below took their registers, spill -- for the whole kernel)
+    int lane_q = lane;
+    asm volatile("" : "+v"(lane_q));
+    if (blk_of(qi) < 0) return;  // wave-uniform
+    const int qpos = blk_of(qi) * 32 + (lane_q & 31);
     const int qrow = qpos < T ? qpos : T - 1;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const uint4 v = *reinterpret_cast<const uint4*>(qbase + (size_t)qrow * ld + 16 * s + 8 * hb);
+      const uint4 v = *reinterpret_cast<const uint4*>(qbase + (size_t)qrow * ld + 16 * s + 8 * (lane_q >> 5));
       qn[qi][s] = *reinterpret_cast<const bf16x8*>(&v);
     }
   };
@@ -1158,6 +1204,17 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
   issue(hd, 0);
 #pragma unroll
   for (int qi = 0; qi < QPW; ++qi) load_q(hd, qi);
+  // Where this kernel waits for its own VMEM operations (round 4).  vmcnt counts loads, stores and LDS-DMAs in issue order, and
+  // hipcc, which cannot count across the loop's back edge, writes `s_waitcnt vmcnt(0)` in front of the first MFMA that reads Q
+  // fragments loaded one pair earlier: that also waited for the eight output stores the wave had issued a moment before (block
+  // 1's S phase for block 0's stores, the next pair's block 0 for block 1's) and, on the DMA waves, for the whole next pair's
+  // K / V -- they could not start their block before their DMAs had landed.  So every Q fragment is "used" (an empty asm) at a
+  // point where its load is old: here for the first pair, and in front of each block's output stores for the next pair's.  hipcc
+  // puts its wait there, where it costs nothing, and none in front of the S phases.
+#pragma unroll
+  for (int qi = 0; qi < QPW; ++qi)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qn[qi][s]));
   const int ksw = (l31 >> 1) & 7;
   const unsigned vlane = (unsigned)(((lane & 15) >> 2) * 64 + (16 * ((lane >> 4) & 1)) * 2 + (lane & 3) * 8);
   int buf = 0;
@@ -1165,23 +1222,80 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
     // the issuing waves' shares of the pair's K / V have landed, then the barrier tells everyone; every wave is also done
     // reading the other half, which the next pair's DMA is about to overwrite.  (Waves 0 - 2 issue no DMA: they do not wait
     // here for their own output stores, the critical path of the pair.)
-    if (w >= NW - NDW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (a DMA wave that computed a block in the previous pair has already seen its DMAs land -- the vmcnt(0) in front of that
+    // block's output stores, below -- and does not wait for those stores here)
+    if (dma_wave && !(hd != (int)blockIdx.x && w < q_blocks)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    P_STAMP(0)
     const int nxt = hd + gridDim.x;
     if (nxt < nheads) issue(nxt, buf ^ 1);
+    P_STAMP(1)
     const unsigned char* sK = smem + buf * BUF;
     const unsigned char* sV = sK + KBYTES;
     const int b = hd / H, h = hd - b * H;
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
-      const int qb = qi * NW + w;
-      if (qb >= NKB || qb >= q_blocks) break;
+      const int qb = blk_of(qi);
+      if (qb < 0 || qb >= q_blocks) continue;  // wave-uniform
       const int qpos = qb * 32 + l31;
       bf16x8 qf[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) qf[s] = qn[qi][s];
       f32x16 sacc[NKB];
       float mx = -INFINITY;
+#if CLIPX_ATTN_SPIPE
+      // S^T = K Q^T, software-pipelined by hand (round 4).  hipcc's own schedule of the plain loop below is one chain per query
+      // block -- `ds_read_b128 v[0:3]; s_waitcnt lgkmcnt(0); v_mfma` 36 times, every fragment through the SAME four registers --
+      // i.e. a full LDS round trip in front of every MFMA (~100 cycles per MFMA in the phase timer, 3.6 k of a block's ~10 k
+      // cycles).  Here the four K fragments of key block kb + 1 are requested (inline asm: this file places the wait) before the
+      // four MFMAs of block kb issue back to back on their accumulator -- nothing between two MFMAs of a chain, which would cost
+      // the dependent-issue cliff of ~43 cycles each -- and the running maximum of block kb - 1 is taken while they run.  Same
+      // MFMAs, same order per accumulator: the same bits.
+      {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        unsigned kaddr[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kaddr[s] = lds_base + buf * BUF + l31 * KROW + (((2 * s + hb) ^ ksw) << 4);
+        i32x4 KF[2][KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("ds_read_b128 %0, %1" : "=v"(KF[0][s]) : "v"(kaddr[s]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(KF[kb & 1][s]));  // (the values the MFMAs read exist from here on)
+          if (kb + 1 < NKB) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+              asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(KF[(kb + 1) & 1][s]) : "v"(kaddr[s]), "n"((kb + 1) * 32 * KROW));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          f32x16 sb;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sb[r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s) sb = attn_mfma(__builtin_bit_cast(bf16x8, KF[kb & 1][s]), qf[s], sb);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kb > 0) {  // (the asm pins these eight v_max3 here, under the last MFMA of the chain: hipcc would sink all 72 behind the phase)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb - 1][r]);
+            asm volatile("" : "+v"(mx));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (kb == NKB - 1) {  // keys past T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+              sb[r] = key < T ? sb[r] : -INFINITY;
+            }
+          }
+          sacc[kb] = sb;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[NKB - 1][r]);
+      }
+#else
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         f32x16 sb;
@@ -1204,6 +1318,10 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sb[r]);
       }
+#endif
+#ifdef CLIPX_ABLATE
+      if (timer) { asm volatile("" : "+v"(mx)); P_STAMP(2) }
+#endif
       if (nxt < nheads) load_q(nxt, qi);  // this block's Q is dead: the next pair's lands under exp + PV
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       if (mx == -INFINITY) mx = 0.f;
@@ -1217,6 +1335,70 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
+#if CLIPX_ATTN_SPIPE
+      // exp + P V, software-pipelined by hand (round 4): hipcc's schedule of the plain loop below puts the two transposing reads
+      // of a V^T fragment right in front of the MFMA that takes it (`ds_read_b64_tr_b16 x2; s_waitcnt lgkmcnt(0); v_mfma`, four
+      // times per key block) and all of a block's exponentials in front of its MFMAs.  Here iteration kb computes P of block kb
+      // (two halves of eight values) while the matrix pipe multiplies block kb - 1: MFMAs 0, 1 | read the V^T fragments of MFMAs
+      // 2, 3 | first half of P | MFMAs 2, 3 | read the fragments of the next block's MFMAs 0, 1 | second half of P -- every read
+      // has half an iteration (~150 cycles of VALU) to land, two fragment sets and one P set are live (a full block ahead spilled).
+      // The sums (r ascending) and each accumulator's MFMAs (kb, then s2 ascending) keep their order: the same bits.
+      {
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        unsigned pw[8];
+        s16x8 vf[2][NB];  // [s2][nb]
+        auto read_v = [&](int kb, int s2) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            // lane (d = 32nb + l31, hb): keys kb*32 + 16*s2 + 4hb + {0..3} and + 8 + {0..3}, each quad one transposing read
+            const unsigned char* vp = sV + nb * VHALF + (kb * 32 + 16 * s2 + 4 * hb) * 64 + vlane;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vp));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vp + 8 * 64));
+            vf[s2][nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        };
+        auto p_half = [&](int kb, int hf) {  // P values r = 8 hf .. 8 hf + 7 of block kb -> pw[4 hf .. 4 hf + 3]
+          const bool short_tail = kb == NKB - 1 && tail_keys <= 4;
+#pragma unroll
+          for (int r = 8 * hf; r < 8 * hf + 8; r += 2) {
+            if (short_tail && r >= 4) {
+              pw[r >> 1] = 0u;
+              continue;
+            }
+            const f32x2_t e = (f32x2_t){sacc[kb][r], sacc[kb][r + 1]} * (f32x2_t){scale_log2e, scale_log2e} + (f32x2_t){nmx, nmx};
+            const f32x2_t pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            sum2 += pp;
+            pw[r >> 1] = attn_pack_p(pp[0], pp[1]);
+          }
+        };
+        auto pv_mfma2 = [&](int s2) {  // the two MFMAs (nb = 0, 1) that take P columns 16 s2 .. + 16 = pw[4 s2 .. + 3]
+          const uint4 w4 = make_uint4(pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            oacc[nb] = attn_mfma(__builtin_bit_cast(bf16x8, vf[s2][nb]), *reinterpret_cast<const bf16x8*>(&w4), oacc[nb]);
+        };
+        read_v(0, 0);
+        p_half(0, 0);
+        p_half(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 1; kb < NKB; ++kb) {
+          pv_mfma2(0);  // block kb - 1
+          __builtin_amdgcn_sched_barrier(0);
+          read_v(kb - 1, 1);
+          p_half(kb, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pv_mfma2(1);
+          __builtin_amdgcn_sched_barrier(0);
+          read_v(kb, 0);
+          p_half(kb, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        pv_mfma2(0);
+        read_v(NKB - 1, 1);
+        pv_mfma2(1);
+      }
+#else
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         bf16x8 pf[2];
@@ -1252,11 +1434,20 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
             oacc[nb] = attn_mfma(__builtin_bit_cast(bf16x8, vv), pf[s2], oacc[nb]);
           }
       }
+#endif
       float sum = sum2[0] + sum2[1];
       sum += __shfl_xor(sum, 32);
       const float inv = sum > 0.f ? 1.f / sum : 0.f;
-      if (qpos < T) {
-        bf16* orow = out + ((size_t)b * T + qpos) * (H * DH) + h * DH;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qn[qi][s]));  // the next pair's Q has landed (see the prologue)
+      // ... and, on a DMA wave, the next pair's K / V (requested a whole block ago): nothing of this wave is in flight when its
+      // stores go out, so the top of the next pair has nothing to wait for but the barrier
+      if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));  // (not hoisted: see load_q)
+      const int opos = qb * 32 + (lane_o & 31);
+      if (opos < T) {
+        bf16* orow = out + ((size_t)b * T + opos) * (H * DH) + h * DH;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1264,11 +1455,19 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[nb][4 * g + e] * inv);
-            *reinterpret_cast<bf16x4*>(orow + 32 * nb + 8 * g + 4 * hb) = o;
+            *reinterpret_cast<bf16x4*>(orow + 32 * nb + 8 * g + 4 * (lane_o >> 5)) = o;
           }
       }
+      P_STAMP(3)
     }
   }
+#ifdef CLIPX_ABLATE
+  if (timer && lane == 0 && blockIdx.x * NW + w < 8192) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g_attn_phase[(blockIdx.x * NW + w) * 4 + i] = tph[i];
+  }
+#endif
+#undef P_STAMP
 }
 
 static int attn_cu_count() {
@@ -1288,6 +1487,18 @@ static hipError_t launch_attention_pk9(const bf16* qkv, bf16* out, int B, int T,
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   const int nheads = B * H, grid = std::min(nheads, attn_cu_count());
+#ifdef CLIPX_ABLATE
+  // tools build only: CLIPX_ATTN_QBLOCKS=n computes the first n query blocks of every pair (6: one block on every wave, 3: one
+  // block on waves 0 - 2) -- how the time of a pair depends on the blocks per wave (profiles/r04r_attention_qblocks.log)
+  static const int qb_env = getenv("CLIPX_ATTN_QBLOCKS") ? atoi(getenv("CLIPX_ATTN_QBLOCKS")) : 0;
+  if (qb_env > 0) q_blocks = qb_env;
+  static const int timer_env = getenv("CLIPX_ATTN_PK_TIMER") ? atoi(getenv("CLIPX_ATTN_PK_TIMER")) : 0;
+  static bool timer_set = false;
+  if (!timer_set) {
+    timer_set = true;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_pk_timer), &timer_env, sizeof(int));
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(384), smem, st, qkv, out, T, H, nheads, (1.f / 8.f) * 1.4426950408889634f,
                      q_blocks > 0 && q_blocks < NKB ? q_blocks : NKB);
   return hipGetLastError();

@@ -82,5 +82,19 @@ int main(int argc, char** argv) {
       printf("  phases, shader cycles per wave (3 query blocks): staging %.0f | S + max %.0f | exp + PV %.0f | store %.0f\n", s4[0], s4[1], s4[2], s4[3]);
     }
   }
+  if (dbgf && getenv("CLIPX_ATTN_PK_TIMER") && atoi(getenv("CLIPX_ATTN_PK_TIMER"))) {
+    // persistent kernel (attention_pk_kernel): per wave index, averaged over the workgroups, shader cycles of the LAST launch
+    const int nwg = std::min(B * H, 256);
+    std::vector<long long> ph((size_t)nwg * 6 * 4);
+    if (!dbgf(ph.data(), nwg * 6 * 4)) {
+      for (int w = 0; w < 6; ++w) {
+        double s4[4] = {0, 0, 0, 0};
+        for (int g = 0; g < nwg; ++g) for (int j = 0; j < 4; ++j) s4[j] += ph[((size_t)g * 6 + w) * 4 + j] / (double)nwg;
+        const double pairs = (double)B * H / nwg;
+        printf("  wave %d, shader cycles per pair: wait + barrier %.0f | DMA issue %.0f | S %.0f | exp + PV + out %.0f | sum %.0f\n", w,
+               s4[0] / pairs, s4[1] / pairs, s4[2] / pairs, s4[3] / pairs, (s4[0] + s4[1] + s4[2] + s4[3]) / pairs);
+      }
+    }
+  }
   return maxerr < 0.02 ? 0 : 1;
 }
