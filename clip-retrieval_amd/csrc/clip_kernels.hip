@@ -1322,7 +1322,11 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
 #ifdef CLIPX_ABLATE
       if (timer) { asm volatile("" : "+v"(mx)); P_STAMP(2) }
 #endif
+#if !CLIPX_ATTN_SPIPE
       if (nxt < nheads) load_q(nxt, qi);  // this block's Q is dead: the next pair's lands under exp + PV
+#endif
+      // (CLIPX_ATTN_SPIPE: requested in the middle of the exp + P V loop instead -- the start of that loop, with all nine score
+      // blocks, both Q sets and the output accumulators live, is the kernel's register peak)
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       if (mx == -INFINITY) mx = 0.f;
       const float nmx = -mx * scale_log2e;
@@ -1338,15 +1342,18 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
 #if CLIPX_ATTN_SPIPE
       // exp + P V, software-pipelined by hand (round 4): hipcc's schedule of the plain loop below puts the two transposing reads
       // of a V^T fragment right in front of the MFMA that takes it (`ds_read_b64_tr_b16 x2; s_waitcnt lgkmcnt(0); v_mfma`, four
-      // times per key block) and all of a block's exponentials in front of its MFMAs.  Here iteration kb computes P of block kb
-      // (two halves of eight values) while the matrix pipe multiplies block kb - 1: MFMAs 0, 1 | read the V^T fragments of MFMAs
-      // 2, 3 | first half of P | MFMAs 2, 3 | read the fragments of the next block's MFMAs 0, 1 | second half of P -- every read
-      // has half an iteration (~150 cycles of VALU) to land, two fragment sets and one P set are live (a full block ahead spilled).
+      // times per key block) and all of a block's exponentials in front of its MFMAs.  Here iteration kb computes P of block kb in
+      // four chunks of four values and issues ONE MFMA of block kb - 1 behind each chunk (an in-order wave that issues two MFMAs
+      // back to back sits out the first one's 32 cycles): M0 | P chunk | M1 | read the V^T fragments of M2, M3 | P chunk | M2 |
+      // P chunk | M3 | read the fragments of the next block's M0, M1 | P chunk.  A chunk's new P values go to the registers whose
+      // old values the MFMA just issued was the last to read (M1 frees P columns 0 - 15, M3 columns 16 - 31), the first chunk of a
+      // block to a spare pair: 10 P registers and two fragment sets are live.
       // The sums (r ascending) and each accumulator's MFMAs (kb, then s2 ascending) keep their order: the same bits.
       {
         typedef short s16x8 __attribute__((ext_vector_type(8)));
-        unsigned pw[8];
-        s16x8 vf[2][NB];  // [s2][nb]
+        unsigned pw[8];     // P of the block the MFMAs are taking: columns 4 j .. 4 j + 3 of the lane's 16 in pw[2 j], pw[2 j + 1]
+        unsigned pnew[8];   // P of the block being computed (hipcc keeps only what is live: see above)
+        s16x8 vf[2][NB];    // [s2][nb]
         auto read_v = [&](int kb, int s2) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
@@ -1357,46 +1364,63 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
             vf[s2][nb] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           }
         };
-        auto p_half = [&](int kb, int hf) {  // P values r = 8 hf .. 8 hf + 7 of block kb -> pw[4 hf .. 4 hf + 3]
+        auto p_chunk = [&](int kb, int c, unsigned* dst) {  // P values r = 4 c .. 4 c + 3 of block kb -> dst[2 c], dst[2 c + 1]
           const bool short_tail = kb == NKB - 1 && tail_keys <= 4;
+          // (the two empty asm statements keep the chunk where it is written: pure VALU work has no order against the scheduling
+          // barriers until it depends on something that has -- hipcc merged chunks and issued the MFMAs in pairs without them)
+          float nmx_c = nmx;
+          asm volatile("" : "+v"(nmx_c));
 #pragma unroll
-          for (int r = 8 * hf; r < 8 * hf + 8; r += 2) {
+          for (int r = 4 * c; r < 4 * c + 4; r += 2) {
             if (short_tail && r >= 4) {
-              pw[r >> 1] = 0u;
+              dst[r >> 1] = 0u;
               continue;
             }
-            const f32x2_t e = (f32x2_t){sacc[kb][r], sacc[kb][r + 1]} * (f32x2_t){scale_log2e, scale_log2e} + (f32x2_t){nmx, nmx};
+            const f32x2_t e = (f32x2_t){sacc[kb][r], sacc[kb][r + 1]} * (f32x2_t){scale_log2e, scale_log2e} + (f32x2_t){nmx_c, nmx_c};
             const f32x2_t pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
             sum2 += pp;
-            pw[r >> 1] = attn_pack_p(pp[0], pp[1]);
+            dst[r >> 1] = attn_pack_p(pp[0], pp[1]);
           }
+          asm volatile("" : "+v"(dst[2 * c]), "+v"(dst[2 * c + 1]));
         };
-        auto pv_mfma2 = [&](int s2) {  // the two MFMAs (nb = 0, 1) that take P columns 16 s2 .. + 16 = pw[4 s2 .. + 3]
+        auto pv_mfma = [&](int m) {  // MFMA m = 2 * s2 + nb: P columns 16 s2 .. + 16 = pw[4 s2 .. + 3]
+          const int s2 = m >> 1, nb = m & 1;
           const uint4 w4 = make_uint4(pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]);
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            oacc[nb] = attn_mfma(__builtin_bit_cast(bf16x8, vf[s2][nb]), *reinterpret_cast<const bf16x8*>(&w4), oacc[nb]);
+          oacc[nb] = attn_mfma(__builtin_bit_cast(bf16x8, vf[s2][nb]), *reinterpret_cast<const bf16x8*>(&w4), oacc[nb]);
         };
         read_v(0, 0);
-        p_half(0, 0);
-        p_half(0, 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p_chunk(0, c, pw);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 1; kb < NKB; ++kb) {
-          pv_mfma2(0);  // block kb - 1
+          pv_mfma(0);  // block kb - 1
+          __builtin_amdgcn_sched_barrier(0);
+          p_chunk(kb, 0, pnew);
+          __builtin_amdgcn_sched_barrier(0);
+          pv_mfma(1);
           __builtin_amdgcn_sched_barrier(0);
           read_v(kb - 1, 1);
-          p_half(kb, 0);
+          p_chunk(kb, 1, pnew);
           __builtin_amdgcn_sched_barrier(0);
-          pv_mfma2(1);
+          pv_mfma(2);
+          __builtin_amdgcn_sched_barrier(0);
+          p_chunk(kb, 2, pnew);
+          __builtin_amdgcn_sched_barrier(0);
+          pv_mfma(3);
           __builtin_amdgcn_sched_barrier(0);
           read_v(kb, 0);
-          p_half(kb, 1);
+          p_chunk(kb, 3, pnew);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pw[e] = pnew[e];
+          if (kb == NKB / 2 && nxt < nheads) load_q(nxt, qi);  // this block's Q is long dead: the next pair's lands under the rest
           __builtin_amdgcn_sched_barrier(0);
         }
-        pv_mfma2(0);
+        pv_mfma(0);
+        pv_mfma(1);
         read_v(NKB - 1, 1);
-        pv_mfma2(1);
+        pv_mfma(2);
+        pv_mfma(3);
       }
 #else
 #pragma unroll
