@@ -1100,14 +1100,32 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 #ifndef CLIPX_ATTN_ROLES
 #define CLIPX_ATTN_ROLES 1
 #endif
-template <int NKB>
-__global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T, int H,
-                                                            int nheads, float scale_log2e, int q_blocks) {
-  constexpr int DH = 64, KS = 4, NW = 6, NDW = CLIPX_ATTN_ROLES ? 2 : 3, QPW = (NKB + NW - 1) / NW, TP = NKB * 32, KROW = 128, NB = 2;
+// NWT = 8 (round 4; T = 32 (NKB - 1) + 1 only, ViT-L/14's 257 = 8 x 32 + 1): EIGHT waves, two on every SIMD, one full query block
+// each -- the 6-wave dealing leaves one SIMD with three blocks (4g) -- and the single query of the ragged last block, which costs a
+// wave a whole block pass above, split along the KEYS: wave w attends it to key block w (wave 0 also to the one-key block 8), leaves
+// (max, sum, 64 partial outputs) in a small LDS table, and wave 0 merges the nine partials (rescaled by 2^((m_j - m) c)) behind the
+// next pair's barrier.  All eight waves issue DMAs (9 of the pair's 72 pieces each).  The 256 full-block rows are computed exactly as
+// by the 6-wave kernel (same bits); the last token's row sums its softmax in nine pieces (f32) and may differ in the last bit before
+// the bf16 rounding.  MEASURED AND NOT USED: 188 us against 162 for six waves on the same box (profiles/r04x_attention_8wave.log;
+// round 3's version of the idea, before the phases were pipelined: 190 against 186) -- a SIMD's VALU is what two waves share, the six-
+// wave dealing already keeps it ~85 % busy on the SIMDs that hold two, and this form adds the tail's and eight DMA issuers' VALU work.
+// Instantiated in the tools build only (CLIPX_ATTN_CFG=13).
+template <int NKB, int NWT = 6>
+__global__ __launch_bounds__(NWT * 64, 1) void attention_pk_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int T, int H,
+                                                                  int nheads, float scale_log2e, int q_blocks) {
+  constexpr bool EIGHT = NWT == 8;
+  constexpr int DH = 64, KS = 4, NW = NWT, NDW = EIGHT ? 8 : (CLIPX_ATTN_ROLES ? 2 : 3), QPW = (NKB + NW - 1) / NW, TP = NKB * 32,
+                KROW = 128, NB = 2;
+  static_assert(NWT == 6 || NWT == 8, "6 waves (any T of NKB blocks) or 8 (T = 32 (NKB - 1) + 1)");
   static_assert(!CLIPX_ATTN_ROLES || NKB == 9, "the role table below is the one of 9 query blocks");
+  static_assert(!EIGHT || (NKB == NW + 1 && QPW == 2), "eight full query blocks + the one-query block");
   constexpr int KBYTES = TP * KROW, VHALF = TP * 64, BUF = KBYTES + 2 * VHALF;
   constexpr int KDMA = TP * 8 / 64 / NDW, VDMA = 2 * TP * 4 / 64 / NDW;
-  static_assert(TP * 8 % (64 * NDW) == 0, "the DMA pieces must divide evenly among the issuing waves");
+  static_assert(EIGHT || TP * 8 % (64 * NDW) == 0, "the DMA pieces must divide evenly among the issuing waves");
+  constexpr int NPIECE = BUF / 1024, PPW = NPIECE / 8, KPIECE = KBYTES / 1024;  // EIGHT: 72 DMA pieces of 1 KiB per pair, 9 per wave
+  static_assert(!EIGHT || NPIECE % 8 == 0, "the DMA pieces must divide evenly among the eight waves");
+  constexpr int MRG = 68;  // EIGHT: floats per partial of the last query: max, sum, 64 outputs (+ pad); two tables (pair parity)
+  const bool tail_on = EIGHT && q_blocks >= NKB;  // (the pooled last block asks for query block 0 only)
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1133,6 +1151,7 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
   // alone), 2 blocks on wave 2's and 1 block + a DMA share on wave 3's (idle half of the pair).  New dealing: the lone waves take
   // two blocks each (2: 2, 7; 3: 3, 8), wave 0 two (0, 6) beside wave 4's one, and waves 1 and 5 one block each plus all the DMAs.
   auto blk_of = [&](int qi) -> int {  // query block qi of this wave (-1: none)
+    if (EIGHT) return qi == 0 ? w : -1;
 #if CLIPX_ATTN_ROLES
     if (qi == 0) return w;
     return w == 0 ? 6 : (w == 2 ? 7 : (w == 3 ? 8 : -1));
@@ -1141,12 +1160,13 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
 #endif
   };
 #if CLIPX_ATTN_ROLES
-  const bool dma_wave = w == 1 || w == 5;
-  const int dma_idx = w == 1 ? 0 : 1;
+  const bool dma_wave = EIGHT || w == 1 || w == 5;
+  const int dma_idx = EIGHT ? w : (w == 1 ? 0 : 1);
 #else
-  const bool dma_wave = w >= NW - NDW;
-  const int dma_idx = w - (NW - NDW);
+  const bool dma_wave = EIGHT || w >= NW - NDW;
+  const int dma_idx = EIGHT ? w : w - (NW - NDW);
 #endif
+  float* mrg = reinterpret_cast<float*>(smem + 2 * BUF);  // EIGHT: [2][NKB][MRG]
 
   // ---- DMA of one pair into LDS half `buf`, by waves NW - NDW .. NW - 1.  Per-lane source offsets (bytes from the pair's q
   // base) are recomputed per piece -- a handful of VALU on waves that have the time.  The lane id goes through an opaque asm per
@@ -1158,6 +1178,28 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
     const char* base = reinterpret_cast<const char*>(qkv + (size_t)b * T * ld + h * DH);
     int lane_v = lane;
     asm volatile("" : "+v"(lane_v));
+    if constexpr (EIGHT) {
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        const int piece = ww * PPW + j;  // wave-uniform: pieces 0 .. KPIECE - 1 are the K image, the rest the two V images
+        unsigned off;
+        if (piece < KPIECE) {
+          const int c = piece * 64 + lane_v;
+          const int key = c >> 3, pos = c & 7;
+          const int kk = key < T ? key : T - 1;
+          off = (unsigned)((kk * ld + H * DH + ((pos ^ ((key >> 1) & 7)) << 3)) * 2);
+        } else {
+          const int c = (piece - KPIECE) * 64 + lane_v;
+          const int nbh = c / (TP * 4), rem = c - nbh * (TP * 4);
+          const int key = rem >> 2, pos = rem & 3;
+          const int kk = key < T ? key : T - 1;
+          off = (unsigned)((kk * ld + 2 * H * DH + 32 * nbh + 8 * pos) * 2);
+        }
+        const unsigned m0 = lds_base + buf * BUF + piece * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(m0) : "memory");
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < KDMA; ++j) {
       const int c = (ww * KDMA + j) * 64 + lane_v;  // 16-B chunk of the K image, lane-linear
@@ -1199,11 +1241,45 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
     }
   };
 
+  bf16x8 qt[KS];  // EIGHT: the last token's row as a B fragment (the same query in every column)
+  auto load_qt = [&](int hd) {
+    const int b = hd / H, h = hd - b * H;
+    const bf16* qbase = qkv + (size_t)b * T * ld + h * DH;
+    int lane_q = lane;
+    asm volatile("" : "+v"(lane_q));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint4 v = *reinterpret_cast<const uint4*>(qbase + (size_t)(T - 1) * ld + 16 * s + 8 * (lane_q >> 5));
+      qt[s] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  };
+  // EIGHT: merge of the nine partials of pair `phd`'s last query (table `par`), by wave 0: lane = d
+  auto merge_tail = [&](int phd, int par) {
+    const float* mt = mrg + par * (NKB * MRG);
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) m = fmaxf(m, mt[j * MRG]);
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) {
+      const float wj = __builtin_amdgcn_exp2f((mt[j * MRG] - m) * scale_log2e);
+      l += wj * mt[j * MRG + 1];
+      o += wj * mt[j * MRG + 2 + lane];
+    }
+    const int pb = phd / H, ph = phd - pb * H;
+    out[((size_t)pb * T + (T - 1)) * (H * DH) + ph * DH + lane] = (bf16)(l > 0.f ? o / l : 0.f);
+  };
+
   int hd = blockIdx.x;
   if (hd >= nheads) return;
   issue(hd, 0);
 #pragma unroll
   for (int qi = 0; qi < QPW; ++qi) load_q(hd, qi);
+  if (tail_on) {
+    load_qt(hd);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qt[s]));
+  }
   // Where this kernel waits for its own VMEM operations (round 4).  vmcnt counts loads, stores and LDS-DMAs in issue order, and
   // hipcc, which cannot count across the loop's back edge, writes `s_waitcnt vmcnt(0)` in front of the first MFMA that reads Q
   // fragments loaded one pair earlier: that also waited for the eight output stores the wave had issued a moment before (block
@@ -1230,6 +1306,8 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
     const int nxt = hd + gridDim.x;
     if (nxt < nheads) issue(nxt, buf ^ 1);
     P_STAMP(1)
+    // EIGHT: the previous pair's partials are complete (the barrier above); this pair's go to the other table
+    if (tail_on && w == 0 && hd != (int)blockIdx.x) merge_tail(hd - (int)gridDim.x, buf ^ 1);
     const unsigned char* sK = smem + buf * BUF;
     const unsigned char* sV = sK + KBYTES;
     const int b = hd / H, h = hd - b * H;
@@ -1464,6 +1542,10 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
       const float inv = sum > 0.f ? 1.f / sum : 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qn[qi][s]));  // the next pair's Q has landed (see the prologue)
+      if (tail_on) {  // ... and the last token's (requested in the previous pair's tail section)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qt[s]));
+      }
       // ... and, on a DMA wave, the next pair's K / V (requested a whole block ago): nothing of this wave is in flight when its
       // stores go out, so the top of the next pair has nothing to wait for but the barrier
       if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1484,6 +1566,93 @@ __global__ __launch_bounds__(384, 1) void attention_pk_kernel(const bf16* __rest
       }
       P_STAMP(3)
     }
+    if (tail_on) {
+      // ---- the last token's row against key block w (wave 0: also the one-key block NKB - 1): S, softmax pieces, P V of ONE
+      // 32-key block; every column of the tile is that one query, lanes 0 and 32 hold the column that is kept
+      bf16x8 qtl[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) qtl[s] = qt[s];
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        if (rep == 1 && w != 0) break;
+        const int kb = rep == 0 ? w : NKB - 1;
+        f32x16 sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sb[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int c = 2 * s + hb;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + l31) * KROW + ((c ^ ksw) << 4));
+          sb = attn_mfma(kf, qtl[s], sb);
+        }
+        if (rep == 0 && nxt < nheads && w != 0) load_qt(nxt);  // (wave 0: behind its second block)
+        if (rep == 1 && nxt < nheads) load_qt(nxt);
+        if (kb == NKB - 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb;
+            sb[r] = key < T ? sb[r] : -INFINITY;
+          }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sb[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float nmx = -mx * scale_log2e;
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t sum2 = {0.f, 0.f};
+        unsigned pw[8];
+        const bool first_quad_only = kb == NKB - 1 && T - (NKB - 1) * 32 <= 4;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          if (first_quad_only && r >= 4) {
+            pw[r >> 1] = 0u;
+            continue;
+          }
+          const f32x2_t e = (f32x2_t){sb[r], sb[r + 1]} * (f32x2_t){scale_log2e, scale_log2e} + (f32x2_t){nmx, nmx};
+          const f32x2_t pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          sum2 += pp;
+          pw[r >> 1] = attn_pack_p(pp[0], pp[1]);
+        }
+        f32x16 oacc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint4 w4 = make_uint4(pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const unsigned char* vp = sV + nb * VHALF + (kb * 32 + 16 * s2 + 4 * hb) * 64 + vlane;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vp));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vp + 8 * 64));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            oacc[nb] = attn_mfma(__builtin_bit_cast(bf16x8, vv), *reinterpret_cast<const bf16x8*>(&w4), oacc[nb]);
+          }
+        }
+        float sum = sum2[0] + sum2[1];
+        sum += __shfl_xor(sum, 32);
+        if (l31 == 0) {  // lanes 0 and 32: the d = 32 nb + 8 g + 4 hb + {0..3} of column 0
+          float* m = mrg + buf * (NKB * MRG) + kb * MRG;
+          if (hb == 0) {
+            m[0] = mx;
+            m[1] = sum;
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) m[2 + 32 * nb + 8 * g + 4 * hb + e] = oacc[nb][4 * g + e];
+        }
+      }
+    }
+  }
+  if (tail_on) {  // the last pair's partials (buf has flipped once more since they were written)
+    __syncthreads();
+    if (w == 0) merge_tail(hd - (int)gridDim.x, buf ^ 1);
   }
 #ifdef CLIPX_ABLATE
   if (timer && lane == 0 && blockIdx.x * NW + w < 8192) {
@@ -1507,10 +1676,24 @@ static int attn_cu_count() {
 static hipError_t launch_attention_pk9(const bf16* qkv, bf16* out, int B, int T, int H, hipStream_t st, int q_blocks) {
   constexpr int NKB = 9, TP = NKB * 32;
   const size_t smem = (size_t)2 * (TP * 128 + 2 * TP * 64);
+  const int nheads = B * H, grid = std::min(nheads, attn_cu_count());
+#ifdef CLIPX_ABLATE
+  // tools build, CLIPX_ATTN_CFG=13: the 8-wave form (NWT = 8 above) -- measured 188 us against 162 for the 6-wave kernel
+  // (profiles/r04x_attention_8wave.log), so the product does not instantiate it
+  static const int cfg8 = getenv("CLIPX_ATTN_CFG") ? atoi(getenv("CLIPX_ATTN_CFG")) : 0;
+  if (cfg8 == 13 && T == (NKB - 1) * 32 + 1) {
+    const size_t smem8 = smem + (size_t)2 * NKB * 68 * sizeof(float);
+    auto k8 = attention_pk_kernel<NKB, 8>;
+    hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8);
+    if (e8 != hipSuccess) return e8;
+    hipLaunchKernelGGL(k8, dim3(grid), dim3(512), smem8, st, qkv, out, T, H, nheads, (1.f / 8.f) * 1.4426950408889634f,
+                       q_blocks > 0 && q_blocks < NKB ? q_blocks : NKB);
+    return hipGetLastError();
+  }
+#endif
   auto kern = attention_pk_kernel<NKB>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  const int nheads = B * H, grid = std::min(nheads, attn_cu_count());
 #ifdef CLIPX_ABLATE
   // tools build only: CLIPX_ATTN_QBLOCKS=n computes the first n query blocks of every pair (6: one block on every wave, 3: one
   // block on waves 0 - 2) -- how the time of a pair depends on the blocks per wave (profiles/r04r_attention_qblocks.log)
