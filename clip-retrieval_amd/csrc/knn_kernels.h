@@ -126,4 +126,16 @@ hipError_t launch_rq_proof(const float* q, int nq, int d, int k, const float* D,
                            unsigned cap, const unsigned* lost, const int* maxnorm, unsigned* need, unsigned* gate,
                            unsigned long long* stats, hipStream_t st);
 
+// ---- int8 first stage of the flat scans (knn_rq_kernels.hip, "int8 first stage"): exact results from half the bytes
+constexpr int KNN_I8_STRIDE = 32;          // the sample pass visits every S-th tile, S = min(this, tiles / 4096): threshold ~ rank (k + 8) S
+constexpr unsigned KNN_I8_CAP = KNN_RQ_CAP;  // hit list entries per query (knn_merge_kernel holds a query's whole list in LDS: 32 768 x 4 B)
+int i8_supported(int d);
+hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
+hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
+                          int kw, int J, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st);
+hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
+                           float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st);
+hipError_t launch_i8_proof(int nq, int k, const float* D, const float* thr_lb, const unsigned* cnt, unsigned cap, const unsigned* lost,
+                           unsigned* need, unsigned* gate, unsigned long long* stats, hipStream_t st);
+
 }  // namespace knnx

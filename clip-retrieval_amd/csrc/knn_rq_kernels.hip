@@ -414,6 +414,446 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
   }
 }
 
+// =============================================================================================
+// int8 first stage (round 4).  The flat index keeps, next to its fp16 rows, an int8 copy x8 = rint(x / c) with one scale per
+// COLUMN (c_j = max_i |x_ij| / 127), and the scan of a query batch reads THAT: half the bytes of a pass over HBM, and
+// v_mfma_i32_16x16x64_i8 at twice the fp16 rate.  Its scores are approximations with a PROVEN error bound, used only to decide
+// which rows are re-scored exactly from the fp16 rows (knn_rq_rescore_kernel) -- the result is the exact top-k, as before:
+//   u = q * c (per column), u8 = rint(u / s_u), s_u = max |u| / 127;   approx(q, i) = s_u * sum_j u8_j x8_ij   (int32, exact)
+//   exact - approx = sum_j u_j (y_ij - x8_ij) + sum_j (u_j - s_u u8_j) x8_ij,   y = x / c
+//   |exact - approx| <= |u| * A + |u - s_u u8| * B =: eps8(q),   A = max_i |y_i - x8_i|, B = max_i |x8_i|   (2-norms; A, B are
+//   maxima over the rows actually stored, computed by the quantisation kernel)
+// Threshold: T(q) = (J-th best score of the exact sample pass, J >= k) - eps_hi(q): at least J rows have exact score >= T, so
+// the top-k all have, and every row with exact >= T has approx >= T - eps8, i.e. int32 sum >= (T - eps8) / s_u: ONE integer
+// compare per score in the scan.  Rows that pass go to the per-query hit lists; if a list overflows the query falls back to
+// the exact scan (as in the fp16 register-stationary path, whose sample pass, hit lists, re-scoring and merge this path shares).
+// How many rows pass depends on the data: for unit vectors with components of similar size (the bench's synthetic index)
+// eps8 ~ 0.02 |q|, ~0.5 sigma of the score distribution -- a few times 10^4 hits per query at 10^8 rows; embeddings with a few
+// dominant columns quantise the QUERY coarsely (one scale for all of u) and pass more rows, up to the fallback.
+// Geometry: an int8 row of d bytes is an fp16 row of d / 2 columns to the tile / DMA helpers above: KS = d / 32 pieces of
+// (16 rows x 64 bytes) per 32-row tile, lane (r = l & 15, q4 = l >> 4) holds bytes 16 q4 .. + 16 of the piece's 64.
+// =============================================================================================
+#if KNNX_MFMA16
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+
+// column maxima: colmax_enc[j] = max_i |x_ij| as the bits of a non-negative float (integer order = float order)
+__global__ __launch_bounds__(256) void knn_i8_colmax_kernel(const _Float16* __restrict__ X, int64_t N, int d, int* __restrict__ colmax_enc) {
+  // a block walks rows blockIdx.x, + gridDim.x, ...; thread t owns columns t, t + 256, ... (<= 4 at d <= 1024)
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = blockIdx.x; r < N; r += gridDim.x) {
+    const _Float16* row = X + (size_t)r * d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = e * 256 + threadIdx.x;
+      if (c < d) m[e] = fmaxf(m[e], fabsf((float)row[c]));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = e * 256 + threadIdx.x;
+    if (c < d) atomicMax(&colmax_enc[c], __float_as_int(m[e]));
+  }
+}
+__global__ void knn_i8_colscale_kernel(const int* __restrict__ colmax_enc, int d, float* __restrict__ colscale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < d) {
+    const float m = __int_as_float(colmax_enc[c]);
+    colscale[c] = m > 0.f ? m / 127.f : 1.f;
+  }
+}
+// one wave per row: x8 = clamp(rint(x / c)), and the maxima A = max |y - x8|, B = max |x8| (2-norms per row) into ab_enc[0..1]
+__global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __restrict__ X, int64_t N, int d, const float* __restrict__ colscale,
+                                                          int8_t* __restrict__ X8, int* __restrict__ ab_enc) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= N) return;
+  float ea = 0.f, eb = 0.f;
+  for (int c0 = 0; c0 < d; c0 += 256) {  // 4 consecutive columns per lane: one 8-byte load, one 4-byte store
+    const int c = c0 + 4 * lane;
+    if (c < d) {
+      const uint2 raw = *reinterpret_cast<const uint2*>(X + (size_t)r * d + c);
+      const _Float16* h = reinterpret_cast<const _Float16*>(&raw);
+      const float4 cs = *reinterpret_cast<const float4*>(colscale + c);
+      const float sc[4] = {cs.x, cs.y, cs.z, cs.w};
+      unsigned packed = 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = (float)h[e] / sc[e];
+        float v = rintf(y);
+        v = fminf(fmaxf(v, -127.f), 127.f);
+        ea += (y - v) * (y - v);
+        eb += v * v;
+        packed |= ((unsigned)(int)v & 0xffu) << (8 * e);
+      }
+      *reinterpret_cast<unsigned*>(X8 + (size_t)r * d + c) = packed;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ea += __shfl_xor(ea, o);
+    eb += __shfl_xor(eb, o);
+  }
+  if (lane == 0) {
+    atomicMax(&ab_enc[0], __float_as_int(sqrtf(ea)));
+    atomicMax(&ab_enc[1], __float_as_int(sqrtf(eb)));
+  }
+}
+
+// queries: one wave per query slot (grid = queries per pass).  Writes the int8 B fragments (qfrag8 [nblk16][d / 64][64 lanes][16 B]:
+// lane (n = l & 15, q4 = l >> 4) holds u8_n[64 s + 16 q4 .. + 16]), the integer admission threshold thr_i and the exact-score
+// lower bound thr_lb (= T) of the proof; resets the hit counters.  Unused slots: zero fragments, thr_i = INT_MAX.
+__global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict__ q, int nq, int d, const float* __restrict__ colscale,
+                                                        const int* __restrict__ ab_enc, const int* __restrict__ maxnorm,
+                                                        const float* __restrict__ samp, int kw, int J, int8_t* __restrict__ qfrag8,
+                                                        int* __restrict__ thr_i, float* __restrict__ thr_lb,
+                                                        unsigned* __restrict__ cnt, unsigned* __restrict__ lost) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int nsl = d / 64;
+  int8_t* dst = qfrag8 + ((size_t)(n >> 4) * nsl * 64 + (n & 15)) * 16;  // + (s * 64 + q4 * 16) * 16 + byte
+  float u[16];  // columns lane + 64 e
+  float mu = 0.f, e2 = 0.f, n2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int c = lane + 64 * e;
+    u[e] = 0.f;
+    if (c < d && n < nq) {
+      const float v = q[(size_t)n * d + c];
+      const float rr = v - (float)(_Float16)v;
+      e2 += rr * rr;
+      n2 += v * v;
+      u[e] = v * colscale[c];
+      mu = fmaxf(mu, fabsf(u[e]));
+    }
+  }
+  float nu2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) nu2 += u[e] * u[e];
+  for (int o = 32; o > 0; o >>= 1) {
+    mu = fmaxf(mu, __shfl_xor(mu, o));
+    e2 += __shfl_xor(e2, o);
+    n2 += __shfl_xor(n2, o);
+    nu2 += __shfl_xor(nu2, o);
+  }
+  const float su = mu > 0.f ? mu / 127.f : 1.f;
+  float er2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int c = lane + 64 * e;
+    if (c < d) {
+      float v = rintf(u[e] / su);
+      v = fminf(fmaxf(v, -127.f), 127.f);
+      er2 += (u[e] - su * v) * (u[e] - su * v);
+      // column c = 64 s + 16 q4 + byte
+      dst[(size_t)((c >> 6) * 64 + ((c >> 4) & 3) * 16) * 16 + (c & 15)] = (int8_t)(int)v;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) er2 += __shfl_xor(er2, o);
+  if (lane == 0) {
+    int ti = 0x7fffffff;
+    float lb = INFINITY;
+    if (n < nq) {
+      const float v = samp[(size_t)n * kw + (J - 1)];
+      if (v > -FLT_MAX) {
+        // eps_hi: the sample scores are fp16-hi approximations of the exact scores (cf. knn_rq_proof_kernel)
+        const float eps_hi = (sqrtf(e2) + (float)d * 1.2e-7f * sqrtf(n2)) * rq_dec_f(*maxnorm);
+        lb = v - eps_hi;
+        const float A = __int_as_float(ab_enc[0]), B = __int_as_float(ab_enc[1]);
+        const float eps8 = (sqrtf(nu2) * A + sqrtf(er2) * B) * 1.00002f + 1e-6f * fabsf(lb);
+        const float t = (lb - eps8) / su;
+        // floor - 1: the float division / subtraction above may round up by an ulp
+        ti = t <= -2.0e9f ? (int)0x80000000 : (t >= 2.0e9f ? 0x7fffffff : (int)floorf(t) - 1);
+      } else {
+        lb = -INFINITY;  // fewer than J sample rows: every row is a hit (indexes far too small for this path)
+        ti = (int)0x80000000;
+      }
+    }
+    thr_i[n] = ti;
+    thr_lb[n] = lb;
+    cnt[n] = 0u;
+    lost[n] = 0u;
+  }
+}
+
+// DMA of the int8 tiles: wave w fetches pieces w, w + NW, w + 2 NW, ... (piece p = 2 * slab + half: the wave's pieces all have half
+// w & 1 and slabs (w >> 1) + (NW / 2) IDX) -- the consecutive-pieces dealing of the fp16 kernel needs an even piece count per wave,
+// and d = 768 has 24 pieces for 8 waves.
+struct Rq8Tile {
+  const char* base;  // tile + this wave's first slab
+  unsigned m0b;      // LDS address of the slot + this wave's first piece
+  unsigned vo;       // per-lane byte offset (row of the wave's half, 16-byte column group)
+};
+template <int KS, int NW>
+__device__ __forceinline__ Rq8Tile rq8_tile(const int8_t* __restrict__ X8, int64_t t, int64_t ntile, int64_t last, const RqLaneOff& lo,
+                                            unsigned lds_base, int slot, int w) {
+  constexpr int TILE_BYTES = KS * 1024;
+  const int64_t tt = t < ntile ? t : last;
+  Rq8Tile r;
+  const int li = tt == last ? 1 : 0;
+  r.vo = (w & 1) ? lo.v1[li] : lo.v[li];
+  r.base = reinterpret_cast<const char*>(X8) + (size_t)tt * TILE_BYTES + (w >> 1) * 64;
+  r.m0b = lds_base + slot * TILE_BYTES + w * 1024;
+  return r;
+}
+#define RQ8_TILE(t_, slot_) rq8_tile<KS, NW>(X8, (t_), ntile, last, lane_off, lds_base, (slot_), w)
+template <int NW, int IDX>
+__device__ __forceinline__ void rq8_issue_one(const Rq8Tile& r) {
+  const char* p = r.base + IDX * (NW / 2) * 64;
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(r.vo), "s"(p), "s"(r.m0b), "n"(IDX * NW * 1024)
+               : "memory", "scc");
+}
+template <int NW, int DPW, int IDX = 0>
+__device__ __forceinline__ void rq8_issue_all(const Rq8Tile& r) {
+  if constexpr (IDX < DPW) {
+    rq8_issue_one<NW, IDX>(r);
+    rq8_issue_all<NW, DPW, IDX + 1>(r);
+  }
+}
+
+template <int KS, int NW, int DPW, int S>
+__device__ __forceinline__ void rq8_ksteps(unsigned xa, i32x4 (&A)[4], i32x4v (&acc)[2][2], const i32x4 (&Q)[2][KS / 2], const Rq8Tile& refill) {
+  if constexpr (S < KS) {
+    if constexpr (S + 3 < KS) rq_dsread<(S + 3) * 1024>(A[(S + 3) & 3], xa);
+    rq_wait_lgkm<(KS - 1 - S < 3 ? KS - 1 - S : 3)>();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[b][S & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[S & 3], Q[b][S >> 1], acc[b][S & 1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S % (KS / DPW) == 1) {
+      rq8_issue_one<NW, S / (KS / DPW)>(refill);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    rq8_ksteps<KS, NW, DPW, S + 1>(xa, A, acc, Q, refill);
+  }
+}
+
+// KS = d / 32 pieces per 32-row tile; 8 waves x 32 queries (two blocks of 16); the structure of knn_rq_scan_kernel
+template <int KS, int NW, int NSLOT>
+__global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int8_t* __restrict__ X8, int64_t N, const int8_t* __restrict__ qfrag8,
+                                                                      const int* __restrict__ thr_i, unsigned* __restrict__ g_cnt, unsigned cap,
+                                                                      float* __restrict__ hit_s, uint32_t* __restrict__ hit_r,
+                                                                      unsigned* __restrict__ g_lost) {
+  constexpr int D = KS * 16;  // the row as fp16-sized columns (tile / DMA helpers)
+  constexpr int TILE_BYTES = KS * 1024, DPW = KS / NW, NSL = KS / 2;
+  static_assert(KS % NW == 0 && KS % 2 == 0, "pieces must divide evenly among the waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* stage = smem + NSLOT * TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qcol = lane & 15, hb = lane >> 4;
+  float* st_s = reinterpret_cast<float*>(stage + w * RQ_STAGE * 12);
+  uint32_t* st_r = reinterpret_cast<uint32_t*>(st_s + RQ_STAGE);
+  uint32_t* st_q = st_r + RQ_STAGE;
+
+  i32x4 Q[2][NSL];
+  int tq[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int blk = w * 2 + b;
+    const i32x4* src = reinterpret_cast<const i32x4*>(qfrag8) + (size_t)blk * NSL * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) Q[b][s] = src[s * 64];
+    tq[b] = thr_i[blk * 16 + qcol];
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) asm volatile("" : "+v"(Q[b][s]));  // all landed before the DMA ring starts (see knn_rq_scan_kernel)
+    asm volatile("" : "+v"(tq[b]));
+  }
+
+  const int64_t ntile = (N + 31) >> 5;
+  const int64_t last = ntile - 1;
+  const RqLaneOff lane_off = rq_lane_offsets(lane, D, (int)(N - 1 - last * 32));
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+
+  int64_t t = blockIdx.x;
+  const int64_t gstride = gridDim.x;
+#pragma unroll
+  for (int i = 0; i < NSLOT - 1; ++i) rq8_issue_all<NW, DPW>(RQ8_TILE(t + (int64_t)i * gstride, i));
+
+  int nst = 0;
+  int slot = 0;
+  for (; t < ntile; t += gstride) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NSLOT - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const Rq8Tile refill = RQ8_TILE(t + (int64_t)(NSLOT - 1) * gstride, slot == 0 ? NSLOT - 1 : slot - 1);
+    i32x4v acc[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[b][0] = acc[b][1] = i32x4v{0, 0, 0, 0};
+    const unsigned xa = lds_base + slot * TILE_BYTES + lane * 16;
+    i32x4 A[4];
+    rq_dsread<0>(A[0], xa);
+    rq_dsread<1024>(A[1], xa);
+    rq_dsread<2048>(A[2], xa);
+    __builtin_amdgcn_sched_barrier(0);
+    rq8_ksteps<KS, NW, DPW, 0>(xa, A, acc, Q, refill);
+
+    // ---- filter: lane (qcol, hb) owns rows row0 + 16 half + e of its query column in each block; integer compares
+    const int64_t row0 = t * 32 + 4 * hb;
+    bool any = false;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      int m = acc[b][0][0];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) m = max(m, acc[b][r >> 2][r & 3]);
+      any |= m >= tq[b];
+    }
+    if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+      bool vmem = false;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int64_t row = row0 + 16 * (r >> 2) + (r & 3);
+          const bool hit = acc[b][r >> 2][r & 3] >= tq[b] && row < N;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+          if (m != 0ull) {
+            const int pos = nst + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned qq = (unsigned)((w * 2 + b) * 16 + qcol);
+            if (hit) {
+              if (pos < RQ_STAGE) {
+                st_s[pos] = (float)acc[b][r >> 2][r & 3];  // (overwritten by the exact score: knn_rq_rescore_kernel)
+                st_r[pos] = (uint32_t)row;
+                st_q[pos] = qq;
+              } else {
+                g_lost[qq] = 1u;
+                vmem = true;
+              }
+            }
+            nst += __builtin_popcountll(m);
+          }
+        }
+      }
+      if (nst > RQ_STAGE) nst = RQ_STAGE;
+      if (nst >= RQ_FLUSH_AT) {
+        vmem = true;
+        for (int i = lane; i < nst; i += 64) {
+          const unsigned qq = st_q[i];
+          const unsigned pos = atomicAdd(&g_cnt[qq], 1u);
+          if (pos < cap) {
+            hit_s[(size_t)qq * cap + pos] = st_s[i];
+            hit_r[(size_t)qq * cap + pos] = st_r[i];
+          }
+        }
+        nst = 0;
+      }
+      if (__builtin_amdgcn_ballot_w64(vmem) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int i = lane; i < nst; i += 64) {
+    const unsigned qq = st_q[i];
+    const unsigned pos = atomicAdd(&g_cnt[qq], 1u);
+    if (pos < cap) {
+      hit_s[(size_t)qq * cap + pos] = st_s[i];
+      hit_r[(size_t)qq * cap + pos] = st_r[i];
+    }
+  }
+}
+
+// proof of the int8 path: the hit list is complete and its k-th exact score reaches the lower bound T -- then every row of the true
+// top-k was a hit (header above).  need / gate / stats as knn_rq_proof_kernel.
+__global__ __launch_bounds__(256) void knn_i8_proof_kernel(int nq, int k, const float* __restrict__ D, const float* __restrict__ thr_lb,
+                                                          const unsigned* __restrict__ cnt, unsigned cap, const unsigned* __restrict__ lost,
+                                                          unsigned* __restrict__ need, unsigned* __restrict__ gate,
+                                                          unsigned long long* __restrict__ stats) {
+  __shared__ unsigned s_need[256];
+  const int qq = threadIdx.x;
+  unsigned nd = 0u;
+  if (qq < nq) {
+    const bool complete = cnt[qq] <= cap && lost[qq] == 0u;
+    const float dk = D[(size_t)qq * k + (k - 1)];
+    const float t = thr_lb[qq];
+    const bool proven = complete && (!(t > -INFINITY) || (dk > -FLT_MAX && dk >= t));
+    nd = proven ? 0u : 1u;
+    need[qq] = nd;
+  }
+  s_need[threadIdx.x] = nd;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    unsigned g = 0u;
+    for (int i = 0; i < 32; ++i) g += s_need[threadIdx.x * 32 + i];
+    gate[threadIdx.x] = g ? 1u : 0u;
+    if (stats && g) atomicAdd(&stats[1], (unsigned long long)g);
+  }
+  if (threadIdx.x == 0 && stats) atomicAdd(&stats[0], (unsigned long long)nq);
+}
+#endif  // KNNX_MFMA16
+
+int i8_supported(int d) { return KNNX_MFMA16 && (d == 512 || d == 768 || d == 1024) ? 1 : 0; }
+
+hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st) {
+#if KNNX_MFMA16
+  hipError_t e = hipMemsetAsync(colmax_enc, 0, (size_t)d * sizeof(int), st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(ab_enc, 0, 2 * sizeof(int), st);
+  if (e != hipSuccess) return e;
+  if (N <= 0) return hipSuccess;
+  const unsigned g1 = (unsigned)std::min<int64_t>(N, 256 * 32);
+  hipLaunchKernelGGL(knn_i8_colmax_kernel, dim3(g1), dim3(256), 0, st, X, N, d, colmax_enc);
+  hipLaunchKernelGGL(knn_i8_colscale_kernel, dim3((d + 255) / 256), dim3(256), 0, st, colmax_enc, d, colscale);
+  // (a launch's grid x block must stay below 2^32 work-items: 100 M rows in one launch silently ran the first 32.9 M only)
+  const int64_t chunk = (int64_t)1 << 23;
+  for (int64_t o = 0; o < N; o += chunk) {
+    const int64_t m = std::min(chunk, N - o);
+    hipLaunchKernelGGL(knn_i8_quant_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, X + (size_t)o * d, m, d, colscale,
+                       X8 + (size_t)o * d, ab_enc);
+  }
+  return hipGetLastError();
+#else
+  return hipErrorInvalidValue;
+#endif
+}
+
+hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
+                          int kw, int J, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st) {
+#if KNNX_MFMA16
+  hipLaunchKernelGGL(knn_i8_prep_kernel, dim3(256), dim3(64), 0, st, q_dev, nq, d, colscale, ab_enc, maxnorm, samp, kw, J, qfrag8, thr_i,
+                     thr_lb, cnt, lost);
+  return hipGetLastError();
+#else
+  return hipErrorInvalidValue;
+#endif
+}
+
+#if KNNX_MFMA16
+template <int KS, int NW, int NSLOT>
+static hipError_t launch_rq8_scan_cfg(const int8_t* X8, int64_t N, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
+                                      float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st) {
+  const size_t smem = (size_t)NSLOT * KS * 1024 + (size_t)NW * RQ_STAGE * 12;
+  auto kern = knn_rq8_scan_kernel<KS, NW, NSLOT>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost);
+  return hipGetLastError();
+}
+#endif
+
+hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
+                           float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st) {
+#if KNNX_MFMA16
+  switch (d) {
+    case 512: return launch_rq8_scan_cfg<16, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+    case 768: return launch_rq8_scan_cfg<24, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+    case 1024: return launch_rq8_scan_cfg<32, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+    default: return hipErrorInvalidValue;
+  }
+#else
+  return hipErrorInvalidValue;
+#endif
+}
+
+hipError_t launch_i8_proof(int nq, int k, const float* D, const float* thr_lb, const unsigned* cnt, unsigned cap, const unsigned* lost,
+                           unsigned* need, unsigned* gate, unsigned long long* stats, hipStream_t st) {
+#if KNNX_MFMA16
+  hipLaunchKernelGGL(knn_i8_proof_kernel, dim3(1), dim3(256), 0, st, nq, k, D, thr_lb, cnt, cap, lost, need, gate, stats);
+  return hipGetLastError();
+#else
+  return hipErrorInvalidValue;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // IVF build: list assignment = argmax over the centroids, for MANY points per launch (takes the place of
 // the autofaiss k-means / add of clip_index.py:12-66 for this index type).  The same register-stationary structure as the

@@ -102,6 +102,20 @@ struct knnx_index {
   std::vector<uint32_t> ivfb_size, ivfb_fill, ivfb_tile0;
   std::vector<uint64_t> ivfb_taken;  // one bit per padded arena row
 
+  // int8 first stage of the flat scans (knn_rq_kernels.hip): allocated and built on first use, rebuilt after the rows change
+  int i8_ok = 1;                  // KNNX_I8=0 disables; cleared for good when its memory cannot be had
+  bool i8_valid = false;          // rows8 / colscale / ab describe the current rows
+  int64_t i8_cap_rows = 0;
+  int8_t* i8_rows = nullptr;      // [ntotal, d]
+  float* i8_colscale = nullptr;   // [d]
+  int *i8_colmax = nullptr, *i8_ab = nullptr;  // [d] (encoded), [2] (encoded A, B)
+  int8_t* i8_qfrag = nullptr;     // [16 blocks][d / 64][64][16]
+  int* i8_thr = nullptr;          // [256]
+  float* i8_lb = nullptr;         // [256]
+  float* i8_hit_s = nullptr;      // [256, KNN_I8_CAP]
+  uint32_t* i8_hit_r = nullptr;
+  unsigned long long i8_served = 0;  // queries answered through the int8 path (knnx_i8_active reports it)
+
   // wide scan (64 queries per pass): candidates, fallback results, proof flags; largest row norm (order-encoded)
   int wide_ok = 1;             // KNNX_WIDE=0 disables
   int* maxnorm = nullptr;
@@ -214,6 +228,10 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
   ix->wide_ok = (wd && wd[0] == '0') ? 0 : 1;
   const char* rq = getenv("KNNX_RQ");
   ix->rq_ok = (rq && rq[0] == '0') ? 0 : 1;
+  {
+    const char* i8 = getenv("KNNX_I8");
+    ix->i8_ok = (i8 && i8[0] == '0') ? 0 : 1;
+  }
   const char* rqm = getenv("KNNX_RQ_MIN_ROWS");
   if (rqm && rqm[0]) ix->rq_min_rows = atoll(rqm);
   const char* sg = getenv("KNNX_RQ_SAMPLE_GRID");
@@ -273,6 +291,15 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->wide_Dfb);
   hipFree(ix->wide_Ifb);
   hipFree(ix->stats);
+  hipFree(ix->i8_rows);
+  hipFree(ix->i8_colscale);
+  hipFree(ix->i8_colmax);
+  hipFree(ix->i8_ab);
+  hipFree(ix->i8_qfrag);
+  hipFree(ix->i8_thr);
+  hipFree(ix->i8_lb);
+  hipFree(ix->i8_hit_s);
+  hipFree(ix->i8_hit_r);
   hipFree(ix->rq_qfrag);
   hipFree(ix->rq_thr);
   hipFree(ix->rq_cnt);
@@ -338,6 +365,7 @@ extern "C" int knnx_reset(knnx_index* ix) {
   if (set_dev(ix)) return KNNX_E_HIP;
   HIPCHK(hipStreamSynchronize(ix->stream));
   ix->ntotal = 0;
+  ix->i8_valid = false;
   HIPCHK(hipMemsetAsync(ix->maxnorm, 0, sizeof(int), ix->stream));
   return KNNX_OK;
 }
@@ -353,7 +381,17 @@ static int grow(knnx_index* ix, int64_t need_rows) {
   if (ix->borrowed) return fail(KNNX_E_STATE, "index borrows caller memory; cannot grow");
   if (need_rows > (int64_t)0xffffffffll) return fail(KNNX_E_UNSUPPORTED, "more than 2^32 rows per device");
   _Float16* nr = nullptr;
-  HIPCHK(hipMalloc(&nr, (size_t)need_rows * ix->d * sizeof(_Float16)));
+  if (hipMalloc(&nr, (size_t)need_rows * ix->d * sizeof(_Float16)) != hipSuccess) {
+    (void)hipGetLastError();
+    // the int8 copy is an accelerator, not data: give its memory back and try once more
+    if (ix->i8_rows) {
+      hipFree(ix->i8_rows);
+      ix->i8_rows = nullptr;
+      ix->i8_cap_rows = 0;
+      ix->i8_valid = false;
+    }
+    HIPCHK(hipMalloc(&nr, (size_t)need_rows * ix->d * sizeof(_Float16)));
+  }
   if (ix->rows && ix->ntotal > 0) {
     hipError_t e = hipMemcpyAsync(nr, ix->rows, (size_t)ix->ntotal * ix->d * sizeof(_Float16),
                                   hipMemcpyDeviceToDevice, ix->stream);
@@ -415,6 +453,7 @@ static int add_common(knnx_index* ix, const void* rows, int64_t n, bool is_f32) 
   }
   if (tmp32) hipFree(tmp32);
   ix->ntotal += n;
+  ix->i8_valid = false;
   return KNNX_OK;
 }
 
@@ -430,6 +469,7 @@ extern "C" int knnx_attach_device_f16(knnx_index* ix, const void* dev_rows, int6
   ix->borrowed = true;
   ix->capacity = n;
   ix->ntotal = n;
+  ix->i8_valid = false;
   if (set_dev(ix)) return KNNX_E_HIP;
   HIPCHK(hipMemsetAsync(ix->maxnorm, 0, sizeof(int), ix->stream));
   HIPCHK(launch_maxnorm(ix->rows, n, ix->d, ix->maxnorm, ix->stream));
@@ -452,6 +492,7 @@ extern "C" int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed) {
   HIPCHK(launch_maxnorm(ix->rows, n, ix->d, ix->maxnorm, ix->stream));
   HIPCHK(hipStreamSynchronize(ix->stream));
   ix->ntotal = n;
+  ix->i8_valid = false;
   return KNNX_OK;
 }
 
@@ -643,13 +684,13 @@ static int rq_alloc(knnx_index* ix) {
   }
   return 0;
 }
-static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st) {
-  int r = rq_alloc(ix);
-  if (r) return r;
+// thresholds of a register-stationary pass: the 64-query scan over every S-th tile, S = min(stride_cap, tiles / 4096); the J-th best
+// sample score of query q -> ix->rq_samp[q * KNN_WIDE_KW + J - 1] (knn_kernels.h: KNN_RQ_STRIDE).  Returns S and J through the pointers.
+static int rq_sample_pass(knnx_index* ix, const float* q_dev, int nq, int k, int stride_cap, hipStream_t st, int* tstride_out, int* J_out,
+                          bool* wide_samp_out) {
   const int d = ix->d;
-  // 1. thresholds: the 64-query scan over every S-th tile; threshold = J-th best sample score (knn_kernels.h: KNN_RQ_STRIDE)
   const int64_t ntiles = (ix->ntotal + 31) / 32;
-  const int tstride = (int)std::max<int64_t>(1, std::min<int64_t>(KNN_RQ_STRIDE, ntiles / 4096));
+  const int tstride = (int)std::max<int64_t>(1, std::min<int64_t>(stride_cap, ntiles / 4096));
   // (the 64-query wide scan where its LDS queues fit, d <= 768; at d = 1024 the exact 32-query scan, whose scores are exact
   // rather than fp16-hi: the threshold then gets a slack of a few eps so that the sample rows themselves still reach it)
   const bool wide_samp = wide_cap(d) > 0;
@@ -698,7 +739,21 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
     HIPCHK(hipStreamWaitEvent(st, ix->rq_join[side - 1], 0));
   }
   const int jfull = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
-  const int J = tstride <= 128 ? jfull : std::max(6, std::min(jfull, (jfull * 128 + tstride - 1) / tstride));
+  *tstride_out = tstride;
+  *J_out = tstride <= 128 ? jfull : std::max(6, std::min(jfull, (jfull * 128 + tstride - 1) / tstride));
+  *wide_samp_out = wide_samp;
+  return 0;
+}
+
+static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st) {
+  int r = rq_alloc(ix);
+  if (r) return r;
+  const int d = ix->d;
+  // 1. thresholds: the sample pass
+  int tstride = 1, J = 1;
+  bool wide_samp = false;
+  r = rq_sample_pass(ix, q_dev, nq, k, KNN_RQ_STRIDE, st, &tstride, &J, &wide_samp);
+  if (r) return r;
   HIPCHK(launch_rq_prep(q_dev, nq, d, ix->rq_qfrag, ix->rq_samp, KNN_WIDE_KW, J, wide_samp ? 0.f : 1e-3f, ix->rq_thr, ix->rq_cnt,
                         ix->rq_lost, st));
   // 2. the pass over the whole index
@@ -730,10 +785,108 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
   return 0;
 }
 
+// ---- int8 first stage (knn_rq_kernels.hip, "int8 first stage"): 1 .. 256 queries in ONE pass over the int8 copy of the rows
+static bool i8_usable(const knnx_index* ix, int nq, int k) {
+  return ix->i8_ok && ix->rq_ok && ix->wide_ok && !ix->ivf_nlist && nq >= 1 && k <= KNN_WIDE_MAX_K && i8_supported(ix->d) &&
+         ix->ntotal >= ix->rq_min_rows && scan_cap(ix->d, KNN_WIDE_KW) > 0;
+}
+// allocate (first use) and build (first use, and after the rows changed) the int8 copy; 1: ready, 0: not available (the caller takes
+// another path; out of memory turns the feature off for this index), < 0: error
+static int i8_ensure(knnx_index* ix, hipStream_t st) {
+  if (ix->i8_valid) return 1;
+  const size_t Q = KNN_RQ_MAX;
+  auto give_up = [&]() {
+    (void)hipGetLastError();
+    ix->i8_ok = 0;
+    hipFree(ix->i8_rows);
+    ix->i8_rows = nullptr;
+    ix->i8_cap_rows = 0;
+    return 0;
+  };
+  if (!ix->i8_colscale) {
+    if (hipMalloc(&ix->i8_colscale, ix->d * sizeof(float)) != hipSuccess || hipMalloc(&ix->i8_colmax, ix->d * sizeof(int)) != hipSuccess ||
+        hipMalloc(&ix->i8_ab, 2 * sizeof(int)) != hipSuccess || hipMalloc(&ix->i8_qfrag, Q * ix->d) != hipSuccess ||
+        hipMalloc(&ix->i8_thr, Q * sizeof(int)) != hipSuccess || hipMalloc(&ix->i8_lb, Q * sizeof(float)) != hipSuccess ||
+        hipMalloc(&ix->i8_hit_s, Q * KNN_I8_CAP * sizeof(float)) != hipSuccess ||
+        hipMalloc(&ix->i8_hit_r, Q * KNN_I8_CAP * sizeof(uint32_t)) != hipSuccess)
+      return give_up();
+  }
+  if (ix->i8_cap_rows < ix->ntotal) {
+    hipFree(ix->i8_rows);
+    ix->i8_rows = nullptr;
+    ix->i8_cap_rows = 0;
+    // (an owned index grows by halves: follow its capacity, so that a stream of add() calls does not reallocate every time)
+    const int64_t want = std::max(ix->ntotal, ix->borrowed ? ix->ntotal : ix->capacity);
+    if (hipMalloc(&ix->i8_rows, (size_t)want * ix->d) != hipSuccess) return give_up();
+    ix->i8_cap_rows = want;
+  }
+  HIPCHK(launch_i8_build(ix->rows, ix->ntotal, ix->d, ix->i8_colmax, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
+  ix->i8_valid = true;
+  return 1;
+}
+static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st) {
+  int r = rq_alloc(ix);
+  if (r) return r;
+  const int d = ix->d;
+  // 1. thresholds: the exact sample pass (denser than the fp16 path's: the int8 bound widens the admission band, a tighter
+  // threshold buys the hits back)
+  int tstride = 1, J = 1;
+  bool wide_samp = false;
+  r = rq_sample_pass(ix, q_dev, nq, k, KNN_I8_STRIDE, st, &tstride, &J, &wide_samp);
+  if (r) return r;
+  HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J, ix->i8_qfrag, ix->i8_thr,
+                        ix->i8_lb, ix->rq_cnt, ix->rq_lost, st));
+  // 2. the pass over the int8 rows
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ix->prof) {
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st));
+  }
+  HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
+                         ix->rq_lost, ix->n_cu, st));
+  if (ix->prof) {
+    HIPCHK(hipEventRecord(e1, st));
+    ix->prof_events.emplace_back(e0, e1);
+  }
+  // 3. exact scores of the hits (fp16 rows), exact top-k among them, proof
+  HIPCHK(launch_rq_rescore(ix->rows, d, q_dev, nq, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r, ix->rq_cntc, st));
+  HIPCHK(launch_merge_u32(ix->i8_hit_s, ix->i8_hit_r, ix->rq_cntc, 1, nq, (int)KNN_I8_CAP, nq, k, ix->id_base, nullptr, D_out, I_out,
+                          nullptr, st));
+  HIPCHK(launch_i8_proof(nq, k, D_out, ix->i8_lb, ix->rq_cnt, KNN_I8_CAP, ix->rq_lost, ix->rq_need, ix->rq_gate, ix->stats, st));
+  // 4. unproven queries (a hit list overflowed): the exact scan of their 32-query group, gated on the device
+  for (int g = 0; g * KNN_NQ < nq; ++g) {
+    const int q0 = g * KNN_NQ, n = std::min(KNN_NQ, nq - q0);
+    r = scan_topk(ix, q_dev + (size_t)q0 * d, n, k, ix->wide_Dfb, ix->wide_Ifb, st, ix->rq_gate + g);
+    if (r) return r;
+    HIPCHK(launch_select(ix->rq_need, q0, n, k, ix->wide_Dfb, ix->wide_Ifb, D_out, I_out, st));
+  }
+  ix->i8_served += (unsigned long long)nq;
+  return 0;
+}
+
+// how many of `remaining` queries the next scan step takes (the same choice scan_step makes)
+static int step_queries(knnx_index* ix, int remaining, int k) {
+  if (i8_usable(ix, remaining, k)) return std::min(KNN_RQ_MAX, remaining);
+  if (rq_usable(ix, remaining, k)) return std::min(rq_queries_per_pass(ix->d), remaining);
+  if (wide_usable(ix, remaining, k)) return std::min(KNN_NQ_MAX, remaining);
+  return std::min(KNN_NQ, remaining);
+}
+
 // one step of a search over device buffers: picks the widest scan that serves the remaining queries; returns the number taken
 static int scan_step(knnx_index* ix, const float* q_dev, int remaining, int k, float* D_out, int64_t* I_out, hipStream_t st,
                      int* taken) {
   int nq, r;
+  if (i8_usable(ix, remaining, k)) {
+    r = i8_ensure(ix, st);
+    if (r < 0) return r;
+    if (r == 1) {
+      nq = std::min(KNN_RQ_MAX, remaining);
+      r = scan_topk_i8(ix, q_dev, nq, k, D_out, I_out, st);
+      *taken = nq;
+      return r;
+    }
+  }
   if (rq_usable(ix, remaining, k)) {
     nq = std::min(rq_queries_per_pass(ix->d), remaining);
     r = scan_topk_rq(ix, q_dev, nq, k, D_out, I_out, st);
@@ -746,6 +899,12 @@ static int scan_step(knnx_index* ix, const float* q_dev, int remaining, int k, f
   }
   *taken = nq;
   return r;
+}
+
+extern "C" int64_t knnx_i8_served(knnx_index* ix) {
+  if (!ix) return -1;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  return (int64_t)ix->i8_served;
 }
 
 extern "C" int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int k, float* D_dev, int64_t* I_dev,
@@ -778,20 +937,20 @@ static int search_fast_locked(knnx_index* ix, const float* q, int n, int k, floa
   if (scratch_acquire(ix, st)) return KNNX_E_HIP;
   for (int o = 0; o < n;) {
     const int rem = n - o;
-    const int nq = rq_usable(ix, rem, k) ? std::min(rq_queries_per_pass(ix->d), rem)
-                                         : (wide_usable(ix, rem, k) ? std::min(KNN_NQ_MAX, rem) : std::min(KNN_NQ, rem));
+    const int nq = step_queries(ix, rem, k);
     memcpy(pin, q + (size_t)o * ix->d, (size_t)nq * ix->d * sizeof(float));
     HIPCHK(hipMemcpyAsync(ix->q_dev, pin, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
     int took = 0;
     r = scan_step(ix, ix->q_dev, nq, k, ix->D_dev, ix->I_dev, st, &took);
     if (r) return r;
-    if (took != nq) return fail(KNNX_E_STATE, "internal: scan step size mismatch");
-    HIPCHK(hipMemcpyAsync(pin + qb, ix->D_dev, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(pin + qb + db, ix->I_dev, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    // (the step may take fewer than were staged: the int8 path can turn itself off -- out of memory -- between the two decisions)
+    if (took <= 0 || took > nq) return fail(KNNX_E_STATE, "internal: scan step size mismatch");
+    HIPCHK(hipMemcpyAsync(pin + qb, ix->D_dev, (size_t)took * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(pin + qb + db, ix->I_dev, (size_t)took * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    memcpy(D + (size_t)o * k, pin + qb, (size_t)nq * k * sizeof(float));
-    memcpy(I + (size_t)o * k, pin + qb + db, (size_t)nq * k * sizeof(int64_t));
-    o += nq;
+    memcpy(D + (size_t)o * k, pin + qb, (size_t)took * k * sizeof(float));
+    memcpy(I + (size_t)o * k, pin + qb + db, (size_t)took * k * sizeof(int64_t));
+    o += took;
   }
   if (scratch_release(ix, st)) return KNNX_E_HIP;
   return 0;

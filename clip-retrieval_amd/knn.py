@@ -253,6 +253,11 @@ class Mi355xIndex(_FaissShaped):
             R = np.ascontiguousarray(R[:, :, : self.d])
         return D, I, R, (pairs[: n.value].copy() if n.value <= self.DEDUP_PAIR_CAP else None)
 
+    def i8_served(self):
+        """Queries answered through the int8 first stage of the flat scans (include/knnx.h: knnx_i8_served); results are exact
+        either way."""
+        return int(self._lib.knnx_i8_served(self._h))
+
     def coalesce_stats(self):
         """(batches served, queries in them, largest batch) of the library's request coalescer."""
         b, q, m = C.c_int64(0), C.c_int64(0), C.c_int64(0)

@@ -217,6 +217,15 @@ int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t
 int knnx_set_coalesce(knnx_index* ix, int on);
 int knnx_coalesce_stats(knnx_index* ix, int64_t* batches, int64_t* queries, int64_t* largest_batch);
 
+/* int8 first stage of the flat scans (round 4; no counterpart in the reference: faiss IndexFlatIP scans its one copy of the rows,
+ * clip_back.py:362).  A flat (non-IVF) index of d = 512 / 768 / 1024 with at least 2^21 rows keeps, when the memory can be had,
+ * an int8 copy of its fp16 rows (one scale per column) and scans THAT with 1 .. 256 queries per pass -- half the bytes, int8 MFMA --
+ * to decide which rows are re-scored exactly from the fp16 rows; the admission threshold carries a proven bound of the quantisation
+ * error, so D and I are the exact top-k as without it (a query whose hit list overflows is re-run by the exact scan).  The copy is
+ * built on the first search after the rows changed (one pass over the rows) and costs ntotal * d bytes; KNNX_I8=0 in the environment
+ * turns it off, and so does a failed allocation.  knnx_i8_served: queries answered through this path so far (-1: null index). */
+int64_t knnx_i8_served(knnx_index* ix);
+
 /* One request of KnnService.knn_search with its dedup fused (clip_back.py:362 + :290-309): the top-k (k <= 64) of ONE query, and
  * the links of the reference's `get_non_uniques` -- every pair of result ranks (i < j) whose stored vectors, L2-normalised in
  * f32 as `normalized()` does (clip_back.py:194-197, :378), have inner product > dedup_thr (the reference: 0.94, strict).  The

@@ -588,9 +588,12 @@ def test_ivf_trained_recall():
 # ---------------------------------------------------------------------------------------------------------------
 # RQ scan: up to 256 queries per pass (csrc/knn_rq_kernels.hip).  KNNX_RQ_MIN_ROWS=0 makes small indexes take the path.
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.fixture
-def rq_on_small_indexes(monkeypatch):
+@pytest.fixture(params=["fp16", "int8"])
+def rq_on_small_indexes(monkeypatch, request):
+    """Both forms of the register-stationary pass: the fp16 scan (KNNX_I8=0) and the int8 first stage in front of it (default)."""
     monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")  # read by knnx_create
+    monkeypatch.setenv("KNNX_I8", "0" if request.param == "fp16" else "1")
+    return request.param
 
 
 @pytest.mark.parametrize("d", [768, 512, 1024])
@@ -615,6 +618,7 @@ def test_rq_scan_256_queries_parity(rq_on_small_indexes, d):
     served, failed = ix.stats()
     assert served - served0 >= 900, "the proof-based scans did not serve these batches"
     assert failed <= 8, f"{failed} proofs failed on ordinary data"  # small index: the sample is the whole index, hits = k + 8
+    assert (ix.i8_served() >= 900) == (rq_on_small_indexes == "int8"), "the wrong form of the pass served these batches"
     ix.close()
 
 
@@ -641,7 +645,10 @@ def test_rq_scan_ties_floods_and_fallback(rq_on_small_indexes):
             Do, Io = o.search(q, k)
             assert np.array_equal(I, Io), f"{name} nq={nq} k={k}: ids (ties in ascending id order)"
             assert np.allclose(D, Do, atol=1e-5)
-        assert ix.stats()[1] > 0, f"{name}: expected failed proofs (fallback path untested otherwise)"
+        if rq_on_small_indexes == "fp16":
+            assert ix.stats()[1] > 0, f"{name}: expected failed proofs (fallback path untested otherwise)"
+        # (int8: ties and 40 000 equal rows are ordinary hits -- its lists hold 32 768 like the fp16 pass's, but its sample pass is the whole index here -- and the proof is about completeness only;
+        # its fallback is exercised by test_i8_first_stage_overflow_falls_back)
         ix.close()
 
 
@@ -673,6 +680,80 @@ def test_rq_full_scale_properties_256_planted_queries():
     for lo in (0, 224):  # the same queries through the exact 32-query scan
         D32, I32 = ix.search(q[lo:lo + 32], 40)
         assert np.array_equal(I32, I[lo:lo + 32]) and np.allclose(D32, D[lo:lo + 32], atol=2e-6)
+    ix.close()
+
+
+def test_i8_first_stage_equals_exact_scans(monkeypatch):
+    """The int8 first stage (default on flat indexes >= 2^21 rows) against the same index with it turned off: 3 M x 768 synthetic
+    rows, batches of 1, 7, 32, 64, 200 and 300 planted + random queries -- ids identical, scores identical (both re-score the same
+    fp16 rows with the same arithmetic), no fallback on this corpus, and the counters say which path served."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import planted_queries
+
+    d, n, seed = 768, 3_000_000, 5
+    rng = np.random.default_rng(2)
+    planted = np.sort(rng.choice(n, 300, replace=False))
+    q = planted_queries(planted, d, seed)
+    q[1::3] = rng.standard_normal((len(q[1::3]), d)).astype(np.float32)  # a third of the queries are not near any row
+    q[2::7] *= 3.7  # ... and some are not unit vectors
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("KNNX_I8", mode)
+        ix = Mi355xIndex(d)
+        ix.synth_fill(n, seed)
+        out = []
+        for nq in (1, 7, 32, 64, 200, 300):
+            out.append(ix.search(q[:nq], 40))
+        served, failed = ix.stats()
+        res[mode] = (out, ix.i8_served(), failed)
+        ix.close()
+    assert res["0"][1] == 0 and res["1"][1] == 1 + 7 + 32 + 64 + 200 + 300, (res["0"][1], res["1"][1])
+    assert res["1"][2] == 0, f"{res['1'][2]} int8 hit lists overflowed on an ordinary corpus"
+    for (D0, I0), (D1, I1) in zip(res["0"][0], res["1"][0]):
+        _check(D1, I1, D0, I0, f"int8 first stage vs exact scans, {len(D0)} queries", min_exact=0.999)
+        assert (I0 == I1).mean() > 0.999, "ids differ between the int8 first stage and the exact scans beyond a near-tie or two"
+    assert np.array_equal(res["1"][0][-1][1][0::3, 0], planted[0::3])  # planted neighbours (the rows of the unperturbed queries)
+
+
+def test_i8_first_stage_after_the_rows_change(monkeypatch):
+    """The int8 copy is rebuilt when rows are added (add() invalidates it): results must follow the rows."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")
+    d = 512
+    x = _data(50_000, d, seed=31)
+    o, ix = FlatIPOracle(d), Mi355xIndex(d)
+    for part in (x[:20_000], x[20_000:]):
+        o.add(part)
+        ix.add(part)
+        q = _queries(40, d, seed=len(part), x=x[: o.ntotal])
+        D, I = ix.search(q, 10)
+        Do, Io = o.search(q, 10)
+        _check(D, I, Do, Io, f"int8 after add ntotal={o.ntotal}")
+    assert ix.i8_served() == 80
+    ix.close()
+
+
+def test_i8_first_stage_overflow_falls_back(monkeypatch):
+    """200 000 copies of one row and queries equal to it: every copy passes the int8 admission, the 32 768-entry hit list
+    overflows, the query is answered by the gated exact scan -- ids in ascending order among the ties."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")
+    d = 768
+    base = _data(1, d, seed=41)
+    x = np.concatenate([_data(3_000, d, seed=42), np.tile(base, (200_000, 1))])
+    o, ix = FlatIPOracle(d), Mi355xIndex(d)
+    o.add(x)
+    ix.add(x)
+    q = _queries(48, d, seed=43, x=x)
+    q[:24] = base.astype(np.float32)
+    D, I = ix.search(q, 40)
+    Do, Io = o.search(q, 40)
+    assert np.array_equal(I, Io) and np.allclose(D, Do, atol=1e-5)
+    assert ix.stats()[1] >= 24, "the flooded queries must have failed their completeness proof"
     ix.close()
 
 
