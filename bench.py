@@ -313,6 +313,8 @@ def main():
         batches = [int(x) for x in args.knn_batches.split(",") if x]
         nq_max = max(batches)
         enc_free = torch.cuda.mem_get_info(dev)[0]
+        # (3 bytes per element: the fp16 rows + the int8 copy the library builds for its first-stage scan, include/knnx.h knnx_i8_served;
+        # at 125 M rows per GPU -- the 8-GPU configuration -- the copy does not fit and the library scans the fp16 rows)
         rows = int(min(rows, (enc_free - (16 << 30)) // (d * 2)))
         # the arena is a torch tensor the index borrows, so that the full-scale cross-check below can read the same bytes
         X = torch.empty((rows, d), dtype=torch.float16, device=dev)
@@ -338,6 +340,7 @@ def main():
             if not hit:
                 failures.append(f"kNN B={nq}: a planted neighbour is not the top hit")
             s0 = ix.stats()
+            i8_0 = ix.i8_served()
             ix.profile(True)
             barrier()
             t1 = time.perf_counter()
@@ -350,20 +353,28 @@ def main():
             s1 = ix.stats()
             scan_ms = ms / max(nl, 1)
             passes = nl / max(args.knn_scans, 1)
-            scan_gbs = rows * d * 2 / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+            i8 = ix.i8_served() - i8_0 >= args.knn_scans * nq  # every timed query went through the int8 first stage
+            esz = 1 if i8 else 2  # bytes per element of the rows the timed pass reads
+            scan_gbs = rows * d * esz / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
             qpp = nq / max(passes, 1)
-            kern = ("knn_rq_scan_kernel (register-stationary queries, up to 256 per pass)" if qpp > 64 else
+            kern = ("knn_rq8_scan_kernel (int8 first stage: int8 copy of the rows, 1..256 register-stationary queries per pass, "
+                    "v_mfma_i32_16x16x64_i8; hits re-scored exactly from the fp16 rows)" if i8 else
+                    "knn_rq_scan_kernel (register-stationary queries, up to 256 per pass)" if qpp > 64 else
                     "knn_scan_kernel<QB=2> (64-query wide scan + exactness proof)" if qpp > 32 else "knn_scan_kernel<QB=1> (32-query exact scan)")
             # a pass is HBM-bound below ~312 queries per pass (2.5 PF / 8 TB/s); every row carries both fractions
-            mfma_tf = 2.0 * rows * d * qpp / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+            # (int8: the pass multiplies all its 128 / 256 query slots whatever the batch; its matrix-pipe roof is the dense int8 one, 2 x bf16)
+            slots = (128 if nq <= 128 else 256) if i8 else qpp  # (int8: 4 or 8 waves x 32 query slots, knn_rq_kernels.hip launch_rq8_scan)
+            mfma_tf = 2.0 * rows * d * slots / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+            mfma_peak = 2.0 * BF16_PEAK_TFLOPS if i8 else BF16_PEAK_TFLOPS
             by_batch.append({"B": nq, "qps": round(args.knn_scans * nq / dk, 1), "ms_per_batch": round(dk / args.knn_scans * 1e3, 3),
                              "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(scan_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": round(scan_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(scan_ms, 3),
-                                          "algorithmic_bytes_per_launch": rows * d * 2, "mfma_frac": round(mfma_tf / BF16_PEAK_TFLOPS, 4)},
+                                          "algorithmic_bytes_per_launch": rows * d * esz, "mfma_frac": round(mfma_tf / mfma_peak, 4)},
+                             "int8_first_stage": i8,
                              "passes_over_hbm": round(passes, 2), "scan_ms": round(scan_ms, 3), "scan_GBps": round(scan_gbs, 1),
                              "hbm_frac": round(scan_gbs / HBM_PEAK_GBS, 4),
-                             "scan_mfma_tflops": round(2.0 * rows * d * qpp / (scan_ms * 1e-3) / 1e12, 1) if scan_ms > 0 else None,
-                             "qps_ceiling_at_8TBps": round(nq / (rows * d * 2 / (HBM_PEAK_GBS * 1e9)), 1),
+                             "scan_mfma_tflops": round(mfma_tf, 1) if scan_ms > 0 else None,
+                             "qps_ceiling_at_8TBps": round(nq / (rows * d * esz / (HBM_PEAK_GBS * 1e9)), 1),
                              "planted_neighbour_top1": hit, "proof_served": s1[0] - s0[0], "proof_failures": s1[1] - s0[1]})
         best = max(by_batch, key=lambda r: r["qps"])
         head = best  # knn.roofline describes the kernel that produced knn.qps; every by_batch row has its own
@@ -446,9 +457,11 @@ def main():
                        "sample": f"torch CPU fp32 matmul + running top-k over 1 M-row blocks, first {n_cpu} rows of the index, B = 1 / 32 / 256 (value = the best, B = {bestc['B']})"}
             del xc
         # the counter bytes of the kernel the roofline object describes (the best row's)
-        kfam = "knn_rq_scan_kernel" if "knn_rq_scan_kernel" in head["roofline"].get("kernel", "") else "knn_scan_kernel"
+        hk = head["roofline"].get("kernel", "")
+        kfam = "knn_rq8_scan_kernel" if "knn_rq8_scan_kernel" in hk else ("knn_rq_scan_kernel" if "knn_rq_scan_kernel" in hk else "knn_scan_kernel")
         ktraffic, _ = pmc_traffic(kfam) if rows == 100_000_000 else (None, None)
-        knn = {"metric": f"QPS@top-{k}, flat IP, fp16 rows in HBM", "qps": best["qps"], "qps_batch": best["B"],
+        knn = {"metric": f"QPS@top-{k}, flat IP, fp16 rows in HBM" + (" (+ int8 copy for the first-stage scan; exact results)" if best.get("int8_first_stage") else ""),
+               "qps": best["qps"], "qps_batch": best["B"], "int8_first_stage": bool(best.get("int8_first_stage")),
                "rows_per_gpu": rows, "total_rows": rows * world, "d": d, "k": k,
                "queries_per_scan": head["B"], "ms_per_batch": head["ms_per_batch"],
                "planted_neighbour_top1": all(r["planted_neighbour_top1"] for r in by_batch),

@@ -830,9 +830,19 @@ static hipError_t launch_rq8_scan_cfg(const int8_t* X8, int64_t N, const int8_t*
 }
 #endif
 
-hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
+hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
                            float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st) {
 #if KNNX_MFMA16
+  // up to 128 queries: four waves hold them all -- half the LDS reads and MFMAs of the 8-wave configuration, which a pass over
+  // int8 rows does not hide behind HBM (8 x 32 slots: 17.4 ms per pass over 100 M x 768 whatever the batch, 76.8 GB in 12.4 ms)
+  if (nq <= 128) {
+    switch (d) {
+      case 512: return launch_rq8_scan_cfg<16, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+      case 768: return launch_rq8_scan_cfg<24, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+      case 1024: return launch_rq8_scan_cfg<32, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (d) {
     case 512: return launch_rq8_scan_cfg<16, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
     case 768: return launch_rq8_scan_cfg<24, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);

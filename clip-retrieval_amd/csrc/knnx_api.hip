@@ -843,7 +843,7 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, st));
   }
-  HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
+  HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, nq, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
                          ix->rq_lost, ix->n_cu, st));
   if (ix->prof) {
     HIPCHK(hipEventRecord(e1, st));

@@ -18,9 +18,9 @@ import csv
 import json
 import sys
 
-GROUPS = {"knn_rq_scan_kernel": "knn_rq_scan_kernel", "knn_scan_kernel": "knn_scan_kernel", "gemm256sp_kernel": "gemm", "gemm_bf16_kernel": "gemm",
+GROUPS = {"knn_rq8_scan_kernel": "knn_rq8_scan_kernel", "knn_rq_scan_kernel": "knn_rq_scan_kernel", "knn_scan_kernel": "knn_scan_kernel", "gemm256sp_kernel": "gemm", "gemm_bf16_kernel": "gemm",
           "attention_kernel": "attention", "attention_pk_kernel": "attention", "layernorm_kernel": "layernorm"}
-SCANS = ("knn_scan_kernel", "knn_rq_scan_kernel")
+SCANS = ("knn_scan_kernel", "knn_rq_scan_kernel", "knn_rq8_scan_kernel")
 
 
 def load(path):
