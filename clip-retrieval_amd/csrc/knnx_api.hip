@@ -1681,6 +1681,11 @@ extern "C" int knnx_ivf_set_lists(knnx_index* ix, int nlist, const uint16_t* cen
   if (ix->rows) hipFree(ix->rows);
   ix->rows = dst;
   ix->capacity = prow;
+  // (an IVF index does not use the int8 first stage: give a copy built while the index was flat back)
+  hipFree(ix->i8_rows);
+  ix->i8_rows = nullptr;
+  ix->i8_cap_rows = 0;
+  ix->i8_valid = false;
   int r = knnx_create(ix->device, ix->d, KNNX_METRIC_INNER_PRODUCT, &ix->cent);
   if (r) return r;
   r = knnx_add_f16(ix->cent, centroids_f16, nlist);
