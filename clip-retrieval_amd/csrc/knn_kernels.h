@@ -131,6 +131,7 @@ constexpr int KNN_I8_STRIDE = 32;          // the sample pass visits every S-th 
 constexpr unsigned KNN_I8_CAP = KNN_RQ_CAP;  // hit list entries per query (knn_merge_kernel holds a query's whole list in LDS: 32 768 x 4 B)
 int i8_supported(int d);
 hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
+hipError_t launch_i8_quant(const _Float16* X, int64_t N, int d, const float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
 hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
                           int kw, int J, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st);
 hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,

@@ -438,20 +438,18 @@ typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 // column maxima: colmax_enc[j] = max_i |x_ij| as the bits of a non-negative float (integer order = float order)
 __global__ __launch_bounds__(256) void knn_i8_colmax_kernel(const _Float16* __restrict__ X, int64_t N, int d, int* __restrict__ colmax_enc) {
-  // a block walks rows blockIdx.x, + gridDim.x, ...; thread t owns columns t, t + 256, ... (<= 4 at d <= 1024)
+  // a block walks rows blockIdx.x, + gridDim.x, ...; thread t owns columns 4 t .. 4 t + 3 (one 8-byte load per row; d <= 1024)
   float m[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t r = blockIdx.x; r < N; r += gridDim.x) {
-    const _Float16* row = X + (size_t)r * d;
+  const int c = 4 * threadIdx.x;
+  if (c < d) {
+    for (int64_t r = blockIdx.x; r < N; r += gridDim.x) {
+      const uint2 raw = *reinterpret_cast<const uint2*>(X + (size_t)r * d + c);
+      const _Float16* h = reinterpret_cast<const _Float16*>(&raw);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = e * 256 + threadIdx.x;
-      if (c < d) m[e] = fmaxf(m[e], fabsf((float)row[c]));
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], fabsf((float)h[e]));
     }
-  }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = e * 256 + threadIdx.x;
-    if (c < d) atomicMax(&colmax_enc[c], __float_as_int(m[e]));
+    for (int e = 0; e < 4; ++e) atomicMax(&colmax_enc[c + e], __float_as_int(m[e]));
   }
 }
 __global__ void knn_i8_colscale_kernel(const int* __restrict__ colmax_enc, int d, float* __restrict__ colscale) {
@@ -461,12 +459,14 @@ __global__ void knn_i8_colscale_kernel(const int* __restrict__ colmax_enc, int d
     colscale[c] = m > 0.f ? m / 127.f : 1.f;
   }
 }
-// one wave per row: x8 = clamp(rint(x / c)), and the maxima A = max |y - x8|, B = max |x8| (2-norms per row) into ab_enc[0..1]
+// a wave per row at a time (grid-stride over the rows): x8 = clamp(rint(x / c)), and the maxima A = max |y - x8|, B = max |x8|
+// (2-norms per row) into ab_enc[0..1] -- ONE atomic pair per wave at the end (a pair per row, 2 x 10^8 atomics on two addresses,
+// made the first version of this kernel take 2.3 s for 100 M rows: profiles/r04zzz_kernel_stats.csv)
 __global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __restrict__ X, int64_t N, int d, const float* __restrict__ colscale,
                                                           int8_t* __restrict__ X8, int* __restrict__ ab_enc) {
   const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= N) return;
+  float ma = 0.f, mb = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < N; r += (int64_t)gridDim.x * 4) {
   float ea = 0.f, eb = 0.f;
   for (int c0 = 0; c0 < d; c0 += 256) {  // 4 consecutive columns per lane: one 8-byte load, one 4-byte store
     const int c = c0 + 4 * lane;
@@ -492,9 +492,12 @@ __global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __res
     ea += __shfl_xor(ea, o);
     eb += __shfl_xor(eb, o);
   }
+  ma = fmaxf(ma, ea);
+  mb = fmaxf(mb, eb);
+  }
   if (lane == 0) {
-    atomicMax(&ab_enc[0], __float_as_int(sqrtf(ea)));
-    atomicMax(&ab_enc[1], __float_as_int(sqrtf(eb)));
+    atomicMax(&ab_enc[0], __float_as_int(sqrtf(ma)));
+    atomicMax(&ab_enc[1], __float_as_int(sqrtf(mb)));
   }
 }
 
@@ -783,6 +786,20 @@ __global__ __launch_bounds__(256) void knn_i8_proof_kernel(int nq, int k, const 
 
 int i8_supported(int d) { return KNNX_MFMA16 && (d == 512 || d == 768 || d == 1024) ? 1 : 0; }
 
+// quantise rows with the column scales that exist (also used for rows added later: values beyond +-127 c clamp, and A / B -- which
+// are maxima over the rows as stored -- grow with them, so the bound stays a bound)
+hipError_t launch_i8_quant(const _Float16* X, int64_t N, int d, const float* colscale, int8_t* X8, int* ab_enc, hipStream_t st) {
+#if KNNX_MFMA16
+  if (N <= 0) return hipSuccess;
+  // grid-stride: a launch's grid x block must stay below 2^32 work-items (100 M rows as 25 M workgroups silently ran the first 32.9 M)
+  const unsigned grid = (unsigned)std::min<int64_t>((N + 3) / 4, 256 * 16);
+  hipLaunchKernelGGL(knn_i8_quant_kernel, dim3(grid), dim3(256), 0, st, X, N, d, colscale, X8, ab_enc);
+  return hipGetLastError();
+#else
+  return hipErrorInvalidValue;
+#endif
+}
+
 hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st) {
 #if KNNX_MFMA16
   hipError_t e = hipMemsetAsync(colmax_enc, 0, (size_t)d * sizeof(int), st);
@@ -793,14 +810,7 @@ hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc,
   const unsigned g1 = (unsigned)std::min<int64_t>(N, 256 * 32);
   hipLaunchKernelGGL(knn_i8_colmax_kernel, dim3(g1), dim3(256), 0, st, X, N, d, colmax_enc);
   hipLaunchKernelGGL(knn_i8_colscale_kernel, dim3((d + 255) / 256), dim3(256), 0, st, colmax_enc, d, colscale);
-  // (a launch's grid x block must stay below 2^32 work-items: 100 M rows in one launch silently ran the first 32.9 M only)
-  const int64_t chunk = (int64_t)1 << 23;
-  for (int64_t o = 0; o < N; o += chunk) {
-    const int64_t m = std::min(chunk, N - o);
-    hipLaunchKernelGGL(knn_i8_quant_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, X + (size_t)o * d, m, d, colscale,
-                       X8 + (size_t)o * d, ab_enc);
-  }
-  return hipGetLastError();
+  return launch_i8_quant(X, N, d, colscale, X8, ab_enc, st);
 #else
   return hipErrorInvalidValue;
 #endif

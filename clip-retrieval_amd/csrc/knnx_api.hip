@@ -106,6 +106,8 @@ struct knnx_index {
   int i8_ok = 1;                  // KNNX_I8=0 disables; cleared for good when its memory cannot be had
   bool i8_valid = false;          // rows8 / colscale / ab describe the current rows
   int64_t i8_cap_rows = 0;
+  int64_t i8_nrows = 0;           // rows [0, i8_nrows) are quantised with the current column scales (add() appends: only the new rows are done)
+  int64_t i8_scale_rows = 0;      // rows the column scales were taken over (a full rebuild once the index has doubled since)
   int8_t* i8_rows = nullptr;      // [ntotal, d]
   float* i8_colscale = nullptr;   // [d]
   int *i8_colmax = nullptr, *i8_ab = nullptr;  // [d] (encoded), [2] (encoded A, B)
@@ -366,6 +368,7 @@ extern "C" int knnx_reset(knnx_index* ix) {
   HIPCHK(hipStreamSynchronize(ix->stream));
   ix->ntotal = 0;
   ix->i8_valid = false;
+  ix->i8_nrows = 0;
   HIPCHK(hipMemsetAsync(ix->maxnorm, 0, sizeof(int), ix->stream));
   return KNNX_OK;
 }
@@ -388,6 +391,7 @@ static int grow(knnx_index* ix, int64_t need_rows) {
       hipFree(ix->i8_rows);
       ix->i8_rows = nullptr;
       ix->i8_cap_rows = 0;
+      ix->i8_nrows = 0;
       ix->i8_valid = false;
     }
     HIPCHK(hipMalloc(&nr, (size_t)need_rows * ix->d * sizeof(_Float16)));
@@ -453,7 +457,7 @@ static int add_common(knnx_index* ix, const void* rows, int64_t n, bool is_f32) 
   }
   if (tmp32) hipFree(tmp32);
   ix->ntotal += n;
-  ix->i8_valid = false;
+  ix->i8_valid = false;  // (the rows quantised so far stay: i8_ensure quantises [i8_nrows, ntotal) only)
   return KNNX_OK;
 }
 
@@ -470,6 +474,7 @@ extern "C" int knnx_attach_device_f16(knnx_index* ix, const void* dev_rows, int6
   ix->capacity = n;
   ix->ntotal = n;
   ix->i8_valid = false;
+  ix->i8_nrows = 0;
   if (set_dev(ix)) return KNNX_E_HIP;
   HIPCHK(hipMemsetAsync(ix->maxnorm, 0, sizeof(int), ix->stream));
   HIPCHK(launch_maxnorm(ix->rows, n, ix->d, ix->maxnorm, ix->stream));
@@ -493,6 +498,7 @@ extern "C" int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed) {
   HIPCHK(hipStreamSynchronize(ix->stream));
   ix->ntotal = n;
   ix->i8_valid = false;
+  ix->i8_nrows = 0;
   return KNNX_OK;
 }
 
@@ -801,6 +807,7 @@ static int i8_ensure(knnx_index* ix, hipStream_t st) {
     hipFree(ix->i8_rows);
     ix->i8_rows = nullptr;
     ix->i8_cap_rows = 0;
+    ix->i8_nrows = 0;
     return 0;
   };
   if (!ix->i8_colscale) {
@@ -812,15 +819,26 @@ static int i8_ensure(knnx_index* ix, hipStream_t st) {
       return give_up();
   }
   if (ix->i8_cap_rows < ix->ntotal) {
-    hipFree(ix->i8_rows);
-    ix->i8_rows = nullptr;
-    ix->i8_cap_rows = 0;
     // (an owned index grows by halves: follow its capacity, so that a stream of add() calls does not reallocate every time)
     const int64_t want = std::max(ix->ntotal, ix->borrowed ? ix->ntotal : ix->capacity);
-    if (hipMalloc(&ix->i8_rows, (size_t)want * ix->d) != hipSuccess) return give_up();
+    int8_t* nr = nullptr;
+    if (hipMalloc(&nr, (size_t)want * ix->d) != hipSuccess) return give_up();
+    if (ix->i8_rows && ix->i8_nrows > 0)
+      HIPCHK(hipMemcpyAsync(nr, ix->i8_rows, (size_t)ix->i8_nrows * ix->d, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(ix->i8_rows);
+    ix->i8_rows = nr;
     ix->i8_cap_rows = want;
   }
-  HIPCHK(launch_i8_build(ix->rows, ix->ntotal, ix->d, ix->i8_colmax, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
+  if (ix->i8_nrows > 0 && ix->i8_nrows <= ix->ntotal && ix->ntotal < 2 * ix->i8_scale_rows) {
+    // rows were appended: quantise the new ones with the scales that exist (values beyond them clamp; A and B grow with what is stored)
+    HIPCHK(launch_i8_quant(ix->rows + (size_t)ix->i8_nrows * ix->d, ix->ntotal - ix->i8_nrows, ix->d, ix->i8_colscale,
+                           ix->i8_rows + (size_t)ix->i8_nrows * ix->d, ix->i8_ab, st));
+  } else {
+    HIPCHK(launch_i8_build(ix->rows, ix->ntotal, ix->d, ix->i8_colmax, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
+    ix->i8_scale_rows = ix->ntotal;
+  }
+  ix->i8_nrows = ix->ntotal;
   ix->i8_valid = true;
   return 1;
 }
@@ -1685,6 +1703,7 @@ extern "C" int knnx_ivf_set_lists(knnx_index* ix, int nlist, const uint16_t* cen
   hipFree(ix->i8_rows);
   ix->i8_rows = nullptr;
   ix->i8_cap_rows = 0;
+  ix->i8_nrows = 0;
   ix->i8_valid = false;
   int r = knnx_create(ix->device, ix->d, KNNX_METRIC_INNER_PRODUCT, &ix->cent);
   if (r) return r;
