@@ -506,12 +506,18 @@ __global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __res
 // lower bound thr_lb (= T) of the proof; resets the hit counters.  Unused slots: zero fragments, thr_i = INT_MAX.
 __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict__ q, int nq, int d, const float* __restrict__ colscale,
                                                         const int* __restrict__ ab_enc, const int* __restrict__ maxnorm,
-                                                        const float* __restrict__ samp, int kw, int J, int8_t* __restrict__ qfrag8,
+                                                        const float* __restrict__ samp, int kw, int J, int planes, int8_t* __restrict__ qfrag8,
                                                         int* __restrict__ thr_i, float* __restrict__ thr_lb,
                                                         unsigned* __restrict__ cnt, unsigned* __restrict__ lost) {
+  // planes = 2: the query is TWO int8 planes, u ~ s_u u8 + (s_u / 128) u8b (the second quantises what the first left), and the scan
+  // compares 128 * sum(u8 x8) + sum(u8b x8) -- for indexes whose columns differ widely in size (CLIP embeddings have a few dominant
+  // dimensions): one scale for all of u then leaves |u - s_u u8| * B as the whole error (1.25 sigma of the scores in a simulation with
+  // two columns 5 x the rest, 3 x 10^5 admitted rows per query at 10^8 rows; two planes: 0.26 sigma, 9 x 10^3).  Second fragment set
+  // at qfrag8 + 256 * d.
   const int n = blockIdx.x, lane = threadIdx.x;
   const int nsl = d / 64;
   int8_t* dst = qfrag8 + ((size_t)(n >> 4) * nsl * 64 + (n & 15)) * 16;  // + (s * 64 + q4 * 16) * 16 + byte
+  int8_t* dst2 = dst + (size_t)256 * d;
   float u[16];  // columns lane + 64 e
   float mu = 0.f, e2 = 0.f, n2 = 0.f;
 #pragma unroll
@@ -544,9 +550,18 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
     if (c < d) {
       float v = rintf(u[e] / su);
       v = fminf(fmaxf(v, -127.f), 127.f);
-      er2 += (u[e] - su * v) * (u[e] - su * v);
+      float res = u[e] - su * v;
       // column c = 64 s + 16 q4 + byte
-      dst[(size_t)((c >> 6) * 64 + ((c >> 4) & 3) * 16) * 16 + (c & 15)] = (int8_t)(int)v;
+      const size_t fo = (size_t)((c >> 6) * 64 + ((c >> 4) & 3) * 16) * 16 + (c & 15);
+      dst[fo] = (int8_t)(int)v;
+      if (planes == 2) {
+        const float su2 = su * (1.f / 128.f);
+        float v2 = rintf(res / su2);
+        v2 = fminf(fmaxf(v2, -127.f), 127.f);
+        res -= su2 * v2;
+        dst2[fo] = (int8_t)(int)v2;
+      }
+      er2 += res * res;
     }
   }
   for (int o = 32; o > 0; o >>= 1) er2 += __shfl_xor(er2, o);
@@ -561,7 +576,7 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
         lb = v - eps_hi;
         const float A = __int_as_float(ab_enc[0]), B = __int_as_float(ab_enc[1]);
         const float eps8 = (sqrtf(nu2) * A + sqrtf(er2) * B) * 1.00002f + 1e-6f * fabsf(lb);
-        const float t = (lb - eps8) / su;
+        const float t = (lb - eps8) / (planes == 2 ? su * (1.f / 128.f) : su);
         // floor - 1: the float division / subtraction above may round up by an ulp
         ti = t <= -2.0e9f ? (int)0x80000000 : (t >= 2.0e9f ? 0x7fffffff : (int)floorf(t) - 1);
       } else {
@@ -611,25 +626,30 @@ __device__ __forceinline__ void rq8_issue_all(const Rq8Tile& r) {
   }
 }
 
-template <int KS, int NW, int DPW, int S>
-__device__ __forceinline__ void rq8_ksteps(unsigned xa, i32x4 (&A)[4], i32x4v (&acc)[2][2], const i32x4 (&Q)[2][KS / 2], const Rq8Tile& refill) {
+template <int KS, int NW, int DPW, int PL, int S>
+__device__ __forceinline__ void rq8_ksteps(unsigned xa, i32x4 (&A)[4], i32x4v (&acc)[PL][2][2], const i32x4 (&Q)[PL][2][KS / 2],
+                                           const Rq8Tile& refill) {
   if constexpr (S < KS) {
     if constexpr (S + 3 < KS) rq_dsread<(S + 3) * 1024>(A[(S + 3) & 3], xa);
     rq_wait_lgkm<(KS - 1 - S < 3 ? KS - 1 - S : 3)>();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[b][S & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[S & 3], Q[b][S >> 1], acc[b][S & 1], 0, 0, 0);
+    for (int p = 0; p < PL; ++p)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[p][b][S & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[S & 3], Q[p][b][S >> 1], acc[p][b][S & 1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S % (KS / DPW) == 1) {
       rq8_issue_one<NW, S / (KS / DPW)>(refill);
       __builtin_amdgcn_sched_barrier(0);
     }
-    rq8_ksteps<KS, NW, DPW, S + 1>(xa, A, acc, Q, refill);
+    rq8_ksteps<KS, NW, DPW, PL, S + 1>(xa, A, acc, Q, refill);
   }
 }
 
 // KS = d / 32 pieces per 32-row tile; 8 waves x 32 queries (two blocks of 16); the structure of knn_rq_scan_kernel
-template <int KS, int NW, int NSLOT>
+// PL = 2: two query planes (knn_i8_prep_kernel), score = 128 * plane 0 + plane 1
+template <int KS, int NW, int NSLOT, int PL>
 __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int8_t* __restrict__ X8, int64_t N, const int8_t* __restrict__ qfrag8,
                                                                       const int* __restrict__ thr_i, unsigned* __restrict__ g_cnt, unsigned cap,
                                                                       float* __restrict__ hit_s, uint32_t* __restrict__ hit_r,
@@ -646,20 +666,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
   uint32_t* st_r = reinterpret_cast<uint32_t*>(st_s + RQ_STAGE);
   uint32_t* st_q = st_r + RQ_STAGE;
 
-  i32x4 Q[2][NSL];
+  i32x4 Q[PL][2][NSL];
   int tq[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int blk = w * 2 + b;
-    const i32x4* src = reinterpret_cast<const i32x4*>(qfrag8) + (size_t)blk * NSL * 64 + lane;
 #pragma unroll
-    for (int s = 0; s < NSL; ++s) Q[b][s] = src[s * 64];
+    for (int p = 0; p < PL; ++p) {
+      const i32x4* src = reinterpret_cast<const i32x4*>(qfrag8 + (size_t)p * 256 * (KS * 32)) + (size_t)blk * NSL * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) Q[p][b][s] = src[s * 64];
+    }
     tq[b] = thr_i[blk * 16 + qcol];
   }
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
 #pragma unroll
-    for (int s = 0; s < NSL; ++s) asm volatile("" : "+v"(Q[b][s]));  // all landed before the DMA ring starts (see knn_rq_scan_kernel)
+    for (int p = 0; p < PL; ++p)
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) asm volatile("" : "+v"(Q[p][b][s]));  // all landed before the DMA ring starts (see knn_rq_scan_kernel)
     asm volatile("" : "+v"(tq[b]));
   }
 
@@ -680,25 +705,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const Rq8Tile refill = RQ8_TILE(t + (int64_t)(NSLOT - 1) * gstride, slot == 0 ? NSLOT - 1 : slot - 1);
-    i32x4v acc[2][2];
+    i32x4v acc[PL][2][2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[b][0] = acc[b][1] = i32x4v{0, 0, 0, 0};
+    for (int p = 0; p < PL; ++p)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[p][b][0] = acc[p][b][1] = i32x4v{0, 0, 0, 0};
     const unsigned xa = lds_base + slot * TILE_BYTES + lane * 16;
     i32x4 A[4];
     rq_dsread<0>(A[0], xa);
     rq_dsread<1024>(A[1], xa);
     rq_dsread<2048>(A[2], xa);
     __builtin_amdgcn_sched_barrier(0);
-    rq8_ksteps<KS, NW, DPW, 0>(xa, A, acc, Q, refill);
+    rq8_ksteps<KS, NW, DPW, PL, 0>(xa, A, acc, Q, refill);
 
     // ---- filter: lane (qcol, hb) owns rows row0 + 16 half + e of its query column in each block; integer compares
     const int64_t row0 = t * 32 + 4 * hb;
+    // (two planes: |128 * plane 0| <= 128 * 127 * 127 * d < 2^31 at d <= 1024, plane 1 adds at most 127 * 127 * d)
+#define RQ8_SC(b, r) (PL == 2 ? acc[0][b][(r) >> 2][(r) & 3] * 128 + acc[PL - 1][b][(r) >> 2][(r) & 3] : acc[0][b][(r) >> 2][(r) & 3])
     bool any = false;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      int m = acc[b][0][0];
+      int m = RQ8_SC(b, 0);
 #pragma unroll
-      for (int r = 1; r < 8; ++r) m = max(m, acc[b][r >> 2][r & 3]);
+      for (int r = 1; r < 8; ++r) m = max(m, RQ8_SC(b, r));
       any |= m >= tq[b];
     }
     if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
@@ -708,14 +737,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int64_t row = row0 + 16 * (r >> 2) + (r & 3);
-          const bool hit = acc[b][r >> 2][r & 3] >= tq[b] && row < N;
+          const bool hit = RQ8_SC(b, r) >= tq[b] && row < N;
           const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
           if (m != 0ull) {
             const int pos = nst + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
             const unsigned qq = (unsigned)((w * 2 + b) * 16 + qcol);
             if (hit) {
               if (pos < RQ_STAGE) {
-                st_s[pos] = (float)acc[b][r >> 2][r & 3];  // (overwritten by the exact score: knn_rq_rescore_kernel)
+                st_s[pos] = (float)RQ8_SC(b, r);  // (overwritten by the exact score: knn_rq_rescore_kernel)
                 st_r[pos] = (uint32_t)row;
                 st_q[pos] = qq;
               } else {
@@ -754,6 +783,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
     }
   }
 }
+#undef RQ8_SC
 
 // proof of the int8 path: the hit list is complete and its k-th exact score reaches the lower bound T -- then every row of the true
 // top-k was a hit (header above).  need / gate / stats as knn_rq_proof_kernel.
@@ -817,10 +847,10 @@ hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc,
 }
 
 hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
-                          int kw, int J, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st) {
+                          int kw, int J, int planes, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st) {
 #if KNNX_MFMA16
-  hipLaunchKernelGGL(knn_i8_prep_kernel, dim3(256), dim3(64), 0, st, q_dev, nq, d, colscale, ab_enc, maxnorm, samp, kw, J, qfrag8, thr_i,
-                     thr_lb, cnt, lost);
+  hipLaunchKernelGGL(knn_i8_prep_kernel, dim3(256), dim3(64), 0, st, q_dev, nq, d, colscale, ab_enc, maxnorm, samp, kw, J, planes, qfrag8,
+                     thr_i, thr_lb, cnt, lost);
   return hipGetLastError();
 #else
   return hipErrorInvalidValue;
@@ -828,11 +858,11 @@ hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colsca
 }
 
 #if KNNX_MFMA16
-template <int KS, int NW, int NSLOT>
+template <int KS, int NW, int NSLOT, int PL = 1>
 static hipError_t launch_rq8_scan_cfg(const int8_t* X8, int64_t N, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
                                       float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st) {
   const size_t smem = (size_t)NSLOT * KS * 1024 + (size_t)NW * RQ_STAGE * 12;
-  auto kern = knn_rq8_scan_kernel<KS, NW, NSLOT>;
+  auto kern = knn_rq8_scan_kernel<KS, NW, NSLOT, PL>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost);
@@ -840,9 +870,18 @@ static hipError_t launch_rq8_scan_cfg(const int8_t* X8, int64_t N, const int8_t*
 }
 #endif
 
-hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
-                           float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st) {
+hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int* thr_i, unsigned* cnt,
+                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st) {
 #if KNNX_MFMA16
+  if (planes == 2) {  // two query planes: 4 waves x 32 queries (twice the fragments per query: 192 registers at d = 768)
+    if (nq > 128) return hipErrorInvalidValue;
+    switch (d) {
+      case 512: return launch_rq8_scan_cfg<16, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+      case 768: return launch_rq8_scan_cfg<24, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+      case 1024: return launch_rq8_scan_cfg<32, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   // up to 128 queries: four waves hold them all -- half the LDS reads and MFMAs of the 8-wave configuration, which a pass over
   // int8 rows does not hide behind HBM (8 x 32 slots: 17.4 ms per pass over 100 M x 768 whatever the batch, 76.8 GB in 12.4 ms)
   if (nq <= 128) {

@@ -108,6 +108,8 @@ struct knnx_index {
   int64_t i8_cap_rows = 0;
   int64_t i8_nrows = 0;           // rows [0, i8_nrows) are quantised with the current column scales (add() appends: only the new rows are done)
   int64_t i8_scale_rows = 0;      // rows the column scales were taken over (a full rebuild once the index has doubled since)
+  int i8_planes = 1;              // int8 planes of a query: 2 when the column scales differ widely (decided at every full build)
+  int i8_planes_env = 0;          // KNNX_I8_PLANES=1|2 forces the choice
   int8_t* i8_rows = nullptr;      // [ntotal, d]
   float* i8_colscale = nullptr;   // [d]
   int *i8_colmax = nullptr, *i8_ab = nullptr;  // [d] (encoded), [2] (encoded A, B)
@@ -233,6 +235,8 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
   {
     const char* i8 = getenv("KNNX_I8");
     ix->i8_ok = (i8 && i8[0] == '0') ? 0 : 1;
+    const char* pl = getenv("KNNX_I8_PLANES");
+    ix->i8_planes_env = (pl && (pl[0] == '1' || pl[0] == '2')) ? pl[0] - '0' : 0;
   }
   const char* rqm = getenv("KNNX_RQ_MIN_ROWS");
   if (rqm && rqm[0]) ix->rq_min_rows = atoll(rqm);
@@ -812,7 +816,7 @@ static int i8_ensure(knnx_index* ix, hipStream_t st) {
   };
   if (!ix->i8_colscale) {
     if (hipMalloc(&ix->i8_colscale, ix->d * sizeof(float)) != hipSuccess || hipMalloc(&ix->i8_colmax, ix->d * sizeof(int)) != hipSuccess ||
-        hipMalloc(&ix->i8_ab, 2 * sizeof(int)) != hipSuccess || hipMalloc(&ix->i8_qfrag, Q * ix->d) != hipSuccess ||
+        hipMalloc(&ix->i8_ab, 2 * sizeof(int)) != hipSuccess || hipMalloc(&ix->i8_qfrag, 2 * Q * ix->d) != hipSuccess ||
         hipMalloc(&ix->i8_thr, Q * sizeof(int)) != hipSuccess || hipMalloc(&ix->i8_lb, Q * sizeof(float)) != hipSuccess ||
         hipMalloc(&ix->i8_hit_s, Q * KNN_I8_CAP * sizeof(float)) != hipSuccess ||
         hipMalloc(&ix->i8_hit_r, Q * KNN_I8_CAP * sizeof(uint32_t)) != hipSuccess)
@@ -837,6 +841,16 @@ static int i8_ensure(knnx_index* ix, hipStream_t st) {
   } else {
     HIPCHK(launch_i8_build(ix->rows, ix->ntotal, ix->d, ix->i8_colmax, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
     ix->i8_scale_rows = ix->ntotal;
+    // one or two int8 planes per query (knn_i8_prep_kernel): a query's u = q * c has ONE scale, so a few columns much larger than
+    // the rest leave the others' components in the rounding error.  Two planes when the largest column scale is more than 3 x the
+    // median one; the choice is part of the build (a readback of d floats: the build has just moved the whole index).
+    std::vector<float> cs((size_t)ix->d);
+    HIPCHK(hipMemcpyAsync(cs.data(), ix->i8_colscale, (size_t)ix->d * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const float cmax = *std::max_element(cs.begin(), cs.end());
+    std::nth_element(cs.begin(), cs.begin() + ix->d / 2, cs.end());
+    const float cmed = cs[(size_t)ix->d / 2];
+    ix->i8_planes = ix->i8_planes_env ? ix->i8_planes_env : (cmax > 3.f * cmed ? 2 : 1);
   }
   ix->i8_nrows = ix->ntotal;
   ix->i8_valid = true;
@@ -852,8 +866,8 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
   bool wide_samp = false;
   r = rq_sample_pass(ix, q_dev, nq, k, KNN_I8_STRIDE, st, &tstride, &J, &wide_samp);
   if (r) return r;
-  HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J, ix->i8_qfrag, ix->i8_thr,
-                        ix->i8_lb, ix->rq_cnt, ix->rq_lost, st));
+  HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J, ix->i8_planes, ix->i8_qfrag,
+                        ix->i8_thr, ix->i8_lb, ix->rq_cnt, ix->rq_lost, st));
   // 2. the pass over the int8 rows
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->prof) {
@@ -861,7 +875,7 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, st));
   }
-  HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, nq, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
+  HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
                          ix->rq_lost, ix->n_cu, st));
   if (ix->prof) {
     HIPCHK(hipEventRecord(e1, st));
@@ -885,7 +899,9 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
 
 // how many of `remaining` queries the next scan step takes (the same choice scan_step makes)
 static int step_queries(knnx_index* ix, int remaining, int k) {
-  if (i8_usable(ix, remaining, k)) return std::min(KNN_RQ_MAX, remaining);
+  // (two planes: 128 queries per int8 pass -- a batch of more goes to the fp16 register-stationary pass, 36 ms for 256 against 2 x 19.6)
+  if (i8_usable(ix, remaining, k) && !(ix->i8_planes == 2 && remaining > 128 && rq_usable(ix, remaining, k)))
+    return std::min(ix->i8_planes == 2 ? 128 : KNN_RQ_MAX, remaining);
   if (rq_usable(ix, remaining, k)) return std::min(rq_queries_per_pass(ix->d), remaining);
   if (wide_usable(ix, remaining, k)) return std::min(KNN_NQ_MAX, remaining);
   return std::min(KNN_NQ, remaining);
@@ -898,8 +914,8 @@ static int scan_step(knnx_index* ix, const float* q_dev, int remaining, int k, f
   if (i8_usable(ix, remaining, k)) {
     r = i8_ensure(ix, st);
     if (r < 0) return r;
-    if (r == 1) {
-      nq = std::min(KNN_RQ_MAX, remaining);
+    if (r == 1 && !(ix->i8_planes == 2 && remaining > 128 && rq_usable(ix, remaining, k))) {
+      nq = std::min(ix->i8_planes == 2 ? 128 : KNN_RQ_MAX, remaining);  // (two planes: four waves x 32 queries per pass)
       r = scan_topk_i8(ix, q_dev, nq, k, D_out, I_out, st);
       *taken = nq;
       return r;
@@ -923,6 +939,11 @@ extern "C" int64_t knnx_i8_served(knnx_index* ix) {
   if (!ix) return -1;
   std::lock_guard<std::mutex> lk(ix->mu);
   return (int64_t)ix->i8_served;
+}
+extern "C" int knnx_i8_planes(knnx_index* ix) {
+  if (!ix) return -1;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  return ix->i8_valid ? ix->i8_planes : 0;
 }
 
 extern "C" int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int k, float* D_dev, int64_t* I_dev,

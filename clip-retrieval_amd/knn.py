@@ -258,6 +258,10 @@ class Mi355xIndex(_FaissShaped):
         either way."""
         return int(self._lib.knnx_i8_served(self._h))
 
+    def i8_planes(self):
+        """0: no int8 copy at the moment; 1 / 2: int8 planes per query of the first stage (include/knnx.h: knnx_i8_planes)."""
+        return int(self._lib.knnx_i8_planes(self._h))
+
     def coalesce_stats(self):
         """(batches served, queries in them, largest batch) of the library's request coalescer."""
         b, q, m = C.c_int64(0), C.c_int64(0), C.c_int64(0)

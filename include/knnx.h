@@ -225,6 +225,11 @@ int knnx_coalesce_stats(knnx_index* ix, int64_t* batches, int64_t* queries, int6
  * built on the first search after the rows changed (one pass over the rows) and costs ntotal * d bytes; KNNX_I8=0 in the environment
  * turns it off, and so does a failed allocation.  knnx_i8_served: queries answered through this path so far (-1: null index). */
 int64_t knnx_i8_served(knnx_index* ix);
+/* 0: no int8 copy at the moment; 1 / 2: int8 planes per query.  A query is quantised as u = q * (column scales) with ONE scale, so an
+ * index with a few columns much larger than the rest (largest column scale > 3 x the median one) gets a second plane for what the
+ * first left -- twice the matrix work, four waves x 32 queries per pass -- instead of admitting (and re-scoring) two orders of
+ * magnitude more rows.  Decided at every full build of the copy; KNNX_I8_PLANES=1|2 forces it. */
+int knnx_i8_planes(knnx_index* ix);
 
 /* One request of KnnService.knn_search with its dedup fused (clip_back.py:362 + :290-309): the top-k (k <= 64) of ONE query, and
  * the links of the reference's `get_non_uniques` -- every pair of result ranks (i < j) whose stored vectors, L2-normalised in

@@ -739,6 +739,44 @@ def test_i8_first_stage_after_the_rows_change(monkeypatch):
     ix.close()
 
 
+def test_i8_first_stage_two_query_planes_for_dominant_columns(monkeypatch):
+    """Embeddings with a few dominant dimensions (two columns 6 x the rest plus a common offset, as CLIP embeddings have): the column
+    scales differ widely, the library picks TWO int8 planes per query, results equal the oracle without a single fallback; an
+    isotropic index picks one plane.  (With one plane forced the same data is still answered exactly -- through wider hit lists.)"""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")
+    d, n = 768, 150_000
+    rng = np.random.default_rng(51)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[:, :2] = 6.0 * x[:, :2] + 3.0
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x = x.astype(np.float16)
+    o = FlatIPOracle(d)
+    o.add(x)
+    q = _queries(200, d, seed=52, x=x)
+    Do, Io = o.search(q, 40)
+    for forced, want in ((None, 2), ("1", 1)):
+        if forced:
+            monkeypatch.setenv("KNNX_I8_PLANES", forced)
+        ix = Mi355xIndex(d)
+        ix.add(x)
+        for lo, hi in ((0, 1), (1, 41), (41, 200)):
+            D, I = ix.search(q[lo:hi], 40)
+            _check(D, I, Do[lo:hi], Io[lo:hi], f"dominant columns, planes={want}, queries {lo}:{hi}")
+        assert ix.i8_planes() == want and ix.i8_served() == 200
+        if want == 2:
+            assert ix.stats()[1] == 0, "two planes must not need the fallback on this corpus"
+        ix.close()
+    monkeypatch.delenv("KNNX_I8_PLANES")
+    iso = Mi355xIndex(d)
+    iso.add(_data(60_000, d, seed=53))
+    iso.search(_queries(3, d, seed=54), 5)
+    assert iso.i8_planes() == 1
+    iso.close()
+
+
 def test_i8_first_stage_overflow_falls_back(monkeypatch):
     """200 000 copies of one row and queries equal to it: every copy passes the int8 admission, the 32 768-entry hit list
     overflows, the query is answered by the gated exact scan -- ids in ascending order among the ties."""
