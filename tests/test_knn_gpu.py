@@ -765,7 +765,8 @@ def test_i8_first_stage_two_query_planes_for_dominant_columns(monkeypatch):
         for lo, hi in ((0, 1), (1, 41), (41, 200)):
             D, I = ix.search(q[lo:hi], 40)
             _check(D, I, Do[lo:hi], Io[lo:hi], f"dominant columns, planes={want}, queries {lo}:{hi}")
-        assert ix.i8_planes() == want and ix.i8_served() == 200
+        # (the 159-query batch: with two planes more than 128 queries go to the fp16 register-stationary pass)
+        assert ix.i8_planes() == want and ix.i8_served() == (41 if want == 2 else 200)
         if want == 2:
             assert ix.stats()[1] == 0, "two planes must not need the fallback on this corpus"
         ix.close()
