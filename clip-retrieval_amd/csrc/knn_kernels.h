@@ -133,9 +133,9 @@ int i8_supported(int d);
 hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
 hipError_t launch_i8_quant(const _Float16* X, int64_t N, int d, const float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
 hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
-                          int kw, int J, int planes, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st);
+                          int kw, int J, int planes, int refine, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st);
 hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int* thr_i, unsigned* cnt,
-                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st);
+                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st);
 hipError_t launch_i8_proof(int nq, int k, const float* D, const float* thr_lb, const unsigned* cnt, unsigned cap, const unsigned* lost,
                            unsigned* need, unsigned* gate, unsigned long long* stats, hipStream_t st);
 

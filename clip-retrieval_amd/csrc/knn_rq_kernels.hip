@@ -506,9 +506,12 @@ __global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __res
 // lower bound thr_lb (= T) of the proof; resets the hit counters.  Unused slots: zero fragments, thr_i = INT_MAX.
 __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict__ q, int nq, int d, const float* __restrict__ colscale,
                                                         const int* __restrict__ ab_enc, const int* __restrict__ maxnorm,
-                                                        const float* __restrict__ samp, int kw, int J, int planes, int8_t* __restrict__ qfrag8,
-                                                        int* __restrict__ thr_i, float* __restrict__ thr_lb,
+                                                        const float* __restrict__ samp, int kw, int J, int planes, int refine,
+                                                        int8_t* __restrict__ qfrag8, int* __restrict__ thr_i, float* __restrict__ thr_lb,
                                                         unsigned* __restrict__ cnt, unsigned* __restrict__ lost) {
+  // refine = 1 (second call of a two-level sample, knnx_api.hip scan_topk_i8): samp holds EXACT scores (re-scored hits of an int8 pass
+  // over every 32nd tile) -- no eps_hi -- and the bound only ever rises: T = max(previous T, J-th best); fewer than J sample hits
+  // leave the previous threshold in place.
   // planes = 2: the query is TWO int8 planes, u ~ s_u u8 + (s_u / 128) u8b (the second quantises what the first left), and the scan
   // compares 128 * sum(u8 x8) + sum(u8b x8) -- for indexes whose columns differ widely in size (CLIP embeddings have a few dominant
   // dimensions): one scale for all of u then leaves |u - s_u u8| * B as the whole error (1.25 sigma of the scores in a simulation with
@@ -568,12 +571,16 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
   if (lane == 0) {
     int ti = 0x7fffffff;
     float lb = INFINITY;
+    bool keep = false;
     if (n < nq) {
       const float v = samp[(size_t)n * kw + (J - 1)];
-      if (v > -FLT_MAX) {
+      if (refine && !(v > -FLT_MAX)) {
+        keep = true;
+      } else if (v > -FLT_MAX) {
         // eps_hi: the sample scores are fp16-hi approximations of the exact scores (cf. knn_rq_proof_kernel)
-        const float eps_hi = (sqrtf(e2) + (float)d * 1.2e-7f * sqrtf(n2)) * rq_dec_f(*maxnorm);
+        const float eps_hi = refine ? 0.f : (sqrtf(e2) + (float)d * 1.2e-7f * sqrtf(n2)) * rq_dec_f(*maxnorm);
         lb = v - eps_hi;
+        if (refine) lb = fmaxf(lb, thr_lb[n]);
         const float A = __int_as_float(ab_enc[0]), B = __int_as_float(ab_enc[1]);
         const float eps8 = (sqrtf(nu2) * A + sqrtf(er2) * B) * 1.00002f + 1e-6f * fabsf(lb);
         const float t = (lb - eps8) / (planes == 2 ? su * (1.f / 128.f) : su);
@@ -584,8 +591,10 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
         ti = (int)0x80000000;
       }
     }
-    thr_i[n] = ti;
-    thr_lb[n] = lb;
+    if (!keep) {
+      thr_i[n] = ti;
+      thr_lb[n] = lb;
+    }
     cnt[n] = 0u;
     lost[n] = 0u;
   }
@@ -599,11 +608,13 @@ struct Rq8Tile {
   unsigned m0b;      // LDS address of the slot + this wave's first piece
   unsigned vo;       // per-lane byte offset (row of the wave's half, 16-byte column group)
 };
+// (t counts the tiles the pass VISITS: tile t * tstep of the index -- tstep > 1 is the sample pass of a two-level threshold; nj = visited
+// tiles; past the end the last visited tile is re-loaded, which keeps the vmcnt arithmetic of the main loop uniform)
 template <int KS, int NW>
-__device__ __forceinline__ Rq8Tile rq8_tile(const int8_t* __restrict__ X8, int64_t t, int64_t ntile, int64_t last, const RqLaneOff& lo,
+__device__ __forceinline__ Rq8Tile rq8_tile(const int8_t* __restrict__ X8, int64_t t, int64_t nj, int tstep, int64_t last, const RqLaneOff& lo,
                                             unsigned lds_base, int slot, int w) {
   constexpr int TILE_BYTES = KS * 1024;
-  const int64_t tt = t < ntile ? t : last;
+  const int64_t tt = (t < nj ? t : nj - 1) * tstep;
   Rq8Tile r;
   const int li = tt == last ? 1 : 0;
   r.vo = (w & 1) ? lo.v1[li] : lo.v[li];
@@ -611,7 +622,7 @@ __device__ __forceinline__ Rq8Tile rq8_tile(const int8_t* __restrict__ X8, int64
   r.m0b = lds_base + slot * TILE_BYTES + w * 1024;
   return r;
 }
-#define RQ8_TILE(t_, slot_) rq8_tile<KS, NW>(X8, (t_), ntile, last, lane_off, lds_base, (slot_), w)
+#define RQ8_TILE(t_, slot_) rq8_tile<KS, NW>(X8, (t_), nj, tstep, last, lane_off, lds_base, (slot_), w)
 template <int NW, int IDX>
 __device__ __forceinline__ void rq8_issue_one(const Rq8Tile& r) {
   const char* p = r.base + IDX * (NW / 2) * 64;
@@ -653,7 +664,7 @@ template <int KS, int NW, int NSLOT, int PL>
 __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int8_t* __restrict__ X8, int64_t N, const int8_t* __restrict__ qfrag8,
                                                                       const int* __restrict__ thr_i, unsigned* __restrict__ g_cnt, unsigned cap,
                                                                       float* __restrict__ hit_s, uint32_t* __restrict__ hit_r,
-                                                                      unsigned* __restrict__ g_lost) {
+                                                                      unsigned* __restrict__ g_lost, int tstep) {
   constexpr int D = KS * 16;  // the row as fp16-sized columns (tile / DMA helpers)
   constexpr int TILE_BYTES = KS * 1024, DPW = KS / NW, NSL = KS / 2;
   static_assert(KS % NW == 0 && KS % 2 == 0, "pieces must divide evenly among the waves");
@@ -690,6 +701,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
 
   const int64_t ntile = (N + 31) >> 5;
   const int64_t last = ntile - 1;
+  const int64_t nj = (ntile + tstep - 1) / tstep;  // tiles this pass visits
   const RqLaneOff lane_off = rq_lane_offsets(lane, D, (int)(N - 1 - last * 32));
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
@@ -700,7 +712,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
 
   int nst = 0;
   int slot = 0;
-  for (; t < ntile; t += gstride) {
+  for (; t < nj; t += gstride) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NSLOT - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
     rq8_ksteps<KS, NW, DPW, PL, 0>(xa, A, acc, Q, refill);
 
     // ---- filter: lane (qcol, hb) owns rows row0 + 16 half + e of its query column in each block; integer compares
-    const int64_t row0 = t * 32 + 4 * hb;
+    const int64_t row0 = t * tstep * 32 + 4 * hb;
     // (two planes: |128 * plane 0| <= 128 * 127 * 127 * d < 2^31 at d <= 1024, plane 1 adds at most 127 * 127 * d)
 #define RQ8_SC(b, r) (PL == 2 ? acc[0][b][(r) >> 2][(r) & 3] * 128 + acc[PL - 1][b][(r) >> 2][(r) & 3] : acc[0][b][(r) >> 2][(r) & 3])
     bool any = false;
@@ -847,10 +859,11 @@ hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc,
 }
 
 hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
-                          int kw, int J, int planes, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st) {
+                          int kw, int J, int planes, int refine, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost,
+                          hipStream_t st) {
 #if KNNX_MFMA16
-  hipLaunchKernelGGL(knn_i8_prep_kernel, dim3(256), dim3(64), 0, st, q_dev, nq, d, colscale, ab_enc, maxnorm, samp, kw, J, planes, qfrag8,
-                     thr_i, thr_lb, cnt, lost);
+  hipLaunchKernelGGL(knn_i8_prep_kernel, dim3(256), dim3(64), 0, st, q_dev, nq, d, colscale, ab_enc, maxnorm, samp, kw, J, planes, refine,
+                     qfrag8, thr_i, thr_lb, cnt, lost);
   return hipGetLastError();
 #else
   return hipErrorInvalidValue;
@@ -860,25 +873,26 @@ hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colsca
 #if KNNX_MFMA16
 template <int KS, int NW, int NSLOT, int PL = 1>
 static hipError_t launch_rq8_scan_cfg(const int8_t* X8, int64_t N, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
-                                      float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st) {
+                                      float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st) {
   const size_t smem = (size_t)NSLOT * KS * 1024 + (size_t)NW * RQ_STAGE * 12;
   auto kern = knn_rq8_scan_kernel<KS, NW, NSLOT, PL>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, tstep);
   return hipGetLastError();
 }
 #endif
 
 hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int* thr_i, unsigned* cnt,
-                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, hipStream_t st) {
+                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st) {
+  if (tstep < 1) return hipErrorInvalidValue;
 #if KNNX_MFMA16
   if (planes == 2) {  // two query planes: 4 waves x 32 queries (twice the fragments per query: 192 registers at d = 768)
     if (nq > 128) return hipErrorInvalidValue;
     switch (d) {
-      case 512: return launch_rq8_scan_cfg<16, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
-      case 768: return launch_rq8_scan_cfg<24, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
-      case 1024: return launch_rq8_scan_cfg<32, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+      case 512: return launch_rq8_scan_cfg<16, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+      case 768: return launch_rq8_scan_cfg<24, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+      case 1024: return launch_rq8_scan_cfg<32, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
       default: return hipErrorInvalidValue;
     }
   }
@@ -886,16 +900,16 @@ hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int plane
   // int8 rows does not hide behind HBM (8 x 32 slots: 17.4 ms per pass over 100 M x 768 whatever the batch, 76.8 GB in 12.4 ms)
   if (nq <= 128) {
     switch (d) {
-      case 512: return launch_rq8_scan_cfg<16, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
-      case 768: return launch_rq8_scan_cfg<24, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
-      case 1024: return launch_rq8_scan_cfg<32, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+      case 512: return launch_rq8_scan_cfg<16, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+      case 768: return launch_rq8_scan_cfg<24, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+      case 1024: return launch_rq8_scan_cfg<32, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
       default: return hipErrorInvalidValue;
     }
   }
   switch (d) {
-    case 512: return launch_rq8_scan_cfg<16, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
-    case 768: return launch_rq8_scan_cfg<24, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
-    case 1024: return launch_rq8_scan_cfg<32, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, st);
+    case 512: return launch_rq8_scan_cfg<16, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+    case 768: return launch_rq8_scan_cfg<24, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+    case 1024: return launch_rq8_scan_cfg<32, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
     default: return hipErrorInvalidValue;
   }
 #else

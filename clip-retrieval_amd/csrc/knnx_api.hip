@@ -864,10 +864,27 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
   // threshold buys the hits back)
   int tstride = 1, J = 1;
   bool wide_samp = false;
-  r = rq_sample_pass(ix, q_dev, nq, k, KNN_I8_STRIDE, st, &tstride, &J, &wide_samp);
+  const int64_t ntiles = (ix->ntotal + 31) / 32;
+  // Up to 64 queries: ONE exact sample pass over every 32nd tile (one 64-query scan, ~0.8 ms at 100 M rows).  More: four such scans
+  // side by side cost ~3 ms of a 25 ms batch, so the threshold comes in two levels -- the coarse exact sample of the fp16 path (every
+  // 763rd tile), then an int8 pass over every 32nd tile with THAT threshold (one pass for all the queries: 2.4 GB), whose hits are
+  // re-scored exactly; their J-th best score is the threshold of the pass over everything.
+  const bool two_level = nq > KNN_NQ_MAX && ntiles >= (int64_t)4096 * KNN_I8_STRIDE;
+  r = rq_sample_pass(ix, q_dev, nq, k, two_level ? KNN_RQ_STRIDE : KNN_I8_STRIDE, st, &tstride, &J, &wide_samp);
   if (r) return r;
-  HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J, ix->i8_planes, ix->i8_qfrag,
+  HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J, ix->i8_planes, 0, ix->i8_qfrag,
                         ix->i8_thr, ix->i8_lb, ix->rq_cnt, ix->rq_lost, st));
+  if (two_level) {
+    HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s,
+                           ix->i8_hit_r, ix->rq_lost, ix->n_cu, KNN_I8_STRIDE, st));
+    HIPCHK(launch_rq_rescore(ix->rows, d, q_dev, nq, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r, ix->rq_cntc, st));
+    // the exact top-64 of the sampled hits, where the sample passes put theirs: the refining prep reads its J-th entry
+    HIPCHK(launch_merge_u32(ix->i8_hit_s, ix->i8_hit_r, ix->rq_cntc, 1, nq, (int)KNN_I8_CAP, nq, KNN_WIDE_KW, 0, nullptr, ix->rq_samp,
+                            ix->rq_samp_i, nullptr, st));
+    const int J2 = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
+    HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J2, ix->i8_planes, 1,
+                          ix->i8_qfrag, ix->i8_thr, ix->i8_lb, ix->rq_cnt, ix->rq_lost, st));
+  }
   // 2. the pass over the int8 rows
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ix->prof) {
@@ -876,7 +893,7 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
     HIPCHK(hipEventRecord(e0, st));
   }
   HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
-                         ix->rq_lost, ix->n_cu, st));
+                         ix->rq_lost, ix->n_cu, 1, st));
   if (ix->prof) {
     HIPCHK(hipEventRecord(e1, st));
     ix->prof_events.emplace_back(e0, e1);
