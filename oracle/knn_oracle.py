@@ -258,3 +258,56 @@ def synth_mixture_rows(rows, d: int, seed: int, n_clusters: int) -> np.ndarray:
     ss = (v * v).sum(axis=1, keepdims=True)
     scale = 1.0 / np.sqrt(ss.astype(np.float64))
     return (v.astype(np.float64) * scale).astype(np.float32).astype(np.float16)
+
+
+# ----------------------------------------------------------------------------------------------
+# The int8 first stage of the flat scans (clip-retrieval_amd/csrc/knn_rq_kernels.hip, "int8 first stage"; no counterpart in the
+# reference or in faiss' IndexFlatIP: it is an accelerator in front of the exact scores, and what has to hold is its BOUND).
+# A float32 restatement of the kernels' arithmetic -- knn_i8_colmax / colscale / quant / prep -- so that the bound and the admission
+# rule can be checked on the CPU against brute force (tests/test_oracle.py); the GPU tests check the kernels' RESULTS against
+# FlatIPOracle.
+# ----------------------------------------------------------------------------------------------
+class Int8FirstStage:
+    """x8 = clamp(rint(x / c)), c_j = max_i |x_ij| / 127 (1 where a column is all zero); queries u = q * c as one or two int8 planes."""
+
+    def __init__(self, rows_fp16, colscale=None):
+        x = np.asarray(rows_fp16, dtype=np.float16).astype(np.float32)
+        if colscale is None:
+            m = np.abs(x).max(axis=0) if len(x) else np.zeros(x.shape[1], np.float32)
+            colscale = np.where(m > 0, m / np.float32(127), np.float32(1)).astype(np.float32)
+        self.c = np.asarray(colscale, dtype=np.float32)
+        y = x / self.c
+        self.x8 = np.clip(np.rint(y), -127, 127).astype(np.float32)
+        # A, B: maxima over the rows AS STORED (clamped values included), 2-norms per row
+        self.A = np.float32(np.sqrt(((y - self.x8) ** 2).sum(axis=1)).max()) if len(x) else np.float32(0)
+        self.B = np.float32(np.sqrt((self.x8 ** 2).sum(axis=1)).max()) if len(x) else np.float32(0)
+        self.x = x
+
+    def quantise_queries(self, q, planes: int = 1):
+        """-> (integer scores' scale s [nq], planes [planes, nq, d] of int8 values as float32, eps8 [nq])."""
+        q = np.asarray(q, dtype=np.float32)
+        u = q * self.c
+        mu = np.abs(u).max(axis=1)
+        su = np.where(mu > 0, mu / np.float32(127), np.float32(1)).astype(np.float32)
+        u8 = np.clip(np.rint(u / su[:, None]), -127, 127).astype(np.float32)
+        res = u - su[:, None] * u8
+        out, s = [u8], su
+        if planes == 2:
+            su2 = su * np.float32(1 / 128)
+            u8b = np.clip(np.rint(res / su2[:, None]), -127, 127).astype(np.float32)
+            res = res - su2[:, None] * u8b
+            out, s = [u8, u8b], su2
+        eps8 = (np.sqrt((u ** 2).sum(axis=1)) * self.A + np.sqrt((res ** 2).sum(axis=1)) * self.B) * np.float32(1.00002)
+        return s, np.stack(out), eps8.astype(np.float32)
+
+    def integer_scores(self, planes_u8):
+        """The int32 sums the scan compares: sum(u8 x8) for one plane, 128 * sum(u8 x8) + sum(u8b x8) for two (exact in int64 here)."""
+        acc = [np.rint(p.astype(np.float64) @ self.x8.astype(np.float64).T).astype(np.int64) for p in planes_u8]
+        return acc[0] if len(acc) == 1 else 128 * acc[0] + acc[1]
+
+    def admitted(self, q, T, planes: int = 1):
+        """Boolean [nq, n]: rows the scan admits for exact-score lower bounds T [nq] (thr_i = floor((T - eps8 - 1e-6 |T|) / s) - 1)."""
+        s, pl, eps8 = self.quantise_queries(q, planes)
+        T = np.asarray(T, dtype=np.float32)
+        thr = np.floor((T - eps8 - np.float32(1e-6) * np.abs(T)) / s).astype(np.int64) - 1
+        return self.integer_scores(pl) >= thr[:, None]

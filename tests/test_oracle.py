@@ -259,3 +259,48 @@ def test_parity_gate_rejects_wrong_rows_and_accepts_the_measured_error():
     assert parity_report(sw, near)["cos"].min() >= NORTH_STAR_BAR  # would have passed
     with pytest.raises(AssertionError):
         parity_gate(sw, near, "negative")  # nearest-row rule catches it
+
+
+@pytest.mark.parametrize("corpus", ["isotropic", "dominant_columns", "appended_rows_clamp", "tiny_and_zero_columns"])
+@pytest.mark.parametrize("planes", [1, 2])
+def test_int8_first_stage_bound_and_admission_hold(corpus, planes):
+    """The inequality the int8 first stage of the flat scans stands on (csrc/knn_rq_kernels.hip; restated in float32 by
+    oracle.knn_oracle.Int8FirstStage): |exact - approx| <= eps8 for EVERY (query, row) pair, hence every row whose exact score reaches a
+    lower bound T is admitted by the integer compare -- on isotropic rows, rows with dominant columns, rows appended after the column
+    scales were fixed (components clamp at +-127), and degenerate columns; with one and with two query planes."""
+    from oracle.knn_oracle import Int8FirstStage
+
+    rng = np.random.default_rng(hash(corpus) % 1000 + planes)
+    d, n = 256, 4000
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    colscale = None
+    if corpus == "dominant_columns":
+        x[:, :3] = 7.0 * x[:, :3] + 4.0
+    if corpus == "tiny_and_zero_columns":
+        x[:, 5] = 0.0
+        x[:, 6] *= 1e-4
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    if corpus == "appended_rows_clamp":
+        colscale = Int8FirstStage(x[:500].astype(np.float16)).c  # scales of the first 500 rows only ...
+        x[500:] *= 2.5                                           # ... and the later rows exceed them
+    st = Int8FirstStage(x.astype(np.float16), colscale)
+    if corpus == "appended_rows_clamp":
+        assert (np.abs(st.x8) == 127).mean() > 0.001, "this corpus is meant to clamp"
+    q = np.concatenate([x[:40] + 0.05 * rng.standard_normal((40, d)).astype(np.float32), 3.0 * rng.standard_normal((24, d)).astype(np.float32)])
+    q = q.astype(np.float32)
+    exact = q.astype(np.float64) @ st.x.astype(np.float64).T
+    s, pl, eps8 = st.quantise_queries(q, planes)
+    approx = s[:, None].astype(np.float64) * st.integer_scores(pl)
+    err = np.abs(exact - approx)
+    assert (err <= eps8[:, None].astype(np.float64)).all(), f"bound violated: max err/eps {np.max(err / eps8[:, None]):.3f}"
+    assert np.max(err / eps8[:, None]) > 0.01, "the bound is vacuous on this corpus (test is not exercising it)"
+    # admission: T = the 10th best exact score of each query; every row at or above it must pass the integer compare
+    T = np.sort(exact, axis=1)[:, -10].astype(np.float32)
+    adm = st.admitted(q, T, planes)
+    must = exact >= T[:, None].astype(np.float64)
+    assert (adm | ~must).all(), "a row whose exact score reaches the threshold was not admitted"
+    # ... and the band is not the whole index (the point of the stage): the unit-norm queries on the well-conditioned corpora
+    # (4 000 rows and a threshold at rank 10 make the band look wide: at 10^8 rows it is a few 10^4 rows, DESIGN 4h)
+    if corpus == "isotropic" or (planes == 2 and corpus == "dominant_columns"):
+        frac = adm[:40].mean()
+        assert frac < 0.25, f"{frac:.2f} of the rows admitted"
