@@ -647,8 +647,8 @@ def test_rq_scan_ties_floods_and_fallback(rq_on_small_indexes):
             assert np.allclose(D, Do, atol=1e-5)
         if rq_on_small_indexes == "fp16":
             assert ix.stats()[1] > 0, f"{name}: expected failed proofs (fallback path untested otherwise)"
-        # (int8: ties and 40 000 equal rows are ordinary hits -- its lists hold 32 768 like the fp16 pass's, but its sample pass is the whole index here -- and the proof is about completeness only;
-        # its fallback is exercised by test_i8_first_stage_overflow_falls_back)
+        # (int8: its proof is about completeness only -- exact ties at the threshold are ordinary hits, so the duplicated corpus needs
+        # no fallback there; the flood overflows its 32 768-entry list as well; test_i8_first_stage_overflow_falls_back asserts that path)
         ix.close()
 
 
