@@ -957,6 +957,15 @@ hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st) {
     if (d == 42) return launch_sp_epi<EPI_BIAS_RESID_F32, 42>(g, grid, st);
     if (d == 43) return launch_sp_epi<EPI_BIAS_RESID_F32, 43>(g, grid, st);
   }
+  {  // phase timer of the encoder's own forms (fp16 operands: QKV / fc1; fp16 in-place residual: out_proj / fc2)
+    const char* dbg = getenv("CLIPX_GEMM_DBG");
+    if (dbg && atoi(dbg) == 16) {
+      if (g.f16 && g.epi == EPI_BIAS_F16) return launch_sp_epi<EPI_BIAS_F16, 16, true>(g, grid, st);
+      if (g.f16 && g.epi == EPI_BIAS_QGELU_BF16) return launch_sp_epi<EPI_BIAS_QGELU_BF16, 16, true>(g, grid, st);
+      if (g.f16 && g.epi == EPI_BIAS_BF16) return launch_sp_epi<EPI_BIAS_BF16, 16, true>(g, grid, st);
+      if (!g.f16 && g.epi == EPI_BIAS_RESID_H16) return launch_sp_epi<EPI_BIAS_RESID_H16, 16>(g, grid, st);
+    }
+  }
 #endif
   if (g.f16) {
     switch (g.epi) {
