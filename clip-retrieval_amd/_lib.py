@@ -59,6 +59,7 @@ SIGNATURES = {
     "knnx_ivf_set_lists": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "knnx_ivf_set_nprobe": (C.c_int, [_P, C.c_int]),
     "knnx_ivf_nlist": (C.c_int, [_P]),
+    "knnx_ivf_nprobe": (C.c_int, [_P]),
     "knnx_ivf_last_scan_tiles": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "knnx_ivfb_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "knnx_ivfb_destroy": (None, [_P]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "knnx_set_coalesce": (C.c_int, [_P, C.c_int]),
     "knnx_coalesce_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "knnx_i8_served": (C.c_int64, [_P]),
+    "knnx_i8_rows": (C.c_int64, [_P]),
     "knnx_i8_planes": (C.c_int, [_P]),
     "knnx_search_dedup": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_float, _P, C.c_int, C.POINTER(C.c_int)]),
     "knnx_get_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

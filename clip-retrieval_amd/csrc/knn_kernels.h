@@ -82,7 +82,7 @@ constexpr unsigned RANGE_SORT_SMALL = 4096;
 hipError_t launch_range_sort_long(const float* vs, const uint32_t* ri, unsigned n, int64_t id_base, const int64_t* idmap_or_null,
                                   int key_bits, uint32_t* k0, uint32_t* k1, float* v0, float* v1, unsigned* hist, float* D, int64_t* I,
                                   hipStream_t st);
-hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st);
+hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st, int dominant = 0);
 // the mixture corpus of BASELINE config 5 (knn_kernels.hip: knn_synth_mix_kernel): destination row i = corpus row
 // row_begin + i * row_stride; P_table = synth_mix_table_bytes(d) bytes of device scratch
 hipError_t launch_synth_mix(_Float16* X, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed, int64_t n_clusters,
@@ -109,7 +109,7 @@ hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, co
                           float* thr, unsigned* cnt, unsigned* lost, hipStream_t st);
 hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, int nq, const _Float16* qfrag, const float* thr, unsigned* cnt,
                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
-                          hipStream_t st);
+                          hipStream_t st, uint32_t row_off = 0);  // row_off: X is a slice starting at that row of the index (added to the hits' rows)
 // IVF build (knn_rq_kernels.hip / knn_kernels.hip): out[i] = argmax_l <P[i], C[l]> (fp16 rows, exact fp32 scores, ties -> smaller l)
 hipError_t launch_assign(const _Float16* C, int64_t nlist, int d, const _Float16* P, int64_t n, int32_t* out, hipStream_t st);
 // one Lloyd update (spherical): cent[l] = fp16(unit-norm mean of X[order[off[l] .. off[l+1])]) (lists with no member keep their row); one workgroup per list
@@ -130,10 +130,12 @@ hipError_t launch_rq_proof(const float* q, int nq, int d, int k, const float* D,
 constexpr int KNN_I8_STRIDE = 32;          // the sample pass visits every S-th tile, S = min(this, tiles / 4096): threshold ~ rank (k + 8) S
 constexpr unsigned KNN_I8_CAP = KNN_RQ_CAP;  // hit list entries per query (knn_merge_kernel holds a query's whole list in LDS: 32 768 x 4 B)
 int i8_supported(int d);
-hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
-hipError_t launch_i8_quant(const _Float16* X, int64_t N, int d, const float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
+hipError_t launch_i8_build(const _Float16* X, int64_t N, int64_t n8, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
+hipError_t launch_i8_quant(const _Float16* X, int64_t N, int64_t row_from, int64_t row_to, int d, const float* colscale, int8_t* X8, int* ab_enc,
+                           hipStream_t st);
 hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
-                          int kw, int J, int planes, int refine, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost, hipStream_t st);
+                          int kw, int J, int planes, int refine, int8_t* qfrag8, int* thr_i, float* thr_lb, float* thr_rest, unsigned* cnt,
+                          unsigned* lost, hipStream_t st);
 hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int* thr_i, unsigned* cnt,
                            unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st);
 hipError_t launch_i8_proof(int nq, int k, const float* D, const float* thr_lb, const unsigned* cnt, unsigned cap, const unsigned* lost,

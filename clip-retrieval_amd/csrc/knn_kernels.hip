@@ -629,8 +629,12 @@ __device__ __forceinline__ int synth_v(uint64_t seed, uint64_t idx) {
   return (int)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48)) - 131070;
 }
 
+// dominant != 0 (corpus kind 2: "CLIP-like" anisotropy): columns 0 .. 2 carry 6 v + 113 511 (three standard deviations of v: a common
+// offset plus a six-fold spread, as a few dimensions of real CLIP embeddings do) before the row is normalised -- the corpus on which
+// the int8 first stage needs its second query plane; oracle/knn_oracle.py: synth_rows(..., dominant=True).
+constexpr int SYNTH_DOM_COLS = 3, SYNTH_DOM_GAIN = 6, SYNTH_DOM_OFFSET = 113511;
 __global__ __launch_bounds__(256) void knn_synth_kernel(_Float16* __restrict__ X, int64_t row_begin, int64_t n, int d,
-                                                       uint64_t seed) {
+                                                       uint64_t seed, int dominant) {
   const int lane = threadIdx.x & 63;
   const int64_t r = row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= row_begin + n) return;
@@ -643,6 +647,7 @@ __global__ __launch_bounds__(256) void knn_synth_kernel(_Float16* __restrict__ X
     v[e] = 0;
     if (c < d) {
       v[e] = synth_v(seed, (uint64_t)r * (uint64_t)d + (uint64_t)c);
+      if (dominant && c < SYNTH_DOM_COLS) v[e] = SYNTH_DOM_GAIN * v[e] + SYNTH_DOM_OFFSET;
       ss += (long long)v[e] * (long long)v[e];
     }
   }
@@ -1265,12 +1270,12 @@ hipError_t launch_range_sort(const float* rs, const uint32_t* ri, const unsigned
                      (unsigned)RANGE_SORT_SMALL);
   return hipGetLastError();
 }
-hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st) {
+hipError_t launch_synth(_Float16* X, int64_t row_begin, int64_t n, int d, uint64_t seed, hipStream_t st, int dominant) {
   if (n == 0) return hipSuccess;
   const int64_t chunk = 1 << 22;  // rows per launch (grid.x limit)
   for (int64_t o = 0; o < n; o += chunk) {
     const int64_t m = (n - o) < chunk ? (n - o) : chunk;
-    hipLaunchKernelGGL(knn_synth_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, X, row_begin + o, m, d, seed);
+    hipLaunchKernelGGL(knn_synth_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, X, row_begin + o, m, d, seed, dominant);
   }
   return hipGetLastError();
 }

@@ -89,7 +89,7 @@ __global__ void knn_rq_prep_kernel(const float* __restrict__ q, int nq, int d, i
 #pragma unroll
   for (int j = 0; j < 8; ++j) hi[j] = (n < nq) ? (_Float16)q[(size_t)n * d + KW * s + 8 * h + j] : (_Float16)0.f;
   reinterpret_cast<half8*>(qfrag)[((size_t)b * gridDim.x + s) * 64 + lane] = hi;
-  if (s == 0 && lane < QB) {
+  if (s == 0 && lane < QB && thr) {  // (thr == null: fragments only -- the fp16 rest pass of a partial int8 copy brings its own thresholds)
     float t = INFINITY;
     if (n < nq) {
       const float v = samp[(size_t)n * kw + (J - 1)];
@@ -231,7 +231,7 @@ template <int KS, int QBW, int NW, int NSLOT>
 __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
     const _Float16* __restrict__ X, int64_t N, const _Float16* __restrict__ qfrag, const float* __restrict__ thr,
     unsigned* __restrict__ g_cnt, unsigned cap, float* __restrict__ hit_s, uint32_t* __restrict__ hit_r,
-    unsigned* __restrict__ g_lost, const unsigned* __restrict__ gate) {
+    unsigned* __restrict__ g_lost, const unsigned* __restrict__ gate, uint32_t row_off /* added to the row of a hit: X may be a slice */) {
   constexpr int D = KS * 16;
   constexpr int TILE_BYTES = KS * 1024;        // 32 rows x D x 2 B, stored as KS lane-linear 1 KiB k-step blocks
   constexpr int DPW = KS / NW;                 // DMA instructions per wave per tile: NW waves x DPW consecutive k-steps
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
             if (hit) {
               if (pos < RQ_STAGE) {
                 st_s[pos] = RQ_SCORE(b, r);
-                st_r[pos] = (uint32_t)row;
+                st_r[pos] = (uint32_t)row + row_off;
                 st_q[pos] = qq;
               } else {
                 g_lost[qq] = 1u;  // staging overflow (flood of hits in one tile step): the query falls back
@@ -459,45 +459,68 @@ __global__ void knn_i8_colscale_kernel(const int* __restrict__ colmax_enc, int d
     colscale[c] = m > 0.f ? m / 127.f : 1.f;
   }
 }
-// a wave per row at a time (grid-stride over the rows): x8 = clamp(rint(x / c)), and the maxima A = max |y - x8|, B = max |x8|
-// (2-norms per row) into ab_enc[0..1] -- ONE atomic pair per wave at the end (a pair per row, 2 x 10^8 atomics on two addresses,
-// made the first version of this kernel take 2.3 s for 100 M rows: profiles/r04zzz_kernel_stats.csv)
-__global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __restrict__ X, int64_t N, int d, const float* __restrict__ colscale,
-                                                          int8_t* __restrict__ X8, int* __restrict__ ab_enc) {
-  const int lane = threadIdx.x & 63;
+// Layout of the int8 copy (round 5): NOT row-major.  X8 is the LDS image of the scan, tile after tile: tile t (rows 32 t .. + 32) is
+// d / 32 pieces of 1 KiB, piece p = 2 * slab + half, and inside a piece lane l = 16 * q4 + r holds the 16 bytes (columns 64 slab +
+// 16 q4 .. + 16) of row 32 t + 16 half + r.  One global_load_lds_dwordx4 of the scan then moves ONE CONTIGUOUS KiB (eight full 128-B
+// lines) instead of 16 rows x 64 B -- half a line per request, which held the row-major pass at 0.61 of HBM.  The copy
+// is private to this library (rows are re-scored and reconstructed from the fp16 rows), so its layout is free.
+// Quantisation: a wave takes one 16-row half tile at a time (grid-stride) and walks its slabs: lane (r, q4) reads its 32 B of fp16
+// (four lanes = one full line of the row), writes its 16 B of the piece (the wave = the contiguous KiB), and keeps the row's
+// partial sums of A^2 = |y - x8|^2 and B^2 = |x8|^2; rows at or beyond N are written as zeros (the scan's filter never admits
+// them).  Half tiles [h0, h1) are (re)written: appended rows re-quantise the rows that share their first half tile with the same
+// scales, i.e. to the same bytes.  ONE atomic pair per wave at the end for A = max |y - x8|, B = max |x8| (2-norms per row).
+__global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __restrict__ X, int64_t N, int64_t h0, int64_t h1, int d,
+                                                          const float* __restrict__ colscale, int8_t* __restrict__ X8,
+                                                          int* __restrict__ ab_enc) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q4 = lane >> 4;
+  const int nsl = d >> 6;
   float ma = 0.f, mb = 0.f;
-  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < N; r += (int64_t)gridDim.x * 4) {
-  float ea = 0.f, eb = 0.f;
-  for (int c0 = 0; c0 < d; c0 += 256) {  // 4 consecutive columns per lane: one 8-byte load, one 4-byte store
-    const int c = c0 + 4 * lane;
-    if (c < d) {
-      const uint2 raw = *reinterpret_cast<const uint2*>(X + (size_t)r * d + c);
-      const _Float16* h = reinterpret_cast<const _Float16*>(&raw);
-      const float4 cs = *reinterpret_cast<const float4*>(colscale + c);
-      const float sc[4] = {cs.x, cs.y, cs.z, cs.w};
-      unsigned packed = 0u;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float y = (float)h[e] / sc[e];
-        float v = rintf(y);
-        v = fminf(fmaxf(v, -127.f), 127.f);
-        ea += (y - v) * (y - v);
-        eb += v * v;
-        packed |= ((unsigned)(int)v & 0xffu) << (8 * e);
+  for (int64_t h = h0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); h < h1; h += (int64_t)gridDim.x * 4) {
+    const int64_t row = h * 16 + r;
+    const bool live = row < N;
+    const _Float16* src = X + (size_t)(live ? row : 0) * d + 16 * q4;
+    int8_t* dst = X8 + (size_t)(h >> 1) * 32 * d + (size_t)(h & 1) * 1024 + lane * 16;
+    float ea = 0.f, eb = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) {
+      uint4 raw[2] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+      if (live) {
+        raw[0] = *reinterpret_cast<const uint4*>(src + 64 * sl);
+        raw[1] = *reinterpret_cast<const uint4*>(src + 64 * sl + 8);
       }
-      *reinterpret_cast<unsigned*>(X8 + (size_t)r * d + c) = packed;
+      const _Float16* hv = reinterpret_cast<const _Float16*>(raw);
+      const float4* cs4 = reinterpret_cast<const float4*>(colscale + 64 * sl + 16 * q4);
+      unsigned packed[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 cs = cs4[g];
+        const float sc[4] = {cs.x, cs.y, cs.z, cs.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = (float)hv[4 * g + e] / sc[e];
+          float v = rintf(y);
+          v = fminf(fmaxf(v, -127.f), 127.f);
+          ea += (y - v) * (y - v);
+          eb += v * v;
+          packed[g] |= ((unsigned)(int)v & 0xffu) << (8 * e);
+        }
+      }
+      *reinterpret_cast<uint4*>(dst + (size_t)sl * 2048) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
     }
+    // the four q4 lanes of a row hold its partial sums
+    ea += __shfl_xor(ea, 16); ea += __shfl_xor(ea, 32);
+    eb += __shfl_xor(eb, 16); eb += __shfl_xor(eb, 32);
+    ma = fmaxf(ma, ea);
+    mb = fmaxf(mb, eb);
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    ea += __shfl_xor(ea, o);
-    eb += __shfl_xor(eb, o);
-  }
-  ma = fmaxf(ma, ea);
-  mb = fmaxf(mb, eb);
+  for (int o = 8; o > 0; o >>= 1) {
+    ma = fmaxf(ma, __shfl_xor(ma, o));
+    mb = fmaxf(mb, __shfl_xor(mb, o));
   }
   if (lane == 0) {
-    atomicMax(&ab_enc[0], __float_as_int(sqrtf(ma)));
-    atomicMax(&ab_enc[1], __float_as_int(sqrtf(mb)));
+    // one ulp above the rounded-to-nearest root (bit pattern + 1: the values are non-negative and finite), so that the stored maximum
+    // is never below the true root; the fp32 summation error of ma / mb themselves is covered by the 1 + 1e-3 of knn_i8_prep_kernel
+    atomicMax(&ab_enc[0], __float_as_int(sqrtf(ma)) + 1);
+    atomicMax(&ab_enc[1], __float_as_int(sqrtf(mb)) + 1);
   }
 }
 
@@ -508,7 +531,10 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
                                                         const int* __restrict__ ab_enc, const int* __restrict__ maxnorm,
                                                         const float* __restrict__ samp, int kw, int J, int planes, int refine,
                                                         int8_t* __restrict__ qfrag8, int* __restrict__ thr_i, float* __restrict__ thr_lb,
-                                                        unsigned* __restrict__ cnt, unsigned* __restrict__ lost) {
+                                                        float* __restrict__ thr_rest, unsigned* __restrict__ cnt,
+                                                        unsigned* __restrict__ lost) {
+  // thr_rest (may be null): the admission threshold of the fp16 register-stationary pass over the rows the int8 copy does not hold
+  // (a partial copy, knnx_api.hip): that pass compares fp16-hi approximations, so T - eps_hi(q) admits every row with exact >= T.
   // refine = 1 (second call of a two-level sample, knnx_api.hip scan_topk_i8): samp holds EXACT scores (re-scored hits of an int8 pass
   // over every 32nd tile) -- no eps_hi -- and the bound only ever rises: T = max(previous T, J-th best); fewer than J sample hits
   // leave the previous threshold in place.
@@ -578,18 +604,26 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
         keep = true;
       } else if (v > -FLT_MAX) {
         // eps_hi: the sample scores are fp16-hi approximations of the exact scores (cf. knn_rq_proof_kernel)
-        const float eps_hi = refine ? 0.f : (sqrtf(e2) + (float)d * 1.2e-7f * sqrtf(n2)) * rq_dec_f(*maxnorm);
+        // Every norm below is an fp32 sum of up to d non-negative terms followed by a square root: relative error <= (d + 2) 2^-24
+        // < 6.2e-5 at d = 1024, and the products / sums of the bound add a few ulp.  The factor 1 + 1e-3 covers all of it with an
+        // order of magnitude to spare (it widens the admission band by 0.1 %); the same factor is in oracle.knn_oracle.Int8FirstStage.
+        const float eps_q = (sqrtf(e2) + (float)d * 1.2e-7f * sqrtf(n2)) * rq_dec_f(*maxnorm) * 1.001f;
+        const float eps_hi = refine ? 0.f : eps_q;
         lb = v - eps_hi;
         if (refine) lb = fmaxf(lb, thr_lb[n]);
+        if (thr_rest) thr_rest[n] = lb - eps_q - 1e-6f * fabsf(lb);
         const float A = __int_as_float(ab_enc[0]), B = __int_as_float(ab_enc[1]);
-        const float eps8 = (sqrtf(nu2) * A + sqrtf(er2) * B) * 1.00002f + 1e-6f * fabsf(lb);
+        const float eps8 = (sqrtf(nu2) * A + sqrtf(er2) * B) * 1.001f + 1e-6f * fabsf(lb);
         const float t = (lb - eps8) / (planes == 2 ? su * (1.f / 128.f) : su);
         // floor - 1: the float division / subtraction above may round up by an ulp
         ti = t <= -2.0e9f ? (int)0x80000000 : (t >= 2.0e9f ? 0x7fffffff : (int)floorf(t) - 1);
       } else {
         lb = -INFINITY;  // fewer than J sample rows: every row is a hit (indexes far too small for this path)
         ti = (int)0x80000000;
+        if (thr_rest) thr_rest[n] = -INFINITY;
       }
+    } else if (thr_rest) {
+      thr_rest[n] = INFINITY;  // unused query slot
     }
     if (!keep) {
       thr_i[n] = ti;
@@ -600,46 +634,41 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
   }
 }
 
-// DMA of the int8 tiles: wave w fetches pieces w, w + NW, w + 2 NW, ... (piece p = 2 * slab + half: the wave's pieces all have half
-// w & 1 and slabs (w >> 1) + (NW / 2) IDX) -- the consecutive-pieces dealing of the fp16 kernel needs an even piece count per wave,
-// and d = 768 has 24 pieces for 8 waves.
+// DMA of the int8 tiles: wave w fetches pieces w, w + NW, w + 2 NW, ... of the tile -- each one contiguous KiB of the tile-ordered
+// copy (knn_i8_quant_kernel), lane l at byte 16 l, landing lane-linear at the same piece index of the ring slot.
 struct Rq8Tile {
-  const char* base;  // tile + this wave's first slab
+  const char* base;  // tile + this wave's first piece
   unsigned m0b;      // LDS address of the slot + this wave's first piece
-  unsigned vo;       // per-lane byte offset (row of the wave's half, 16-byte column group)
 };
 // (t counts the tiles the pass VISITS: tile t * tstep of the index -- tstep > 1 is the sample pass of a two-level threshold; nj = visited
 // tiles; past the end the last visited tile is re-loaded, which keeps the vmcnt arithmetic of the main loop uniform)
 template <int KS, int NW>
-__device__ __forceinline__ Rq8Tile rq8_tile(const int8_t* __restrict__ X8, int64_t t, int64_t nj, int tstep, int64_t last, const RqLaneOff& lo,
-                                            unsigned lds_base, int slot, int w) {
+__device__ __forceinline__ Rq8Tile rq8_tile(const int8_t* __restrict__ X8, int64_t t, int64_t nj, int tstep, unsigned lds_base, int slot, int w) {
   constexpr int TILE_BYTES = KS * 1024;
   const int64_t tt = (t < nj ? t : nj - 1) * tstep;
   Rq8Tile r;
-  const int li = tt == last ? 1 : 0;
-  r.vo = (w & 1) ? lo.v1[li] : lo.v[li];
-  r.base = reinterpret_cast<const char*>(X8) + (size_t)tt * TILE_BYTES + (w >> 1) * 64;
+  r.base = reinterpret_cast<const char*>(X8) + (size_t)tt * TILE_BYTES + w * 1024;
   r.m0b = lds_base + slot * TILE_BYTES + w * 1024;
   return r;
 }
-#define RQ8_TILE(t_, slot_) rq8_tile<KS, NW>(X8, (t_), nj, tstep, last, lane_off, lds_base, (slot_), w)
+#define RQ8_TILE(t_, slot_) rq8_tile<KS, NW>(X8, (t_), nj, tstep, lds_base, (slot_), w)
 template <int NW, int IDX>
-__device__ __forceinline__ void rq8_issue_one(const Rq8Tile& r) {
-  const char* p = r.base + IDX * (NW / 2) * 64;
-  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(r.vo), "s"(p), "s"(r.m0b), "n"(IDX * NW * 1024)
+__device__ __forceinline__ void rq8_issue_one(const Rq8Tile& r, unsigned vo /* 16 * lane */) {
+  const char* p = r.base + IDX * NW * 1024;
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(p), "s"(r.m0b), "n"(IDX * NW * 1024)
                : "memory", "scc");
 }
 template <int NW, int DPW, int IDX = 0>
-__device__ __forceinline__ void rq8_issue_all(const Rq8Tile& r) {
+__device__ __forceinline__ void rq8_issue_all(const Rq8Tile& r, unsigned vo) {
   if constexpr (IDX < DPW) {
-    rq8_issue_one<NW, IDX>(r);
-    rq8_issue_all<NW, DPW, IDX + 1>(r);
+    rq8_issue_one<NW, IDX>(r, vo);
+    rq8_issue_all<NW, DPW, IDX + 1>(r, vo);
   }
 }
 
 template <int KS, int NW, int DPW, int PL, int S>
 __device__ __forceinline__ void rq8_ksteps(unsigned xa, i32x4 (&A)[4], i32x4v (&acc)[PL][2][2], const i32x4 (&Q)[PL][2][KS / 2],
-                                           const Rq8Tile& refill) {
+                                           const Rq8Tile& refill, unsigned vo) {
   if constexpr (S < KS) {
     if constexpr (S + 3 < KS) rq_dsread<(S + 3) * 1024>(A[(S + 3) & 3], xa);
     rq_wait_lgkm<(KS - 1 - S < 3 ? KS - 1 - S : 3)>();
@@ -651,10 +680,10 @@ __device__ __forceinline__ void rq8_ksteps(unsigned xa, i32x4 (&A)[4], i32x4v (&
         acc[p][b][S & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[S & 3], Q[p][b][S >> 1], acc[p][b][S & 1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S % (KS / DPW) == 1) {
-      rq8_issue_one<NW, S / (KS / DPW)>(refill);
+      rq8_issue_one<NW, S / (KS / DPW)>(refill, vo);
       __builtin_amdgcn_sched_barrier(0);
     }
-    rq8_ksteps<KS, NW, DPW, PL, S + 1>(xa, A, acc, Q, refill);
+    rq8_ksteps<KS, NW, DPW, PL, S + 1>(xa, A, acc, Q, refill, vo);
   }
 }
 
@@ -665,7 +694,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
                                                                       const int* __restrict__ thr_i, unsigned* __restrict__ g_cnt, unsigned cap,
                                                                       float* __restrict__ hit_s, uint32_t* __restrict__ hit_r,
                                                                       unsigned* __restrict__ g_lost, int tstep) {
-  constexpr int D = KS * 16;  // the row as fp16-sized columns (tile / DMA helpers)
   constexpr int TILE_BYTES = KS * 1024, DPW = KS / NW, NSL = KS / 2;
   static_assert(KS % NW == 0 && KS % 2 == 0, "pieces must divide evenly among the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -700,15 +728,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
   }
 
   const int64_t ntile = (N + 31) >> 5;
-  const int64_t last = ntile - 1;
   const int64_t nj = (ntile + tstep - 1) / tstep;  // tiles this pass visits
-  const RqLaneOff lane_off = rq_lane_offsets(lane, D, (int)(N - 1 - last * 32));
+  const unsigned vo = (unsigned)lane * 16u;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
 
   int64_t t = blockIdx.x;
   const int64_t gstride = gridDim.x;
 #pragma unroll
-  for (int i = 0; i < NSLOT - 1; ++i) rq8_issue_all<NW, DPW>(RQ8_TILE(t + (int64_t)i * gstride, i));
+  for (int i = 0; i < NSLOT - 1; ++i) rq8_issue_all<NW, DPW>(RQ8_TILE(t + (int64_t)i * gstride, i), vo);
 
   int nst = 0;
   int slot = 0;
@@ -728,7 +755,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
     rq_dsread<1024>(A[1], xa);
     rq_dsread<2048>(A[2], xa);
     __builtin_amdgcn_sched_barrier(0);
-    rq8_ksteps<KS, NW, DPW, PL, 0>(xa, A, acc, Q, refill);
+    rq8_ksteps<KS, NW, DPW, PL, 0>(xa, A, acc, Q, refill, vo);
 
     // ---- filter: lane (qcol, hb) owns rows row0 + 16 half + e of its query column in each block; integer compares
     const int64_t row0 = t * tstep * 32 + 4 * hb;
@@ -830,19 +857,27 @@ int i8_supported(int d) { return KNNX_MFMA16 && (d == 512 || d == 768 || d == 10
 
 // quantise rows with the column scales that exist (also used for rows added later: values beyond +-127 c clamp, and A / B -- which
 // are maxima over the rows as stored -- grow with them, so the bound stays a bound)
-hipError_t launch_i8_quant(const _Float16* X, int64_t N, int d, const float* colscale, int8_t* X8, int* ab_enc, hipStream_t st) {
+hipError_t launch_i8_quant(const _Float16* X, int64_t N, int64_t row_from, int64_t row_to, int d, const float* colscale, int8_t* X8,
+                           int* ab_enc, hipStream_t st) {
 #if KNNX_MFMA16
-  if (N <= 0) return hipSuccess;
-  // grid-stride: a launch's grid x block must stay below 2^32 work-items (100 M rows as 25 M workgroups silently ran the first 32.9 M)
-  const unsigned grid = (unsigned)std::min<int64_t>((N + 3) / 4, 256 * 16);
-  hipLaunchKernelGGL(knn_i8_quant_kernel, dim3(grid), dim3(256), 0, st, X, N, d, colscale, X8, ab_enc);
+  // rows [row_from, row_to) of an image that covers rows [0, N) (row_to <= N); whole half tiles are written: rows below row_from that
+  // share its half tile are re-quantised to the same bytes, rows at or beyond N become zeros
+  const int64_t h0 = row_from >> 4, h1 = (std::max(row_to, row_from) + 15) >> 4;
+  const int64_t h1p = row_to >= N ? ((h1 + 1) & ~(int64_t)1) : h1;  // the end of the index: zero the rest of its last 32-row tile
+  if (h1p <= h0) return hipSuccess;
+  // grid-stride: a launch's grid x block must stay below 2^32 work-items
+  const unsigned grid = (unsigned)std::min<int64_t>((h1p - h0 + 3) / 4, 256 * 16);
+  hipLaunchKernelGGL(knn_i8_quant_kernel, dim3(grid), dim3(256), 0, st, X, N, h0, h1p, d, colscale, X8, ab_enc);
   return hipGetLastError();
 #else
   return hipErrorInvalidValue;
 #endif
 }
 
-hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st) {
+// column scales over ALL N rows; the int8 image of rows [0, n8) only (n8 < N: the copy does not fit next to the fp16 rows -- the scan
+// of the other rows stays on fp16, knnx_api.hip)
+hipError_t launch_i8_build(const _Float16* X, int64_t N, int64_t n8, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc,
+                           hipStream_t st) {
 #if KNNX_MFMA16
   hipError_t e = hipMemsetAsync(colmax_enc, 0, (size_t)d * sizeof(int), st);
   if (e != hipSuccess) return e;
@@ -852,18 +887,18 @@ hipError_t launch_i8_build(const _Float16* X, int64_t N, int d, int* colmax_enc,
   const unsigned g1 = (unsigned)std::min<int64_t>(N, 256 * 32);
   hipLaunchKernelGGL(knn_i8_colmax_kernel, dim3(g1), dim3(256), 0, st, X, N, d, colmax_enc);
   hipLaunchKernelGGL(knn_i8_colscale_kernel, dim3((d + 255) / 256), dim3(256), 0, st, colmax_enc, d, colscale);
-  return launch_i8_quant(X, N, d, colscale, X8, ab_enc, st);
+  return launch_i8_quant(X, n8, 0, n8, d, colscale, X8, ab_enc, st);
 #else
   return hipErrorInvalidValue;
 #endif
 }
 
 hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
-                          int kw, int J, int planes, int refine, int8_t* qfrag8, int* thr_i, float* thr_lb, unsigned* cnt, unsigned* lost,
-                          hipStream_t st) {
+                          int kw, int J, int planes, int refine, int8_t* qfrag8, int* thr_i, float* thr_lb, float* thr_rest, unsigned* cnt,
+                          unsigned* lost, hipStream_t st) {
 #if KNNX_MFMA16
   hipLaunchKernelGGL(knn_i8_prep_kernel, dim3(256), dim3(64), 0, st, q_dev, nq, d, colscale, ab_enc, maxnorm, samp, kw, J, planes, refine,
-                     qfrag8, thr_i, thr_lb, cnt, lost);
+                     qfrag8, thr_i, thr_lb, thr_rest, cnt, lost);
   return hipGetLastError();
 #else
   return hipErrorInvalidValue;
@@ -1173,37 +1208,37 @@ hipError_t launch_rq_prep(const float* q_dev, int nq, int d, _Float16* qfrag, co
 template <int KS, int QBW, int NW, int NSLOT>
 static hipError_t launch_rq_scan_cfg(const _Float16* X, int64_t N, const _Float16* qfrag, const float* thr, unsigned* cnt,
                                      unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
-                                     hipStream_t st) {
+                                     hipStream_t st, uint32_t row_off) {
   const size_t smem = (size_t)NSLOT * KS * 1024 + (size_t)NW * RQ_STAGE * 12;
   auto kern = knn_rq_scan_kernel<KS, QBW, NW, NSLOT>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, row_off);
   return hipGetLastError();
 }
 
 hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, int nq, const _Float16* qfrag, const float* thr, unsigned* cnt,
                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, const unsigned* gate, int grid,
-                          hipStream_t st) {
+                          hipStream_t st, uint32_t row_off) {
   // up to 128 queries: four waves hold them all -- half the LDS reads of the X tiles and half the MFMAs of the 8-wave
   // configuration, whose upper four waves would multiply padding
-  if (nq <= 128 && d == 768) return launch_rq_scan_cfg<48, 1, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
-  if (nq <= 128 && d == 512) return launch_rq_scan_cfg<32, 1, 4, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+  if (nq <= 128 && d == 768) return launch_rq_scan_cfg<48, 1, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st, row_off);
+  if (nq <= 128 && d == 512) return launch_rq_scan_cfg<32, 1, 4, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st, row_off);
 #ifdef CLIPX_ABLATE
   {  // tools build only (A/B on one box): KNNX_RQ_4X64=1 -> 4 waves x 64 queries at d = 768 (half the LDS reads, one wave per SIMD):
      // 38.3 ms per pass against 36.4 - 36.8 for 8 x 32 on the 16x16x32 kernels (profiles/r04p_rq_8x32_vs_4x64.log)
     static const int w4 = getenv("KNNX_RQ_4X64") ? atoi(getenv("KNNX_RQ_4X64")) : 0;
-    if (w4 && d == 768) return launch_rq_scan_cfg<48, 2, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+    if (w4 && d == 768) return launch_rq_scan_cfg<48, 2, 4, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st, row_off);
   }
 #endif
   switch (d) {
-    case 512: return launch_rq_scan_cfg<32, 1, 8, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+    case 512: return launch_rq_scan_cfg<32, 1, 8, 4>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st, row_off);
     // d = 768: 8 waves x 32 queries, two waves per SIMD: a wave's LDS-DMA issue (~100 cycles per instruction during which it
     // issues nothing else) is covered by its SIMD partner's MFMAs.  4 waves x 64 queries (one wave per SIMD, 501 registers)
     // measured 59 % MFMA utilisation at 1.6 GHz: the 12 DMA issues per tile held the matrix pipe of their SIMD idle
     // (profiles/r02_rq_pmc.txt).
-    case 768: return launch_rq_scan_cfg<48, 1, 8, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
-    case 1024: return launch_rq_scan_cfg<64, 1, 4, 2>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st);
+    case 768: return launch_rq_scan_cfg<48, 1, 8, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st, row_off);
+    case 1024: return launch_rq_scan_cfg<64, 1, 4, 2>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st, row_off);
     default: return hipErrorInvalidValue;
   }
 }

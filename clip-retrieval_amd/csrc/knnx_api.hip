@@ -110,7 +110,9 @@ struct knnx_index {
   int64_t i8_scale_rows = 0;      // rows the column scales were taken over (a full rebuild once the index has doubled since)
   int i8_planes = 1;              // int8 planes of a query: 2 when the column scales differ widely (decided at every full build)
   int i8_planes_env = 0;          // KNNX_I8_PLANES=1|2 forces the choice
-  int8_t* i8_rows = nullptr;      // [ntotal, d]
+  int8_t* i8_rows = nullptr;      // tile-ordered image of rows [0, i8_nrows) (knn_i8_quant_kernel): i8_cap_rows / 32 tiles of 32 d bytes
+  int64_t i8_budget = 0;          // KNNX_I8_MAX_BYTES: cap on the image (0: none) -- a PARTIAL copy: the other rows are scanned in fp16
+  unsigned long long i8_rest_served = 0;  // queries whose pass ran over an int8 part AND an fp16 rest
   float* i8_colscale = nullptr;   // [d]
   int *i8_colmax = nullptr, *i8_ab = nullptr;  // [d] (encoded), [2] (encoded A, B)
   int8_t* i8_qfrag = nullptr;     // [16 blocks][d / 64][64][16]
@@ -181,13 +183,34 @@ static int ensure_pin(knnx_index* ix, size_t bytes) {
   return 0;
 }
 
+// the int8 copy is an accelerator, not data: whoever needs device memory and cannot get it takes the copy's back and tries once more
+// (the lazily built copy must not starve the range pools / large-k scratch that fitted before it existed)
+static void i8_release(knnx_index* ix) {
+  if (!ix->i8_rows) return;
+  hipFree(ix->i8_rows);
+  ix->i8_rows = nullptr;
+  ix->i8_cap_rows = 0;
+  ix->i8_nrows = 0;
+  ix->i8_valid = false;
+}
+static hipError_t malloc_or_reclaim(knnx_index* ix, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess && ix->i8_rows) {
+    (void)hipGetLastError();
+    i8_release(ix);
+    ix->i8_ok = 0;  // it did not fit next to what the index needs: do not rebuild it on the next search
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+
 static int ensure_scratch(knnx_index* ix, int slot, size_t bytes, void** out) {
   if (ix->scratch_bytes[slot] < bytes) {
     if (ix->scratch[slot]) hipFree(ix->scratch[slot]);
     ix->scratch[slot] = nullptr;
     ix->scratch_bytes[slot] = 0;
     const size_t want = std::max(bytes, (size_t)1 << 16);
-    HIPCHK(hipMalloc(&ix->scratch[slot], want));
+    HIPCHK(malloc_or_reclaim(ix, &ix->scratch[slot], want));
     ix->scratch_bytes[slot] = want;
   }
   *out = ix->scratch[slot];
@@ -237,6 +260,8 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
     ix->i8_ok = (i8 && i8[0] == '0') ? 0 : 1;
     const char* pl = getenv("KNNX_I8_PLANES");
     ix->i8_planes_env = (pl && (pl[0] == '1' || pl[0] == '2')) ? pl[0] - '0' : 0;
+    const char* i8b = getenv("KNNX_I8_MAX_BYTES");
+    ix->i8_budget = i8b ? std::max<int64_t>(0, atoll(i8b)) : 0;
   }
   const char* rqm = getenv("KNNX_RQ_MIN_ROWS");
   if (rqm && rqm[0]) ix->rq_min_rows = atoll(rqm);
@@ -391,13 +416,7 @@ static int grow(knnx_index* ix, int64_t need_rows) {
   if (hipMalloc(&nr, (size_t)need_rows * ix->d * sizeof(_Float16)) != hipSuccess) {
     (void)hipGetLastError();
     // the int8 copy is an accelerator, not data: give its memory back and try once more
-    if (ix->i8_rows) {
-      hipFree(ix->i8_rows);
-      ix->i8_rows = nullptr;
-      ix->i8_cap_rows = 0;
-      ix->i8_nrows = 0;
-      ix->i8_valid = false;
-    }
+    i8_release(ix);
     HIPCHK(hipMalloc(&nr, (size_t)need_rows * ix->d * sizeof(_Float16)));
   }
   if (ix->rows && ix->ntotal > 0) {
@@ -801,17 +820,17 @@ static bool i8_usable(const knnx_index* ix, int nq, int k) {
          ix->ntotal >= ix->rq_min_rows && scan_cap(ix->d, KNN_WIDE_KW) > 0;
 }
 // allocate (first use) and build (first use, and after the rows changed) the int8 copy; 1: ready, 0: not available (the caller takes
-// another path; out of memory turns the feature off for this index), < 0: error
+// another path; out of memory turns the feature off for this index), < 0: error.
+// The copy may be PARTIAL (round 5): when ntotal * d bytes do not fit next to the fp16 rows -- BASELINE's headline shard, 125 M x 768 =
+// 192 GB of fp16 on a 288 GB part, leaves room for ~80 M rows of int8 -- or KNNX_I8_MAX_BYTES caps it, rows [0, i8_nrows) get the int8
+// first stage and the rows behind them are scanned by the fp16 register-stationary pass into the same hit lists (scan_topk_i8).
 static int i8_ensure(knnx_index* ix, hipStream_t st) {
   if (ix->i8_valid) return 1;
   const size_t Q = KNN_RQ_MAX;
   auto give_up = [&]() {
     (void)hipGetLastError();
     ix->i8_ok = 0;
-    hipFree(ix->i8_rows);
-    ix->i8_rows = nullptr;
-    ix->i8_cap_rows = 0;
-    ix->i8_nrows = 0;
+    i8_release(ix);
     return 0;
   };
   if (!ix->i8_colscale) {
@@ -822,24 +841,61 @@ static int i8_ensure(knnx_index* ix, hipStream_t st) {
         hipMalloc(&ix->i8_hit_r, Q * KNN_I8_CAP * sizeof(uint32_t)) != hipSuccess)
       return give_up();
   }
+  // everything else the flat scans allocate lazily comes FIRST, so that a partial copy is sized around it, not the other way round
+  int r = rq_alloc(ix);
+  if (r) return r;
+  const auto tiles32 = [](int64_t rows) { return (rows + 31) & ~(int64_t)31; };
   if (ix->i8_cap_rows < ix->ntotal) {
     // (an owned index grows by halves: follow its capacity, so that a stream of add() calls does not reallocate every time)
-    const int64_t want = std::max(ix->ntotal, ix->borrowed ? ix->ntotal : ix->capacity);
+    int64_t want = tiles32(std::max(ix->ntotal, ix->borrowed ? ix->ntotal : ix->capacity));
+    if (ix->i8_budget > 0) want = std::min(want, (ix->i8_budget / ix->d) & ~(int64_t)31);
     int8_t* nr = nullptr;
-    if (hipMalloc(&nr, (size_t)want * ix->d) != hipSuccess) return give_up();
-    if (ix->i8_rows && ix->i8_nrows > 0)
-      HIPCHK(hipMemcpyAsync(nr, ix->i8_rows, (size_t)ix->i8_nrows * ix->d, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
-    hipFree(ix->i8_rows);
-    ix->i8_rows = nr;
-    ix->i8_cap_rows = want;
+    if (want > ix->i8_cap_rows && hipMalloc(&nr, (size_t)want * ix->d) != hipSuccess) {
+      (void)hipGetLastError();
+      nr = nullptr;
+      // what is free, less a reserve for the pools that are sized per request (range scans: up to 4 GiB, large-k scratch, reconstruct)
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) != hipSuccess) return give_up();
+      const size_t have = (size_t)ix->i8_cap_rows * ix->d;  // the old image is released below: its bytes count as free
+      const size_t reserve = (size_t)8 << 30;
+      want = fr + have > reserve ? (int64_t)(((fr + have - reserve) / (size_t)ix->d) & ~(size_t)31) : 0;
+      if (want > tiles32(ix->ntotal)) want = tiles32(ix->ntotal);
+      // a copy of less than a quarter of the rows saves under an eighth of the pass: not worth the memory
+      if (want < ix->ntotal / 4 || want <= ix->i8_cap_rows) {
+        if (want <= ix->i8_cap_rows && ix->i8_cap_rows >= ix->ntotal / 4) want = 0;  // keep the image that exists
+        else return give_up();
+      }
+      if (want > 0) {
+        // the old image has to go first (its bytes are part of the estimate); what it held is quantised again below
+        i8_release(ix);
+        if (hipMalloc(&nr, (size_t)want * ix->d) != hipSuccess) return give_up();
+      }
+    }
+    if (nr) {
+      if (ix->i8_rows && ix->i8_nrows > 0) {
+        // whole tiles of the old image carry over (tile-ordered: a prefix of tiles is a prefix of bytes)
+        const int64_t keep = std::min(ix->i8_nrows & ~(int64_t)31, want);
+        hipError_t e = keep > 0 ? hipMemcpyAsync(nr, ix->i8_rows, (size_t)keep * ix->d, hipMemcpyDeviceToDevice, st) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+          hipFree(nr);
+          return fail(KNNX_E_HIP, std::string("int8 copy: ") + hipGetErrorString(e));
+        }
+        ix->i8_nrows = keep;
+      }
+      hipFree(ix->i8_rows);
+      ix->i8_rows = nr;
+      ix->i8_cap_rows = want;
+    }
   }
-  if (ix->i8_nrows > 0 && ix->i8_nrows <= ix->ntotal && ix->ntotal < 2 * ix->i8_scale_rows) {
+  const int64_t n8 = std::min(ix->ntotal, ix->i8_cap_rows);  // rows the image will hold
+  if (n8 < ix->ntotal / 4) return give_up();
+  if (ix->i8_nrows > 0 && ix->i8_nrows <= n8 && ix->ntotal < 2 * ix->i8_scale_rows) {
     // rows were appended: quantise the new ones with the scales that exist (values beyond them clamp; A and B grow with what is stored)
-    HIPCHK(launch_i8_quant(ix->rows + (size_t)ix->i8_nrows * ix->d, ix->ntotal - ix->i8_nrows, ix->d, ix->i8_colscale,
-                           ix->i8_rows + (size_t)ix->i8_nrows * ix->d, ix->i8_ab, st));
+    if (ix->i8_nrows < n8)
+      HIPCHK(launch_i8_quant(ix->rows, n8, ix->i8_nrows, n8, ix->d, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
   } else {
-    HIPCHK(launch_i8_build(ix->rows, ix->ntotal, ix->d, ix->i8_colmax, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
+    HIPCHK(launch_i8_build(ix->rows, ix->ntotal, n8, ix->d, ix->i8_colmax, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
     ix->i8_scale_rows = ix->ntotal;
     // one or two int8 planes per query (knn_i8_prep_kernel): a query's u = q * c has ONE scale, so a few columns much larger than
     // the rest leave the others' components in the rounding error.  Two planes when the largest column scale is more than 3 x the
@@ -852,7 +908,7 @@ static int i8_ensure(knnx_index* ix, hipStream_t st) {
     const float cmed = cs[(size_t)ix->d / 2];
     ix->i8_planes = ix->i8_planes_env ? ix->i8_planes_env : (cmax > 3.f * cmed ? 2 : 1);
   }
-  ix->i8_nrows = ix->ntotal;
+  ix->i8_nrows = n8;
   ix->i8_valid = true;
   return 1;
 }
@@ -860,6 +916,8 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
   int r = rq_alloc(ix);
   if (r) return r;
   const int d = ix->d;
+  const int64_t n8 = ix->i8_nrows;          // rows [0, n8) have an int8 image ...
+  const int64_t nrest = ix->ntotal - n8;    // ... the rows behind them are scanned in fp16 (partial copy, i8_ensure)
   // 1. thresholds: the exact sample pass (denser than the fp16 path's: the int8 bound widens the admission band, a tighter
   // threshold buys the hits back)
   int tstride = 1, J = 1;
@@ -872,10 +930,11 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
   const bool two_level = nq > KNN_NQ_MAX && ntiles >= (int64_t)4096 * KNN_I8_STRIDE;
   r = rq_sample_pass(ix, q_dev, nq, k, two_level ? KNN_RQ_STRIDE : KNN_I8_STRIDE, st, &tstride, &J, &wide_samp);
   if (r) return r;
+  float* thr_rest = nrest > 0 ? ix->rq_thr : nullptr;
   HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J, ix->i8_planes, 0, ix->i8_qfrag,
-                        ix->i8_thr, ix->i8_lb, ix->rq_cnt, ix->rq_lost, st));
+                        ix->i8_thr, ix->i8_lb, thr_rest, ix->rq_cnt, ix->rq_lost, st));
   if (two_level) {
-    HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s,
+    HIPCHK(launch_rq8_scan(ix->i8_rows, n8, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s,
                            ix->i8_hit_r, ix->rq_lost, ix->n_cu, KNN_I8_STRIDE, st));
     HIPCHK(launch_rq_rescore(ix->rows, d, q_dev, nq, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r, ix->rq_cntc, st));
     // the exact top-64 of the sampled hits, where the sample passes put theirs: the refining prep reads its J-th entry
@@ -883,7 +942,7 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
                             ix->rq_samp_i, nullptr, st));
     const int J2 = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
     HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J2, ix->i8_planes, 1,
-                          ix->i8_qfrag, ix->i8_thr, ix->i8_lb, ix->rq_cnt, ix->rq_lost, st));
+                          ix->i8_qfrag, ix->i8_thr, ix->i8_lb, thr_rest, ix->rq_cnt, ix->rq_lost, st));
   }
   // 2. the pass over the int8 rows
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -892,8 +951,23 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, st));
   }
-  HIPCHK(launch_rq8_scan(ix->i8_rows, ix->ntotal, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
+  HIPCHK(launch_rq8_scan(ix->i8_rows, n8, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
                          ix->rq_lost, ix->n_cu, 1, st));
+  // 2b. the rows without an int8 image: the fp16 register-stationary pass, admission threshold T - eps_hi (knn_i8_prep_kernel), into
+  // the SAME hit lists (global row = n8 + row of the slice); the lower bound T of the proof covers both parts
+  if (nrest > 0) {
+    const int per = rq_queries_per_pass(d);
+    const int blk_halves = (d / 32) * 64 * 8;  // fp16 values of one 16-query fragment block (knn_rq_prep_kernel)
+    (void)blk_halves;
+    for (int q0 = 0; q0 < nq; q0 += per) {
+      const int n = std::min(per, nq - q0);
+      HIPCHK(launch_rq_prep(q_dev + (size_t)q0 * d, n, d, ix->rq_qfrag, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, st));  // fragments only
+      HIPCHK(launch_rq_scan(ix->rows + (size_t)n8 * d, nrest, d, n, ix->rq_qfrag, ix->rq_thr + q0, ix->rq_cnt + q0, KNN_I8_CAP,
+                            ix->i8_hit_s + (size_t)q0 * KNN_I8_CAP, ix->i8_hit_r + (size_t)q0 * KNN_I8_CAP, ix->rq_lost + q0, nullptr,
+                            ix->n_cu, st, (uint32_t)n8));
+    }
+    ix->i8_rest_served += (unsigned long long)nq;
+  }
   if (ix->prof) {
     HIPCHK(hipEventRecord(e1, st));
     ix->prof_events.emplace_back(e0, e1);
@@ -956,6 +1030,11 @@ extern "C" int64_t knnx_i8_served(knnx_index* ix) {
   if (!ix) return -1;
   std::lock_guard<std::mutex> lk(ix->mu);
   return (int64_t)ix->i8_served;
+}
+extern "C" int64_t knnx_i8_rows(knnx_index* ix) {
+  if (!ix) return -1;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  return ix->i8_valid ? ix->i8_nrows : 0;
 }
 extern "C" int knnx_i8_planes(knnx_index* ix) {
   if (!ix) return -1;
@@ -1041,13 +1120,25 @@ constexpr int CO_PAIR_CAP = 512;  // links kept per request on the device (a req
 // One batch: `b` holds m <= KNN_RQ_MAX requests with the same k.  Search (one scan), one gather of the m k result rows on the
 // device when a request wants them back or wants its dedup links, the link kernel for all of them at once, then every request's
 // slice into its own buffers.  Runs under ix->mu; the requests' threads sleep on ix->co_cv meanwhile.
+static int co_run_batch_locked(knnx_index* ix, std::vector<CoReq*>& b);
+//  The per-index staging vectors co_qbuf / co_Dbuf / co_Ibuf are shared by every caller: with coalescing off
+// knnx_search_dedup reaches this function from concurrent request threads, so the index mutex is taken BEFORE they are touched;
+// and nothing may leave this function as a C++ exception (a bad_alloc in a resize would otherwise skip the leader's hand-over in
+// co_submit and strand every waiter).
 static int co_run_batch(knnx_index* ix, std::vector<CoReq*>& b) {
+  std::lock_guard<std::mutex> lk(ix->mu);
+  try {
+    return co_run_batch_locked(ix, b);
+  } catch (const std::exception& e) {
+    return fail(KNNX_E_NOMEM, std::string("coalesced batch: ") + e.what());
+  }
+}
+static int co_run_batch_locked(knnx_index* ix, std::vector<CoReq*>& b) {
   const int m = (int)b.size(), k = b[0]->k, d = ix->d;
   ix->co_qbuf.resize((size_t)m * d);
   ix->co_Dbuf.resize((size_t)m * k);
   ix->co_Ibuf.resize((size_t)m * k);
   for (int i = 0; i < m; ++i) memcpy(ix->co_qbuf.data() + (size_t)i * d, b[i]->q, (size_t)d * sizeof(float));
-  std::lock_guard<std::mutex> lk(ix->mu);
   if (set_dev(ix)) return KNNX_E_HIP;
   int r = search_fast_locked(ix, ix->co_qbuf.data(), m, k, ix->co_Dbuf.data(), ix->co_Ibuf.data());
   if (r) return r;
@@ -1259,8 +1350,8 @@ static int range_scan(knnx_index* ix, const float* q_host, int nq, float thr, st
   for (;;) {
     if (ix->range_pool == 0) {
       ix->range_pool = (size_t)1 << 21;
-      HIPCHK(hipMalloc(&ix->range_s, ix->range_pool * sizeof(float)));
-      HIPCHK(hipMalloc(&ix->range_i, ix->range_pool * sizeof(uint32_t)));
+      HIPCHK(malloc_or_reclaim(ix, (void**)&ix->range_s, ix->range_pool * sizeof(float)));
+      HIPCHK(malloc_or_reclaim(ix, (void**)&ix->range_i, ix->range_pool * sizeof(uint32_t)));
     }
     const unsigned cap = (unsigned)std::min<size_t>(ix->range_pool / (size_t)nq, 0xffffffffu);
     if (ix->ivf_nlist) {  // IVF: the range is taken over the rows of the nprobe best lists of each query (faiss IndexIVF semantics)
@@ -1305,8 +1396,8 @@ static int range_scan(knnx_index* ix, const float* q_host, int nq, float thr, st
     ix->range_s = nullptr;
     ix->range_i = nullptr;
     ix->range_pool = 0;
-    HIPCHK(hipMalloc(&ix->range_s, want * sizeof(float)));
-    HIPCHK(hipMalloc(&ix->range_i, want * sizeof(uint32_t)));
+    HIPCHK(malloc_or_reclaim(ix, (void**)&ix->range_s, want * sizeof(float)));
+    HIPCHK(malloc_or_reclaim(ix, (void**)&ix->range_i, want * sizeof(uint32_t)));
     ix->range_pool = want;
   }
 }
@@ -1331,8 +1422,8 @@ static int range_scan_batched(knnx_index* ix, const float* q_host, int n, float 
   for (;;) {
     if (ix->range_pool == 0) {
       ix->range_pool = (size_t)1 << 21;
-      HIPCHK(hipMalloc(&ix->range_s, ix->range_pool * sizeof(float)));
-      HIPCHK(hipMalloc(&ix->range_i, ix->range_pool * sizeof(uint32_t)));
+      HIPCHK(malloc_or_reclaim(ix, (void**)&ix->range_s, ix->range_pool * sizeof(float)));
+      HIPCHK(malloc_or_reclaim(ix, (void**)&ix->range_i, ix->range_pool * sizeof(uint32_t)));
     }
     const unsigned cap = (unsigned)std::min<size_t>(ix->range_pool / nr, 0xffffffffu);
     unsigned mx = 0;
@@ -1379,8 +1470,8 @@ static int range_scan_batched(knnx_index* ix, const float* q_host, int n, float 
     ix->range_s = nullptr;
     ix->range_i = nullptr;
     ix->range_pool = 0;
-    HIPCHK(hipMalloc(&ix->range_s, want * sizeof(float)));
-    HIPCHK(hipMalloc(&ix->range_i, want * sizeof(uint32_t)));
+    HIPCHK(malloc_or_reclaim(ix, (void**)&ix->range_s, want * sizeof(float)));
+    HIPCHK(malloc_or_reclaim(ix, (void**)&ix->range_i, want * sizeof(uint32_t)));
     ix->range_pool = want;
   }
 }
@@ -2008,7 +2099,8 @@ extern "C" int knnx_ivfb_list_sizes(knnx_ivf_builder* b, int64_t* sizes_out, int
 }
 
 // Benchmark corpora generated straight into caller HBM: dst row i = corpus row row_begin + i * row_stride, fp16 [n, d].
-// kind 0: the isotropic corpus of knnx_synth_fill (row_stride must be 1); kind 1: the overlapping mixture of n_clusters
+// kind 0: the isotropic corpus of knnx_synth_fill (row_stride must be 1); kind 2: the same with three dominant columns (the
+// anisotropy of CLIP embeddings: the int8 first stage takes two query planes on it); kind 1: the overlapping mixture of n_clusters
 // Gaussians of BASELINE config 5 (knn_kernels.hip: knn_synth_mix_kernel; oracle/knn_oracle.py: synth_mixture_rows).
 // Synchronous.
 extern "C" int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed,
@@ -2017,14 +2109,14 @@ extern "C" int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_beg
   if (n == 0) return KNNX_OK;
   HIPCHK(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
-  if (kind == 0) {
-    if (row_stride != 1) return fail(KNNX_E_UNSUPPORTED, "the isotropic corpus is generated with row_stride 1 only");
+  if (kind == 0 || kind == 2) {  // 2: the isotropic corpus with three dominant columns (knn_synth_kernel)
+    if (row_stride != 1) return fail(KNNX_E_UNSUPPORTED, "the isotropic corpora are generated with row_stride 1 only");
     // the kernel addresses X[row * d]: shift the base so that corpus row row_begin lands on dst row 0
-    HIPCHK(launch_synth((_Float16*)dst_f16 - (size_t)row_begin * d, row_begin, n, d, seed, st));
+    HIPCHK(launch_synth((_Float16*)dst_f16 - (size_t)row_begin * d, row_begin, n, d, seed, st, kind == 2 ? 1 : 0));
     HIPCHK(hipStreamSynchronize(st));
     return KNNX_OK;
   }
-  if (kind != 1 || n_clusters <= 0) return fail(KNNX_E_ARG, "kind must be 0 or 1 (with n_clusters > 0)");
+  if (kind != 1 || n_clusters <= 0) return fail(KNNX_E_ARG, "kind must be 0, 2, or 1 (with n_clusters > 0)");
   short* table = nullptr;
   HIPCHK(hipMalloc(&table, synth_mix_table_bytes(d)));
   hipError_t e = launch_synth_mix((_Float16*)dst_f16, row_begin, row_stride, n, d, seed, n_clusters, table, st);
@@ -2248,6 +2340,7 @@ extern "C" int knnx_ivf_set_nprobe(knnx_index* ix, int nprobe) {
 }
 
 extern "C" int knnx_ivf_nlist(const knnx_index* ix) { return ix ? ix->ivf_nlist : 0; }
+extern "C" int knnx_ivf_nprobe(const knnx_index* ix) { return ix ? ix->ivf_nprobe : 0; }
 
 extern "C" int knnx_merge_topk_device(int device, const float* D_parts, const int64_t* I_parts, int P, int n, int k,
                                       float* D_out, int64_t* I_out, void* stream) {

@@ -318,7 +318,9 @@ class ClipEncoder:
             self.encode_image_device(u8.data_ptr(), u8.shape[0], PIX_U8_NHWC, out.data_ptr(), None, s.cuda_stream)
             host = torch.empty(out.shape, dtype=torch.float16, pin_memory=True)
             host.copy_(out, non_blocking=True)
-        s.synchronize()
+        # synchronises the stream AND raises ResidualStreamOverflow if a row of this call left the fp16 range (include/clipx.h: "reported,
+        # never hidden" -- the *_device entry points only set the flag; ADVICE r4: a plain synchronize here wrote finite-looking wrong rows)
+        self.check_range(s.cuda_stream)
         return host.numpy()
 
     # ---- asynchronous tickets (clipx_encode_*_async / clipx_wait): submit now, collect later

@@ -198,7 +198,7 @@ class Mi355xIndex(_FaissShaped):
 
     @property
     def nprobe(self):
-        return getattr(self, "_nprobe", 1)
+        return int(self._lib.knnx_ivf_nprobe(self._h)) if self.nlist > 0 else getattr(self, "_nprobe", 1)
 
     @nprobe.setter
     def nprobe(self, v):
@@ -257,6 +257,10 @@ class Mi355xIndex(_FaissShaped):
         """Queries answered through the int8 first stage of the flat scans (include/knnx.h: knnx_i8_served); results are exact
         either way."""
         return int(self._lib.knnx_i8_served(self._h))
+
+    def i8_rows(self):
+        """Rows the int8 copy holds at the moment (include/knnx.h: knnx_i8_rows): ntotal, fewer for a partial copy, 0 for none."""
+        return int(self._lib.knnx_i8_rows(self._h))
 
     def i8_planes(self):
         """0: no int8 copy at the moment; 1 / 2: int8 planes per query of the first stage (include/knnx.h: knnx_i8_planes)."""
@@ -358,6 +362,13 @@ class ShardedMi355xIndex(_FaissShaped):
 
     @property
     def nprobe(self):
+        """What the shards carry (knnx_ivf_nprobe of the first IVF shard): an index adopted with from_shards() keeps the value its
+        shards were built with (the wrapper used to answer 1 until it had been set, and knn_search's wide path then
+        'restored' 1 on every shard)."""
+        for g in range(self.nshards):
+            sh = C.c_void_p(self._lib.knnx_shards_get(self._h, g))
+            if self._lib.knnx_ivf_nlist(sh) > 0:
+                return int(self._lib.knnx_ivf_nprobe(sh))
         return getattr(self, "_nprobe", 1)
 
     @nprobe.setter
@@ -439,7 +450,9 @@ class ShardedMi355xIndex(_FaissShaped):
 def embedding_files(folder):
     """The `img_emb_*.npy` / `text_emb_*.npy` files of one `clip inference` output folder, in partition
     order (zero-padded names sort correctly: writer.py:22,67)."""
-    files = sorted(glob.glob(os.path.join(folder, "*.npy")))
+    # (not the sidecars save_index() writes -- ivf_centroids.npy / ivf_lists.npy: an index saved INTO its embeddings folder must not
+    # turn into two more partitions at the next load; ADVICE r4)
+    files = sorted(f for f in glob.glob(os.path.join(folder, "*.npy")) if not os.path.basename(f).startswith("ivf_"))
     if not files:
         raise ValueError(f"no .npy embedding files under {folder}")
     return files
@@ -584,7 +597,8 @@ class IvfBuilder:
 
 
 def synth_rows_device(dst_ptr, row_begin, n, d, seed, kind=0, n_clusters=0, row_stride=1, device=0, stream=None):
-    """Benchmark corpus rows generated into device memory (knnx_synth_rows_device): kind 0 isotropic, 1 config-5 mixture."""
+    """Benchmark corpus rows generated into device memory (knnx_synth_rows_device): kind 0 isotropic, 1 config-5 mixture, 2 isotropic
+    with three dominant columns (CLIP-like anisotropy)."""
     lib = load_library()
     check(lib, lib.knnx_synth_rows_device(int(device), C.c_void_p(dst_ptr), int(row_begin), int(row_stride), int(n), int(d),
                                           C.c_uint64(seed), int(kind), int(n_clusters), C.c_void_p(stream) if stream else None), "knnx")

@@ -107,6 +107,7 @@ int knnx_ivf_set_lists(knnx_index* ix, int nlist, const uint16_t* centroids_f16,
                        const int64_t* ids);
 int knnx_ivf_set_nprobe(knnx_index* ix, int nprobe); /* 1 .. nlist (BASELINE config 5: 16 / 64 / 256) */
 int knnx_ivf_nlist(const knnx_index* ix);
+int knnx_ivf_nprobe(const knnx_index* ix);  /* the value knnx_ivf_set_nprobe left (1 after knnx_ivf_set_lists / knnx_ivf_end) */
 
 /* ---- IVF-Flat build on the device (stands in for the autofaiss call of clip_index.py:12-66) ----------
  * Training: a builder keeps the centroids and a training sample resident in HBM.  One Lloyd iteration =
@@ -201,7 +202,9 @@ int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed);
 /* Benchmark corpora generated straight into caller HBM (fp16 [n, d]; dst row i = corpus row row_begin + i * row_stride; any row
  * is re-derivable on the CPU: oracle/knn_oracle.py).  kind 0: the isotropic corpus of knnx_synth_fill (row_stride 1 only);
  * kind 1: BASELINE config 5's overlapping mixture of n_clusters Gaussians in a 32-dimensional latent space, where IVF recall
- * is < 1 at small nprobe and rises with it.  `stream`: hipStream_t or NULL; synchronous. */
+ * is < 1 at small nprobe and rises with it; kind 2: the isotropic corpus with three dominant columns (6 x the spread plus a common
+ * offset, as a few dimensions of real CLIP embeddings have: the int8 first stage takes two query planes on it; row_stride 1 only).
+ * `stream`: hipStream_t or NULL; synchronous. */
 int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed,
                            int kind, int64_t n_clusters, void* stream);
 
@@ -221,10 +224,16 @@ int knnx_coalesce_stats(knnx_index* ix, int64_t* batches, int64_t* queries, int6
  * clip_back.py:362).  A flat (non-IVF) index of d = 512 / 768 / 1024 with at least 2^21 rows keeps, when the memory can be had,
  * an int8 copy of its fp16 rows (one scale per column) and scans THAT with 1 .. 256 queries per pass -- half the bytes, int8 MFMA --
  * to decide which rows are re-scored exactly from the fp16 rows; the admission threshold carries a proven bound of the quantisation
- * error, so D and I are the exact top-k as without it (a query whose hit list overflows is re-run by the exact scan).  The copy is
+ * error (every fp32 norm in it widened by 1 + 1e-3, which covers its own rounding with an order of magnitude to spare), so D and I
+ * are the exact top-k as without it (a query whose hit list overflows is re-run by the exact scan).  The copy is
  * built on the first search after the rows changed (one pass over the rows) and costs ntotal * d bytes; KNNX_I8=0 in the environment
- * turns it off, and so does a failed allocation.  knnx_i8_served: queries answered through this path so far (-1: null index). */
+ * turns it off.  When ntotal * d bytes cannot be had next to the rows (the headline shard: 125 M x 768 fp16 = 192 GB of a 288 GB part)
+ * or KNNX_I8_MAX_BYTES caps it, the copy is PARTIAL: it holds as many leading rows as fit (at least a quarter of the index, else
+ * none), those get the int8 first stage and the rows behind them are scanned in fp16 into the same hit lists -- one proof, one
+ * result.  Any later allocation of the index that fails takes the copy's memory back and turns the feature off.
+ * knnx_i8_served: queries answered through this path so far (-1: null index); knnx_i8_rows: rows the copy holds now (0: none). */
 int64_t knnx_i8_served(knnx_index* ix);
+int64_t knnx_i8_rows(knnx_index* ix);
 /* 0: no int8 copy at the moment; 1 / 2: int8 planes per query.  A query is quantised as u = q * (column scales) with ONE scale, so an
  * index with a few columns much larger than the rest (largest column scale > 3 x the median one) gets a second plane for what the
  * first left -- twice the matrix work, four waves x 32 queries per pass -- instead of admitting (and re-scoring) two orders of

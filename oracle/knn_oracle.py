@@ -193,8 +193,9 @@ def _mix64(z):
     return z ^ (z >> np.uint64(31))
 
 
-def synth_rows(rows, d: int, seed: int) -> np.ndarray:
-    """fp16 [len(rows), d]: row r = fp16(fp32(v / sqrt(sum v^2))), v = Irwin-Hall(4) of a splitmix64 hash."""
+def synth_rows(rows, d: int, seed: int, dominant: bool = False) -> np.ndarray:
+    """fp16 [len(rows), d]: row r = fp16(fp32(v / sqrt(sum v^2))), v = Irwin-Hall(4) of a splitmix64 hash.  dominant (corpus kind 2 of
+    knnx_synth_rows_device): columns 0..2 carry 6 v + 113 511 before the normalisation."""
     rows = np.asarray(rows, dtype=np.uint64).reshape(-1, 1)
     cols = np.arange(d, dtype=np.uint64).reshape(1, -1)
     with np.errstate(over="ignore"):
@@ -202,6 +203,8 @@ def synth_rows(rows, d: int, seed: int) -> np.ndarray:
         h = _mix64(np.uint64(seed) ^ (idx * np.uint64(0x9E3779B97F4A7C15)))
     v = ((h & np.uint64(0xFFFF)) + ((h >> np.uint64(16)) & np.uint64(0xFFFF)) + ((h >> np.uint64(32)) & np.uint64(0xFFFF))
          + (h >> np.uint64(48))).astype(np.int64) - 131070
+    if dominant:
+        v[:, :3] = 6 * v[:, :3] + 113511
     ss = (v * v).sum(axis=1, keepdims=True)
     scale = 1.0 / np.sqrt(ss.astype(np.float64))
     return (v.astype(np.float64) * scale).astype(np.float32).astype(np.float16)
@@ -270,6 +273,8 @@ def synth_mixture_rows(rows, d: int, seed: int, n_clusters: int) -> np.ndarray:
 class Int8FirstStage:
     """x8 = clamp(rint(x / c)), c_j = max_i |x_ij| / 127 (1 where a column is all zero); queries u = q * c as one or two int8 planes."""
 
+    SAFETY = np.float32(1.001)
+
     def __init__(self, rows_fp16, colscale=None):
         x = np.asarray(rows_fp16, dtype=np.float16).astype(np.float32)
         if colscale is None:
@@ -278,9 +283,11 @@ class Int8FirstStage:
         self.c = np.asarray(colscale, dtype=np.float32)
         y = x / self.c
         self.x8 = np.clip(np.rint(y), -127, 127).astype(np.float32)
-        # A, B: maxima over the rows AS STORED (clamped values included), 2-norms per row
-        self.A = np.float32(np.sqrt(((y - self.x8) ** 2).sum(axis=1)).max()) if len(x) else np.float32(0)
-        self.B = np.float32(np.sqrt((self.x8 ** 2).sum(axis=1)).max()) if len(x) else np.float32(0)
+        # A, B: maxima over the rows AS STORED (clamped values included), 2-norms per row; the kernel stores the root one ulp above
+        # round-to-nearest (knn_i8_quant_kernel: bit pattern + 1) so that the maximum is never below the true root
+        up = lambda v: np.nextafter(np.float32(v), np.float32(np.inf))
+        self.A = up(np.sqrt(((y - self.x8) ** 2).sum(axis=1, dtype=np.float32)).max()) if len(x) else np.float32(0)
+        self.B = up(np.sqrt((self.x8 ** 2).sum(axis=1, dtype=np.float32)).max()) if len(x) else np.float32(0)
         self.x = x
 
     def quantise_queries(self, q, planes: int = 1):
@@ -297,7 +304,9 @@ class Int8FirstStage:
             u8b = np.clip(np.rint(res / su2[:, None]), -127, 127).astype(np.float32)
             res = res - su2[:, None] * u8b
             out, s = [u8, u8b], su2
-        eps8 = (np.sqrt((u ** 2).sum(axis=1)) * self.A + np.sqrt((res ** 2).sum(axis=1)) * self.B) * np.float32(1.00002)
+        # SAFETY = 1 + 1e-3 (knn_i8_prep_kernel): every norm here is an fp32 sum of up to d non-negative terms and a square root,
+        # relative error <= (d + 2) 2^-24 < 6.2e-5 at d = 1024 (round 4 had 1 + 2e-5, below that worst case: VERDICT r4 weak #1)
+        eps8 = (np.sqrt((u ** 2).sum(axis=1, dtype=np.float32)) * self.A + np.sqrt((res ** 2).sum(axis=1, dtype=np.float32)) * self.B) * self.SAFETY
         return s, np.stack(out), eps8.astype(np.float32)
 
     def integer_scores(self, planes_u8):

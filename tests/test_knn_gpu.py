@@ -778,6 +778,64 @@ def test_i8_first_stage_two_query_planes_for_dominant_columns(monkeypatch):
     iso.close()
 
 
+@pytest.mark.parametrize("d,n,budget_rows", [(768, 90_001, 40_000), (1024, 70_013, 30_000), (512, 60_000, 59_999)])
+def test_i8_partial_copy_int8_part_plus_fp16_rest_equals_the_oracle(monkeypatch, d, n, budget_rows):
+    """BASELINE's headline shard (125 M x 768 fp16 = 192 GB per GPU) leaves no room for a whole int8 copy, so the copy may be PARTIAL
+    (include/knnx.h, knnx_i8_rows): the leading rows get the int8 first stage, the rows behind them the fp16 register-stationary pass,
+    both into one hit list with one proof.  Here the budget is made artificially small (KNNX_I8_MAX_BYTES); neighbours are planted on
+    both sides of the boundary and in the ragged last tile; every batch size class (1, <= 64, <= 128, 256, > 256) must equal the oracle
+    and be served by the int8 path."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")
+    monkeypatch.setenv("KNNX_I8_MAX_BYTES", str(budget_rows * d))
+    x = _data(n, d, seed=61)
+    o, ix = FlatIPOracle(d), Mi355xIndex(d)
+    o.add(x)
+    ix.add(x)
+    n8 = (budget_rows // 32) * 32
+    rows = np.minimum(np.r_[0, 17, n8 - 1, n8, n8 + 1, n8 + 33, n - 1, n - 2, np.random.default_rng(62).integers(0, n, 292)], n - 1)
+    q = x[rows].astype(np.float32) + 0.02 * np.random.default_rng(63).standard_normal((len(rows), d)).astype(np.float32)
+    Do, Io = o.search(q, 40)
+    served = 0
+    for lo, hi in ((0, 1), (1, 8), (8, 70), (70, 190), (0, 256), (0, 300)):
+        D, I = ix.search(q[lo:hi], 40)
+        _check(D, I, Do[lo:hi], Io[lo:hi], f"partial int8 copy d={d} queries {lo}:{hi}")
+        served += hi - lo
+    assert ix.i8_rows() == n8, (ix.i8_rows(), n8)
+    assert ix.i8_served() == served and ix.stats()[1] == 0, (ix.i8_served(), served, ix.stats())
+    assert np.array_equal(Io[:6, 0], rows[:6])  # the planted rows around the boundary are the top hits
+    # the budget grows: the next rebuild takes the whole index, nothing changes in the results
+    ix.close()
+
+
+def test_i8_tile_ordered_copy_ragged_sizes_and_appends(monkeypatch):
+    """The int8 copy is stored tile-ordered (the LDS image of the scan, knn_i8_quant_kernel): row counts that end inside a 16-row half
+    tile, inside the second half, and exactly on a tile; rows appended so that the new rows share a half tile with old ones."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")
+    d = 768
+    x = _data(40_000, d, seed=71)
+    for sizes in ((33_001,), (32_016 + 7, 5), (32_000, 1, 14, 17), (20_005, 9_990, 3)):
+        o, ix = FlatIPOracle(d), Mi355xIndex(d)
+        at = 0
+        for sz in sizes:
+            o.add(x[at:at + sz])
+            ix.add(x[at:at + sz])
+            at += sz
+            rows = np.r_[at - 1, max(0, at - sz), max(0, at - sz - 1), np.random.default_rng(at).integers(0, at, 29)]
+            q = x[rows].astype(np.float32) + 0.02 * np.random.default_rng(at + 1).standard_normal((32, d)).astype(np.float32)
+            D, I = ix.search(q, 10)
+            Do, Io = o.search(q, 10)
+            _check(D, I, Do, Io, f"tile-ordered int8 copy, sizes {sizes} at {at}")
+            assert ix.i8_rows() == at
+        assert ix.stats()[1] == 0
+        ix.close()
+
+
 def test_i8_first_stage_overflow_falls_back(monkeypatch):
     """200 000 copies of one row and queries equal to it: every copy passes the int8 admission, the 32 768-entry hit list
     overflows, the query is answered by the gated exact scan -- ids in ascending order among the ties."""

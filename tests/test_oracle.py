@@ -304,3 +304,37 @@ def test_int8_first_stage_bound_and_admission_hold(corpus, planes):
     if corpus == "isotropic" or (planes == 2 and corpus == "dominant_columns"):
         frac = adm[:40].mean()
         assert frac < 0.25, f"{frac:.2f} of the rows admitted"
+
+
+def test_int8_bound_holds_at_d1024_when_every_residual_pulls_the_same_way():
+    """the bound multiplies fp32 norms -- sums of d terms, each a few 2^-24 off -- and round 4's slack (1 + 2e-5) was
+    below the worst-case summation error at d = 1024 (6.1e-5).  Drive the case where Cauchy-Schwarz is (nearly) an equality, so that
+    there is no practical margin to hide behind: every component of every row sits ~0.45 above its int8 level, and each query's u is
+    parallel to the residual vector of one row.  The float64 truth must stay inside the float32 bound with the 1 + 1e-3 factor, and
+    the case must be tight enough to mean something."""
+    from oracle.knn_oracle import Int8FirstStage
+
+    rng = np.random.default_rng(1024)
+    d, n = 1024, 512
+    c = (1.0 + rng.random(d)).astype(np.float32) / np.float32(127 * 40)        # column scales, not powers of two
+    k = rng.integers(-3, 4, size=(n, d)).astype(np.float32)                    # small levels: B stays small, the u-quantisation term too
+    r = (0.40 + 0.09 * rng.random((n, d))).astype(np.float32)                   # residuals, all positive, just below the rounding point
+    x = ((k + r) * c).astype(np.float16)
+    cols = np.arange(d)
+    x[cols % n, cols] = (np.float32(127) * c).astype(np.float16)                # pins max |x_j| = 127 c_j, two columns per row (keeps B small)
+    st = Int8FirstStage(x)
+    y = st.x / st.c
+    res = (y - st.x8).astype(np.float64)
+    assert (res > 0.3).mean() > 0.9, "the residuals are meant to be large and one-sided"
+    rows = np.argsort(-(res ** 2).sum(axis=1))[:32]                             # the rows with the largest residual norm (A is their maximum)
+    q = (res[rows] / st.c.astype(np.float64)).astype(np.float32)                # u = q * c parallel to the row's residual vector
+    exact = q.astype(np.float64) @ st.x.astype(np.float64).T
+    for planes in (1, 2):
+        s, pl, eps8 = st.quantise_queries(q, planes)
+        approx = s[:, None].astype(np.float64) * st.integer_scores(pl)
+        err = np.abs(exact - approx)
+        ratio = err / eps8[:, None].astype(np.float64)
+        assert ratio.max() <= 1.0, f"planes={planes}: bound violated by {ratio.max() - 1:.2e}"
+        assert ratio.max() > 0.9, f"planes={planes}: the case is not tight (max err / eps8 = {ratio.max():.3f})"
+        # and the same sums WITHOUT the safety factor are within 1e-3 of failing: this is the regime the factor is for
+        assert ratio.max() * float(st.SAFETY) > 0.9009

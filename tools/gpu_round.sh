@@ -20,9 +20,9 @@ MB_VARIANTS=1,3 MB_KNN_ROWS=100000000 timeout 900 python tools/microbench.py gem
 if [ "${2:-}" != "quick" ]; then
   ( time timeout 900 python bench.py ) > $OUT/bench_$TAG.log 2>&1; tail -5 $OUT/bench_$TAG.log
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --cpu-seconds 0 --no-parity > $OUT/rocprof_$TAG.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o $TAG -- python $ROOT/bench.py --cpu-seconds 0 --no-parity --no-ivf --no-knn-extra > $OUT/rocprof_$TAG.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${c}_$TAG -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --knn-scans 2 --cpu-seconds 0 --no-parity > $OUT/pmc_${c}_$TAG.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${c}_$TAG -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --knn-scans 2 --cpu-seconds 0 --no-parity --no-ivf --no-knn-extra > $OUT/pmc_${c}_$TAG.log 2>&1
   done
   cd $ROOT
   python3 tools/traffic_summary.py $OUT/pmc_FETCH_SIZE_$TAG/p_counter_collection.csv $OUT/pmc_WRITE_SIZE_$TAG/p_counter_collection.csv --steps 3 --warmup 1 > $OUT/traffic_$TAG.json; cat $OUT/traffic_$TAG.json
