@@ -49,6 +49,18 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def pmc_mfma_busy(family):
+    """Measured matrix-pipe utilisation of a kernel family: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) from the
+    rocprofv3 --pmc pass of this same command (tools/gpu_round.sh -> tools/mfma_busy_summary.py -> profiles/mfma_busy.json); None when
+    the file is absent.  The `frac` beside it is arithmetic (flops / time / peak): the two differ by the clock the part sustained."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "mfma_busy.json")) as f:
+            k = json.load(f)["families"][family]
+        return k["mfma_busy_frac"], k["effective_clock_ghz"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +197,9 @@ def main():
                 "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / BF16_PEAK_TFLOPS, 4),
                 "per": "step", "launches_per_step": g["launches"] // max(args.steps, 1), "ms_per_step": round(g["ms"] / max(args.steps, 1), 3),
                 "algorithmic_tflop_per_step": round(gemm_tflops * g["ms"] / max(args.steps, 1) / 1e3, 3),
+                "mfma_busy_frac": pmc_mfma_busy("gemm")[0] if (args.model == "ViT-L/14" and B == 256) else None,
+                "mfma_busy_clock_ghz": pmc_mfma_busy("gemm")[1] if (args.model == "ViT-L/14" and B == 256) else None,
+                "mfma_busy_source": "profiles/mfma_busy.json: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass of this command (tools/gpu_round.sh, separate run); busy cycles / (1024 SIMDs x kernel cycles)",
                 "traffic": traffic, "traffic_unit": traffic_unit, "traffic_run": "separate --pmc pass" if traffic else None,
                 "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command (tools/gpu_round.sh); counters cannot be read inside the timed run" if traffic else None}
 

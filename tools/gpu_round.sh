@@ -24,7 +24,9 @@ if [ "${2:-}" != "quick" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${c}_$TAG -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --knn-scans 2 --cpu-seconds 0 --no-parity --no-ivf --no-knn-extra > $OUT/pmc_${c}_$TAG.log 2>&1
   done
+  timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_MFMA_$TAG -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --knn-scans 2 --cpu-seconds 0 --no-parity --no-ivf --no-knn-extra > $OUT/pmc_MFMA_$TAG.log 2>&1
   cd $ROOT
-  python3 tools/traffic_summary.py $OUT/pmc_FETCH_SIZE_$TAG/p_counter_collection.csv $OUT/pmc_WRITE_SIZE_$TAG/p_counter_collection.csv --steps 3 --warmup 1 > $OUT/traffic_$TAG.json; cat $OUT/traffic_$TAG.json
+  python3 tools/mfma_busy_summary.py $(find $OUT/pmc_MFMA_$TAG -name 'p_counter_collection.csv' | head -1) > $OUT/mfma_busy_$TAG.json; head -c 1500 $OUT/mfma_busy_$TAG.json
+  python3 tools/traffic_summary.py $(find $OUT/pmc_FETCH_SIZE_$TAG -name 'p_counter_collection.csv' | head -1) $(find $OUT/pmc_WRITE_SIZE_$TAG -name 'p_counter_collection.csv' | head -1) --steps 3 --warmup 1 > $OUT/traffic_$TAG.json; cat $OUT/traffic_$TAG.json
   ls -R $OUT/prof_$TAG | head
 fi
