@@ -92,6 +92,7 @@ SIGNATURES = {
     "knnx_shards_synth_fill": (C.c_int, [_P, C.c_int64, C.c_uint64]),
     "knnx_shards_ntotal": (C.c_int64, [_P]),
     "knnx_shards_count": (C.c_int, [_P]),
+    "knnx_shards_exchange": (C.c_int, [_P]),
     "knnx_shards_get": (_P, [_P, C.c_int]),
     "knnx_shards_search": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "knnx_shards_reconstruct": (C.c_int, [_P, _P, C.c_int64, _P]),

@@ -10,11 +10,20 @@
 //     peer-to-peer over xGMI into one buffer on devices[0] (hipMemcpyPeerAsync: the exchange is a few KB, latency-bound,
 //     a direct copy per shard is the one-step exchange SURVEY 8(e) asks for), and the same merge kernel that follows the
 //     RCCL all-gather of the one-process-per-GPU path (knnx_merge_topk_device) produces the final top-k;
+//     -- or, when every shard sits on its own device and librccl.so can be loaded (round 5; SURVEY 8(e): "RCCL ncclAllGather of
+//     B * k * 12 B per rank inside one process (ncclCommInitAll)"), by ONE grouped all-gather over RCCL: a communicator per device
+//     from ncclCommInitAll, ncclGroupStart; per device ncclAllGather(D) + ncclAllGather(I) on its own stream; ncclGroupEnd -- every
+//     device then holds all P lists and devices[0] merges.  RCCL is loaded with dlopen on first use (the library has no link-time
+//     dependency on it and a one-GPU process never loads it); KNNX_SHARDS_RCCL=0 keeps the peer copies, =1 also takes RCCL for a
+//     single shard (the one-GPU test of this path).  knnx_shards_exchange() says which one is in use.  NEVER RUN ON MORE THAN ONE
+//     GPU by its author (one-GPU test boxes): correct by construction and by the single-device communicator test only.
 //   * reconstruct: ids are routed to the owning shard by row range.
 // Built on the public entry points of include/knnx.h only.  No CPU arithmetic: the host routes ids and pointers.
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <float.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
@@ -29,6 +38,39 @@ extern "C" int knnx_set_error(int code, const char* msg);  // knnx_api.hip: sets
 
 namespace {
 
+// ---- RCCL through dlopen: the five entry points the exchange needs (rccl.h: ncclResult_t = int, ncclSuccess = 0; ncclFloat32 = 7,
+// ncclInt64 = 4 in ncclDataType_t -- the values of rccl.h / nccl.h, checked by the single-device test)
+struct Rccl {
+  void* so = nullptr;
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t st) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+constexpr int RCCL_INT64 = 4, RCCL_FLOAT32 = 7;
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.so) break;
+    }
+    if (!r.so) return;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.so, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.so, "ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.so, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.so, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
+    r.ok = r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd;
+  });
+  return r;
+}
+
 struct Shard {
   knnx_index* ix = nullptr;
   int device = 0;
@@ -38,6 +80,9 @@ struct Shard {
   float* q = nullptr;          // [cap_q, d]
   float* D = nullptr;          // [cap_q, 64]
   int64_t* I = nullptr;
+  void* comm = nullptr;        // RCCL communicator of this device (rank = shard index), or null
+  float* agD = nullptr;        // RCCL: all P lists as this device receives them, [P, cap_q, 64]
+  int64_t* agI = nullptr;
 };
 
 }  // namespace
@@ -56,6 +101,7 @@ struct knnx_shards {
   int64_t* mI = nullptr;
   void* pin = nullptr;         // pinned: queries | D | I
   size_t pin_q = 0, pin_d = 0;
+  bool use_rccl = false;       // the per-shard top-k lists travel by one grouped ncclAllGather instead of peer copies
 };
 
 #define SHIP(expr)                                                                                                  \
@@ -93,6 +139,30 @@ static int shards_finish_setup(knnx_shards* s) {
   s->pin_q = (size_t)s->cap_q * s->d * sizeof(float);
   s->pin_d = (size_t)s->cap_q * KNNX_MAX_K_FAST * sizeof(float);
   SHIP(hipHostMalloc(&s->pin, s->pin_q + s->pin_d + (size_t)s->cap_q * KNNX_MAX_K_FAST * sizeof(int64_t), hipHostMallocDefault));
+  // ---- RCCL exchange: every shard on its own device (a communicator cannot hold one GPU twice), P > 1 unless forced
+  const char* env = getenv("KNNX_SHARDS_RCCL");
+  const int want = env ? atoi(env) : -1;  // -1: automatic
+  bool distinct = true;
+  for (int g = 0; g < P; ++g)
+    for (int o = 0; o < g; ++o) distinct = distinct && s->sh[o].device != s->sh[g].device;
+  if (want != 0 && distinct && (P > 1 || want == 1) && rccl().ok) {
+    std::vector<int> devs(P);
+    std::vector<void*> comms(P, nullptr);
+    for (int g = 0; g < P; ++g) devs[g] = s->sh[g].device;
+    if (rccl().CommInitAll(comms.data(), P, devs.data()) == 0) {
+      bool mem = true;
+      for (int g = 0; g < P && mem; ++g) {
+        Shard& h = s->sh[g];
+        h.comm = comms[g];
+        mem = hipSetDevice(h.device) == hipSuccess &&
+              hipMalloc(&h.agD, (size_t)P * s->cap_q * KNNX_MAX_K_FAST * sizeof(float)) == hipSuccess &&
+              hipMalloc(&h.agI, (size_t)P * s->cap_q * KNNX_MAX_K_FAST * sizeof(int64_t)) == hipSuccess;
+      }
+      s->use_rccl = mem;
+      if (!mem) (void)hipGetLastError();
+    }
+    (void)hipSetDevice(s->sh[0].device);
+  }
   return KNNX_OK;
 }
 
@@ -154,6 +224,9 @@ extern "C" void knnx_shards_destroy(knnx_shards* s) {
     if (h.q) (void)hipFree(h.q);
     if (h.D) (void)hipFree(h.D);
     if (h.I) (void)hipFree(h.I);
+    if (h.comm && rccl().ok) (void)rccl().CommDestroy(h.comm);
+    if (h.agD) (void)hipFree(h.agD);
+    if (h.agI) (void)hipFree(h.agI);
     if (h.ev) (void)hipEventDestroy(h.ev);
     if (h.st) (void)hipStreamDestroy(h.st);
     if (h.ix) knnx_destroy(h.ix);
@@ -170,6 +243,7 @@ extern "C" void knnx_shards_destroy(knnx_shards* s) {
 }
 
 extern "C" int knnx_shards_count(const knnx_shards* s) { return s ? (int)s->sh.size() : 0; }
+extern "C" int knnx_shards_exchange(const knnx_shards* s) { return s ? (s->use_rccl ? 1 : 0) : -1; }
 extern "C" knnx_index* knnx_shards_get(knnx_shards* s, int g) { return (s && g >= 0 && g < (int)s->sh.size()) ? s->sh[g].ix : nullptr; }
 
 extern "C" int64_t knnx_shards_ntotal(const knnx_shards* s) {
@@ -248,6 +322,7 @@ static int shards_search_fast(knnx_shards* s, const float* q, int n, int k, floa
       int r = knnx_search_device(h.ix, h.q, nb, k, h.D, h.I, h.st);
       if (r) return r;
       const size_t cnt = (size_t)nb * k;
+      if (s->use_rccl) continue;  // exchanged below, all shards in one group
       if (h.device == s->sh[0].device) {
         SHIP(hipMemcpyAsync(s->gD + (size_t)g * cnt, h.D, cnt * sizeof(float), hipMemcpyDeviceToDevice, h.st));
         SHIP(hipMemcpyAsync(s->gI + (size_t)g * cnt, h.I, cnt * sizeof(int64_t), hipMemcpyDeviceToDevice, h.st));
@@ -257,9 +332,33 @@ static int shards_search_fast(knnx_shards* s, const float* q, int n, int k, floa
       }
       SHIP(hipEventRecord(h.ev, h.st));
     }
-    SHIP(hipSetDevice(s->sh[0].device));
-    for (int g = 0; g < P; ++g) SHIP(hipStreamWaitEvent(s->st0, s->sh[g].ev, 0));
-    int r = knnx_merge_topk_device(s->sh[0].device, s->gD, s->gI, P, nb, k, s->mD, s->mI, s->st0);
+    const float* partD = s->gD;
+    const int64_t* partI = s->gI;
+    if (s->use_rccl) {
+      // ONE grouped exchange: every device contributes its nb * k (score, id) pairs -- nb * k * 12 bytes -- and receives all P lists,
+      // rank-major = shard-major = ascending id order, the layout the merge kernel takes
+      const size_t cnt = (size_t)nb * k;
+      int rc = rccl().GroupStart();
+      for (int g = 0; g < P && rc == 0; ++g) {
+        Shard& h = s->sh[g];
+        rc = rccl().AllGather(h.D, h.agD, cnt, RCCL_FLOAT32, h.comm, h.st);
+        if (rc == 0) rc = rccl().AllGather(h.I, h.agI, cnt, RCCL_INT64, h.comm, h.st);
+      }
+      const int rc2 = rccl().GroupEnd();
+      if (rc == 0) rc = rc2;
+      if (rc != 0)
+        return knnx_set_error(KNNX_E_HIP, (std::string("RCCL all-gather of the per-shard top-k: ") +
+                                           (rccl().GetErrorString ? rccl().GetErrorString(rc) : "error")).c_str());
+      SHIP(hipSetDevice(s->sh[0].device));
+      SHIP(hipEventRecord(s->sh[0].ev, s->sh[0].st));
+      SHIP(hipStreamWaitEvent(s->st0, s->sh[0].ev, 0));
+      partD = s->sh[0].agD;
+      partI = s->sh[0].agI;
+    } else {
+      SHIP(hipSetDevice(s->sh[0].device));
+      for (int g = 0; g < P; ++g) SHIP(hipStreamWaitEvent(s->st0, s->sh[g].ev, 0));
+    }
+    int r = knnx_merge_topk_device(s->sh[0].device, partD, partI, P, nb, k, s->mD, s->mI, s->st0);
     if (r) return r;
     SHIP(hipMemcpyAsync(pin + s->pin_q, s->mD, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, s->st0));
     SHIP(hipMemcpyAsync(pin + s->pin_q + s->pin_d, s->mI, (size_t)nb * k * sizeof(int64_t), hipMemcpyDeviceToHost, s->st0));

@@ -99,10 +99,17 @@ class ShardedIndex:
         import torch  # pylint: disable=import-outside-toplevel
         import torch.distributed as dist  # pylint: disable=import-outside-toplevel
 
-        D, I = self.local.search(x, k)
         if self.world == 1:
-            return D, I
+            return self.local.search(x, k)
         on_gpu = dist.get_backend(self.group) == "nccl"
+        if on_gpu and k <= 64:
+            # RCCL: upload the queries once and stay on the device -- local scan into the record buffer, all-gather, merge -- only
+            # the merged [n, k] comes back (round 5: the local results used to travel device -> numpy -> device before the gather)
+            dev = torch.device("cuda", torch.cuda.current_device())
+            q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev, non_blocking=False)
+            Do, Io = self.search_device(q, k)
+            return Do.cpu().numpy(), Io.cpu().numpy()
+        D, I = self.local.search(x, k)
         dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
         n = D.shape[0]
         rec, Iv, Dv = self._record_buffer(n, k, dev)

@@ -384,6 +384,11 @@ class ShardedMi355xIndex(_FaissShaped):
     def nshards(self):
         return int(self._lib.knnx_shards_count(self._h))
 
+    @property
+    def exchange(self):
+        """'rccl' (one grouped ncclAllGather of the per-shard top-k lists) or 'peer-copies' (include/knnx.h: knnx_shards_exchange)."""
+        return "rccl" if int(self._lib.knnx_shards_exchange(self._h)) == 1 else "peer-copies"
+
     def reserve(self, total_rows):
         """Fix the row range of every shard; must precede add()."""
         check(self._lib, self._lib.knnx_shards_reserve(self._h, int(total_rows)), "knnx")
@@ -604,15 +609,58 @@ def synth_rows_device(dst_ptr, row_begin, n, d, seed, kind=0, n_clusters=0, row_
                                           C.c_uint64(seed), int(kind), int(n_clusters), C.c_void_p(stream) if stream else None), "knnx")
 
 
-def train_ivf_centroids_device(builder, sample_ptr, n_sample, niter=8, seed=0):
+def rebalance_centroids(cent, sizes, rng, small=0.5, big=2.0, eps=0.05):
+    """Split-and-merge step of the k-means (what faiss' Clustering does for empty clusters -- `split_clusters` -- extended to the
+    small ones): every list with fewer than `small` x the mean size (smallest first, and only while it is under a quarter of the list it
+    would split) gives its centroid up, and the currently largest list (above `big` x the mean) is split by replacing its centroid c with the unit vectors of c + delta and c - delta (delta = eps |c| times a
+    random sign vector / sqrt(d)): the next Lloyd iteration deals the big list's members between the two halves, the small list's
+    few members move to their next-nearest centroids.  Round 5: BASELINE config 5's shard had lists of 1 / 1 880 /
+    14 993 rows (min / median / max) and scanned 1.2 - 1.3 x the bytes of the balanced-list model.  Returns the number of splits;
+    `cent` (float32 [nlist, d]) is changed in place."""
+    import heapq  # pylint: disable=import-outside-toplevel
+
+    sizes = np.asarray(sizes, dtype=np.float64)
+    mean = sizes.mean()
+    donors = [int(i) for i in np.argsort(sizes) if sizes[i] < small * mean]
+    heap = [(-float(sizes[i]), int(i)) for i in np.flatnonzero(sizes > big * mean)]
+    heapq.heapify(heap)
+    taken = set(donors)
+    n = 0
+    for i in donors:
+        while heap and heap[0][1] in taken:
+            heapq.heappop(heap)
+        if not heap or -heap[0][0] <= big * mean:
+            break
+        if sizes[i] > -heap[0][0] / 4:  # giving up a list a quarter the size of the one it would split gains nothing
+            break
+        s, j = heapq.heappop(heap)
+        c = cent[j].astype(np.float64)
+        delta = eps * np.linalg.norm(c) / np.sqrt(c.size) * rng.choice((-1.0, 1.0), size=c.size)
+        a, b = c + delta, c - delta
+        cent[j] = (a / max(np.linalg.norm(a), 1e-30)).astype(cent.dtype)
+        cent[i] = (b / max(np.linalg.norm(b), 1e-30)).astype(cent.dtype)
+        heapq.heappush(heap, (s / 2, j))  # each half may be split again
+        heapq.heappush(heap, (s / 2, i))
+        taken.discard(i)
+        n += 1
+    return n
+
+
+def train_ivf_centroids_device(builder, sample_ptr, n_sample, niter=8, seed=0, balance=True):
     """k-means over a device-resident sample with `builder` (IvfBuilder): seeds from distinct random sample rows, runs
-    `niter` Lloyd iterations, re-seeds empty lists on random sample rows.  Returns the list sizes of the last iteration."""
+    `niter` Lloyd iterations, re-seeds empty lists on random sample rows and -- `balance`, all but the last two iterations -- moves the
+    centroids of the smallest lists into the largest ones (rebalance_centroids).  Returns the list sizes of the last iteration."""
     rng = np.random.default_rng(seed)
     builder.set_sample_device(sample_ptr, n_sample)
     builder.seed_from_sample(np.arange(builder.nlist), np.sort(rng.choice(n_sample, builder.nlist, replace=False)))
     sizes = None
-    for _ in range(niter):
+    for it in range(niter):
         sizes = builder.lloyd()
+        if balance and it < niter - 2 and builder.nlist >= 16:
+            cent = builder.centroids().astype(np.float32)
+            if rebalance_centroids(cent, sizes, rng):
+                builder.set_centroids(cent.astype(np.float16))
+                continue
         empty = np.flatnonzero(sizes == 0)
         if empty.size:
             builder.seed_from_sample(empty, rng.choice(n_sample, empty.size, replace=False))
@@ -714,8 +762,13 @@ def train_ivf_centroids(x_f16, nlist, niter=8, seed=0, device=0, max_points_per_
     b = IvfBuilder(d, nlist, device)
     b.set_sample(sample)
     b.set_centroids(sample[rng.choice(sample.shape[0], nlist, replace=False)])
-    for _ in range(niter):
+    for it in range(niter):
         sizes = b.update(b.assign_sample())
+        if it < niter - 2 and nlist >= 16:  # split-and-merge: the smallest lists' centroids move into the largest lists
+            cent = b.centroids().astype(np.float32)
+            if rebalance_centroids(cent, sizes, rng):
+                b.set_centroids(cent.astype(np.float16))
+                continue
         empty = np.flatnonzero(sizes == 0)
         if empty.size:  # re-seed empty clusters on random points (faiss splits big clusters; any re-seed is valid)
             cent = b.centroids()

@@ -635,3 +635,39 @@ def test_folder_rows_is_the_concatenation_of_the_partitions(tmp_path):
     np.save(tmp_path / "img_emb_4.npy", np.zeros((2, 8), np.float16))
     with pytest.raises(ValueError):
         FolderRows(str(tmp_path))
+
+
+def test_kmeans_rebalancing_splits_the_big_lists_and_retires_the_small_ones():
+    """knn.rebalance_centroids (the split-and-merge step of the IVF k-means, reference: autofaiss / faiss Clustering behind
+    clip_index.py:12-66).  Eight heavy clusters and fifty-six light ones, one initial centroid on each: plain Lloyd keeps one list per
+    cluster (3 000 rows against 50); with the step the light lists' centroids are handed to the heavy clusters, whose lists end
+    several times smaller -- the same number of lists, every row still in exactly one.  (The kernels' k-means is checked on the GPU:
+    tests/test_knn_gpu.py.)"""
+    from clip_retrieval_amd.knn import rebalance_centroids
+
+    rng = np.random.default_rng(5)
+    d, nlist = 32, 64
+    pops = np.r_[np.full(8, 3000), np.full(56, 50)]
+    centres = rng.standard_normal((nlist, d))
+    x = np.concatenate([c + 0.35 * rng.standard_normal((n, d)) for c, n in zip(centres, pops)])
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+
+    def lloyd(balance):
+        r = np.random.default_rng(7)
+        cent = (centres / np.linalg.norm(centres, axis=1, keepdims=True)).astype(np.float32)
+        splits = 0
+        for it in range(10):
+            a = np.argmax(x @ cent.T, axis=1)
+            sizes = np.bincount(a, minlength=nlist)
+            for l in np.flatnonzero(sizes):
+                m = x[a == l].mean(axis=0)
+                cent[l] = m / np.linalg.norm(m)
+            if balance and it < 8:
+                splits += rebalance_centroids(cent, sizes, r)
+        return np.bincount(np.argmax(x @ cent.T, axis=1), minlength=nlist), splits
+
+    (plain, _), (bal, splits) = lloyd(False), lloyd(True)
+    assert plain.sum() == bal.sum() == len(x) and len(bal) == nlist
+    assert plain.max() >= 2900 and splits >= 16
+    assert bal.max() <= plain.max() / 2.5, (plain.max(), bal.max())
+    assert bal.max() <= 2.2 * bal.mean(), (bal.max(), bal.mean())    # nothing left above the split threshold (2 x the mean) by much

@@ -922,6 +922,35 @@ def test_sharded_index_two_shards_on_one_gpu_vs_flat_oracle():
     ix.close()
 
 
+def test_sharded_index_rccl_exchange_single_device_communicator(monkeypatch):
+    """The RCCL form of the exchange (SURVEY 8e: ncclCommInitAll + ncclAllGather of the per-shard top-k lists inside one process;
+    csrc/knnx_sharded.hip, loaded with dlopen): a communicator cannot hold one GPU twice, so on a one-GPU box the path is exercised
+    with ONE shard (KNNX_SHARDS_RCCL=1 forces it) -- communicator creation, the grouped all-gather of scores (float32) and ids
+    (int64), the merge behind it, teardown -- and must equal the flat oracle; with three shards on one device the library must fall
+    back to peer copies by itself.  More than one GPU has never run this path."""
+    from clip_retrieval_amd.knn import ShardedMi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    d, n = 768, 20_003
+    x = _data(n, d, seed=91)
+    o = FlatIPOracle(d)
+    o.add(x)
+    monkeypatch.setenv("KNNX_SHARDS_RCCL", "1")
+    ix = ShardedMi355xIndex(d, [0])
+    assert ix.exchange == "rccl", "librccl.so could not be loaded / ncclCommInitAll failed on the one device"
+    ix.reserve(n)
+    ix.add(x)
+    for nq, k in [(1, 40), (33, 40), (70, 7)]:
+        q = _queries(nq, d, seed=nq + k, x=x)
+        D, I = ix.search(q, k)
+        Do, Io = o.search(q, k)
+        _check(D, I, Do, Io, f"RCCL exchange nq={nq} k={k}")
+    ix.close()
+    three = ShardedMi355xIndex(d, [0, 0, 0])
+    assert three.exchange == "peer-copies"
+    three.close()
+
+
 def test_sharded_index_adopts_ivf_shards():
     """Config-5 layout on one GPU: every shard is an IVF-Flat index over its row range with the SAME centroids
     (replicated coarse quantiser) and global ids; the sharded handle must return what one IVF index over all rows returns."""
