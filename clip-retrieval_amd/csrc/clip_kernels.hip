@@ -552,12 +552,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
         b.tail_m0 = b.M;
       }
       const bool tail_inside = b.tail_nb > 0;
-#ifdef CLIPX_ABLATE
-      // variant 5 (tools build only): the two-workgroups-per-CU experiment of gemm2wg.hip (bitwise equal, 25-35 % slower)
-      hipError_t e = g.variant == 5 ? launch_gemm2wg(b, g.n_cu, st) : launch_gemm256sp(b, g.n_cu, st);
-#else
       hipError_t e = launch_gemm256sp(b, g.n_cu, st);
-#endif
       if (e != hipSuccess) return e;
       if (b.M == g.M || tail_inside) return hipSuccess;
       GemmArgs r = g;  // remaining rows [bulk*256, M)
@@ -1092,7 +1087,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 // S^T / softmax / PV arithmetic is the kernel's above, operation for operation: the outputs are the same bits.
 // (Also built and measured: two 3-wave workgroups per CU, one LDS image each, K of the next pair requested as soon as the last
 // S phase is over and V at the top of its own pair: every wave issues 24 DMAs per pair -- 212 us.
-// profiles/r03_rejected/attention_persistent_3wave_split_dma.patch)
+// the patch is in the repository's history, round 3)
 // =============================================================================================
 #ifndef CLIPX_ATTN_SPIPE
 #define CLIPX_ATTN_SPIPE 1

@@ -475,7 +475,7 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   //   rstd = rowstats(x);    h = act((x @ Wfc1'^T) * rstd + c_fc1);  x = fp16(x + h @ Wfc2^T + b_fc2)
   // (LayerNorm partial statistics computed by the residual epilogues instead of the rowstats pass were built twice in round 3
   // and measured slower on the same box -- the extra epilogue work costs more GEMM time than the 134 MB re-read it saves:
-  // profiles/r03_rejected/fused_layernorm_stats.patch)
+  // the patch is in the repository's history, round 3)
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& L = t.L[l];
     int r;

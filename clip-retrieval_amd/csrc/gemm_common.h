@@ -148,7 +148,5 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
 
 // bulk-tile launcher of gemm256sp.hip: rows [0, g.M) must be a multiple of 256, N % 256 == 0, K % 128 == 0
 hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st);
-// two out-of-phase 128x256 workgroups per CU (gemm2wg.hip): M % 128 == 0, N % 256 == 0, K % 128 == 0
-hipError_t launch_gemm2wg(const GemmArgs& g, int n_cu, hipStream_t st);
 
 }  // namespace clipx
