@@ -687,6 +687,16 @@ __device__ __forceinline__ void rq8_ksteps(unsigned xa, i32x4 (&A)[4], i32x4v (&
   }
 }
 
+#ifdef CLIPX_ABLATE
+// tools build, KNNX_RQ8_TIMER=1: shader cycles per wave in [0] the wait + barrier at the top of a tile, [1] the k-loop (fragment reads,
+// MFMAs, refill DMAs), [2] the filter, [3] tiles  -> g_rq8_phase[(workgroup * 8 + wave) * 4 + i]; read back with knnx_dbg_rq8_phases()
+// (tools/rq8_phases.py; profiles/r05o_rq8_phases*.log)
+__device__ long long g_rq8_phase[256 * 8 * 4];
+__device__ int g_rq8_timer = 0;
+#define RQ8_STAMP(i) if (timer) { const long long n_ = (long long)__builtin_readcyclecounter(); tph[i] += n_ - tst; tst = n_; }
+#else
+#define RQ8_STAMP(i)
+#endif
 // KS = d / 32 pieces per 32-row tile; 8 waves x 32 queries (two blocks of 16); the structure of knn_rq_scan_kernel
 // PL = 2: two query planes (knn_i8_prep_kernel), score = 128 * plane 0 + plane 1
 template <int KS, int NW, int NSLOT, int PL>
@@ -739,10 +749,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
 
   int nst = 0;
   int slot = 0;
+#ifdef CLIPX_ABLATE
+  const bool timer = g_rq8_timer != 0;
+  long long tph[4] = {0, 0, 0, 0};
+  long long tst = timer ? (long long)__builtin_readcyclecounter() : 0;
+#endif
   for (; t < nj; t += gstride) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NSLOT - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    RQ8_STAMP(0)
     const Rq8Tile refill = RQ8_TILE(t + (int64_t)(NSLOT - 1) * gstride, slot == 0 ? NSLOT - 1 : slot - 1);
     i32x4v acc[PL][2][2];
 #pragma unroll
@@ -756,6 +772,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
     rq_dsread<2048>(A[2], xa);
     __builtin_amdgcn_sched_barrier(0);
     rq8_ksteps<KS, NW, DPW, PL, 0>(xa, A, acc, Q, refill, vo);
+    RQ8_STAMP(1)
 
     // ---- filter: lane (qcol, hb) owns rows row0 + 16 half + e of its query column in each block; integer compares
     const int64_t row0 = t * tstep * 32 + 4 * hb;
@@ -811,7 +828,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
       if (__builtin_amdgcn_ballot_w64(vmem) != 0ull) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
+#ifdef CLIPX_ABLATE
+    RQ8_STAMP(2)
+    if (timer) tph[3] += 1;
+#endif
   }
+#ifdef CLIPX_ABLATE
+  if (timer && lane == 0 && blockIdx.x < 256 && w < 8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g_rq8_phase[(blockIdx.x * 8 + w) * 4 + i] = tph[i];
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int i = lane; i < nst; i += 64) {
     const unsigned qq = st_q[i];
@@ -918,9 +945,21 @@ static hipError_t launch_rq8_scan_cfg(const int8_t* X8, int64_t N, const int8_t*
 }
 #endif
 
+#if defined(CLIPX_ABLATE) && KNNX_MFMA16
+extern "C" int knnx_dbg_rq8_phases(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rq8_phase), (size_t)n * sizeof(long long));
+}
+#endif
 hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int* thr_i, unsigned* cnt,
                            unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st) {
   if (tstep < 1) return hipErrorInvalidValue;
+#if defined(CLIPX_ABLATE) && KNNX_MFMA16
+  {
+    static const int tm = getenv("KNNX_RQ8_TIMER") ? atoi(getenv("KNNX_RQ8_TIMER")) : 0;
+    static bool set = false;
+    if (!set) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rq8_timer), &tm, sizeof(int)); set = true; }
+  }
+#endif
 #if KNNX_MFMA16
   if (planes == 2) {  // two query planes: 4 waves x 32 queries (twice the fragments per query: 192 registers at d = 768)
     if (nq > 128) return hipErrorInvalidValue;
