@@ -561,7 +561,7 @@ def main():
             # the int8 copy does not fit whole next to it, the library keeps a partial one (include/knnx.h)
             knn["by_shard_size"] = [knn_leg(125_000_000, 0, [1, 64, 256], 3, False, False, False)]
             # ... and the default size on a corpus with dominant columns, where the int8 first stage needs two query planes (the isotropic
-            # corpus above is its favourable case: DESIGN 4h)
+            # corpus above is its favourable case: DESIGN 4.3)
             knn["anisotropic_corpus"] = knn_leg(rows, 2, [1, 64, 256], 3, False, False, False)
 
     # ---- BASELINE config 5 (opt-in: minutes): one GPU's IVF-Flat shard at its stated size, built on the device, served

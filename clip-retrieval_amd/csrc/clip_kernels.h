@@ -18,7 +18,7 @@ enum GemmEpilogue {
                             // (out_proj, fc2): a third of the bytes of the f32 read-modify-write + bf16 shadow of EPI 3
   EPI_BIAS_F16 = 7          // out IEEE fp16 [M,N] = acc * rowscale + bias: EPI 0 with three more mantissa bits.  The QKV projection
                             // (round 4): q and k feed the softmax logits, where the bf16 rounding of EPI 0 was the largest single
-                            // error of the encoder on weights with large LayerNorm gains (tools/emulate_fp16_stream.py, DESIGN 4d)
+                            // error of the encoder on weights with large LayerNorm gains (tools/emulate_fp16_stream.py, DESIGN 4.2)
 };
 
 struct GemmArgs {

@@ -824,7 +824,7 @@ hipError_t launch_im2col(const void* pixels, int fmt, int B, int S, int P, int K
 // Operand type of the attention products (round 4): q, k, v arrive as IEEE fp16 (the QKV projection's EPI_BIAS_F16 epilogue) and
 // the probabilities P are rounded to fp16 as well: v_mfma_f32_32x32x16_f16 issues at the rate of the bf16 form, and the three extra
 // mantissa bits of q and k are worth an order of magnitude in the embedding's error where LayerNorm gains are large (the
-// logits q.k are where the bf16 rounding hurt most: tools/emulate_fp16_stream.py, DESIGN 4d).  The 16-bit values keep travelling
+// logits q.k are where the bf16 rounding hurt most: tools/emulate_fp16_stream.py, DESIGN 4.2).  The 16-bit values keep travelling
 // through `bf16`-typed pointers and fragments: every load, LDS staging step and transposition moves bits.
 __device__ __forceinline__ f32x16 attn_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW + 3) / 4) void attention_kernel(co
 #define CLIPX_ATTN_ROLES 1
 #endif
 // NWT = 8 (round 4; T = 32 (NKB - 1) + 1 only, ViT-L/14's 257 = 8 x 32 + 1): EIGHT waves, two on every SIMD, one full query block
-// each -- the 6-wave dealing leaves one SIMD with three blocks (4g) -- and the single query of the ragged last block, which costs a
+// each -- the 6-wave dealing leaves one SIMD with three blocks -- and the single query of the ragged last block, which costs a
 // wave a whole block pass above, split along the KEYS: wave w attends it to key block w (wave 0 also to the one-key block 8), leaves
 // (max, sum, 64 partial outputs) in a small LDS table, and wave 0 merges the nine partials (rescaled by 2^((m_j - m) c)) behind the
 // next pair's barrier.  All eight waves issue DMAs (9 of the pair's 72 pieces each).  The 256 full-block rows are computed exactly as

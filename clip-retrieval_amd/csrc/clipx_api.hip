@@ -93,7 +93,7 @@ struct clipx_handle {
   // xn = THE residual stream, IEEE fp16 [rows, width] (fp16 bits behind the bf16-typed pointer): read as the A operand of the
   // LayerNorm-folded GEMMs (QKV, fc1) and updated in place by the residual epilogues of out_proj / fc2.  Round 3: it replaced
   // an f32 stream + bf16 shadow (673 MB -> 269 MB moved per residual GEMM at ViT-L/14 bs 256; same accuracy: the stream has
-  // 3 mantissa bits more than the bf16 operands it used to be rounded to, DESIGN 4b).
+  // 3 mantissa bits more than the bf16 operands it used to be rounded to, DESIGN 4.1).
   bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *patches = nullptr;
   bool single_query = false;   // the API call being served is ONE sample (set by the entry points, not per chunk: the last
                                // chunk of a 7-sample call is one sample too, and must equal its row of an unchunked call)

@@ -26,7 +26,7 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(frag_t a, frag_t b, f32x16 c) {
 // this power-managed part the 16x16x32 form sustains ~10 % more TFLOP/s: +13 % on register-only loops, +9 % on this library's GEMM
 // skeleton (fragment reads + LDS-DMA + barrier; tools/mfma_power_probe.hip, tools/mfma_probe2.hip, profiles/r04i_*, r04j_*): a quarter
 // of the accumulator registers are read and written per instruction for half the flops.  It is also the instruction the vendor's
-// assembly kernel uses (DESIGN 4e).  All kernels switch together: an output element is the sum of its k-slabs in ascending order of
+// assembly kernel uses (DESIGN 4.1).  All kernels switch together: an output element is the sum of its k-slabs in ascending order of
 // 32, whichever kernel computes it, so rows stay bit-identical across kernels, batch chunkings and the ragged tail.
 //
 // Accumulator layout.  A 32 x 32 output block (32 weight rows n x 32 activation rows m, the weights being the MFMA A operand) is 16

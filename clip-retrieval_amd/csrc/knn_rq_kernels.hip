@@ -41,7 +41,7 @@
 namespace knnx {
 
 // KNNX_MFMA16 (default 1, round 4): the scan and the assignment kernel multiply with v_mfma_f32_16x16x32_f16 instead of
-// v_mfma_f32_32x32x16_f16 -- on this power-managed part the 16 x 16 x 32 shape sustains more TFLOP/s (DESIGN 4f: the same switch as
+// v_mfma_f32_32x32x16_f16 -- on this power-managed part the 16 x 16 x 32 shape sustains more TFLOP/s (DESIGN 4.1: the same switch as
 // the encoder's GEMMs, CLIPX_MFMA16; -DCLIPX_MFMA16=0 / -DKNNX_MFMA16=0 builds the previous kernels for the A/B).  What changes is
 // the fragment shape, nothing else: a 1-KiB LDS piece is (16 rows x 32 columns) -- lane (r = l & 15, q4 = l >> 4) holds row r,
 // columns 8 q4 .. + 8 of the 32-column slab -- instead of (32 rows x 16 columns); a 32-row tile is still d / 16 pieces, piece
@@ -462,7 +462,7 @@ __global__ void knn_i8_colscale_kernel(const int* __restrict__ colmax_enc, int d
 // Layout of the int8 copy (round 5): NOT row-major.  X8 is the LDS image of the scan, tile after tile: tile t (rows 32 t .. + 32) is
 // d / 32 pieces of 1 KiB, piece p = 2 * slab + half, and inside a piece lane l = 16 * q4 + r holds the 16 bytes (columns 64 slab +
 // 16 q4 .. + 16) of row 32 t + 16 half + r.  One global_load_lds_dwordx4 of the scan then moves ONE CONTIGUOUS KiB (eight full 128-B
-// lines) instead of 16 rows x 64 B -- half a line per request, which held the row-major pass at 0.61 of HBM (DESIGN 4h).  The copy
+// lines) instead of 16 rows x 64 B -- half a line per request, which held the row-major pass at 0.61 of HBM (DESIGN 4.3).  The copy
 // is private to this library (rows are re-scored and reconstructed from the fp16 rows), so its layout is free.
 // Quantisation: a wave takes one 16-row half tile at a time (grid-stride) and walks its slabs: lane (r, q4) reads its 32 B of fp16
 // (four lanes = one full line of the row), writes its 16 B of the piece (the wave = the contiguous KiB), and keeps the row's

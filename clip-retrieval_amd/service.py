@@ -15,7 +15,7 @@ onto KnnService.  The arithmetic is re-designed for the GPU rat
   * violence   clip_back.py:327-331's einsum + argmax over the two prompt embeddings, the product in fp32 FMA on the GPU (the prompts
                as one resident bias-free Linear layer), argmax on the host (ties -> the smaller index, like np.argmax);
   * metadata   ids grouped by Arrow record batch, ONE `RecordBatch.take` per touched batch instead of a concat of 1-row slices per
-               id (README.md:432: 41.5 ms); a single `Table.take` over chunked string columns measured 75 x slower (DESIGN 5b);
+               id (README.md:432: 41.5 ms); a single `Table.take` over chunked string columns measured 75 x slower (DESIGN 5);
   * safety     the H14 detector (h14_nsfw_model.py:16-34: seven fp32 Linear layers, ReLU between) runs on the GPU behind the
                reference's `.predict(embeddings, batch_size)` (`Mi355xSafetyHead`, csrc/postfilter.hip); any other object with
                `.predict` (the autokeras L/14 model) is called as the reference calls it.

@@ -135,7 +135,7 @@ int clipx_encode_text_device_ids(clipx_handle* h, const int32_t* ids_dev, const 
 int clipx_resize_crop_u8_device(int device, const void* src_dev, const int64_t* offsets, const int32_t* hw, int B, int S, void* out_dev,
                                 void* stream);
 
-/* Range guard.  The encoder keeps the residual stream of both towers in IEEE fp16 (DESIGN 4b): exact for every checkpoint that is
+/* Range guard.  The encoder keeps the residual stream of both towers in IEEE fp16 (DESIGN 4.1): exact for every checkpoint that is
  * trained or served in fp16 (the reference's CUDA path runs the whole model in fp16, mapper.py:35-41), but a model whose
  * activations exceed 65 504 (possible for bf16-trained checkpoints) would overflow to inf, and LayerNorm turns a row holding inf
  * into a finite-looking WRONG embedding.  Every state of the stream is therefore checked on the device (one compare inside the

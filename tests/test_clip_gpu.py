@@ -454,7 +454,7 @@ def test_parity_with_trained_like_weight_statistics(name, B, outliers):
     Bar: the north-star 1e-3 on the raw cosine, nearest-oracle-row == own row, centred cosine >= 0.9 (these weights push every
     embedding onto a common direction: the closest WRONG row sits at 0.97 .. 0.995), and no range flag.
     Round 4 made q, k, v IEEE fp16 for this test: with bf16 q / k the 30 x gains cost tiny-H/14 1 - cos = 2e-3
-    (tools/emulate_fp16_stream.py --exact qkv_bf16; DESIGN 4d)."""
+    (tools/emulate_fp16_stream.py --exact qkv_bf16; DESIGN 4.2)."""
     from clip_retrieval_amd.encoder import ClipEncoder
     from oracle.clip_oracle import ARCHS, NORTH_STAR_BAR, HFClipOracle, mapper_semantics, normalise_u8_nhwc, parity_gate, synth_pixels_u8, synth_tokens
 

@@ -300,7 +300,7 @@ def test_int8_first_stage_bound_and_admission_hold(corpus, planes):
     must = exact >= T[:, None].astype(np.float64)
     assert (adm | ~must).all(), "a row whose exact score reaches the threshold was not admitted"
     # ... and the band is not the whole index (the point of the stage): the unit-norm queries on the well-conditioned corpora
-    # (4 000 rows and a threshold at rank 10 make the band look wide: at 10^8 rows it is a few 10^4 rows, DESIGN 4h)
+    # (4 000 rows and a threshold at rank 10 make the band look wide: at 10^8 rows it is a few 10^4 rows, DESIGN 4.3)
     if corpus == "isotropic" or (planes == 2 and corpus == "dominant_columns"):
         frac = adm[:40].mean()
         assert frac < 0.25, f"{frac:.2f} of the rows admitted"

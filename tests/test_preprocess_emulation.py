@@ -2,7 +2,7 @@
 shim (threadIdx / blockIdx as thread-locals, one std::thread per lane, __syncthreads = a pthread barrier, the dynamic LDS a
 heap buffer) together with the library's own host-side coefficient code, and must reproduce Pillow byte for byte.  The GPU
 tests (tests/test_preprocess_gpu.py) hold the real thing to the same bar; this one keeps the kernel's index arithmetic under
-test where there is no GPU (it is also how the v_ashr_pk_u8_i32 mis-selection was told apart from a logic error: DESIGN 4c)."""
+test where there is no GPU (it is also how the v_ashr_pk_u8_i32 mis-selection was told apart from a logic error: DESIGN 4.5)."""
 import ctypes as C
 import os
 import shutil

@@ -1,4 +1,4 @@
-"""numpy simulation behind DESIGN 4h: how wide the admission band of the int8 first stage is, in sigmas of the score distribution,
+"""numpy simulation behind DESIGN 4.3: how wide the admission band of the int8 first stage is, in sigmas of the score distribution,
 for isotropic unit vectors and for embeddings with a few dominant columns, with one and with two int8 planes per query -- and how many
 rows per query that admits at 10^8 rows for a threshold at z = 4 (about rank 3 000).  CPU only:  python tools/i8_bound_sim.py"""
 import os
