@@ -76,13 +76,18 @@ def main():
                     help="torch threads of the CPU baseline (all 256 cores of the GPU box oversubscribe torch's CPU GEMMs: 0.07 samples/s)")
     ap.add_argument("--parity-rows", type=int, default=64, help="rows of the timed batch the CPU oracle checks (and is timed on); all rows are checked for finite / unit norm")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: the line is marked parity=null")
+    ap.add_argument("--no-host-path", dest="host_path", action="store_false", help="skip the pinned-host-buffer leg (value_incl_h2d_d2h)")
     ap.add_argument("--no-ab", action="store_true", help="profiling runs only: skip the rectangular-text A/B (its extra steps would enter the per-step counter averages)")
+    ap.add_argument("--profile-run", action="store_true", help="counter / kernel-trace runs (tools/gpu_round.sh): only the legs whose steps "
+                    "tools/traffic_summary.py counts -- no parity, no CPU legs, no rectangular-text A/B, no host-buffer leg, no extra kNN legs, no ivf")
     ap.add_argument("--no-knn-extra", dest="knn_extra", action="store_false",
                     help="skip the two extra kNN legs (125 M x 768 = the per-GPU shard of the headline configuration; the anisotropic corpus)")
     ap.add_argument("--no-ivf", dest="ivf", action="store_false", help="skip BASELINE config 5's per-GPU shard (tools/config5.py: IVF-Flat "
                     "125 M x 1024, nlist 65 536, built on the device, served; embedded as `ivf`, ~1 minute)")
     ap.add_argument("--ivf-rows", type=int, default=125_000_000)
     args = ap.parse_args()
+    if args.profile_run:
+        args.no_parity, args.no_ab, args.knn_extra, args.ivf, args.cpu_seconds, args.host_path = True, True, False, False, 0.0, False
     refuse_debug_environment()
 
     import numpy as np
@@ -238,36 +243,37 @@ def main():
         extras["value_ragged_text_same_timing"] = round(world * args.steps * B / ab["ragged"], 1)
     enc.check_range(stream)  # CLIPX_E_RANGE: no launch of this run may have overflowed the fp16 residual stream
 
-    # What ClipMapper.__call__ includes and `value` does not ("device-only AND including H2D/D2H"): the same batches from
-    # pinned HOST buffers -- f32 NCHW pixels + int32 tokens in, fp16 rows out on the host -- through the asynchronous tickets
-    # (clipx_encode_*_async / clipx_wait: upload, both towers, download; two steps in flight so that a step's copies overlap its
-    # neighbour's kernels, as a pipelined Runner would drive it).  Never `value`.
-    pin_pix, pin_ids = torch.from_numpy(pix_host).pin_memory(), torch.from_numpy(ids_host).pin_memory()
-    def host_step():
-        return enc.submit_image(pin_pix.numpy()), enc.submit_text(pin_ids.numpy())
-    prev = host_step()
-    for h in prev:
-        enc.collect(h)
-    barrier()
-    t1 = time.perf_counter()
-    prev = host_step()
-    for _ in range(args.steps - 1):
-        cur = host_step()
+    if args.host_path:
+        # What ClipMapper.__call__ includes and `value` does not ("device-only AND including H2D/D2H"): the same batches from
+        # pinned HOST buffers -- f32 NCHW pixels + int32 tokens in, fp16 rows out on the host -- through the asynchronous tickets
+        # (clipx_encode_*_async / clipx_wait: upload, both towers, download; two steps in flight so that a step's copies overlap its
+        # neighbour's kernels, as a pipelined Runner would drive it).  Never `value`.
+        pin_pix, pin_ids = torch.from_numpy(pix_host).pin_memory(), torch.from_numpy(ids_host).pin_memory()
+        def host_step():
+            return enc.submit_image(pin_pix.numpy()), enc.submit_text(pin_ids.numpy())
+        prev = host_step()
         for h in prev:
             enc.collect(h)
-        prev = cur
-    emb_host = [enc.collect(h) for h in prev]
-    barrier()
-    dt_host = max_over_ranks(time.perf_counter() - t1)
-    extras["value_incl_h2d_d2h"] = round(world * args.steps * B / dt_host, 1)
-    extras["ms_per_step_incl_h2d_d2h"] = round(dt_host / args.steps * 1e3, 3)
-    extras["incl_h2d_d2h_note"] = ("pinned host f32 NCHW pixels (154 MB per batch) + int32 tokens in, fp16 embeddings out on the host, "
-                                   "clipx_encode_image_async / _text_async + clipx_wait, two steps in flight; `value` keeps its definition (inputs resident in HBM)")
-    dev_rows = (out_i.cpu().numpy(), out_t.cpu().numpy())
-    extras["host_path_bitwise_equal_to_device_path"] = bool(np.array_equal(emb_host[0], dev_rows[0]) and np.array_equal(emb_host[1], dev_rows[1]))
-    if not all(np.allclose(a.astype(np.float32), b.astype(np.float32), rtol=0, atol=1e-3) for a, b in zip(emb_host, dev_rows)):
-        failures.append("the host-buffer path returned other embeddings than the device path on the same batch")
-    del pin_pix, pin_ids
+        barrier()
+        t1 = time.perf_counter()
+        prev = host_step()
+        for _ in range(args.steps - 1):
+            cur = host_step()
+            for h in prev:
+                enc.collect(h)
+            prev = cur
+        emb_host = [enc.collect(h) for h in prev]
+        barrier()
+        dt_host = max_over_ranks(time.perf_counter() - t1)
+        extras["value_incl_h2d_d2h"] = round(world * args.steps * B / dt_host, 1)
+        extras["ms_per_step_incl_h2d_d2h"] = round(dt_host / args.steps * 1e3, 3)
+        extras["incl_h2d_d2h_note"] = ("pinned host f32 NCHW pixels (154 MB per batch) + int32 tokens in, fp16 embeddings out on the host, "
+                                       "clipx_encode_image_async / _text_async + clipx_wait, two steps in flight; `value` keeps its definition (inputs resident in HBM)")
+        dev_rows = (out_i.cpu().numpy(), out_t.cpu().numpy())
+        extras["host_path_bitwise_equal_to_device_path"] = bool(np.array_equal(emb_host[0], dev_rows[0]) and np.array_equal(emb_host[1], dev_rows[1]))
+        if not all(np.allclose(a.astype(np.float32), b.astype(np.float32), rtol=0, atol=1e-3) for a, b in zip(emb_host, dev_rows)):
+            failures.append("the host-buffer path returned other embeddings than the device path on the same batch")
+        del pin_pix, pin_ids
 
     # FLOPs that RUN per step (counters of the launches: GEMMs + attention), not the model formula: the last block's out-proj / MLP
     # (and, in the image tower, all but the first query block of its attention) are computed on the pooled rows only

@@ -37,10 +37,16 @@ for key, c in rows.items():
     inst[short(key[0])].append((dur[key], cyc, c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc)))
 out = {"instantiations": {}, "families": {}}
 fam = collections.defaultdict(list)
+MIN_US = 100.0  # GRBM_GUI_ACTIVE of a dispatch includes a few microseconds of dispatch overhead: below ~100 us it inflates the cycle
+                # count (a 13 us kernel reads as 3.8 "GHz") and deflates the fraction -- such launches are listed but not aggregated
 for name, v in sorted(inst.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
     us = sum(x[0] for x in v)
-    out["instantiations"][name] = {"launches": len(v), "mean_us": round(us / len(v), 1), "effective_clock_ghz": round(sum(x[1] for x in v) / us / 1e3, 3),
-                                   "mfma_busy_frac": round(sum(x[0] * x[2] for x in v) / us, 4)}
+    long = us / len(v) >= MIN_US
+    out["instantiations"][name] = {"launches": len(v), "mean_us": round(us / len(v), 1),
+                                   "effective_clock_ghz": round(sum(x[1] for x in v) / us / 1e3, 3) if long else None,
+                                   "mfma_busy_frac": round(sum(x[0] * x[2] for x in v) / us, 4) if long else None}
+    if not long:
+        continue
     for k, f in FAMILIES.items():
         if k in name:
             fam[f] += v
