@@ -671,3 +671,14 @@ def test_kmeans_rebalancing_splits_the_big_lists_and_retires_the_small_ones():
     assert plain.max() >= 2900 and splits >= 16
     assert bal.max() <= plain.max() / 2.5, (plain.max(), bal.max())
     assert bal.max() <= 2.2 * bal.mean(), (bal.max(), bal.mean())    # nothing left above the split threshold (2 x the mean) by much
+
+
+def test_embedding_files_ignore_the_sidecars_of_a_saved_index(tmp_path):
+    """save_index() writes ivf_centroids.npy / ivf_lists.npy; saved INTO the embeddings folder they must not become two more
+    partitions at the next load (knn.embedding_files is what load_index / FolderRows glob with)."""
+    from clip_retrieval_amd.knn import embedding_files
+
+    for name in ("img_emb_0.npy", "img_emb_1.npy", "ivf_centroids.npy", "ivf_lists.npy"):
+        np.save(tmp_path / name, np.zeros((2, 4), np.float16))
+    got = [os.path.basename(f) for f in embedding_files(str(tmp_path))]
+    assert got == ["img_emb_0.npy", "img_emb_1.npy"]

@@ -1,6 +1,7 @@
 """GPU parity tests of the search half: HIP kernels (through the C ABI / faiss-shaped wrapper) vs the numpy oracle.
 Bar (north_star): identical top-k id sets on the same index; scores are fp32 so they are compared to 1e-5 and
 ids at the k-th boundary may swap only when their scores differ by < 2e-6 (fp32 summation order)."""
+import ctypes as C
 import threading
 
 import numpy as np
@@ -969,8 +970,49 @@ def test_sharded_index_adopts_ivf_shards():
     D, I = ix.search(q, 10)
     Do, Io = ora.search(q, 10, nprobe)
     _check(D, I, Do, Io, "sharded ivf")
+    # the wrapper reports the nprobe its adopted shards carry (it used to say 1 until set, and a "restore" then wrote 1)
+    assert ix.nprobe == nprobe
+    ix.nprobe = 9
+    assert ix.nprobe == 9 and all(int(ix._lib.knnx_ivf_nprobe(C.c_void_p(ix._lib.knnx_shards_get(ix._h, g)))) == 9 for g in range(2))
+    ix.nprobe = nprobe
     ix.close()
     assert all(sh._h is None for sh in shards)  # ownership moved
+
+
+def test_uncoalesced_dedup_requests_from_many_threads_do_not_share_staging():
+    """with coalescing off, knnx_search_dedup reaches the batch runner from every request thread at once; the per-index
+    staging vectors are touched under the index mutex now.  32 threads x 6 requests against a coalesce=False index must each get
+    exactly what a serial call gets (ids, scores, R, links)."""
+    import threading
+
+    from clip_retrieval_amd.knn import Mi355xIndex
+
+    d, n = 768, 40_000
+    x = _data(n, d, seed=77)
+    x[1000:1010] = x[0:10]  # near-duplicates: some requests have links
+    ix = Mi355xIndex(d, coalesce=False)
+    ix.add(x)
+    qs = _queries(32 * 6, d, seed=78, x=x)
+    want = [ix.search_dedup(qs[i:i + 1], 40, 0.94, want_r=True) for i in range(len(qs))]
+    got = [None] * len(qs)
+    errs = []
+
+    def work(t):
+        try:
+            for j in range(6):
+                i = t * 6 + j
+                got[i] = ix.search_dedup(qs[i:i + 1], 40, 0.94, want_r=True)
+        except Exception as e:  # pylint: disable=broad-except
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(32)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[:3]
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert np.array_equal(w[1], g[1]) and np.array_equal(w[0], g[0]) and np.array_equal(w[2], g[2]), f"request {i} differs from its serial answer"
+        assert (w[3] is None and g[3] is None) or np.array_equal(w[3], g[3]), f"request {i}: links differ"
+    ix.close()
 
 
 def test_load_index_from_numpy_writer_output(tmp_path):
