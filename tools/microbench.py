@@ -268,7 +268,7 @@ if "reader" in what:
                     t0 = time.perf_counter()
                     got = sum(b["image_tensor"].shape[0] if "image_tensor" in b else b["image_raw"]["hw"].shape[0] for b in r)
                     dt = time.perf_counter() - t0
-                print(f"WebdatasetReader {got} JPEG 256x256 + captions, {prep.__name__}, {workers} decode "
+                print(f"WebdatasetReader {got} JPEG 256x256 + captions, {getattr(prep, '__name__', type(prep).__name__)}, {workers} decode "
                       f"{'processes' if procs else 'threads'}: {got / dt:.0f} samples/s", flush=True)
     t0 = time.perf_counter()
     k = sum(1 for _ in WebdatasetReader(Sampler(0, 1), clip_preprocess_u8, HashTokenizer(), [path], 256, 8)._raw_samples())
