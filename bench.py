@@ -418,11 +418,13 @@ def main():
                 i8 = ix.i8_served() - i8_0 >= scans * nq  # every timed query went through the int8 first stage
                 n8 = ix.i8_rows() if i8 else 0          # rows the pass read as int8 (a partial copy: the rest as fp16, same launch bracket)
                 planes = ix.i8_planes() if i8 else 0
+                ndom = len(ix.i8_dominant()) if i8 else 0
                 pass_bytes = n8 * d + (rows - n8) * d * 2   # ALGORITHMIC bytes of one pass: every row read once, 1 or 2 bytes per element
                 scan_gbs = pass_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
                 qpp = nq / max(passes, 1)
                 kern = ((f"knn_rq8_scan_kernel over {n8} rows (int8 first stage: tile-ordered int8 copy, 1..256 register-stationary queries per "
-                         f"pass, {planes} query plane(s), v_mfma_i32_16x16x64_i8; hits re-scored exactly from the fp16 rows)"
+                         f"pass, {planes} query plane(s)" + (f" + {ndom} dominant columns as 14-bit digits on v_dot4c_i32_i8" if ndom else "")
+                         + ", v_mfma_i32_16x16x64_i8; hits re-scored exactly from the fp16 rows)"
                          + (f" + knn_rq_scan_kernel over the {rows - n8} rows the copy does not hold (fp16, same hit lists)" if n8 < rows else ""))
                         if i8 else
                         "knn_rq_scan_kernel (register-stationary queries, up to 256 per pass)" if qpp > 64 else
@@ -436,7 +438,7 @@ def main():
                                  "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(scan_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": round(scan_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(scan_ms, 3),
                                               "algorithmic_bytes_per_launch": pass_bytes, "mfma_frac": round(mfma_tf / mfma_peak, 4)},
-                                 "int8_first_stage": i8, "int8_rows": n8, "int8_query_planes": planes,
+                                 "int8_first_stage": i8, "int8_rows": n8, "int8_query_planes": planes, "int8_dominant_columns": ndom,
                                  "passes_over_hbm": round(passes, 2), "scan_ms": round(scan_ms, 3), "scan_GBps": round(scan_gbs, 1),
                                  "hbm_frac": round(scan_gbs / HBM_PEAK_GBS, 4),
                                  "scan_mfma_tflops": round(mfma_tf, 1) if scan_ms > 0 else None,
@@ -566,8 +568,9 @@ def main():
             # the per-GPU shard of the HEADLINE configuration (BASELINE metric: 1 B x 768 over 8 GPUs = 125 M rows = 192 GB of fp16 per GPU):
             # the int8 copy does not fit whole next to it, the library keeps a partial one (include/knnx.h)
             knn["by_shard_size"] = [knn_leg(125_000_000, 0, [1, 64, 256], 3, False, False, False)]
-            # ... and the default size on a corpus with dominant columns, where the int8 first stage needs two query planes (the isotropic
-            # corpus above is its favourable case: DESIGN 4.3)
+            # ... and the default size on a corpus with dominant columns (three columns 6 x the rest plus an offset, as CLIP embeddings
+            # have), where one plain int8 plane admits 100 x more rows: the first stage keeps those columns as 14-bit digits (round 5;
+            # two planes before -- DESIGN 4.3).  The isotropic corpus above is the favourable case.
             knn["anisotropic_corpus"] = knn_leg(rows, 2, [1, 64, 256], 3, False, False, False)
 
     # ---- BASELINE config 5 (opt-in: minutes): one GPU's IVF-Flat shard at its stated size, built on the device, served

@@ -102,6 +102,7 @@ SIGNATURES = {
     "knnx_i8_served": (C.c_int64, [_P]),
     "knnx_i8_rows": (C.c_int64, [_P]),
     "knnx_i8_planes": (C.c_int, [_P]),
+    "knnx_i8_dominant": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "knnx_search_dedup": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_float, _P, C.c_int, C.POINTER(C.c_int)]),
     "knnx_get_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "knnx_profile_enable": (C.c_int, [_P, C.c_int]),

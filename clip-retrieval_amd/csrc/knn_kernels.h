@@ -130,14 +130,24 @@ hipError_t launch_rq_proof(const float* q, int nq, int d, int k, const float* D,
 constexpr int KNN_I8_STRIDE = 32;          // the sample pass visits every S-th tile, S = min(this, tiles / 4096): threshold ~ rank (k + 8) S
 constexpr unsigned KNN_I8_CAP = KNN_RQ_CAP;  // hit list entries per query (knn_merge_kernel holds a query's whole list in LDS: 32 768 x 4 B)
 int i8_supported(int d);
-hipError_t launch_i8_build(const _Float16* X, int64_t N, int64_t n8, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc, hipStream_t st);
-hipError_t launch_i8_quant(const _Float16* X, int64_t N, int64_t row_from, int64_t row_to, int d, const float* colscale, int8_t* X8, int* ab_enc,
-                           hipStream_t st);
-hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
-                          int kw, int J, int planes, int refine, int8_t* qfrag8, int* thr_i, float* thr_lb, float* thr_rest, unsigned* cnt,
-                          unsigned* lost, hipStream_t st);
-hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int* thr_i, unsigned* cnt,
-                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st);
+// Dominant columns of an index: up to four columns whose scale is far above the others' sit in BYTES 0..3 of every row of
+// the int8 image (a column permutation private to the image: position p of the image holds column p of the row, except the nfix
+// positions listed here) and are left out of the int8 MFMA product; the scan adds their part with 14-bit query digits on the
+// vector ALU (knn_rq8_scan_kernel, DOM).  n = 0: no dominant columns, the image is in column order.
+struct I8Dom {
+  int n = 0;     // dominant columns = positions 0 .. n - 1
+  int nfix = 0;  // positions whose column is not the position
+  int pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int src[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+hipError_t launch_i8_scales(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int* ab_enc, hipStream_t st);
+hipError_t launch_i8_quant(const _Float16* X, int64_t N, int64_t row_from, int64_t row_to, int d, const float* colscale, const I8Dom& dom,
+                           int8_t* X8, int* ab_enc, hipStream_t st);
+hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const I8Dom& dom, const int* ab_enc, const int* maxnorm,
+                          const float* samp, int kw, int J, int planes, int refine, int8_t* qfrag8, int8_t* qdom, int* thr_i, float* thr_lb,
+                          float* thr_rest, unsigned* cnt, unsigned* lost, hipStream_t st);
+hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int8_t* qdom, const int* thr_i,
+                           unsigned* cnt, unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st);
 hipError_t launch_i8_proof(int nq, int k, const float* D, const float* thr_lb, const unsigned* cnt, unsigned cap, const unsigned* lost,
                            unsigned* need, unsigned* gate, unsigned long long* stats, hipStream_t st);
 

@@ -470,15 +470,18 @@ __global__ void knn_i8_colscale_kernel(const int* __restrict__ colmax_enc, int d
 // them).  Half tiles [h0, h1) are (re)written: appended rows re-quantise the rows that share their first half tile with the same
 // scales, i.e. to the same bytes.  ONE atomic pair per wave at the end for A = max |y - x8|, B = max |x8| (2-norms per row).
 __global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __restrict__ X, int64_t N, int64_t h0, int64_t h1, int d,
-                                                          const float* __restrict__ colscale, int8_t* __restrict__ X8,
-                                                          int* __restrict__ ab_enc) {
+                                                          const float* __restrict__ colscale, const I8Dom dom,
+                                                          int8_t* __restrict__ X8, int* __restrict__ ab_enc) {
+  // dom (knn_kernels.h): position p of the image holds column p, except the dom.nfix positions dom.pos[f], which hold column dom.src[f]
+  // (dominant columns swapped into positions 0 .. dom.n - 1); A and B are norms over all positions, i.e. over all columns
   const int lane = threadIdx.x & 63, r = lane & 15, q4 = lane >> 4;
   const int nsl = d >> 6;
   float ma = 0.f, mb = 0.f;
   for (int64_t h = h0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); h < h1; h += (int64_t)gridDim.x * 4) {
     const int64_t row = h * 16 + r;
     const bool live = row < N;
-    const _Float16* src = X + (size_t)(live ? row : 0) * d + 16 * q4;
+    const _Float16* xrow = X + (size_t)(live ? row : 0) * d;
+    const _Float16* src = xrow + 16 * q4;
     int8_t* dst = X8 + (size_t)(h >> 1) * 32 * d + (size_t)(h & 1) * 1024 + lane * 16;
     float ea = 0.f, eb = 0.f;
     for (int sl = 0; sl < nsl; ++sl) {
@@ -489,14 +492,30 @@ __global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __res
       }
       const _Float16* hv = reinterpret_cast<const _Float16*>(raw);
       const float4* cs4 = reinterpret_cast<const float4*>(colscale + 64 * sl + 16 * q4);
-      unsigned packed[4] = {0u, 0u, 0u, 0u};
+      float xv[16], sc[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 cs = cs4[g];
-        const float sc[4] = {cs.x, cs.y, cs.z, cs.w};
+        sc[4 * g] = cs.x; sc[4 * g + 1] = cs.y; sc[4 * g + 2] = cs.z; sc[4 * g + 3] = cs.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[4 * g + e] = (float)hv[4 * g + e];
+      }
+      for (int f = 0; f < dom.nfix; ++f) {
+        if ((dom.pos[f] >> 4) == 4 * sl + q4) {
+          const int e0 = dom.pos[f] & 15;
+          const float xs = live ? (float)xrow[dom.src[f]] : 0.f;
+          const float ss = colscale[dom.src[f]];
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (e == e0) { xv[e] = xs; sc[e] = ss; }
+        }
+      }
+      unsigned packed[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float y = (float)hv[4 * g + e] / sc[e];
+          const float y = xv[4 * g + e] / sc[4 * g + e];
           float v = rintf(y);
           v = fminf(fmaxf(v, -127.f), 127.f);
           ea += (y - v) * (y - v);
@@ -528,9 +547,10 @@ __global__ __launch_bounds__(256) void knn_i8_quant_kernel(const _Float16* __res
 // lane (n = l & 15, q4 = l >> 4) holds u8_n[64 s + 16 q4 .. + 16]), the integer admission threshold thr_i and the exact-score
 // lower bound thr_lb (= T) of the proof; resets the hit counters.  Unused slots: zero fragments, thr_i = INT_MAX.
 __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict__ q, int nq, int d, const float* __restrict__ colscale,
-                                                        const int* __restrict__ ab_enc, const int* __restrict__ maxnorm,
+                                                        const I8Dom dom, const int* __restrict__ ab_enc, const int* __restrict__ maxnorm,
                                                         const float* __restrict__ samp, int kw, int J, int planes, int refine,
-                                                        int8_t* __restrict__ qfrag8, int* __restrict__ thr_i, float* __restrict__ thr_lb,
+                                                        int8_t* __restrict__ qfrag8, int8_t* __restrict__ qdom, int* __restrict__ thr_i,
+                                                        float* __restrict__ thr_lb,
                                                         float* __restrict__ thr_rest, unsigned* __restrict__ cnt,
                                                         unsigned* __restrict__ lost) {
   // thr_rest (may be null): the admission threshold of the fp16 register-stationary pass over the rows the int8 copy does not hold
@@ -543,6 +563,12 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
   // dimensions): one scale for all of u then leaves |u - s_u u8| * B as the whole error (1.25 sigma of the scores in a simulation with
   // two columns 5 x the rest, 3 x 10^5 admitted rows per query at 10^8 rows; two planes: 0.26 sigma, 9 x 10^3).  Second fragment set
   // at qfrag8 + 256 * d.
+  // dom.n > 0 (one plane): positions 0 .. dom.n - 1 of the image hold the index's dominant columns (I8Dom).  The query's components there
+  // do not take part in the scale: s_u = max over the OTHER positions / 127, their fragment bytes are zero, and each is quantised to a
+  // 14-bit integer t = 128 hi + lo (|hi| <= 127, |lo| <= 64) with the same s_u -- qdom[n][4] = lo, qdom[1024 + n][4] = hi, which the scan
+  // multiplies with bytes 0..3 of each row on the vector ALU.  The bound is unchanged: u8 is the integer vector (t_0 .. t_{n-1}, u8 of the
+  // rest), res = u - s_u u8 over ALL positions, |u|, A, B as before -- only the integers at the dominant positions have 14 bits
+  // instead of 7, so a dominant component costs the error of ITS rounding (s_u / 2) instead of setting s_u for everything else.
   const int n = blockIdx.x, lane = threadIdx.x;
   const int nsl = d / 64;
   int8_t* dst = qfrag8 + ((size_t)(n >> 4) * nsl * 64 + (n & 15)) * 16;  // + (s * 64 + q4 * 16) * 16 + byte
@@ -554,12 +580,15 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
     const int c = lane + 64 * e;
     u[e] = 0.f;
     if (c < d && n < nq) {
-      const float v = q[(size_t)n * d + c];
+      int sc = c;
+      for (int f = 0; f < dom.nfix; ++f)
+        if (dom.pos[f] == c) sc = dom.src[f];
+      const float v = q[(size_t)n * d + sc];
       const float rr = v - (float)(_Float16)v;
       e2 += rr * rr;
       n2 += v * v;
-      u[e] = v * colscale[c];
-      mu = fmaxf(mu, fabsf(u[e]));
+      u[e] = v * colscale[sc];
+      if (c >= dom.n) mu = fmaxf(mu, fabsf(u[e]));
     }
   }
   float nu2 = 0.f;
@@ -578,10 +607,20 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
     const int c = lane + 64 * e;
     if (c < d) {
       float v = rintf(u[e] / su);
+      // position c = 64 s + 16 q4 + byte
+      const size_t fo = (size_t)((c >> 6) * 64 + ((c >> 4) & 3) * 16) * 16 + (c & 15);
+      if (c < dom.n) {  // (e = 0, lane < dom.n)
+        v = fminf(fmaxf(v, -16256.f), 16256.f);
+        const float hi = rintf(v * (1.f / 128.f));
+        qdom[n * 4 + c] = (int8_t)(int)(v - 128.f * hi);
+        qdom[1024 + n * 4 + c] = (int8_t)(int)hi;
+        const float resd = u[e] - su * v;
+        er2 += resd * resd;
+        dst[fo] = 0;
+        continue;
+      }
       v = fminf(fmaxf(v, -127.f), 127.f);
       float res = u[e] - su * v;
-      // column c = 64 s + 16 q4 + byte
-      const size_t fo = (size_t)((c >> 6) * 64 + ((c >> 4) & 3) * 16) * 16 + (c & 15);
       dst[fo] = (int8_t)(int)v;
       if (planes == 2) {
         const float su2 = su * (1.f / 128.f);
@@ -594,6 +633,7 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
     }
   }
   for (int o = 32; o > 0; o >>= 1) er2 += __shfl_xor(er2, o);
+  if (qdom && lane < 4 && (lane >= dom.n || n >= nq)) qdom[n * 4 + lane] = qdom[1024 + n * 4 + lane] = 0;
   if (lane == 0) {
     int ti = 0x7fffffff;
     float lb = INFINITY;
@@ -699,9 +739,12 @@ __device__ int g_rq8_timer = 0;
 #endif
 // KS = d / 32 pieces per 32-row tile; 8 waves x 32 queries (two blocks of 16); the structure of knn_rq_scan_kernel
 // PL = 2: two query planes (knn_i8_prep_kernel), score = 128 * plane 0 + plane 1
-template <int KS, int NW, int NSLOT, int PL>
+// DOM: the index has dominant columns (I8Dom) -- bytes 0..3 of each row, zero in the query fragments; after the k-loop a lane reads those
+// four bytes of its eight rows from the tile in LDS (one ds_read_b32 each) and adds dot4(x, lo) + 128 dot4(x, hi) with its queries'
+// 14-bit digits (v_dot4c_i32_i8: two per score) to the MFMA sums -- the filter below then sees the full integer score
+template <int KS, int NW, int NSLOT, int PL, bool DOM>
 __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int8_t* __restrict__ X8, int64_t N, const int8_t* __restrict__ qfrag8,
-                                                                      const int* __restrict__ thr_i, unsigned* __restrict__ g_cnt, unsigned cap,
+                                                                      const int8_t* __restrict__ qdom, const int* __restrict__ thr_i, unsigned* __restrict__ g_cnt, unsigned cap,
                                                                       float* __restrict__ hit_s, uint32_t* __restrict__ hit_r,
                                                                       unsigned* __restrict__ g_lost, int tstep) {
   constexpr int TILE_BYTES = KS * 1024, DPW = KS / NW, NSL = KS / 2;
@@ -728,6 +771,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
     }
     tq[b] = thr_i[blk * 16 + qcol];
   }
+  int dlo[2] = {0, 0}, dhi[2] = {0, 0};
+  if constexpr (DOM) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      dlo[b] = reinterpret_cast<const int*>(qdom)[(w * 2 + b) * 16 + qcol];
+      dhi[b] = reinterpret_cast<const int*>(qdom)[256 + (w * 2 + b) * 16 + qcol];
+    }
+  }
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
 #pragma unroll
@@ -735,6 +786,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
 #pragma unroll
       for (int s = 0; s < NSL; ++s) asm volatile("" : "+v"(Q[p][b][s]));  // all landed before the DMA ring starts (see knn_rq_scan_kernel)
     asm volatile("" : "+v"(tq[b]));
+    if constexpr (DOM) asm volatile("" : "+v"(dlo[b]), "+v"(dhi[b]));
   }
 
   const int64_t ntile = (N + 31) >> 5;
@@ -772,6 +824,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq8_scan_kernel(const int
     rq_dsread<2048>(A[2], xa);
     __builtin_amdgcn_sched_barrier(0);
     rq8_ksteps<KS, NW, DPW, PL, 0>(xa, A, acc, Q, refill, vo);
+    if constexpr (DOM) {
+      // rows 16 half + 4 hb + e of the tile: piece `half` (slab 0), lane (q4 = 0, r = 4 hb + e), its first four bytes
+      const unsigned da = lds_base + slot * TILE_BYTES + hb * 64;
+      int x4[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(x4[r]) : "v"(da), "n"((r >> 2) * 1024 + (r & 3) * 16) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(x4[r]));
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int c = __builtin_amdgcn_sdot4(x4[r], dhi[b], 0, false) << 7;
+          acc[0][b][r >> 2][r & 3] += __builtin_amdgcn_sdot4(x4[r], dlo[b], c, false);
+        }
+    }
     RQ8_STAMP(1)
 
     // ---- filter: lane (qcol, hb) owns rows row0 + 16 half + e of its query column in each block; integer compares
@@ -884,8 +954,8 @@ int i8_supported(int d) { return KNNX_MFMA16 && (d == 512 || d == 768 || d == 10
 
 // quantise rows with the column scales that exist (also used for rows added later: values beyond +-127 c clamp, and A / B -- which
 // are maxima over the rows as stored -- grow with them, so the bound stays a bound)
-hipError_t launch_i8_quant(const _Float16* X, int64_t N, int64_t row_from, int64_t row_to, int d, const float* colscale, int8_t* X8,
-                           int* ab_enc, hipStream_t st) {
+hipError_t launch_i8_quant(const _Float16* X, int64_t N, int64_t row_from, int64_t row_to, int d, const float* colscale, const I8Dom& dom,
+                           int8_t* X8, int* ab_enc, hipStream_t st) {
 #if KNNX_MFMA16
   // rows [row_from, row_to) of an image that covers rows [0, N) (row_to <= N); whole half tiles are written: rows below row_from that
   // share its half tile are re-quantised to the same bytes, rows at or beyond N become zeros
@@ -894,38 +964,36 @@ hipError_t launch_i8_quant(const _Float16* X, int64_t N, int64_t row_from, int64
   if (h1p <= h0) return hipSuccess;
   // grid-stride: a launch's grid x block must stay below 2^32 work-items
   const unsigned grid = (unsigned)std::min<int64_t>((h1p - h0 + 3) / 4, 256 * 16);
-  hipLaunchKernelGGL(knn_i8_quant_kernel, dim3(grid), dim3(256), 0, st, X, N, h0, h1p, d, colscale, X8, ab_enc);
+  hipLaunchKernelGGL(knn_i8_quant_kernel, dim3(grid), dim3(256), 0, st, X, N, h0, h1p, d, colscale, dom, X8, ab_enc);
   return hipGetLastError();
 #else
   return hipErrorInvalidValue;
 #endif
 }
 
-// column scales over ALL N rows; the int8 image of rows [0, n8) only (n8 < N: the copy does not fit next to the fp16 rows -- the scan
-// of the other rows stays on fp16, knnx_api.hip)
-hipError_t launch_i8_build(const _Float16* X, int64_t N, int64_t n8, int d, int* colmax_enc, float* colscale, int8_t* X8, int* ab_enc,
-                           hipStream_t st) {
+// column scales over ALL N rows (the image itself may hold fewer: launch_i8_quant); resets A and B
+hipError_t launch_i8_scales(const _Float16* X, int64_t N, int d, int* colmax_enc, float* colscale, int* ab_enc, hipStream_t st) {
 #if KNNX_MFMA16
   hipError_t e = hipMemsetAsync(colmax_enc, 0, (size_t)d * sizeof(int), st);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(ab_enc, 0, 2 * sizeof(int), st);
   if (e != hipSuccess) return e;
-  if (N <= 0) return hipSuccess;
-  const unsigned g1 = (unsigned)std::min<int64_t>(N, 256 * 32);
+  const unsigned g1 = (unsigned)std::min<int64_t>(std::max<int64_t>(N, 1), 256 * 32);
   hipLaunchKernelGGL(knn_i8_colmax_kernel, dim3(g1), dim3(256), 0, st, X, N, d, colmax_enc);
   hipLaunchKernelGGL(knn_i8_colscale_kernel, dim3((d + 255) / 256), dim3(256), 0, st, colmax_enc, d, colscale);
-  return launch_i8_quant(X, n8, 0, n8, d, colscale, X8, ab_enc, st);
+  return hipGetLastError();
 #else
   return hipErrorInvalidValue;
 #endif
 }
 
-hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const int* ab_enc, const int* maxnorm, const float* samp,
-                          int kw, int J, int planes, int refine, int8_t* qfrag8, int* thr_i, float* thr_lb, float* thr_rest, unsigned* cnt,
-                          unsigned* lost, hipStream_t st) {
+hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colscale, const I8Dom& dom, const int* ab_enc, const int* maxnorm,
+                          const float* samp, int kw, int J, int planes, int refine, int8_t* qfrag8, int8_t* qdom, int* thr_i, float* thr_lb,
+                          float* thr_rest, unsigned* cnt, unsigned* lost, hipStream_t st) {
 #if KNNX_MFMA16
-  hipLaunchKernelGGL(knn_i8_prep_kernel, dim3(256), dim3(64), 0, st, q_dev, nq, d, colscale, ab_enc, maxnorm, samp, kw, J, planes, refine,
-                     qfrag8, thr_i, thr_lb, thr_rest, cnt, lost);
+  if (dom.n > 0 && (planes != 1 || !qdom)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(knn_i8_prep_kernel, dim3(256), dim3(64), 0, st, q_dev, nq, d, colscale, dom, ab_enc, maxnorm, samp, kw, J, planes, refine,
+                     qfrag8, qdom, thr_i, thr_lb, thr_rest, cnt, lost);
   return hipGetLastError();
 #else
   return hipErrorInvalidValue;
@@ -933,14 +1001,14 @@ hipError_t launch_i8_prep(const float* q_dev, int nq, int d, const float* colsca
 }
 
 #if KNNX_MFMA16
-template <int KS, int NW, int NSLOT, int PL = 1>
-static hipError_t launch_rq8_scan_cfg(const int8_t* X8, int64_t N, const int8_t* qfrag8, const int* thr_i, unsigned* cnt, unsigned cap,
-                                      float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st) {
+template <int KS, int NW, int NSLOT, int PL = 1, bool DOM = false>
+static hipError_t launch_rq8_scan_cfg(const int8_t* X8, int64_t N, const int8_t* qfrag8, const int8_t* qdom, const int* thr_i, unsigned* cnt,
+                                      unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st) {
   const size_t smem = (size_t)NSLOT * KS * 1024 + (size_t)NW * RQ_STAGE * 12;
-  auto kern = knn_rq8_scan_kernel<KS, NW, NSLOT, PL>;
+  auto kern = knn_rq8_scan_kernel<KS, NW, NSLOT, PL, DOM>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, tstep);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, X8, N, qfrag8, qdom, thr_i, cnt, cap, hit_s, hit_r, lost, tstep);
   return hipGetLastError();
 }
 #endif
@@ -950,9 +1018,10 @@ extern "C" int knnx_dbg_rq8_phases(long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rq8_phase), (size_t)n * sizeof(long long));
 }
 #endif
-hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int* thr_i, unsigned* cnt,
-                           unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st) {
-  if (tstep < 1) return hipErrorInvalidValue;
+hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int planes, const int8_t* qfrag8, const int8_t* qdom, const int* thr_i,
+                           unsigned* cnt, unsigned cap, float* hit_s, uint32_t* hit_r, unsigned* lost, int grid, int tstep, hipStream_t st) {
+  // qdom != nullptr: the index has dominant columns (one plane; I8Dom)
+  if (tstep < 1 || (qdom && planes != 1)) return hipErrorInvalidValue;
 #if defined(CLIPX_ABLATE) && KNNX_MFMA16
   {
     static const int tm = getenv("KNNX_RQ8_TIMER") ? atoi(getenv("KNNX_RQ8_TIMER")) : 0;
@@ -961,12 +1030,13 @@ hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int plane
   }
 #endif
 #if KNNX_MFMA16
+#define RQ8_ARGS X8, N, qfrag8, qdom, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st
   if (planes == 2) {  // two query planes: 4 waves x 32 queries (twice the fragments per query: 192 registers at d = 768)
     if (nq > 128) return hipErrorInvalidValue;
     switch (d) {
-      case 512: return launch_rq8_scan_cfg<16, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
-      case 768: return launch_rq8_scan_cfg<24, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
-      case 1024: return launch_rq8_scan_cfg<32, 4, 4, 2>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+      case 512: return launch_rq8_scan_cfg<16, 4, 4, 2>(RQ8_ARGS);
+      case 768: return launch_rq8_scan_cfg<24, 4, 4, 2>(RQ8_ARGS);
+      case 1024: return launch_rq8_scan_cfg<32, 4, 4, 2>(RQ8_ARGS);
       default: return hipErrorInvalidValue;
     }
   }
@@ -974,18 +1044,19 @@ hipError_t launch_rq8_scan(const int8_t* X8, int64_t N, int d, int nq, int plane
   // int8 rows does not hide behind HBM (8 x 32 slots: 17.4 ms per pass over 100 M x 768 whatever the batch, 76.8 GB in 12.4 ms)
   if (nq <= 128) {
     switch (d) {
-      case 512: return launch_rq8_scan_cfg<16, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
-      case 768: return launch_rq8_scan_cfg<24, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
-      case 1024: return launch_rq8_scan_cfg<32, 4, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+      case 512: return qdom ? launch_rq8_scan_cfg<16, 4, 4, 1, true>(RQ8_ARGS) : launch_rq8_scan_cfg<16, 4, 4>(RQ8_ARGS);
+      case 768: return qdom ? launch_rq8_scan_cfg<24, 4, 4, 1, true>(RQ8_ARGS) : launch_rq8_scan_cfg<24, 4, 4>(RQ8_ARGS);
+      case 1024: return qdom ? launch_rq8_scan_cfg<32, 4, 4, 1, true>(RQ8_ARGS) : launch_rq8_scan_cfg<32, 4, 4>(RQ8_ARGS);
       default: return hipErrorInvalidValue;
     }
   }
   switch (d) {
-    case 512: return launch_rq8_scan_cfg<16, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
-    case 768: return launch_rq8_scan_cfg<24, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
-    case 1024: return launch_rq8_scan_cfg<32, 8, 4>(X8, N, qfrag8, thr_i, cnt, cap, hit_s, hit_r, lost, grid, tstep, st);
+    case 512: return qdom ? launch_rq8_scan_cfg<16, 8, 4, 1, true>(RQ8_ARGS) : launch_rq8_scan_cfg<16, 8, 4>(RQ8_ARGS);
+    case 768: return qdom ? launch_rq8_scan_cfg<24, 8, 4, 1, true>(RQ8_ARGS) : launch_rq8_scan_cfg<24, 8, 4>(RQ8_ARGS);
+    case 1024: return qdom ? launch_rq8_scan_cfg<32, 8, 4, 1, true>(RQ8_ARGS) : launch_rq8_scan_cfg<32, 8, 4>(RQ8_ARGS);
     default: return hipErrorInvalidValue;
   }
+#undef RQ8_ARGS
 #else
   return hipErrorInvalidValue;
 #endif

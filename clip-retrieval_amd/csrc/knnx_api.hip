@@ -109,7 +109,10 @@ struct knnx_index {
   int64_t i8_nrows = 0;           // rows [0, i8_nrows) are quantised with the current column scales (add() appends: only the new rows are done)
   int64_t i8_scale_rows = 0;      // rows the column scales were taken over (a full rebuild once the index has doubled since)
   int i8_planes = 1;              // int8 planes of a query: 2 when the column scales differ widely (decided at every full build)
-  int i8_planes_env = 0;          // KNNX_I8_PLANES=1|2 forces the choice
+  int i8_planes_env = 0;          // KNNX_I8_PLANES=1|2 forces the choice (and switches the dominant-column form off)
+  I8Dom i8_dom;                   // dominant columns of the index (knn_kernels.h), decided with the planes
+  int i8_dom_off = 0;             // KNNX_I8_DOM=0: never use the dominant-column form (two planes instead)
+  int8_t* i8_qdom = nullptr;      // [2][256][4] the queries' 14-bit digits at the dominant positions (knn_i8_prep_kernel)
   int8_t* i8_rows = nullptr;      // tile-ordered image of rows [0, i8_nrows) (knn_i8_quant_kernel): i8_cap_rows / 32 tiles of 32 d bytes
   int64_t i8_budget = 0;          // KNNX_I8_MAX_BYTES: cap on the image (0: none) -- a PARTIAL copy: the other rows are scanned in fp16
   unsigned long long i8_rest_served = 0;  // queries whose pass ran over an int8 part AND an fp16 rest
@@ -260,6 +263,8 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
     ix->i8_ok = (i8 && i8[0] == '0') ? 0 : 1;
     const char* pl = getenv("KNNX_I8_PLANES");
     ix->i8_planes_env = (pl && (pl[0] == '1' || pl[0] == '2')) ? pl[0] - '0' : 0;
+    const char* dm = getenv("KNNX_I8_DOM");
+    ix->i8_dom_off = (dm && dm[0] == '0') ? 1 : 0;
     const char* i8b = getenv("KNNX_I8_MAX_BYTES");
     ix->i8_budget = i8b ? std::max<int64_t>(0, atoll(i8b)) : 0;
   }
@@ -324,6 +329,7 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->stats);
   hipFree(ix->i8_rows);
   hipFree(ix->i8_colscale);
+  hipFree(ix->i8_qdom);
   hipFree(ix->i8_colmax);
   hipFree(ix->i8_ab);
   hipFree(ix->i8_qfrag);
@@ -836,6 +842,7 @@ static int i8_ensure(knnx_index* ix, hipStream_t st) {
   if (!ix->i8_colscale) {
     if (hipMalloc(&ix->i8_colscale, ix->d * sizeof(float)) != hipSuccess || hipMalloc(&ix->i8_colmax, ix->d * sizeof(int)) != hipSuccess ||
         hipMalloc(&ix->i8_ab, 2 * sizeof(int)) != hipSuccess || hipMalloc(&ix->i8_qfrag, 2 * Q * ix->d) != hipSuccess ||
+        hipMalloc(&ix->i8_qdom, 2 * Q * 4) != hipSuccess ||
         hipMalloc(&ix->i8_thr, Q * sizeof(int)) != hipSuccess || hipMalloc(&ix->i8_lb, Q * sizeof(float)) != hipSuccess ||
         hipMalloc(&ix->i8_hit_s, Q * KNN_I8_CAP * sizeof(float)) != hipSuccess ||
         hipMalloc(&ix->i8_hit_r, Q * KNN_I8_CAP * sizeof(uint32_t)) != hipSuccess)
@@ -893,20 +900,48 @@ static int i8_ensure(knnx_index* ix, hipStream_t st) {
   if (ix->i8_nrows > 0 && ix->i8_nrows <= n8 && ix->ntotal < 2 * ix->i8_scale_rows) {
     // rows were appended: quantise the new ones with the scales that exist (values beyond them clamp; A and B grow with what is stored)
     if (ix->i8_nrows < n8)
-      HIPCHK(launch_i8_quant(ix->rows, n8, ix->i8_nrows, n8, ix->d, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
+      HIPCHK(launch_i8_quant(ix->rows, n8, ix->i8_nrows, n8, ix->d, ix->i8_colscale, ix->i8_dom, ix->i8_rows, ix->i8_ab, st));
   } else {
-    HIPCHK(launch_i8_build(ix->rows, ix->ntotal, n8, ix->d, ix->i8_colmax, ix->i8_colscale, ix->i8_rows, ix->i8_ab, st));
+    HIPCHK(launch_i8_scales(ix->rows, ix->ntotal, ix->d, ix->i8_colmax, ix->i8_colscale, ix->i8_ab, st));
     ix->i8_scale_rows = ix->ntotal;
-    // one or two int8 planes per query (knn_i8_prep_kernel): a query's u = q * c has ONE scale, so a few columns much larger than
-    // the rest leave the others' components in the rounding error.  Two planes when the largest column scale is more than 3 x the
-    // median one; the choice is part of the build (a readback of d floats: the build has just moved the whole index).
+    // The form of the first stage is part of the build (a readback of d floats: the build is about to move the whole index).  A query's
+    // u = q * c has ONE scale, so a few columns much larger than the rest (CLIP embeddings have them) leave the others' components in
+    // the rounding error.  Columns whose scale is more than 3 x the median one are "dominant":
+    //   1 .. 4 of them: they move to bytes 0..3 of each row of the image and the scan handles them with 14-bit query digits (I8Dom) --
+    //                   one plane, 256 queries per pass
+    //   more:           two int8 planes per query (twice the MFMAs, 128 queries per pass)
     std::vector<float> cs((size_t)ix->d);
     HIPCHK(hipMemcpyAsync(cs.data(), ix->i8_colscale, (size_t)ix->d * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const float cmax = *std::max_element(cs.begin(), cs.end());
-    std::nth_element(cs.begin(), cs.begin() + ix->d / 2, cs.end());
-    const float cmed = cs[(size_t)ix->d / 2];
-    ix->i8_planes = ix->i8_planes_env ? ix->i8_planes_env : (cmax > 3.f * cmed ? 2 : 1);
+    std::vector<float> sorted(cs);
+    std::nth_element(sorted.begin(), sorted.begin() + ix->d / 2, sorted.end());
+    const float cmed = sorted[(size_t)ix->d / 2];
+    std::vector<int> big;
+    for (int c = 0; c < ix->d; ++c)
+      if (cs[(size_t)c] > 3.f * cmed) big.push_back(c);
+    ix->i8_dom = I8Dom();
+    if (ix->i8_planes_env) {
+      ix->i8_planes = ix->i8_planes_env;
+    } else if (!big.empty() && big.size() <= 4 && !ix->i8_dom_off) {
+      ix->i8_planes = 1;
+      // the permutation that brings them to positions 0 .. n - 1: a swap per dominant column
+      std::vector<int> perm((size_t)ix->d);
+      for (int c = 0; c < ix->d; ++c) perm[(size_t)c] = c;
+      for (size_t j = 0; j < big.size(); ++j) {
+        const size_t at = (size_t)(std::find(perm.begin(), perm.end(), big[j]) - perm.begin());
+        std::swap(perm[j], perm[at]);
+      }
+      ix->i8_dom.n = (int)big.size();
+      for (int c = 0; c < ix->d; ++c)
+        if (perm[(size_t)c] != c) {
+          ix->i8_dom.pos[ix->i8_dom.nfix] = c;
+          ix->i8_dom.src[ix->i8_dom.nfix] = perm[(size_t)c];
+          ++ix->i8_dom.nfix;  // (at most two positions per swap: 8)
+        }
+    } else {
+      ix->i8_planes = big.empty() ? 1 : 2;
+    }
+    HIPCHK(launch_i8_quant(ix->rows, n8, 0, n8, ix->d, ix->i8_colscale, ix->i8_dom, ix->i8_rows, ix->i8_ab, st));
   }
   ix->i8_nrows = n8;
   ix->i8_valid = true;
@@ -931,18 +966,19 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
   r = rq_sample_pass(ix, q_dev, nq, k, two_level ? KNN_RQ_STRIDE : KNN_I8_STRIDE, st, &tstride, &J, &wide_samp);
   if (r) return r;
   float* thr_rest = nrest > 0 ? ix->rq_thr : nullptr;
-  HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J, ix->i8_planes, 0, ix->i8_qfrag,
-                        ix->i8_thr, ix->i8_lb, thr_rest, ix->rq_cnt, ix->rq_lost, st));
+  const int8_t* qdom = ix->i8_dom.n > 0 ? ix->i8_qdom : nullptr;
+  HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_dom, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J, ix->i8_planes, 0,
+                        ix->i8_qfrag, ix->i8_qdom, ix->i8_thr, ix->i8_lb, thr_rest, ix->rq_cnt, ix->rq_lost, st));
   if (two_level) {
-    HIPCHK(launch_rq8_scan(ix->i8_rows, n8, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s,
+    HIPCHK(launch_rq8_scan(ix->i8_rows, n8, d, nq, ix->i8_planes, ix->i8_qfrag, qdom, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s,
                            ix->i8_hit_r, ix->rq_lost, ix->n_cu, KNN_I8_STRIDE, st));
     HIPCHK(launch_rq_rescore(ix->rows, d, q_dev, nq, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r, ix->rq_cntc, st));
     // the exact top-64 of the sampled hits, where the sample passes put theirs: the refining prep reads its J-th entry
     HIPCHK(launch_merge_u32(ix->i8_hit_s, ix->i8_hit_r, ix->rq_cntc, 1, nq, (int)KNN_I8_CAP, nq, KNN_WIDE_KW, 0, nullptr, ix->rq_samp,
                             ix->rq_samp_i, nullptr, st));
     const int J2 = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
-    HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J2, ix->i8_planes, 1,
-                          ix->i8_qfrag, ix->i8_thr, ix->i8_lb, thr_rest, ix->rq_cnt, ix->rq_lost, st));
+    HIPCHK(launch_i8_prep(q_dev, nq, d, ix->i8_colscale, ix->i8_dom, ix->i8_ab, ix->maxnorm, ix->rq_samp, KNN_WIDE_KW, J2, ix->i8_planes, 1,
+                          ix->i8_qfrag, ix->i8_qdom, ix->i8_thr, ix->i8_lb, thr_rest, ix->rq_cnt, ix->rq_lost, st));
   }
   // 2. the pass over the int8 rows
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -951,7 +987,7 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, st));
   }
-  HIPCHK(launch_rq8_scan(ix->i8_rows, n8, d, nq, ix->i8_planes, ix->i8_qfrag, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
+  HIPCHK(launch_rq8_scan(ix->i8_rows, n8, d, nq, ix->i8_planes, ix->i8_qfrag, qdom, ix->i8_thr, ix->rq_cnt, KNN_I8_CAP, ix->i8_hit_s, ix->i8_hit_r,
                          ix->rq_lost, ix->n_cu, 1, st));
   // 2b. the rows without an int8 image: the fp16 register-stationary pass, admission threshold T - eps_hi (knn_i8_prep_kernel), into
   // the SAME hit lists (global row = n8 + row of the slice); the lower bound T of the proof covers both parts
@@ -1040,6 +1076,18 @@ extern "C" int knnx_i8_planes(knnx_index* ix) {
   if (!ix) return -1;
   std::lock_guard<std::mutex> lk(ix->mu);
   return ix->i8_valid ? ix->i8_planes : 0;
+}
+extern "C" int knnx_i8_dominant(knnx_index* ix, int* cols4) {
+  if (!ix) return -1;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!ix->i8_valid) return 0;
+  for (int j = 0; j < ix->i8_dom.n && cols4; ++j) {
+    int c = j;  // the column at position j
+    for (int f = 0; f < ix->i8_dom.nfix; ++f)
+      if (ix->i8_dom.pos[f] == j) c = ix->i8_dom.src[f];
+    cols4[j] = c;
+  }
+  return ix->i8_dom.n;
 }
 
 extern "C" int knnx_search_device(knnx_index* ix, const float* q_dev, int n, int k, float* D_dev, int64_t* I_dev,

@@ -266,6 +266,12 @@ class Mi355xIndex(_FaissShaped):
         """0: no int8 copy at the moment; 1 / 2: int8 planes per query of the first stage (include/knnx.h: knnx_i8_planes)."""
         return int(self._lib.knnx_i8_planes(self._h))
 
+    def i8_dominant(self):
+        """Columns the int8 first stage treats as dominant (include/knnx.h: knnx_i8_dominant): a list of 0 .. 4 column numbers."""
+        cols = (C.c_int * 4)()
+        n = int(self._lib.knnx_i8_dominant(self._h, cols))
+        return [int(cols[j]) for j in range(max(n, 0))]
+
     def coalesce_stats(self):
         """(batches served, queries in them, largest batch) of the library's request coalescer."""
         b, q, m = C.c_int64(0), C.c_int64(0), C.c_int64(0)

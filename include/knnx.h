@@ -239,10 +239,18 @@ int knnx_coalesce_stats(knnx_index* ix, int64_t* batches, int64_t* queries, int6
 int64_t knnx_i8_served(knnx_index* ix);
 int64_t knnx_i8_rows(knnx_index* ix);
 /* 0: no int8 copy at the moment; 1 / 2: int8 planes per query.  A query is quantised as u = q * (column scales) with ONE scale, so an
- * index with a few columns much larger than the rest (largest column scale > 3 x the median one) gets a second plane for what the
- * first left -- twice the matrix work, four waves x 32 queries per pass -- instead of admitting (and re-scoring) two orders of
- * magnitude more rows.  Decided at every full build of the copy; KNNX_I8_PLANES=1|2 forces it. */
+ * index with a few columns much larger than the rest ("dominant": column scale > 3 x the median one; CLIP embeddings have them)
+ * would leave the other components in the rounding error and admit (and re-score) two orders of magnitude more rows.  Decided at
+ * every full build of the copy:
+ *   no dominant column:  one plane
+ *   1 .. 4 of them:      one plane; the copy keeps those columns in bytes 0..3 of each row (its layout is private), the matrix product
+ *                        leaves them out and the scan adds their part with 14-bit query digits on the vector ALU (round 5) -- the
+ *                        speed of one plane, 256 queries per pass.  knnx_i8_dominant: how many, and which columns (cols4: room for
+ *                        4 ints, may be NULL); 0 when the index has none or the form is off (KNNX_I8_DOM=0 in the environment)
+ *   more:                a second plane for what the first left -- twice the matrix work, four waves x 32 queries per pass
+ * KNNX_I8_PLANES=1|2 forces the plane count (and switches the dominant-column form off). */
 int knnx_i8_planes(knnx_index* ix);
+int knnx_i8_dominant(knnx_index* ix, int* cols4);
 
 /* One request of KnnService.knn_search with its dedup fused (clip_back.py:362 + :290-309): the top-k (k <= 64) of ONE query, and
  * the links of the reference's `get_non_uniques` -- every pair of result ranks (i < j) whose stored vectors, L2-normalised in

@@ -290,13 +290,32 @@ class Int8FirstStage:
         self.B = up(np.sqrt((self.x8 ** 2).sum(axis=1, dtype=np.float32)).max()) if len(x) else np.float32(0)
         self.x = x
 
-    def quantise_queries(self, q, planes: int = 1):
-        """-> (integer scores' scale s [nq], planes [planes, nq, d] of int8 values as float32, eps8 [nq])."""
+    def form(self, force_planes: int = 0, allow_dominant: bool = True):
+        """-> (planes, dominant columns): the choice the library makes at every full build of the copy (knnx_api.hip i8_ensure).
+        Columns whose scale is more than 3 x the median one are dominant; 1 .. 4 of them -> one plane with those columns as 14-bit
+        query digits, more -> two planes."""
+        med = np.partition(self.c, len(self.c) // 2)[len(self.c) // 2]
+        big = [int(j) for j in np.nonzero(self.c > np.float32(3) * med)[0]]
+        if force_planes:
+            return force_planes, []
+        if big and len(big) <= 4 and allow_dominant:
+            return 1, big
+        return (2 if big else 1), []
+
+    def quantise_queries(self, q, planes: int = 1, dominant=()):
+        """-> (integer scores' scale s [nq], planes [planes, nq, d] of integer values as float32, eps8 [nq]).
+        dominant (one plane only): columns left out of the scale, s_u = max over the OTHER columns / 127, and quantised with that s_u to
+        14-bit integers (|t| <= 127 * 128; the scan splits them into two int8 digits, knn_i8_prep_kernel)."""
         q = np.asarray(q, dtype=np.float32)
         u = q * self.c
-        mu = np.abs(u).max(axis=1)
+        dominant = list(dominant)
+        assert not dominant or planes == 1
+        rest = np.ones(u.shape[1], dtype=bool)
+        rest[dominant] = False
+        mu = np.abs(u[:, rest]).max(axis=1)
         su = np.where(mu > 0, mu / np.float32(127), np.float32(1)).astype(np.float32)
-        u8 = np.clip(np.rint(u / su[:, None]), -127, 127).astype(np.float32)
+        lim = np.where(rest, np.float32(127), np.float32(16256))
+        u8 = np.clip(np.rint(u / su[:, None]), -lim, lim).astype(np.float32)
         res = u - su[:, None] * u8
         out, s = [u8], su
         if planes == 2:
@@ -314,9 +333,9 @@ class Int8FirstStage:
         acc = [np.rint(p.astype(np.float64) @ self.x8.astype(np.float64).T).astype(np.int64) for p in planes_u8]
         return acc[0] if len(acc) == 1 else 128 * acc[0] + acc[1]
 
-    def admitted(self, q, T, planes: int = 1):
+    def admitted(self, q, T, planes: int = 1, dominant=()):
         """Boolean [nq, n]: rows the scan admits for exact-score lower bounds T [nq] (thr_i = floor((T - eps8 - 1e-6 |T|) / s) - 1)."""
-        s, pl, eps8 = self.quantise_queries(q, planes)
+        s, pl, eps8 = self.quantise_queries(q, planes, dominant)
         T = np.asarray(T, dtype=np.float32)
         thr = np.floor((T - eps8 - np.float32(1e-6) * np.abs(T)) / s).astype(np.int64) - 1
         return self.integer_scores(pl) >= thr[:, None]

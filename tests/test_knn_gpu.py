@@ -740,10 +740,12 @@ def test_i8_first_stage_after_the_rows_change(monkeypatch):
     ix.close()
 
 
-def test_i8_first_stage_two_query_planes_for_dominant_columns(monkeypatch):
+def test_i8_first_stage_forms_for_dominant_columns(monkeypatch):
     """Embeddings with a few dominant dimensions (two columns 6 x the rest plus a common offset, as CLIP embeddings have): the column
-    scales differ widely, the library picks TWO int8 planes per query, results equal the oracle without a single fallback; an
-    isotropic index picks one plane.  (With one plane forced the same data is still answered exactly -- through wider hit lists.)"""
+    scales differ widely.  Round 5: the library keeps ONE int8 plane, moves the dominant columns to the front of its private copy and
+    gives the queries 14-bit digits there (knnx_i8_dominant) -- results equal the oracle without a single fallback, every batch size
+    on the int8 path.  With that form off (KNNX_I8_DOM=0) it picks TWO planes (round 4), again without fallbacks; with one plain plane
+    forced the same data is still answered exactly -- through wider hit lists.  An isotropic index: one plane, no dominant column."""
     from clip_retrieval_amd.knn import Mi355xIndex
     from oracle.knn_oracle import FlatIPOracle
 
@@ -758,25 +760,77 @@ def test_i8_first_stage_two_query_planes_for_dominant_columns(monkeypatch):
     o.add(x)
     q = _queries(200, d, seed=52, x=x)
     Do, Io = o.search(q, 40)
-    for forced, want in ((None, 2), ("1", 1)):
-        if forced:
-            monkeypatch.setenv("KNNX_I8_PLANES", forced)
+    for env, planes, dom in (({}, 1, [0, 1]), ({"KNNX_I8_DOM": "0"}, 2, []), ({"KNNX_I8_PLANES": "1"}, 1, [])):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
         ix = Mi355xIndex(d)
         ix.add(x)
         for lo, hi in ((0, 1), (1, 41), (41, 200)):
             D, I = ix.search(q[lo:hi], 40)
-            _check(D, I, Do[lo:hi], Io[lo:hi], f"dominant columns, planes={want}, queries {lo}:{hi}")
+            _check(D, I, Do[lo:hi], Io[lo:hi], f"dominant columns, {env}, queries {lo}:{hi}")
         # (the 159-query batch: with two planes more than 128 queries go to the fp16 register-stationary pass)
-        assert ix.i8_planes() == want and ix.i8_served() == (41 if want == 2 else 200)
-        if want == 2:
-            assert ix.stats()[1] == 0, "two planes must not need the fallback on this corpus"
+        assert ix.i8_planes() == planes and ix.i8_dominant() == dom
+        assert ix.i8_served() == (41 if planes == 2 else 200)
+        if planes == 2 or dom:
+            assert ix.stats()[1] == 0, f"{env}: must not need the fallback on this corpus"
         ix.close()
-    monkeypatch.delenv("KNNX_I8_PLANES")
+        for k_ in env:
+            monkeypatch.delenv(k_)
     iso = Mi355xIndex(d)
     iso.add(_data(60_000, d, seed=53))
     iso.search(_queries(3, d, seed=54), 5)
-    assert iso.i8_planes() == 1
+    assert iso.i8_planes() == 1 and iso.i8_dominant() == []
     iso.close()
+
+
+@pytest.mark.parametrize("d,n,cols", [(512, 70_003, [5]), (768, 90_017, [700, 2, 63]), (1024, 64_000, [1023, 0, 511, 512]),
+                                      (768, 50_000, [1, 2, 3, 64, 65])])
+def test_i8_dominant_columns_anywhere_in_the_row(monkeypatch, d, n, cols):
+    """The dominant-column form of the int8 first stage (include/knnx.h, knnx_i8_dominant): the columns may sit anywhere -- the copy
+    permutes them to its first bytes (a dominant column that already sits among the first four, and one that has to swap with another
+    dominant column's target, included) --, rows may be appended afterwards (quantised with the same permutation), the copy may be
+    partial, the last tile ragged; five dominant columns are one too many for the form and get two planes.  Every batch size class
+    equals the oracle, served by the int8 path without fallbacks."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle, Int8FirstStage
+
+    monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")
+    if d == 768 and len(cols) == 3:
+        monkeypatch.setenv("KNNX_I8_MAX_BYTES", str(60_000 * d))  # a partial copy: rows behind it go through the fp16 pass
+    rng = np.random.default_rng(d + len(cols))
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[:, cols] = 6.0 * x[:, cols] + 3.0 * rng.choice([-1.0, 1.0], size=len(cols)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x = x.astype(np.float16)
+    n0 = n - 4_001  # the rest is appended after the first search
+    o = FlatIPOracle(d)
+    o.add(x[:n0])
+    ix = Mi355xIndex(d)
+    ix.add(x[:n0])
+    want_planes, want_dom = Int8FirstStage(x[:n0]).form()
+    assert (want_planes, want_dom) == ((1, sorted(cols)) if len(cols) <= 4 else (2, []))
+    served = 0
+    for step in range(2):
+        nq_all = 300 if want_planes == 1 else 100
+        q = _queries(nq_all, d, seed=60 + step, x=x[: o.ntotal])
+        # neighbours planted in the last rows (ragged tile; after the append: appended rows)
+        q[:4] = x[o.ntotal - 4: o.ntotal].astype(np.float32) + 0.01 * rng.standard_normal((4, d)).astype(np.float32)
+        Do, Io = o.search(q, 10)
+        for lo, hi in ((0, 1), (1, 34), (34, 100), (100, nq_all)):
+            if hi <= lo:
+                continue
+            D, I = ix.search(q[lo:hi], 10)
+            _check(D, I, Do[lo:hi], Io[lo:hi], f"dominant {cols} d={d} step {step} queries {lo}:{hi}")
+        served += nq_all
+        assert set(Io[:4, 0]) == set(range(o.ntotal - 4, o.ntotal))
+        assert ix.i8_planes() == want_planes and sorted(ix.i8_dominant()) == want_dom
+        assert ix.i8_served() == served and ix.stats()[1] == 0
+        if step == 0:
+            o.add(x[n0:])
+            ix.add(x[n0:])
+    if d == 768 and len(cols) == 3:
+        assert ix.i8_rows() == 60_000 - 60_000 % 32
+    ix.close()
 
 
 @pytest.mark.parametrize("d,n,budget_rows", [(768, 90_001, 40_000), (1024, 70_013, 30_000), (512, 60_000, 59_999)])

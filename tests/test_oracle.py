@@ -262,15 +262,20 @@ def test_parity_gate_rejects_wrong_rows_and_accepts_the_measured_error():
 
 
 @pytest.mark.parametrize("corpus", ["isotropic", "dominant_columns", "appended_rows_clamp", "tiny_and_zero_columns"])
-@pytest.mark.parametrize("planes", [1, 2])
+@pytest.mark.parametrize("planes", [1, 2, "dominant"])
 def test_int8_first_stage_bound_and_admission_hold(corpus, planes):
     """The inequality the int8 first stage of the flat scans stands on (csrc/knn_rq_kernels.hip; restated in float32 by
     oracle.knn_oracle.Int8FirstStage): |exact - approx| <= eps8 for EVERY (query, row) pair, hence every row whose exact score reaches a
     lower bound T is admitted by the integer compare -- on isotropic rows, rows with dominant columns, rows appended after the column
-    scales were fixed (components clamp at +-127), and degenerate columns; with one and with two query planes."""
+    scales were fixed (components clamp at +-127), and degenerate columns; with one and with two query planes, and with one plane whose
+    dominant columns are 14-bit digits (round 5: columns 0..2 where the corpus has them, else three arbitrary ones -- the bound
+    does not care which)."""
     from oracle.knn_oracle import Int8FirstStage
 
-    rng = np.random.default_rng(hash(corpus) % 1000 + planes)
+    dominant = ()
+    if planes == "dominant":
+        planes, dominant = 1, (0, 1, 2)
+    rng = np.random.default_rng(sum(map(ord, corpus)) + planes + 10 * len(dominant))
     d, n = 256, 4000
     x = rng.standard_normal((n, d)).astype(np.float32)
     colscale = None
@@ -289,21 +294,34 @@ def test_int8_first_stage_bound_and_admission_hold(corpus, planes):
     q = np.concatenate([x[:40] + 0.05 * rng.standard_normal((40, d)).astype(np.float32), 3.0 * rng.standard_normal((24, d)).astype(np.float32)])
     q = q.astype(np.float32)
     exact = q.astype(np.float64) @ st.x.astype(np.float64).T
-    s, pl, eps8 = st.quantise_queries(q, planes)
+    if corpus == "dominant_columns":
+        assert st.form() == (1, [0, 1, 2]) and st.form(allow_dominant=False) == (2, []) and st.form(force_planes=1) == (1, [])
+    elif corpus == "isotropic":
+        assert st.form() == (1, [])
+    s, pl, eps8 = st.quantise_queries(q, planes, dominant)
+    if dominant:
+        assert np.abs(pl[0][:, 3:]).max() <= 127 and np.abs(pl[0][:, :3]).max() <= 16256
+        if corpus == "dominant_columns":
+            assert np.abs(pl[0][:40, :3]).max() > 127, "the digits at the dominant columns are meant to need more than 7 bits"
     approx = s[:, None].astype(np.float64) * st.integer_scores(pl)
     err = np.abs(exact - approx)
     assert (err <= eps8[:, None].astype(np.float64)).all(), f"bound violated: max err/eps {np.max(err / eps8[:, None]):.3f}"
     assert np.max(err / eps8[:, None]) > 0.01, "the bound is vacuous on this corpus (test is not exercising it)"
     # admission: T = the 10th best exact score of each query; every row at or above it must pass the integer compare
     T = np.sort(exact, axis=1)[:, -10].astype(np.float32)
-    adm = st.admitted(q, T, planes)
+    adm = st.admitted(q, T, planes, dominant)
     must = exact >= T[:, None].astype(np.float64)
     assert (adm | ~must).all(), "a row whose exact score reaches the threshold was not admitted"
     # ... and the band is not the whole index (the point of the stage): the unit-norm queries on the well-conditioned corpora
     # (4 000 rows and a threshold at rank 10 make the band look wide: at 10^8 rows it is a few 10^4 rows)
-    if corpus == "isotropic" or (planes == 2 and corpus == "dominant_columns"):
+    if corpus == "isotropic" or ((planes == 2 or dominant) and corpus == "dominant_columns"):
         frac = adm[:40].mean()
         assert frac < 0.25, f"{frac:.2f} of the rows admitted"
+        if dominant and corpus == "dominant_columns":
+            # the point of the form: the band of one plane + digits is about that of two planes, far below one plane's
+            one = st.admitted(q, T, 1)[:40].mean()
+            two = st.admitted(q, T, 2)[:40].mean()
+            assert frac < 0.5 * one and frac < 2.0 * two + 0.01, (frac, one, two)
 
 
 def test_int8_bound_holds_at_d1024_when_every_residual_pulls_the_same_way():
