@@ -207,7 +207,8 @@ int knnx_synth_fill(knnx_index* ix, int64_t n, uint64_t seed);
  * is re-derivable on the CPU: oracle/knn_oracle.py).  kind 0: the isotropic corpus of knnx_synth_fill (row_stride 1 only);
  * kind 1: BASELINE config 5's overlapping mixture of n_clusters Gaussians in a 32-dimensional latent space, where IVF recall
  * is < 1 at small nprobe and rises with it; kind 2: the isotropic corpus with three dominant columns (6 x the spread plus a common
- * offset, as a few dimensions of real CLIP embeddings have: the int8 first stage takes two query planes on it; row_stride 1 only).
+ * offset, as a few dimensions of real CLIP embeddings have: the int8 first stage treats them as dominant columns, knnx_i8_dominant;
+ * row_stride 1 only).
  * `stream`: hipStream_t or NULL; synchronous. */
 int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed,
                            int kind, int64_t n_clusters, void* stream);
