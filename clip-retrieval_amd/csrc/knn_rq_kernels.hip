@@ -429,7 +429,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void knn_rq_scan_kernel(
 // the exact scan (as in the fp16 register-stationary path, whose sample pass, hit lists, re-scoring and merge this path shares).
 // How many rows pass depends on the data: for unit vectors with components of similar size (the bench's synthetic index)
 // eps8 ~ 0.02 |q|, ~0.5 sigma of the score distribution -- a few times 10^4 hits per query at 10^8 rows; embeddings with a few
-// dominant columns quantise the QUERY coarsely (one scale for all of u) and pass more rows, up to the fallback.
+// dominant columns would quantise the QUERY coarsely (one scale for all of u) and pass more rows, up to the fallback: those indexes
+// get the dominant-column form (I8Dom, round 5: the dominant components as 14-bit integers outside the MFMA product) or, with more
+// than four such columns, two int8 planes per query (round 4) -- knnx_api.hip i8_ensure decides at every full build of the copy.
 // Geometry: an int8 row of d bytes is an fp16 row of d / 2 columns to the tile / DMA helpers above: KS = d / 32 pieces of
 // (16 rows x 64 bytes) per 32-row tile, lane (r = l & 15, q4 = l >> 4) holds bytes 16 q4 .. + 16 of the piece's 64.
 // =============================================================================================
