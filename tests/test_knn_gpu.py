@@ -833,6 +833,43 @@ def test_i8_dominant_columns_anywhere_in_the_row(monkeypatch, d, n, cols):
     ix.close()
 
 
+def test_i8_dominant_digits_clamp_and_dominant_only_queries_stay_exact(monkeypatch):
+    """Edges of the dominant-column form (tests/test_oracle.py::test_int8_dominant_digits_edge_cases_keep_the_bound has the arithmetic):
+    one column ~200 x the rest, so that the queries' components there exceed 14 bits and clamp, and queries that live only in that column
+    (no scale from the others: every row is admitted, the lists overflow, the gated exact scan answers).  Results equal the oracle
+    either way; the bound may cost fallbacks here, never a wrong id."""
+    from clip_retrieval_amd.knn import Mi355xIndex
+    from oracle.knn_oracle import FlatIPOracle
+
+    monkeypatch.setenv("KNNX_RQ_MIN_ROWS", "0")
+    d, n = 768, 80_000
+    rng = np.random.default_rng(91)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[:, 7] = 50.0 * x[:, 7] + 30.0
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x = x.astype(np.float16)
+    o = FlatIPOracle(d)
+    o.add(x)
+    ix = Mi355xIndex(d)
+    ix.add(x)
+    q = _queries(70, d, seed=92, x=x)
+    q[:60, 7] *= 4.0  # (queries are not normalised by the index: four times the corpus' own component takes the digits past 14 bits)
+    q[60:] = 0.0
+    q[60:, 7] = np.linspace(-1.0, 1.0, 10, dtype=np.float32)
+    q[64, 7] = 0.0  # ... and the zero vector
+    Do, Io = o.search(q, 10)
+    for lo, hi in ((0, 1), (1, 60), (60, 70), (0, 70)):
+        D, I = ix.search(q[lo:hi], 10)
+        m = min(hi, 60)  # queries [lo, m) have all their components, [max(lo, 60), hi) only the dominant one
+        if lo < m:
+            _check(D[: m - lo], I[: m - lo], Do[lo:m], Io[lo:m], f"clamped digits, queries {lo}:{m}")
+        # the dominant-only queries score every row by ONE column: thousands of ties within rounding -- compare the scores
+        if hi > 60:
+            np.testing.assert_allclose(D[max(60, lo) - lo:], Do[max(lo, 60):hi], rtol=0, atol=2e-6)
+    assert ix.i8_dominant() == [7] and ix.i8_served() == 1 + 59 + 10 + 70
+    ix.close()
+
+
 @pytest.mark.parametrize("d,n,budget_rows", [(768, 90_001, 40_000), (1024, 70_013, 30_000), (512, 60_000, 59_999)])
 def test_i8_partial_copy_int8_part_plus_fp16_rest_equals_the_oracle(monkeypatch, d, n, budget_rows):
     """BASELINE's headline shard (125 M x 768 fp16 = 192 GB per GPU) leaves no room for a whole int8 copy, so the copy may be PARTIAL

@@ -324,6 +324,38 @@ def test_int8_first_stage_bound_and_admission_hold(corpus, planes):
             assert frac < 0.5 * one and frac < 2.0 * two + 0.01, (frac, one, two)
 
 
+def test_int8_dominant_digits_edge_cases_keep_the_bound():
+    """The dominant-column form at its edges (knn_i8_prep_kernel): a dominant component beyond 14 bits clamps at +-127 * 128 (the residual
+    carries the rest: the bound widens, it does not break); a query that lives ONLY in the dominant columns has no scale from the others
+    (s_u = 1, every digit rounds to zero, approx = 0: everything is admitted); the 14-bit integer splits into int8 digits hi, lo with
+    |hi| <= 127, |lo| <= 64 and 128 hi + lo = t for every t in range."""
+    from oracle.knn_oracle import Int8FirstStage
+
+    rng = np.random.default_rng(77)
+    d, n = 128, 3000
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[:, 7] = 50.0 * x[:, 7] + 30.0
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    st = Int8FirstStage(x.astype(np.float16))
+    assert st.form() == (1, [7])
+    q = np.concatenate([x[:16] + 0.02 * rng.standard_normal((16, d)).astype(np.float32), np.eye(d, dtype=np.float32)[[7]] * 0.8])
+    q[:16, 7] *= 4.0  # (queries are not normalised by the index: a component four times the corpus' own takes the digits past 14 bits)
+    s, pl, eps8 = st.quantise_queries(q, 1, [7])
+    assert np.abs(pl[0][:16, 7]).max() == 16256, "the first queries are meant to clamp at the 14-bit limit"
+    assert (pl[0][16] == 0).all() and s[16] == 1.0
+    exact = q.astype(np.float64) @ st.x.astype(np.float64).T
+    err = np.abs(exact - s[:, None].astype(np.float64) * st.integer_scores(pl))
+    assert (err <= eps8[:, None].astype(np.float64)).all()
+    T = np.sort(exact, axis=1)[:, -10].astype(np.float32)
+    adm = st.admitted(q, T, 1, [7])
+    assert (adm | ~(exact >= T[:, None])).all() and adm[16].all()
+    # the digits
+    t = np.arange(-16256, 16257, dtype=np.float32)
+    hi = np.rint(t * np.float32(1 / 128))
+    lo = t - np.float32(128) * hi
+    assert np.abs(hi).max() == 127 and np.abs(lo).max() == 64 and (128 * hi + lo == t).all()
+
+
 def test_int8_bound_holds_at_d1024_when_every_residual_pulls_the_same_way():
     """the bound multiplies fp32 norms -- sums of d terms, each a few 2^-24 off -- and round 4's slack (1 + 2e-5) was
     below the worst-case summation error at d = 1024 (6.1e-5).  Drive the case where Cauchy-Schwarz is (nearly) an equality, so that
