@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static int splitk_factor(const GemmArgs& g) {
   if (!g.splitk_ws || g.M > 1024 || g.epi == EPI_TABLE_F32 || g.epi == EPI_RAW_F32) return 1;
   const int nk = g.K / G_BK;
-  // Measured at M = 257 (profiles/r02j_b1_kernels.txt): every launch has a floor of ~4.5 us, a split GEMM + its reduction
+  // Measured at M = 257 (round 2 kernel trace, no longer kept under profiles/): every launch has a floor of ~4.5 us, a split GEMM + its reduction
   // cost 9.9 + 5.0 us whatever K is, the unsplit kernel 12 us at K = 1024 and 36 us at K = 4096: only long K loops pay.
   // A single m-tile (the text query, M = 77: 6 .. 24 workgroups) gains from splitting shorter loops too (0.69 -> 0.62 ms).
   if (nk < 8 || (nk < 32 && g.M > G_TM)) return 1;

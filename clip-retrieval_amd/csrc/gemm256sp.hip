@@ -5,12 +5,14 @@
 // The linear layers inside `model.encode_image/encode_text` (reference clip_retrieval/clip_inference/mapper.py:57,65).
 //
 //   * one 512-thread workgroup per CU, persistent over output tiles as one continuous K-tile stream.
-//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 4x2 v_mfma_f32_32x32x16_bf16 tiles (128 accumulator VGPRs).
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 blocks of v_mfma_f32_16x16x32_{bf16,f16} (128 accumulator VGPRs;
+//     CLIPX_MFMA16 = 1 since round 4 -- the 32x32x16 form is kept behind CLIPX_MFMA16 = 0 for A/B only).
 //   * LDS: 2 K-tile buffers x (M operand 256 rows + N operand 256 rows) x 128 B = 128 KiB, filled by LDS-DMA
 //     (global_load_lds_dwordx4, 8 per wave per K-tile, SGPR base + one of four per-lane offsets, M0 = one s_add),
 //     chunk-XOR swizzled through the source address; + 32 KiB of per-wave scratch for the epilogue transposition.
-//   * per K-tile each wave runs 4 k-steps of {6 ds_read_b128 for the NEXT step, 8 MFMA of this step} from two
-//     register sets; the single s_barrier of the K-tile sits BEFORE the last step's MFMAs:
+//   * per K-tile each wave runs 8 units of {2 or 6 ds_read_b128 for the NEXT unit, 8 MFMA of this unit} from two
+//     register sets (32x32x16 form: 4 k-steps of 6 reads + 8 MFMA); the single s_barrier of the K-tile sits BEFORE the last
+//     unit's MFMAs:
 //         step 3:  lgkmcnt(0); vmcnt(1)  [K-tile g+1 landed; the L2 prefetch may stay in flight]; s_barrier;
 //                  ds_read step 0 of K-tile g+1; 8 MFMA; stage K-tile g+2 into the buffer just released;
 //                  one dword LDS-DMA that pulls 12 lines of K-tile g+4 into the L2 (see "L2 prefetch" below)

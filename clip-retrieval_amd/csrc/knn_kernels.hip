@@ -631,7 +631,8 @@ __device__ __forceinline__ int synth_v(uint64_t seed, uint64_t idx) {
 
 // dominant != 0 (corpus kind 2: "CLIP-like" anisotropy): columns 0 .. 2 carry 6 v + 113 511 (three standard deviations of v: a common
 // offset plus a six-fold spread, as a few dimensions of real CLIP embeddings do) before the row is normalised -- the corpus on which
-// the int8 first stage needs its second query plane; oracle/knn_oracle.py: synth_rows(..., dominant=True).
+// one plain int8 plane fails; the first stage keeps those columns as 14-bit query digits (the 1-plane dominant-column form, DESIGN
+// 4.3; two planes before round 5); oracle/knn_oracle.py: synth_rows(..., dominant=True).
 constexpr int SYNTH_DOM_COLS = 3, SYNTH_DOM_GAIN = 6, SYNTH_DOM_OFFSET = 113511;
 __global__ __launch_bounds__(256) void knn_synth_kernel(_Float16* __restrict__ X, int64_t row_begin, int64_t n, int d,
                                                        uint64_t seed, int dominant) {

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
   int8_t* dst = qfrag8 + ((size_t)(n >> 4) * nsl * 64 + (n & 15)) * 16;  // + (s * 64 + q4 * 16) * 16 + byte
   int8_t* dst2 = dst + (size_t)256 * d;
   float u[16];  // columns lane + 64 e
-  float mu = 0.f, e2 = 0.f, n2 = 0.f;
+  float mu = 0.f, mud = 0.f, e2 = 0.f, n2 = 0.f;  // mud: the largest dominant component
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int c = lane + 64 * e;
@@ -591,6 +591,7 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
       n2 += v * v;
       u[e] = v * colscale[sc];
       if (c >= dom.n) mu = fmaxf(mu, fabsf(u[e]));
+      else mud = fmaxf(mud, fabsf(u[e]));
     }
   }
   float nu2 = 0.f;
@@ -598,11 +599,14 @@ __global__ __launch_bounds__(64) void knn_i8_prep_kernel(const float* __restrict
   for (int e = 0; e < 16; ++e) nu2 += u[e] * u[e];
   for (int o = 32; o > 0; o >>= 1) {
     mu = fmaxf(mu, __shfl_xor(mu, o));
+    mud = fmaxf(mud, __shfl_xor(mud, o));
     e2 += __shfl_xor(e2, o);
     n2 += __shfl_xor(n2, o);
     nu2 += __shfl_xor(nu2, o);
   }
-  const float su = mu > 0.f ? mu / 127.f : 1.f;
+  // a query that is zero outside the dominant columns takes its scale from THEM (their 14-bit range): with s_u = 1 the digits would
+  // round to zero, eps8 would admit every row and the query would fall back to the exact scan
+  const float su = mu > 0.f ? mu / 127.f : (mud > 0.f ? mud / 16256.f : 1.f);
   float er2 = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -1348,7 +1352,7 @@ hipError_t launch_rq_scan(const _Float16* X, int64_t N, int d, int nq, const _Fl
     // d = 768: 8 waves x 32 queries, two waves per SIMD: a wave's LDS-DMA issue (~100 cycles per instruction during which it
     // issues nothing else) is covered by its SIMD partner's MFMAs.  4 waves x 64 queries (one wave per SIMD, 501 registers)
     // measured 59 % MFMA utilisation at 1.6 GHz: the 12 DMA issues per tile held the matrix pipe of their SIMD idle
-    // (profiles/r02_rq_pmc.txt).
+    // (round 2 counter run; the file is no longer kept under profiles/).
     case 768: return launch_rq_scan_cfg<48, 1, 8, 3>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st, row_off);
     case 1024: return launch_rq_scan_cfg<64, 1, 4, 2>(X, N, qfrag, thr, cnt, cap, hit_s, hit_r, lost, gate, grid, st, row_off);
     default: return hipErrorInvalidValue;

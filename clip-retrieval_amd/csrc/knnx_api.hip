@@ -404,6 +404,10 @@ extern "C" int knnx_reset(knnx_index* ix) {
   ix->ntotal = 0;
   ix->i8_valid = false;
   ix->i8_nrows = 0;
+  {  // a copy that was given up for lack of memory may be tried again for the new rows; KNNX_I8=0 still rules
+    const char* i8 = getenv("KNNX_I8");
+    ix->i8_ok = (i8 && i8[0] == '0') ? 0 : 1;
+  }
   HIPCHK(hipMemsetAsync(ix->maxnorm, 0, sizeof(int), ix->stream));
   return KNNX_OK;
 }
@@ -2148,7 +2152,7 @@ extern "C" int knnx_ivfb_list_sizes(knnx_ivf_builder* b, int64_t* sizes_out, int
 
 // Benchmark corpora generated straight into caller HBM: dst row i = corpus row row_begin + i * row_stride, fp16 [n, d].
 // kind 0: the isotropic corpus of knnx_synth_fill (row_stride must be 1); kind 2: the same with three dominant columns (the
-// anisotropy of CLIP embeddings: the int8 first stage takes two query planes on it); kind 1: the overlapping mixture of n_clusters
+// anisotropy of CLIP embeddings: the int8 first stage takes its 1-plane dominant-column form on it, include/knnx.h); kind 1: the overlapping mixture of n_clusters
 // Gaussians of BASELINE config 5 (knn_kernels.hip: knn_synth_mix_kernel; oracle/knn_oracle.py: synth_mixture_rows).
 // Synchronous.
 extern "C" int knnx_synth_rows_device(int device, void* dst_f16, int64_t row_begin, int64_t row_stride, int64_t n, int d, uint64_t seed,

@@ -10,13 +10,15 @@
 //     peer-to-peer over xGMI into one buffer on devices[0] (hipMemcpyPeerAsync: the exchange is a few KB, latency-bound,
 //     a direct copy per shard is the one-step exchange SURVEY 8(e) asks for), and the same merge kernel that follows the
 //     RCCL all-gather of the one-process-per-GPU path (knnx_merge_topk_device) produces the final top-k;
-//     -- or, when every shard sits on its own device and librccl.so can be loaded (round 5; SURVEY 8(e): "RCCL ncclAllGather of
+//     -- or, OPT-IN with KNNX_SHARDS_RCCL=1, when every shard sits on its own device and librccl.so can be loaded (round 5; SURVEY 8(e): "RCCL ncclAllGather of
 //     B * k * 12 B per rank inside one process (ncclCommInitAll)"), by ONE grouped all-gather over RCCL: a communicator per device
 //     from ncclCommInitAll, ncclGroupStart; per device ncclAllGather(D) + ncclAllGather(I) on its own stream; ncclGroupEnd -- every
 //     device then holds all P lists and devices[0] merges.  RCCL is loaded with dlopen on first use (the library has no link-time
-//     dependency on it and a one-GPU process never loads it); KNNX_SHARDS_RCCL=0 keeps the peer copies, =1 also takes RCCL for a
-//     single shard (the one-GPU test of this path).  knnx_shards_exchange() says which one is in use.  NEVER RUN ON MORE THAN ONE
-//     GPU by its author (one-GPU test boxes): correct by construction and by the single-device communicator test only.
+//     dependency on it and a process that does not ask for it never loads it); the default is the peer copies, KNNX_SHARDS_RCCL=1 takes
+//     RCCL (also for a single shard: the one-GPU test of this path).  knnx_shards_exchange() says which one is in use.  NEVER RUN ON
+//     MORE THAN ONE GPU by its author (one-GPU test boxes): correct by construction and by the single-device communicator test only --
+//     which is why it is opt-in, and why an exchange that returns an error hands the batch (and the index, from then on) to the peer
+//     copies instead of failing the search.
 //   * reconstruct: ids are routed to the owning shard by row range.
 // Built on the public entry points of include/knnx.h only.  No CPU arithmetic: the host routes ids and pointers.
 
@@ -111,6 +113,21 @@ struct knnx_shards {
       return knnx_set_error(_e == hipErrorOutOfMemory ? KNNX_E_NOMEM : KNNX_E_HIP, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
   } while (0)
 
+// give the RCCL exchange up: communicators destroyed, receive buffers freed, the peer-copy form from now on
+static void shards_drop_rccl(knnx_shards* s) {
+  s->use_rccl = false;
+  for (auto& h : s->sh) {
+    (void)hipSetDevice(h.device);
+    if (h.comm && rccl().ok) (void)rccl().CommDestroy(h.comm);
+    if (h.agD) (void)hipFree(h.agD);
+    if (h.agI) (void)hipFree(h.agI);
+    h.comm = nullptr;
+    h.agD = nullptr;
+    h.agI = nullptr;
+  }
+  if (!s->sh.empty()) (void)hipSetDevice(s->sh[0].device);
+}
+
 static int shards_finish_setup(knnx_shards* s) {
   const int P = (int)s->sh.size();
   for (int g = 0; g < P; ++g) {
@@ -139,27 +156,31 @@ static int shards_finish_setup(knnx_shards* s) {
   s->pin_q = (size_t)s->cap_q * s->d * sizeof(float);
   s->pin_d = (size_t)s->cap_q * KNNX_MAX_K_FAST * sizeof(float);
   SHIP(hipHostMalloc(&s->pin, s->pin_q + s->pin_d + (size_t)s->cap_q * KNNX_MAX_K_FAST * sizeof(int64_t), hipHostMallocDefault));
-  // ---- RCCL exchange: every shard on its own device (a communicator cannot hold one GPU twice), P > 1 unless forced
+  // ---- RCCL exchange: every shard on its own device (a communicator cannot hold one GPU twice).  OPT-IN (KNNX_SHARDS_RCCL=1) until it
+  // has run on a box with more than one GPU: the peer-copy form is the default, and a failing exchange falls back to it.
   const char* env = getenv("KNNX_SHARDS_RCCL");
-  const int want = env ? atoi(env) : -1;  // -1: automatic
+  const int want = env ? atoi(env) : 0;
   bool distinct = true;
   for (int g = 0; g < P; ++g)
     for (int o = 0; o < g; ++o) distinct = distinct && s->sh[o].device != s->sh[g].device;
-  if (want != 0 && distinct && (P > 1 || want == 1) && rccl().ok) {
+  if (want == 1 && distinct && rccl().ok) {
     std::vector<int> devs(P);
     std::vector<void*> comms(P, nullptr);
     for (int g = 0; g < P; ++g) devs[g] = s->sh[g].device;
     if (rccl().CommInitAll(comms.data(), P, devs.data()) == 0) {
       bool mem = true;
+      for (int g = 0; g < P; ++g) s->sh[g].comm = comms[g];  // all of them, so that a failure below can destroy all of them
       for (int g = 0; g < P && mem; ++g) {
         Shard& h = s->sh[g];
-        h.comm = comms[g];
         mem = hipSetDevice(h.device) == hipSuccess &&
               hipMalloc(&h.agD, (size_t)P * s->cap_q * KNNX_MAX_K_FAST * sizeof(float)) == hipSuccess &&
               hipMalloc(&h.agI, (size_t)P * s->cap_q * KNNX_MAX_K_FAST * sizeof(int64_t)) == hipSuccess;
       }
       s->use_rccl = mem;
-      if (!mem) (void)hipGetLastError();
+      if (!mem) {
+        (void)hipGetLastError();
+        shards_drop_rccl(s);
+      }
     }
     (void)hipSetDevice(s->sh[0].device);
   }
@@ -321,19 +342,10 @@ static int shards_search_fast(knnx_shards* s, const float* q, int n, int k, floa
       SHIP(hipMemcpyAsync(h.q, pin, (size_t)nb * d * sizeof(float), hipMemcpyHostToDevice, h.st));
       int r = knnx_search_device(h.ix, h.q, nb, k, h.D, h.I, h.st);
       if (r) return r;
-      const size_t cnt = (size_t)nb * k;
-      if (s->use_rccl) continue;  // exchanged below, all shards in one group
-      if (h.device == s->sh[0].device) {
-        SHIP(hipMemcpyAsync(s->gD + (size_t)g * cnt, h.D, cnt * sizeof(float), hipMemcpyDeviceToDevice, h.st));
-        SHIP(hipMemcpyAsync(s->gI + (size_t)g * cnt, h.I, cnt * sizeof(int64_t), hipMemcpyDeviceToDevice, h.st));
-      } else {
-        SHIP(hipMemcpyPeerAsync(s->gD + (size_t)g * cnt, s->sh[0].device, h.D, h.device, cnt * sizeof(float), h.st));
-        SHIP(hipMemcpyPeerAsync(s->gI + (size_t)g * cnt, s->sh[0].device, h.I, h.device, cnt * sizeof(int64_t), h.st));
-      }
-      SHIP(hipEventRecord(h.ev, h.st));
     }
     const float* partD = s->gD;
     const int64_t* partI = s->gI;
+    bool gathered = false;
     if (s->use_rccl) {
       // ONE grouped exchange: every device contributes its nb * k (score, id) pairs -- nb * k * 12 bytes -- and receives all P lists,
       // rank-major = shard-major = ascending id order, the layout the merge kernel takes
@@ -346,15 +358,38 @@ static int shards_search_fast(knnx_shards* s, const float* q, int n, int k, floa
       }
       const int rc2 = rccl().GroupEnd();
       if (rc == 0) rc = rc2;
-      if (rc != 0)
-        return knnx_set_error(KNNX_E_HIP, (std::string("RCCL all-gather of the per-shard top-k: ") +
-                                           (rccl().GetErrorString ? rccl().GetErrorString(rc) : "error")).c_str());
-      SHIP(hipSetDevice(s->sh[0].device));
-      SHIP(hipEventRecord(s->sh[0].ev, s->sh[0].st));
-      SHIP(hipStreamWaitEvent(s->st0, s->sh[0].ev, 0));
-      partD = s->sh[0].agD;
-      partI = s->sh[0].agI;
-    } else {
+      if (rc == 0) {
+        SHIP(hipSetDevice(s->sh[0].device));
+        SHIP(hipEventRecord(s->sh[0].ev, s->sh[0].st));
+        SHIP(hipStreamWaitEvent(s->st0, s->sh[0].ev, 0));
+        partD = s->sh[0].agD;
+        partI = s->sh[0].agI;
+        gathered = true;
+      } else {
+        // the exchange failed: this index answers through peer copies from now on, starting with this very batch (the per-shard
+        // lists are still in h.D / h.I, ordered on h.st)
+        for (auto& h : s->sh) {
+          (void)hipSetDevice(h.device);
+          (void)hipStreamSynchronize(h.st);
+        }
+        (void)hipGetLastError();
+        shards_drop_rccl(s);
+      }
+    }
+    if (!gathered) {
+      for (int g = 0; g < P; ++g) {
+        Shard& h = s->sh[g];
+        const size_t cnt = (size_t)nb * k;
+        SHIP(hipSetDevice(h.device));
+        if (h.device == s->sh[0].device) {
+          SHIP(hipMemcpyAsync(s->gD + (size_t)g * cnt, h.D, cnt * sizeof(float), hipMemcpyDeviceToDevice, h.st));
+          SHIP(hipMemcpyAsync(s->gI + (size_t)g * cnt, h.I, cnt * sizeof(int64_t), hipMemcpyDeviceToDevice, h.st));
+        } else {
+          SHIP(hipMemcpyPeerAsync(s->gD + (size_t)g * cnt, s->sh[0].device, h.D, h.device, cnt * sizeof(float), h.st));
+          SHIP(hipMemcpyPeerAsync(s->gI + (size_t)g * cnt, s->sh[0].device, h.I, h.device, cnt * sizeof(int64_t), h.st));
+        }
+        SHIP(hipEventRecord(h.ev, h.st));
+      }
       SHIP(hipSetDevice(s->sh[0].device));
       for (int g = 0; g < P; ++g) SHIP(hipStreamWaitEvent(s->st0, s->sh[g].ev, 0));
     }

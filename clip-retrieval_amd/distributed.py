@@ -48,7 +48,12 @@ def shard_rows(total_rows, world_size, rank):
 class ShardedIndex:
     """faiss-shaped `search` over a row-sharded index; collective: every rank must call with the same queries."""
 
-    def __init__(self, local_index, group=None):
+    def __init__(self, local_index, group=None, force_gather=False):
+        """`force_gather`: run the exchange step (all-gather + merge) even at world size 1, where a single shard's result is
+        already the answer -- so that one GPU can execute the code path N > 1 ranks take (tests; CLIPX_FORCE_GATHER=1 does the
+        same from the environment)."""
+        import os  # pylint: disable=import-outside-toplevel
+
         import torch.distributed as dist  # pylint: disable=import-outside-toplevel
 
         self.local = local_index
@@ -56,6 +61,20 @@ class ShardedIndex:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.d = local_index.d
+        self.force_gather = bool(force_gather or os.environ.get("CLIPX_FORCE_GATHER") == "1") and dist.is_initialized()
+
+    def _pad_queries(self, x):
+        """float32 [n, d] -> contiguous float32 [n, d_padded]: the device entry points read rows of the local index's padded
+        width (d rounded up to a multiple of 256; e.g. the 640-dimensional RN50x4 embeddings), zeros in the extra columns."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dpad = int(getattr(self.local, "_dpad", self.d))
+        if x.ndim != 2 or x.shape[1] not in (self.d, dpad):
+            raise AssertionError(f"queries must be [n, {self.d}], got {x.shape}")
+        if x.shape[1] == dpad:
+            return x
+        out = np.zeros((x.shape[0], dpad), dtype=np.float32)
+        out[:, : self.d] = x
+        return out
 
     @property
     def ntotal(self):
@@ -99,14 +118,15 @@ class ShardedIndex:
         import torch  # pylint: disable=import-outside-toplevel
         import torch.distributed as dist  # pylint: disable=import-outside-toplevel
 
-        if self.world == 1:
+        if self.world == 1 and not self.force_gather:
             return self.local.search(x, k)
         on_gpu = dist.get_backend(self.group) == "nccl"
-        if on_gpu and k <= 64:
+        if on_gpu and k <= 64 and hasattr(self.local, "search_device"):
             # RCCL: upload the queries once and stay on the device -- local scan into the record buffer, all-gather, merge -- only
-            # the merged [n, k] comes back (round 5: the local results used to travel device -> numpy -> device before the gather)
+            # the merged [n, k] comes back (round 5: the local results used to travel device -> numpy -> device before the gather).
+            # A faiss-shaped local index without `search_device` (ShardedMi355xIndex, a test double) takes the host path below.
             dev = torch.device("cuda", torch.cuda.current_device())
-            q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev, non_blocking=False)
+            q = torch.from_numpy(self._pad_queries(x)).to(dev, non_blocking=False)
             Do, Io = self.search_device(q, k)
             return Do.cpu().numpy(), Io.cpu().numpy()
         D, I = self.local.search(x, k)
@@ -123,6 +143,7 @@ class ShardedIndex:
 
     def search_device(self, q_cuda, k):
         """CUDA tensors end to end: local scan -> all_gather (RCCL) -> merge kernel.  Returns (D, I) on the GPU.
+        `q_cuda`: float32 [n, d_padded] (see _pad_queries; d itself when d % 256 == 0).
 
         The scan is launched on a dedicated torch side stream (the C ABI reads a NULL stream as "the index's own
         stream", which torch's collectives would not be ordered against); the caller's current stream waits for it
@@ -130,6 +151,9 @@ class ShardedIndex:
         import torch  # pylint: disable=import-outside-toplevel
         import torch.distributed as dist  # pylint: disable=import-outside-toplevel
 
+        dpad = int(getattr(self.local, "_dpad", self.d))
+        if q_cuda.dim() != 2 or q_cuda.shape[1] != dpad or q_cuda.dtype != torch.float32 or not q_cuda.is_contiguous():
+            raise AssertionError(f"search_device expects contiguous float32 [n, {dpad}] queries (padded width), got {tuple(q_cuda.shape)} {q_cuda.dtype}")
         n = q_cuda.shape[0]
         rec, I, D = self._record_buffer(n, k, q_cuda.device)  # the local scan writes straight into the record buffer
         if getattr(self, "_side", None) is None:
@@ -138,7 +162,7 @@ class ShardedIndex:
         self._side.wait_stream(cur)  # q_cuda, D, I were produced / allocated on the caller's stream
         self.local.search_device(q_cuda.data_ptr(), n, k, D.data_ptr(), I.data_ptr(), self._side.cuda_stream)
         cur.wait_stream(self._side)
-        if self.world == 1:
+        if self.world == 1 and not self.force_gather:
             return D, I
         Dg, Ig = self._gather_records(rec, n, k)
         return self.merge_device(Dg, Ig, k)

@@ -175,9 +175,10 @@ int knnx_shards_add_f32(knnx_shards* s, const float* rows, int64_t n);
 int knnx_shards_synth_fill(knnx_shards* s, int64_t rows_per_shard, uint64_t seed);
 int64_t knnx_shards_ntotal(const knnx_shards* s);
 int knnx_shards_count(const knnx_shards* s);
-/* How the per-shard top-k lists reach devices[0]: 1 = one grouped ncclAllGather over RCCL (every shard on its own device and
- * librccl.so loadable -- loaded with dlopen on first use; KNNX_SHARDS_RCCL=0 turns it off, =1 also takes it for a single shard),
- * 0 = hipMemcpyPeerAsync per shard, -1 = null handle.  Either way the same merge kernel produces the result. */
+/* How the per-shard top-k lists reach devices[0]: 0 = hipMemcpyPeerAsync per shard (the default), 1 = one grouped ncclAllGather over
+ * RCCL (opt-in: KNNX_SHARDS_RCCL=1 in the environment when the handle is created, every shard on its own device and librccl.so
+ * loadable -- loaded with dlopen on first use; an exchange that fails switches the handle back to 0 and the batch is answered through
+ * the peer copies), -1 = null handle.  Either way the same merge kernel produces the result. */
 int knnx_shards_exchange(const knnx_shards* s);
 knnx_index* knnx_shards_get(knnx_shards* s, int g); /* borrowed: profiling, nprobe */
 /* faiss Index.search / search_and_reconstruct / reconstruct_batch / range_search over all shards. */

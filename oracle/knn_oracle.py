@@ -313,7 +313,9 @@ class Int8FirstStage:
         rest = np.ones(u.shape[1], dtype=bool)
         rest[dominant] = False
         mu = np.abs(u[:, rest]).max(axis=1)
-        su = np.where(mu > 0, mu / np.float32(127), np.float32(1)).astype(np.float32)
+        # zero outside the dominant columns: the scale comes from the dominant components' 14-bit range (knn_i8_prep_kernel)
+        mud = np.abs(u[:, dominant]).max(axis=1) if dominant else np.zeros(u.shape[0], dtype=np.float32)
+        su = np.where(mu > 0, mu / np.float32(127), np.where(mud > 0, mud / np.float32(16256), np.float32(1))).astype(np.float32)
         lim = np.where(rest, np.float32(127), np.float32(16256))
         u8 = np.clip(np.rint(u / su[:, None]), -lim, lim).astype(np.float32)
         res = u - su[:, None] * u8

@@ -99,3 +99,27 @@ def test_shard_rows_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_device_fast_path_pads_queries_to_the_local_index_width():
+    """the RCCL fast path hands the queries to `local.search_device`, which reads rows of the PADDED width (d rounded up to
+    a multiple of 256: 640-dimensional RN50x4 embeddings -> 768); a local index without `search_device` must not take that path."""
+    from clip_retrieval_amd.distributed import ShardedIndex
+
+    class _Padded:
+        d, _dpad, ntotal = 640, 768, 0
+
+        def search_device(self, *a):  # pragma: no cover - never called on the CPU
+            raise AssertionError
+
+    sh = ShardedIndex(_Padded())
+    q = np.random.default_rng(0).standard_normal((3, 640)).astype(np.float32)
+    p = sh._pad_queries(q)
+    assert p.shape == (3, 768) and p.dtype == np.float32 and p.flags.c_contiguous
+    assert np.array_equal(p[:, :640], q) and not p[:, 640:].any()
+    assert sh._pad_queries(p) is p  # already padded: passed through
+    with pytest.raises(AssertionError):
+        sh._pad_queries(q[:, :100])
+    with pytest.raises(AssertionError):  # search_device refuses an unpadded tensor instead of reading past its rows
+        sh.search_device(torch.zeros(3, 640), 5)
+    assert not hasattr(_LocalOracleShard, "search_device")  # the gloo stand-in goes through local.search + gather

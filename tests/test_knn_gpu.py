@@ -836,8 +836,9 @@ def test_i8_dominant_columns_anywhere_in_the_row(monkeypatch, d, n, cols):
 def test_i8_dominant_digits_clamp_and_dominant_only_queries_stay_exact(monkeypatch):
     """Edges of the dominant-column form (tests/test_oracle.py::test_int8_dominant_digits_edge_cases_keep_the_bound has the arithmetic):
     one column ~200 x the rest, so that the queries' components there exceed 14 bits and clamp, and queries that live only in that column
-    (no scale from the others: every row is admitted, the lists overflow, the gated exact scan answers).  Results equal the oracle
-    either way; the bound may cost fallbacks here, never a wrong id."""
+    (no scale from the others: since round 6 they take it from the dominant components' 14-bit range -- before, every digit rounded to
+    zero, every row was admitted and the gated exact scan answered).  Results equal the oracle either way; the bound may cost
+    fallbacks here, never a wrong id."""
     from clip_retrieval_amd.knn import Mi355xIndex
     from oracle.knn_oracle import FlatIPOracle
 

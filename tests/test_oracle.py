@@ -327,7 +327,8 @@ def test_int8_first_stage_bound_and_admission_hold(corpus, planes):
 def test_int8_dominant_digits_edge_cases_keep_the_bound():
     """The dominant-column form at its edges (knn_i8_prep_kernel): a dominant component beyond 14 bits clamps at +-127 * 128 (the residual
     carries the rest: the bound widens, it does not break); a query that lives ONLY in the dominant columns has no scale from the others
-    (s_u = 1, every digit rounds to zero, approx = 0: everything is admitted); the 14-bit integer splits into int8 digits hi, lo with
+    and takes it from its dominant components' 14-bit range (round 6, ADVICE r5: s_u = max |u_dom| / 16256 -- with s_u = 1 every digit
+    rounded to zero and every row was admitted); the zero vector keeps s_u = 1; the 14-bit integer splits into int8 digits hi, lo with
     |hi| <= 127, |lo| <= 64 and 128 hi + lo = t for every t in range."""
     from oracle.knn_oracle import Int8FirstStage
 
@@ -338,17 +339,20 @@ def test_int8_dominant_digits_edge_cases_keep_the_bound():
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     st = Int8FirstStage(x.astype(np.float16))
     assert st.form() == (1, [7])
-    q = np.concatenate([x[:16] + 0.02 * rng.standard_normal((16, d)).astype(np.float32), np.eye(d, dtype=np.float32)[[7]] * 0.8])
+    q = np.concatenate([x[:16] + 0.02 * rng.standard_normal((16, d)).astype(np.float32), np.eye(d, dtype=np.float32)[[7]] * 0.8,
+                        np.zeros((1, d), dtype=np.float32)])
     q[:16, 7] *= 4.0  # (queries are not normalised by the index: a component four times the corpus' own takes the digits past 14 bits)
     s, pl, eps8 = st.quantise_queries(q, 1, [7])
     assert np.abs(pl[0][:16, 7]).max() == 16256, "the first queries are meant to clamp at the 14-bit limit"
-    assert (pl[0][16] == 0).all() and s[16] == 1.0
+    assert abs(pl[0][16, 7]) == 16256 and not np.delete(pl[0][16], 7).any() and s[16] == np.float32(abs(q[16, 7] * st.c[7])) / np.float32(16256)
+    assert (pl[0][17] == 0).all() and s[17] == 1.0
     exact = q.astype(np.float64) @ st.x.astype(np.float64).T
     err = np.abs(exact - s[:, None].astype(np.float64) * st.integer_scores(pl))
     assert (err <= eps8[:, None].astype(np.float64)).all()
     T = np.sort(exact, axis=1)[:, -10].astype(np.float32)
     adm = st.admitted(q, T, 1, [7])
-    assert (adm | ~(exact >= T[:, None])).all() and adm[16].all()
+    assert (adm | ~(exact >= T[:, None])).all() and adm[17].all()
+    assert adm[16].mean() < 0.5, "a dominant-only query now filters (it used to admit every row; what is left is the |u| A term)"
     # the digits
     t = np.arange(-16256, 16257, dtype=np.float32)
     hi = np.rint(t * np.float32(1 / 128))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of two builds of the library on the flat scans (one process per build, same box): python tools/ab_knn_ring.py <lib.so> [rows]
+"""A/B of two builds of the library on the flat scans (one process per build, same box): python tools/ab_knn_libs.py <lib.so> [rows]
 Prints per batch size the whole-call time and the main scan kernel's, int8 first stage on and (KNNX_I8=0) off."""
 import ctypes as C
 import os
