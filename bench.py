@@ -61,6 +61,176 @@ def pmc_mfma_busy(family):
         return None, None
 
 
+def headline_numbers(line):
+    """(flat dict of the numbers README / DESIGN quote, <= 12 stderr lines with the same numbers) from the finished result line.
+    Key names carry the value class: knn_* = configs[2] (100 M x 768 isotropic), knn125m_* = the per-GPU shard of the headline
+    configuration (125 M x 768), knn_aniso_* = the corpus with dominant columns, ivf_* = configs[4]'s shard, pipeline_* = configs[3]'s."""
+    h = {"encode_samples_per_s": line["value"], "encode_gemm_frac": line["roofline"]["frac"], "encode_ms_per_step": line["ms_per_step"]}
+    out = [f"HEADLINE encode {line['value']} samples/s ({line['ms_per_step']} ms/step, GEMM {line['roofline']['achieved']} TF = frac {line['roofline']['frac']})"
+           + (f"; incl H2D/D2H {line['value_incl_h2d_d2h']}" if line.get("value_incl_h2d_d2h") else "")]
+    par = line.get("parity")
+    if par:
+        h["encode_parity_ok"] = bool(par["ok"])
+        h["encode_cos_min"] = round(min(par["image_cos_min"], par["text_cos_min"]), 7)
+        out.append(f"HEADLINE parity ok={par['ok']} rows={par['checked']} image_cos_min={par['image_cos_min']:.7f} text_cos_min={par['text_cos_min']:.7f}")
+    if line.get("cpu_baseline"):
+        h["cpu_encode_samples_per_s"] = line["cpu_baseline"]["value"]
+
+    def rows_of(leg, prefix, label):
+        if not leg:
+            return
+        parts = []
+        for r in leg["by_batch"]:
+            b = r["B"]
+            h[f"{prefix}_qps_b{b}"] = r["qps"]
+            h[f"{prefix}_pass_ms_b{b}"] = r["scan_ms"]
+            h[f"{prefix}_hbm_frac_b{b}"] = r["hbm_frac"]
+            parts.append(f"B={b}: {r['qps']} QPS, batch {r['ms_per_batch']} ms, pass {r['scan_ms']} ms, hbm {r['hbm_frac']}")
+        h[f"{prefix}_proof_failures"] = leg["wide_fallbacks"]
+        h[f"{prefix}_planted_top1"] = bool(leg["planted_neighbour_top1"])
+        out.append(f"HEADLINE {label} " + " | ".join(parts) + f" | fallbacks {leg['wide_fallbacks']}")
+
+    knn = line.get("knn")
+    if knn:
+        rows_of(knn, "knn", f"kNN {knn['rows_per_gpu'] // 1_000_000}Mx768 isotropic")
+        for sub in knn.get("by_shard_size") or []:
+            rows_of(sub, "knn125m" if sub["rows_per_gpu"] == 125_000_000 else f"knn{sub['rows_per_gpu'] // 1_000_000}m", f"kNN {sub['rows_per_gpu'] // 1_000_000}Mx768 shard")
+        rows_of(knn.get("anisotropic_corpus"), "knn_aniso", "kNN 100Mx768 dominant-columns")
+        ck = knn.get("checks") or {}
+        c1, c2 = ck.get("first_1M_rows_vs_numpy_oracle"), ck.get("full_index_vs_torch_matmul_topk")
+        if c1:
+            h["knn_check_first_1m_vs_numpy_oracle"] = bool(c1["id_lists_identical"] or c1["id_sets_equal_up_to_2e-6_ties"])
+        if c2:
+            h["knn_check_full_index_vs_torch"] = bool(c2["id_sets_equal_up_to_1e-5_ties"])
+        h["knn_check_planted_top1"] = bool(knn["planted_neighbour_top1"])
+        cb, hs = knn.get("cpu_baseline"), knn.get("host_search_and_reconstruct")
+        if cb:
+            h["cpu_knn_qps_extrapolated"] = cb["value"]
+        if hs:
+            for r in hs:
+                h[f"knn_host_search_and_reconstruct_ms_b{r['B']}"] = r["ms_per_call"]
+        out.append("HEADLINE kNN checks: planted_top1=%s first_1M_vs_numpy=%s full_index_vs_torch=%s | cpu %s QPS | host search_and_reconstruct %s" % (
+            h["knn_check_planted_top1"], h.get("knn_check_first_1m_vs_numpy_oracle"), h.get("knn_check_full_index_vs_torch"),
+            cb["value"] if cb else None, ", ".join(f"B={r['B']} {r['ms_per_call']} ms" for r in hs) if hs else None))
+    ivf = line.get("ivf")
+    if ivf:
+        parts = []
+        for r in ivf.get("by_nprobe", []):
+            npb = r["nprobe"]
+            b32, b256 = r.get("batch32") or {}, r.get("batch256") or {}
+            served = max((x["qps"] for x in r.get("served", []) if not x.get("deduplicate")), default=None)
+            h[f"ivf_np{npb}_recall40"] = r["recall_at_40_vs_exact_whole_shard"]
+            h[f"ivf_np{npb}_qps_b32"] = b32.get("qps")
+            h[f"ivf_np{npb}_ms_b256"] = b256.get("ms_per_batch")
+            h[f"ivf_np{npb}_served_qps"] = served
+            parts.append(f"np{npb}: recall {r['recall_at_40_vs_exact_whole_shard']}, B32 {b32.get('qps')} QPS, B256 {b256.get('ms_per_batch')} ms, served {served}")
+        out.append(f"HEADLINE IVF {ivf['rows'] // 1_000_000}Mx{ivf['d']} nlist {ivf['nlist']} " + " | ".join(parts))
+    pl = line.get("pipeline")
+    if pl:
+        for k_ in ("samples_per_s_u8", "samples_per_s_jpeg", "frac_of_value"):
+            if pl.get(k_) is not None:
+                h["pipeline_" + k_] = pl[k_]
+        out.append(f"HEADLINE pipeline (tar shards -> reader -> runner -> writer) u8 {pl.get('samples_per_s_u8')} samples/s, jpeg {pl.get('samples_per_s_jpeg')}, frac_of_value {pl.get('frac_of_value')}")
+    return h, [ln[:330] for ln in out[:12]]
+
+
+def pipeline_leg(model, value, device, shards_n=8, per_shard=2048, workers=16, log=lambda m: None):
+    """BASELINE configs[3]'s single-GPU share: synthetic tar shards in /dev/shm (seeded, untimed) ->
+    `worker()` -> WebdatasetReader (decode processes) -> pipelined Runner -> ClipMapper (asynchronous tickets of the C ABI) ->
+    NumpyWriter, timed wall to wall -- the reference's own loop (runner.py:27-64, reader.py:125-205) around the hot path.
+    Two variants: members that are PRE-DECODED uint8 224 x 224 x 3 (binary PPM: a 15-byte header + the pixels; what is left of the
+    reader is tar iteration, a memcpy and batching) and JPEG members of 256 x 256 with decode on the host, resize + centre crop on
+    the GPU (`gpu_resize=True`).  Partition 0 of 2 is the untimed start-up (model build, decode processes, warm-up), partition 1 is
+    timed; outputs are checked for the writer's file names, shapes and dtypes (writer.py:67-106)."""
+    import glob
+    import gzip
+    import io
+    import shutil
+    import tarfile
+    import tempfile
+
+    import numpy as np
+    from PIL import Image
+
+    from clip_retrieval_amd.reader import _DecodePool
+    from clip_retrieval_amd.worker import worker
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (8 << 30) else None
+    tmp = tempfile.mkdtemp(prefix="clipx_pipeline_", dir=base)
+    out = {"shards": shards_n, "members_per_shard": per_shard, "decode_processes": workers, "model": model, "where": tmp,
+           "timed": f"partition 1 of 2 ({shards_n // 2} shards x {per_shard} samples) through worker(); partition 0 is the untimed start-up"}
+    old_bpe = os.environ.get("CLIP_BPE_PATH")
+    try:
+        rng = np.random.default_rng(11)
+        bpe = os.path.join(tmp, "bpe_simple_vocab_16e6.txt.gz")  # a stand-in merges file (the real vocabulary is not available offline)
+        with gzip.open(bpe, "wt", encoding="utf-8") as f:
+            f.write("#version: 0.2\nt h\nth e</w>\no f</w>\np h\n")
+        os.environ["CLIP_BPE_PATH"] = bpe
+        n_distinct = 256
+        ppm, jpg = [], []
+        for i in range(n_distinct):
+            a = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+            ppm.append(b"P6\n224 224\n255\n" + a.tobytes())
+            g = np.linspace(0, 255, 256, dtype=np.float32)
+            b = (g[None, :, None] * 0.5 + g[:, None, None] * 0.5 + rng.normal(0, 12, (256, 256, 3))).clip(0, 255).astype(np.uint8)
+            buf = io.BytesIO()
+            Image.fromarray(np.roll(b, 7 * i, axis=1)).save(buf, format="JPEG", quality=90)
+            jpg.append(buf.getvalue())
+        for variant, ext, payloads, kw in (("u8", "ppm", ppm, dict(gpu_normalise=True)), ("jpeg", "jpg", jpg, dict(gpu_resize=True))):
+            shards = []
+            for sh in range(shards_n):
+                path = os.path.join(tmp, f"{variant}_{sh:03d}.tar")
+                with tarfile.open(path, "w") as tf:
+                    for i in range(per_shard):
+                        k = sh * per_shard + i
+                        for e, data in ((ext, payloads[k % n_distinct]), ("txt", f"a photo number {k} of something".encode())):
+                            ti = tarfile.TarInfo(f"{sh:03d}{i:06d}.{e}")
+                            ti.size = len(data)
+                            tf.addfile(ti, io.BytesIO(data))
+                shards.append(path)
+            folder = os.path.join(tmp, "out_" + variant)
+            args = dict(input_dataset=shards, output_folder=folder, output_partition_count=2, input_format="webdataset", batch_size=256,
+                        num_prepro_workers=workers, enable_text=True, enable_image=True, enable_metadata=False, wds_image_key=ext,
+                        clip_model="random:" + model, device=device, **kw)
+            import contextlib
+
+            with contextlib.redirect_stdout(sys.stderr):  # worker() prints its progress like the reference: keep stdout for the line
+                worker([0], **args)
+                t0 = time.perf_counter()
+                worker([1], **args)
+                el = time.perf_counter() - t0
+            n_timed = len(range(1, shards_n, 2)) * per_shard  # Sampler: partition 1 of 2 takes the odd shards (runner.py:13-14)
+            names = sorted(os.path.relpath(f, folder) for f in glob.glob(folder + "/*/*") if "stats" not in f)
+            want = sorted([f"img_emb/img_emb_{i}.npy" for i in range(2)] + [f"text_emb/text_emb_{i}.npy" for i in range(2)]
+                          + [f"metadata/metadata_{i}.parquet" for i in range(2)])
+            img, txt = np.load(folder + "/img_emb/img_emb_1.npy", mmap_mode="r"), np.load(folder + "/text_emb/text_emb_1.npy", mmap_mode="r")
+            with open(folder + "/stats/1.json") as f:
+                stats = json.load(f)
+            ok = bool(names == want and img.shape == txt.shape == (n_timed, img.shape[1]) and img.dtype == np.float16 == txt.dtype
+                      and stats["sample_count"] == n_timed and np.isfinite(np.asarray(img[:256], dtype=np.float32)).all())
+            out[variant] = {"samples_per_s": round(n_timed / el, 1), "seconds": round(el, 3), "samples": n_timed, "member": ext,
+                            "member_bytes": len(payloads[0]), "outputs_ok": ok,
+                            "stats_sum": {k_: round(float(v), 3) for k_, v in stats.items() if k_.endswith("_duration")}}
+            log(f"pipeline {variant}: {n_timed} samples in {el:.3f} s = {n_timed / el:.0f} samples/s; outputs ok = {ok}; stats {out[variant]['stats_sum']}")
+            for f in shards:
+                os.remove(f)
+            shutil.rmtree(folder, ignore_errors=True)
+        out["samples_per_s_u8"] = out["u8"]["samples_per_s"]
+        out["samples_per_s_jpeg"] = out["jpeg"]["samples_per_s"]
+        out["frac_of_value"] = round(out["samples_per_s_u8"] / value, 4) if value else None
+        out["jpeg_frac_of_value"] = round(out["samples_per_s_jpeg"] / value, 4) if value else None
+        # reader-bound: the summed read_duration (time the loop waited for a batch) is a sizeable share of the partition's wall time
+        out["reader_bound"] = {v: bool(out[v]["stats_sum"].get("read_duration", 0.0) > 0.15 * out[v]["seconds"]) for v in ("u8", "jpeg")}
+    finally:
+        _DecodePool.shutdown()
+        shutil.rmtree(tmp, ignore_errors=True)
+        if old_bpe is None:
+            os.environ.pop("CLIP_BPE_PATH", None)
+        else:
+            os.environ["CLIP_BPE_PATH"] = old_bpe
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,9 +255,12 @@ def main():
     ap.add_argument("--no-ivf", dest="ivf", action="store_false", help="skip BASELINE config 5's per-GPU shard (tools/config5.py: IVF-Flat "
                     "125 M x 1024, nlist 65 536, built on the device, served; embedded as `ivf`, ~1 minute)")
     ap.add_argument("--ivf-rows", type=int, default=125_000_000)
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="skip BASELINE config 4's single-GPU share (tar shards -> "
+                    "worker() -> reader -> pipelined Runner -> writer, pre-decoded uint8 and JPEG members; embedded as `pipeline`, ~30 s)")
     args = ap.parse_args()
     if args.profile_run:
         args.no_parity, args.no_ab, args.knn_extra, args.ivf, args.cpu_seconds, args.host_path = True, True, False, False, 0.0, False
+        args.pipeline = False
     refuse_debug_environment()
 
     import numpy as np
@@ -103,17 +276,21 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under the launcher (torch.distributed.run sets RANK / MASTER_ADDR / MASTER_PORT) the process group is created even at world size 1,
+    # so that `--nproc-per-node 1` executes what N ranks execute: init_process_group("nccl") = RCCL, the barrier, the MAX all-reduce of
+    # the timings, the broadcast of the planted queries (tests/test_launcher_gpu.py runs exactly that on the one GPU of a test box).
+    use_dist = world > 1 or all(k in os.environ for k in ("RANK", "MASTER_ADDR", "MASTER_PORT"))
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -389,9 +566,9 @@ def main():
             q = torch.empty(nq_max, d, dtype=torch.float32, device=dev)
             if rank == 0:
                 q.copy_(torch.from_numpy(perturbed_queries(ix.reconstruct_batch(planted_local))))
-            if world > 1:
+            if use_dist:
                 dist.broadcast(q, src=0)
-            sh = ShardedIndex(ix)
+            sh = ShardedIndex(ix)  # (CLIPX_FORCE_GATHER=1: the all-gather + merge also at world size 1 -- tests only)
             by_batch = []
             checks = {}
             for nq in batches:
@@ -557,7 +734,9 @@ def main():
                    "planted_neighbour_top1": all(r["planted_neighbour_top1"] for r in by_batch),
                    "wide_fallbacks": sum(r["proof_failures"] for r in by_batch),
                    "roofline": {**head["roofline"], "traffic": ktraffic, "traffic_run": "separate --pmc pass" if ktraffic else None},
-                   "by_batch": by_batch, "checks": checks or None, "cpu_baseline": cpu_knn, "host_search_and_reconstruct": host}
+                   "by_batch": by_batch, "checks": checks or None, "cpu_baseline": cpu_knn, "host_search_and_reconstruct": host,
+                   "exchange": ("dist.all_gather_into_tensor of B*k*12 bytes per rank on nccl (RCCL) + knnx_merge_topk_device" if (world > 1 or sh.force_gather)
+                                else "none (one shard: its top-k is the answer)")}
             ix.close()
             del X, sh, ix
             torch.cuda.empty_cache()
@@ -572,6 +751,13 @@ def main():
             # have), where one plain int8 plane admits 100 x more rows: the first stage keeps those columns as 14-bit digits (round 5;
             # two planes before -- DESIGN 4.3).  The isotropic corpus above is the favourable case.
             knn["anisotropic_corpus"] = knn_leg(rows, 2, [1, 64, 256], 3, False, False, False)
+
+    # ---- BASELINE config 4's single-GPU share: the reference's whole loop around the hot path, wall to wall
+    pipeline = None
+    if args.pipeline and single:
+        pipeline = pipeline_leg(args.model, value, local_rank, log=lambda m: sys.stderr.write(m + "\n"))
+        if not (pipeline["u8"]["outputs_ok"] and pipeline["jpeg"]["outputs_ok"]):
+            failures.append(f"pipeline leg: written files / shapes / dtypes / row counts are not the writer's: {pipeline}")
 
     # ---- BASELINE config 5 (opt-in: minutes): one GPU's IVF-Flat shard at its stated size, built on the device, served
     ivf = None
@@ -590,7 +776,7 @@ def main():
 
     if failures:
         sys.stderr.write("bench.py: parity gate FAILED, no result line is printed:\n  " + "\n  ".join(failures) + "\n")
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         sys.exit(1)
     if rank == 0:
@@ -603,12 +789,25 @@ def main():
                                    "(BASELINE.json configs[1]); random-init weights"
                                    + (f" | kNN: flat IP top-40 over {knn['rows_per_gpu']} x 768 fp16 rows per GPU resident in HBM, query batches "
                                       f"{args.knn_batches} (configs[2]; reported under `knn`)" if knn else "")
+                                   + (" | tar shards -> reader -> runner -> writer (configs[3]'s per-GPU share) under `pipeline`" if pipeline else "")
                                    + (" | IVF-Flat shard of configs[4] under `ivf`" if ivf else ""),
-                       "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)"},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "knn": knn, "ivf": ivf, **extras,
+                       "global_batch": B * world, "parallelism": f"replicas x{world} (no collective)",
+                       "process_group": ("nccl (RCCL), world %d" % world) if use_dist else None,
+                       "knn_exchange": knn.get("exchange") if knn else None},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "knn": knn, "pipeline": pipeline, "ivf": ivf, **extras,
         }
+        # The whole headline, driver-visible: the driver keeps the standard keys, the NAMES of the extra ones, the
+        # last ~10 KB of stdout and the last ~2 KB of stderr.  So: scalars whose names carry the value class at the top level, a
+        # compact `headline` object as the LAST key of the line, and the same numbers as <= 12 short stderr lines that end the run.
+        scal, summary = headline_numbers(line)
+        line.update(scal)
+        line["headline"] = scal
+        sys.stdout.flush()
         print(json.dumps(line))
-    if world > 1:
+        sys.stdout.flush()
+        sys.stderr.write("\n".join(summary) + "\n")
+        sys.stderr.flush()
+    if use_dist:
         dist.destroy_process_group()
 
 

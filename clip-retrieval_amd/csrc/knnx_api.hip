@@ -2399,6 +2399,13 @@ extern "C" int knnx_merge_topk_device(int device, const float* D_parts, const in
   if (!D_parts || !I_parts || !D_out || !I_out || P <= 0 || n < 0 || k <= 0) return fail(KNNX_E_ARG, "bad merge arguments");
   if (n == 0) return KNNX_OK;
   HIPCHK(hipSetDevice(device));
+  if (k > KNNX_MAX_K_FAST) {
+    // large k (the front end's num_result_ids = 3000): every shard's list is sorted (score desc, id asc, -1 padding at its tail), so the
+    // P-way merge of sorted lists applies -- the kernel the in-process sharded index uses for the same case (knnx_sharded.hip)
+    if (P > 64) return fail(KNNX_E_ARG, "merge of k > 64 results takes at most 64 shards");
+    HIPCHK(launch_merge_sorted(D_parts, I_parts, P, n, k, D_out, I_out, (hipStream_t)stream));
+    return KNNX_OK;
+  }
   HIPCHK(launch_merge_i64(D_parts, I_parts, P, n, k, k, D_out, I_out, (hipStream_t)stream));
   return KNNX_OK;
 }

@@ -149,7 +149,8 @@ int knnx_ivfb_list_sizes(knnx_ivf_builder* b, int64_t* sizes_out, int reset);
 int knnx_ivf_add_assigned_device(knnx_index* ix, const void* rows_dev_f16, int64_t n, int64_t id0, const int32_t* lists_dev);
 
 /* Merge P per-shard results ([P, n, k] each, already global ids) into the top-k [n, k];
- * the step after the RCCL all-gather of a row-sharded index.  Device buffers. */
+ * the step after the RCCL all-gather of a row-sharded index.  Device buffers.  k <= 64: any order within a list;
+ * k > 64: every list sorted as knnx_search returns it (score descending, -1 padding at the tail), P <= 64. */
 int knnx_merge_topk_device(int device, const float* D_parts, const int64_t* I_parts, int P, int n,
                            int k, float* D_out, int64_t* I_out, void* stream);
 

@@ -956,15 +956,18 @@ def test_i8_first_stage_overflow_falls_back(monkeypatch):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("P", [2, 8])
 def test_device_merge_kernel_vs_oracle(P):
-    """knnx_merge_topk_device (the step after the all-gather / peer copies): ties across shards, short lists, k = 1..64."""
+    """knnx_merge_topk_device (the step after the all-gather / peer copies): ties across shards, short lists, k = 1..64; k > 64 (the
+    front end's num_result_ids = 3000 through a rank-per-GPU ShardedIndex) takes the P-way merge of sorted lists."""
     import torch
     from clip_retrieval_amd.distributed import ShardedIndex
     from oracle.knn_oracle import merge_topk
 
     rng = np.random.default_rng(P)
-    for n, k in [(5, 40), (1, 1), (64, 64), (3, 17)]:
+    for n, k in [(5, 40), (1, 1), (64, 64), (3, 17), (4, 65), (2, 3000)]:
         D = np.sort(rng.standard_normal((P, n, k)).astype(np.float32), axis=-1)[..., ::-1].copy()
         I = rng.permutation(P * n * k).reshape(P, n, k).astype(np.int64) + (1 << 33)  # ids beyond 32 bits
+        if k > 64:  # shard-major ids, as row shards have them (shard p holds the ids [p * n * k, (p + 1) * n * k) of this draw)
+            I = (np.arange(P * n * k, dtype=np.int64).reshape(P, n, k) + (1 << 33))
         if P > 1 and k > 10:
             D[1, :, 10:] = D[0, :, 10:]  # exact score ties across shards -> id order decides
         if k > 30:

@@ -259,6 +259,55 @@ def test_worker_on_the_gpu_over_tar_shards(tiny_checkpoints, tmp_path):
         assert json.loads((out2 / "stats" / f"{i}.json").read_text())["sample_count"] == 9
 
 
+def test_gpu_worker_under_the_launcher_environment(tiny_checkpoints, tmp_path, monkeypatch):
+    """worker.gpu_worker() as one rank of a `torch.distributed.run` launch: RANK / LOCAL_RANK / WORLD_SIZE from the
+    environment, the output partitions dealt with get_task_list (slurm_worker.py:16-37), the process bound to GPU LOCAL_RANK, then
+    worker.worker() -- no collective anywhere.  World 1: both partitions, the same bytes as a direct worker() call; rank 1 of a
+    world of 2 (still GPU 0 here): partition 1 only."""
+    from PIL import Image
+
+    from clip_retrieval_amd.worker import gpu_worker, worker
+
+    _, _, dirs = tiny_checkpoints
+    rng = np.random.default_rng(5)
+    shards, k = [], 0
+    for t in range(2):
+        p = tmp_path / f"{t:03d}.tar"
+        with tarfile.open(p, "w") as tf:
+            for _ in range(5):
+                img = rng.integers(0, 256, (48 + 8 * (k % 3), 64, 3), dtype=np.uint8)
+                buf = io.BytesIO()
+                Image.fromarray(img).save(buf, format="JPEG", quality=90)
+                for ext, data in (("jpg", buf.getvalue()), ("txt", ("a photo of a cat" if k % 2 else "the dog").encode())):
+                    ti = tarfile.TarInfo(f"{k:06d}.{ext}")
+                    ti.size = len(data)
+                    tf.addfile(ti, io.BytesIO(data))
+                k += 1
+        shards.append(str(p))
+    common = dict(input_dataset=shards, output_partition_count=2, input_format="webdataset", batch_size=4, num_prepro_workers=2,
+                  enable_text=True, enable_image=True, enable_metadata=False, clip_model="tiny-test", clip_cache_path=dirs["openai"])
+    worker(tasks=[0, 1], output_folder=str(tmp_path / "direct"), device=0, **common)
+    for key in ("SLURM_PROCID", "SLURM_LOCALID", "WORKER_ARGS_PATH", "NUM_TASKS"):
+        monkeypatch.delenv(key, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    gpu_worker(output_folder=str(tmp_path / "rank0of1"), **common)
+    for i in range(2):
+        for sub, name in (("img_emb", f"img_emb_{i}.npy"), ("text_emb", f"text_emb_{i}.npy")):
+            a, b = np.load(tmp_path / "direct" / sub / name), np.load(tmp_path / "rank0of1" / sub / name)
+            assert a.shape[0] == 5
+            assert np.array_equal(a, b), (sub, name)
+        assert json.loads((tmp_path / "rank0of1" / "stats" / f"{i}.json").read_text())["sample_count"] == 5
+    assert torch.cuda.current_device() == 0
+    # rank 1 of 2 (both "GPUs" are device 0 on this box: LOCAL_RANK stays 0): only its own partition is written
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    gpu_worker(output_folder=str(tmp_path / "rank1of2"), **common)
+    assert sorted(os.listdir(tmp_path / "rank1of2" / "img_emb")) == ["img_emb_1.npy"]
+    assert np.array_equal(np.load(tmp_path / "rank1of2" / "img_emb" / "img_emb_1.npy"), np.load(tmp_path / "direct" / "img_emb" / "img_emb_1.npy"))
+
+
 def _h14_state_dict(seed=0, input_size=1024):
     """A state dict with the H14 detector's keys and shapes (h14_nsfw_model.py:16-34), seeded random weights scaled like
     torch's Linear init so the activations keep O(1) magnitude through the stack."""
