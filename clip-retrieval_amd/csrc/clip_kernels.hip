@@ -547,12 +547,12 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       b.tail_m0 = b.tail_nb = 0;
       // exactly one m-tile left over (ViT-L/14 at bs 256: 257 m-tiles on 256 CUs): it rides in the same launch
       // (gemm256sp.hip: gemm256_tail) instead of a second, nearly empty one.  CLIPX_GEMM_VARIANT=4 keeps the separate launch (A/B).
-      if (g.M - b.M == 256 && g.variant == 3 && g.row0 == 0) {
+      if (g.M - b.M == 256 && (g.variant == 3 || g.variant == 6) && g.row0 == 0) {
         b.tail_nb = gemm256_tail_blocks(g.N, g.K, g.n_cu);
         b.tail_m0 = b.M;
       }
       const bool tail_inside = b.tail_nb > 0;
-      hipError_t e = launch_gemm256sp(b, g.n_cu, st);
+      hipError_t e = (g.variant == 6 && gemm256w4_supports(b)) ? launch_gemm256w4(b, g.n_cu, st) : launch_gemm256sp(b, g.n_cu, st);
       if (e != hipSuccess) return e;
       if (b.M == g.M || tail_inside) return hipSuccess;
       GemmArgs r = g;  // remaining rows [bulk*256, M)

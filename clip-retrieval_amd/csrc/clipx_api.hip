@@ -72,7 +72,7 @@ struct clipx_handle {
   int host_chunk = 256;  // chunk of the host-buffer pipeline (H2D of chunk i+1 overlaps the kernels of chunk i); measured
                          // at B=256: chunks of 32/64/128/256 -> 92/65/58/56.5 ms, small chunks lose more GEMM efficiency than
                          // the overlap wins
-  int gemm_variant = 3;
+  int gemm_variant = 6;  // 6: the 4-wave 256x256 kernel (gemm256w4.hip) where it has the form, the 8-wave one (variant 3) elsewhere
   int n_cu = 256;
   std::mutex mu;
   hipStream_t stream = nullptr, copy_stream = nullptr;
@@ -341,7 +341,7 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   if (hc && atoi(hc) > 0) h->host_chunk = atoi(hc);
   h->host_chunk = std::min(h->host_chunk, h->max_batch);
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
-  if (gv) h->gemm_variant = std::min(5, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
+  if (gv) h->gemm_variant = std::min(6, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
   const char* rgt = getenv("CLIPX_RAGGED_TEXT");
   if (rgt && rgt[0] == '0') h->ragged_text = false;
   const char* fl = getenv("CLIPX_FULL_LAST_BLOCK");
@@ -945,7 +945,7 @@ static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const f
     g.rowscale = ones[device];
   }
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
-  g.variant = gv ? std::min(5, std::max(0, atoi(gv))) : 3;
+  g.variant = gv ? std::min(6, std::max(0, atoi(gv))) : 6;
   int ncu = 0;
   HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
   g.n_cu = ncu;

@@ -148,5 +148,8 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
 
 // bulk-tile launcher of gemm256sp.hip: rows [0, g.M) must be a multiple of 256, N % 256 == 0, K % 128 == 0
 hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st);
+// the 4-wave form of the same tile (gemm256w4.hip): 16-bit-output epilogues and the fp16 in-place residual, K >= 256
+bool gemm256w4_supports(const GemmArgs& g);
+hipError_t launch_gemm256w4(const GemmArgs& g, int n_cu, hipStream_t st);
 
 }  // namespace clipx

@@ -30,14 +30,15 @@ def lib():
 
 
 # ------------------------------------------------------------------------------------------ per-kernel
-@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("variant", [0, 1, 3, 6])
 @pytest.mark.parametrize("M,N,K", [(257, 128, 64), (514, 1024, 1024), (1000, 2304, 768), (130, 768, 3072), (65, 128, 640),
                                    (33357, 512, 128), (65792, 1024, 1024), (2048, 4096, 1024), (19712, 768, 3072), (16384, 256, 256),
                                    (16640, 256, 384), (8192, 1024, 640), (65536, 512, 2048)])
 def test_gemm_epilogues(lib, variant, M, N, K):
     """out = A W^T + b with bf16 operands: reference is the fp32 matmul of the SAME bf16-rounded operands,
     so only accumulation order differs (tol 2e-3 * |row| scale for bf16 outputs = 1 bf16 ulp + sum noise).
-    variant 3 (default) = persistent 256x256 kernel for the whole m-tiles + 128x128 kernel for the peeled rows;
+    variant 3 = persistent 8-wave 256x256 kernel for the whole m-tiles + 128x128 kernel for the peeled rows; variant 6 (default) =
+    the 4-wave 256x256 kernel (gemm256w4.hip) for the forms it has (16-bit outputs, K >= 256), variant 3 otherwise;
     (33357,512,128): 260 tiles -> two tiles per workgroup with K = one iteration; (65792,1024,1024): the ViT-L/14
     bs=256 out_proj shape (4 tiles per workgroup + 256 peeled rows)."""
     from clip_retrieval_amd._lib import check
@@ -644,7 +645,7 @@ def test_gemm_layernorm_fold_hooks_both_kernels(lib, M, N, K):
     rs = torch.rand(M, generator=g, device="cuda") + 0.5
     st = torch.cuda.current_stream().cuda_stream
     outs = {}
-    for variant in (3, 1):
+    for variant in (3, 1, 6):
         os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
         x = x0.clone()
         x16 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
@@ -656,8 +657,9 @@ def test_gemm_layernorm_fold_hooks_both_kernels(lib, M, N, K):
         assert bad.numel() == 0, f"variant {variant}: shadow != bf16(x) at {bad[:5].tolist()} ({bad.shape[0]} elements)"
         outs[variant] = (x, x16, y)
     os.environ.pop("CLIPX_GEMM_VARIANT")
-    for a, b in zip(outs[3], outs[1]):
-        assert torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16), b.view(torch.int32 if b.dtype == torch.float32 else torch.int16))
+    for other in (1, 6):
+        for a, b in zip(outs[3], outs[other]):
+            assert torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16), b.view(torch.int32 if b.dtype == torch.float32 else torch.int16))
     ref = (A.float() @ W.float().T)
     want = ref * rs[:, None] + bias
     assert (outs[3][2].float() - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))
@@ -720,7 +722,7 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
     rs = torch.rand(M, generator=g, device="cuda") * 0.3 + 0.05
     st = torch.cuda.current_stream().cuda_stream
     outs = {}
-    for variant in (3, 1):
+    for variant in (3, 1, 6):
         os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
         x = x0.clone()
         check(lib, lib.clipx_gemm_bf16_ex_device(0, _ptr(A), _ptr(W), _ptr(bias), _ptr(x), M, N, K, 6, None, None, C.c_void_p(st)), "clipx")
@@ -739,9 +741,10 @@ def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
         torch.cuda.synchronize()
         outs[variant] = [x] + ys
     os.environ.pop("CLIPX_GEMM_VARIANT")
-    for i, (a, b) in enumerate(zip(outs[3], outs[1])):
-        bad = (a.view(torch.int32 if a.dtype == torch.float32 else torch.int16) != b.view(torch.int32 if b.dtype == torch.float32 else torch.int16)).nonzero()
-        assert bad.numel() == 0, f"output {i}: the two kernels differ at {bad[:5].tolist()} ({bad.shape[0]} elements)"
+    for other in (1, 6):
+        for i, (a, b) in enumerate(zip(outs[3], outs[other])):
+            bad = (a.view(torch.int32 if a.dtype == torch.float32 else torch.int16) != b.view(torch.int32 if b.dtype == torch.float32 else torch.int16)).nonzero()
+            assert bad.numel() == 0, f"output {i}: variants 3 and {other} differ at {bad[:5].tolist()} ({bad.shape[0]} elements)"
     want = x0.float() + (A.float() @ W.float().T + bias)
     err = (outs[3][0].float() - want).abs()
     tol = 1e-3 + 1.2e-3 * want.abs()   # fp16: 2^-11 relative rounding + fp32 accumulation-order noise

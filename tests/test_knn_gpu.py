@@ -968,7 +968,9 @@ def test_device_merge_kernel_vs_oracle(P):
         I = rng.permutation(P * n * k).reshape(P, n, k).astype(np.int64) + (1 << 33)  # ids beyond 32 bits
         if k > 64:  # shard-major ids, as row shards have them (shard p holds the ids [p * n * k, (p + 1) * n * k) of this draw)
             I = (np.arange(P * n * k, dtype=np.int64).reshape(P, n, k) + (1 << 33))
-        if P > 1 and k > 10:
+        if P > 1 and k > 64:
+            D[1] = D[0]  # (k > 64 merges SORTED lists: a whole list of ties keeps shard 1 sorted) -> id order decides
+        elif P > 1 and k > 10:
             D[1, :, 10:] = D[0, :, 10:]  # exact score ties across shards -> id order decides
         if k > 30:
             I[P - 1, 0, 30:] = -1  # a short list

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ISA lint for the kernels that issue VMEM instructions from inline asm (gemm256sp.hip).
+"""ISA lint for the kernels that issue VMEM instructions from inline asm (gemm256sp.hip, gemm256w4.hip).
 
 hipcc's hazard recognizer does not look inside inline asm, so two gfx9 hazards have to be kept away by construction:
   * an SGPR written by a VALU (v_readlane / v_readfirstlane, e.g. the reload of a spilled SGPR) must not be read by a
@@ -32,6 +32,8 @@ def check(path):
     for m in re.finditer(r"\.name:\s+(\S+).*?\.vgpr_spill_count:\s+(\d+)", text, re.S):
         # EPI 4 (patch embedding: once per forward) always spilled; EPI 3 (the f32 residual epilogue: a test hook since the residual
         # stream moved to fp16 in round 3, not launched by the encoder) spills 6 registers since the 16x16x32 form (round 4)
+        if "gemm256w4_kernel" in m.group(1) and int(m.group(2)):
+            findings.append(f"{m.group(1)}: {m.group(2)} VGPR spills")
         if "gemm256sp_kernel" in m.group(1) and "ILi4E" not in m.group(1) and "ILi3E" not in m.group(1) and int(m.group(2)):
             findings.append(f"{m.group(1)}: {m.group(2)} VGPR spills")
     ins = [l.strip() for l in text.split("\n")]

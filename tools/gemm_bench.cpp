@@ -192,8 +192,10 @@ int main(int argc, char** argv) {
         sustained[c] = b3[1] / burst;
       }
     typedef int (*dbg_fn)(long long*, int);
-    dbg_fn dbgf = (dbg_fn)dlsym(h, "clipx_dbg_phase_cycles");
-    for (size_t c = 0; c < cfgs.size() && dbgf; ++c) {
+    dbg_fn dbgf8 = (dbg_fn)dlsym(h, "clipx_dbg_phase_cycles"), dbgf4 = (dbg_fn)dlsym(h, "clipx_dbg_phase_cycles_w4");
+    for (size_t c = 0; c < cfgs.size(); ++c) {
+      dbg_fn dbgf = cfgs[c].v == "6" ? dbgf4 : dbgf8;  // variant 6 = the 4-wave kernel (gemm256w4.hip): [1] = first K-tile after an epilogue, [3] / [5] = the others
+      if (!dbgf) continue;
       if (cfgs[c].d != "16" && cfgs[c].d != "19" && cfgs[c].d != "20" && cfgs[c].d != "21" && cfgs[c].d != "22" && cfgs[c].d != "23" && cfgs[c].d != "25") continue;
       set_cfg(cfgs[c]);
       gemm(0, dA, dW, db, dO, M, N, K, epi, st);

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512) void stores(char* __restrict__ dst, size_t spa
 
 template <int MODE>
 static void run(char* dst, size_t span, long long* clk, int waves, int rows, int pitch, int n, const char* what) {
-  const int grid = 256;
+  const int grid = getenv("STORE_PROBE_GRID") ? atoi(getenv("STORE_PROBE_GRID")) : 256;  // fewer workgroups: is the rate per CU or per chip?
   for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(stores<MODE>, dim3(grid), dim3(waves * 64), 0, 0, dst, span - 1, rows, pitch, n, clk);
   hipDeviceSynchronize();
   std::vector<long long> h(grid);
@@ -48,7 +48,7 @@ static void run(char* dst, size_t span, long long* clk, int waves, int rows, int
   for (auto x : h) c += x;
   c /= grid;
   const double per = c / ((double)n * waves);
-  printf("%-44s waves %d rows/instr %d pitch %6d  cyc/store/CU %6.1f  B/clk/CU %5.1f\n", what, waves, rows, pitch, per, 1024.0 / per);
+  printf("grid %3d %-44s waves %d rows/instr %d pitch %6d  cyc/store/CU %6.1f  B/clk/CU %5.1f\n", grid, what, waves, rows, pitch, per, 1024.0 / per);
 }
 
 int main() {
