@@ -123,7 +123,9 @@ def headline_numbers(line):
             h[f"ivf_np{npb}_qps_b32"] = b32.get("qps")
             h[f"ivf_np{npb}_ms_b256"] = b256.get("ms_per_batch")
             h[f"ivf_np{npb}_served_qps"] = served
-            parts.append(f"np{npb}: recall {r['recall_at_40_vs_exact_whole_shard']}, B32 {b32.get('qps')} QPS, B256 {b256.get('ms_per_batch')} ms, served {served}")
+            h[f"ivf_np{npb}_b256_scanned_over_union"] = b256.get("scanned_over_union")
+            parts.append(f"np{npb}: recall {r['recall_at_40_vs_exact_whole_shard']}, B32 {b32.get('qps')} QPS, B256 {b256.get('ms_per_batch')} ms "
+                         f"({b256.get('passes')} pass, {b256.get('scanned_over_union')} x union), served {served}")
         out.append(f"HEADLINE IVF {ivf['rows'] // 1_000_000}Mx{ivf['d']} nlist {ivf['nlist']} " + " | ".join(parts))
     pl = line.get("pipeline")
     if pl:

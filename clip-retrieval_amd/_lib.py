@@ -61,6 +61,7 @@ SIGNATURES = {
     "knnx_ivf_nlist": (C.c_int, [_P]),
     "knnx_ivf_nprobe": (C.c_int, [_P]),
     "knnx_ivf_last_scan_tiles": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "knnx_ivf_last_scan_union_tiles": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "knnx_ivfb_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "knnx_ivfb_destroy": (None, [_P]),
     "knnx_ivfb_set_centroids": (C.c_int, [_P, _P]),

@@ -41,11 +41,16 @@ struct ScanArgs {
   int wide;              // 1: QB = 2 wide scan (64 queries, approximate scores; flat top-k only)
   const unsigned* gate;  // run only if *gate != 0 (null: always)
   int tstride;           // flat scans: visit every tstride-th 32-row tile only (0 / 1 = all): the sample pass of the RQ scan
+  // nblk > 1: ceil(nq / 32) blocks of 32 queries side by side in ONE launch (modes 0 and 2, not wide; grid % nblk == 0): qfrag
+  // [nblk][d * 64], thr_g [32 nblk], work [nblk][work_stride], nwork [nblk], part_* block-major (knn_kernels.hip: knn_scan_kernel)
+  int nblk;
+  unsigned work_stride;
 };
 
 size_t scan_smem_bytes(int d, int cap, int nq_slots);
 hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_g, unsigned* range_cnt, int wide,
                        const unsigned* gate, hipStream_t st);
+hipError_t launch_prep_blocks(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_a, int* thr_b_or_null, hipStream_t st);
 hipError_t launch_maxnorm(const _Float16* X, int64_t n, int d, int* maxnorm_enc, hipStream_t st);
 hipError_t launch_rescore(const _Float16* X, int d, const float* q, const int64_t* cand, const float* approx, int nq, int kw,
                           int k, int64_t id_base, const int* maxnorm_enc, float* D, int64_t* I, unsigned* need, unsigned* gate,
@@ -55,14 +60,15 @@ hipError_t launch_select(const unsigned* need, int q0, int nq, int k, const floa
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st);
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
                             int nq, int k, int64_t id_base, const int64_t* idmap_or_null, float* D, int64_t* I,
-                            const unsigned* gate_or_null, hipStream_t st);
+                            const unsigned* gate_or_null, hipStream_t st, int blk_q = 0);  // blk_q = 32: block-major partial lists
 // IVF-Flat helpers (see knn_kernels.hip)
 hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
                                const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
-                               hipStream_t st);
+                               hipStream_t st, unsigned work_stride = 0);
 hipError_t launch_ivf_worklist_from_scores(const float* scores, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
                                            const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
-                                           hipStream_t st);
+                                           hipStream_t st, unsigned work_stride = 0);
+hipError_t launch_ivf_union_tiles(const unsigned* masks, int nblk, int nlist, const unsigned* ntile, unsigned* out, hipStream_t st);
 hipError_t launch_ivf_relayout(const _Float16* src, _Float16* dst, int d, int nlist, const int64_t* src0, const unsigned* tile0,
                                const unsigned* ntile, const unsigned* size, const int64_t* ids, int64_t id_lo, int64_t n_ids,
                                int64_t* idmap, uint32_t* inv, hipStream_t st);

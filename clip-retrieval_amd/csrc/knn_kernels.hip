@@ -51,12 +51,23 @@ __device__ __forceinline__ bool better(float sa, uint32_t ia, float sb, uint32_t
 // query preparation: f32 [nq, d] -> hi/lo fp16 MFMA fragments; resets the per-scan global state
 // ---------------------------------------------------------------------------------------------
 // wide = 1: slot 1 holds the fp16 hi part of query n + 32 instead of the lo part of query n (QB = 2 scan)
+// gridDim.y > 1 (the multi-block IVF pass): block b = blockIdx.y prepares queries [32 b, 32 b + 32) into the b-th fragment image
+// and resets thresholds [32 b, 32 b + 32) of thr_g and of thr_g2 (the coarse and the fine scan of one pass: two arrays).
 __global__ void knn_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
                                         _Float16* __restrict__ qfrag, int* __restrict__ thr_g,
-                                        unsigned* __restrict__ range_cnt, int wide, const unsigned* __restrict__ gate) {
+                                        unsigned* __restrict__ range_cnt, int wide, const unsigned* __restrict__ gate,
+                                        int* __restrict__ thr_g2) {
   if (gate && *gate == 0) return;
   const int s = blockIdx.x;  // k-step
   const int lane = threadIdx.x;
+  if (gridDim.y > 1) {
+    const int b = blockIdx.y;
+    q += (size_t)b * 32 * d;
+    nq -= 32 * b;
+    qfrag += (size_t)b * d * 64;
+    thr_g += 32 * b;
+    if (thr_g2) thr_g2 += 32 * b;
+  }
   const int n = lane & 31, h = lane >> 5;
   half8 hi, lo;
 #pragma unroll
@@ -71,8 +82,9 @@ __global__ void knn_prep_queries_kernel(const float* __restrict__ q, int nq, int
   half8* out = reinterpret_cast<half8*>(qfrag);
   out[(size_t)(s * 2 + 0) * 64 + lane] = hi;
   out[(size_t)(s * 2 + 1) * 64 + lane] = lo;
-  if (s == 0 && lane < KNN_NQ_MAX) {
+  if (s == 0 && lane < (gridDim.y > 1 ? KNN_NQ : KNN_NQ_MAX)) {
     thr_g[lane] = enc_f(-INFINITY);
+    if (thr_g2) thr_g2[lane] = enc_f(-INFINITY);
     if (range_cnt && lane < KNN_NQ) range_cnt[lane] = 0u;
   }
 }
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     int* __restrict__ thr_g, float* __restrict__ part_s, uint32_t* __restrict__ part_i, int* __restrict__ part_n,
     float range_thr, unsigned* __restrict__ range_cnt, unsigned range_cap, float* __restrict__ range_s,
     uint32_t* __restrict__ range_i, const uint4* __restrict__ work, const unsigned* __restrict__ nwork_ptr,
-    const unsigned* __restrict__ gate, int tstride) {
+    const unsigned* __restrict__ gate, int tstride, int nblk, unsigned work_stride) {
   constexpr int D = NCH * 128;
   constexpr int KS = D / 16;
   constexpr int NQ = 32 * QB;  // queries (= queues, thresholds) of this scan
@@ -164,6 +176,22 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int q = lane & 31, hb = lane >> 5;
+
+  // nblk > 1 (QB = 1 only): SEVERAL 32-query blocks in one launch -- the IVF pass of a batch of up to 32 nblk queries.  Workgroup g
+  // serves query block g % nblk (its own fragment image, thresholds, work list, result slots) as member g / nblk of that block's
+  // gridDim.x / nblk workgroups: nblk independent scans side by side, one launch and one set of small kernels around it.
+  const int blk = nblk > 1 ? (int)(blockIdx.x % (unsigned)nblk) : 0;
+  const int bidx = nblk > 1 ? (int)(blockIdx.x / (unsigned)nblk) : (int)blockIdx.x;
+  const int bgrid = nblk > 1 ? (int)(gridDim.x / (unsigned)nblk) : (int)gridDim.x;
+  if (nblk > 1) {
+    qfrag += (size_t)blk * D * 64;
+    nq = nq - 32 * blk < 32 ? nq - 32 * blk : 32;
+    thr_g += 32 * blk;
+    if (IVF) {
+      work += (size_t)blk * work_stride;
+      nwork_ptr += blk;
+    }
+  }
 
   // stage the query fragments (already in fragment order) and reset the queues
   {
@@ -203,20 +231,20 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  int64_t grp = blockIdx.x;
+  int64_t grp = bidx;
   if (IVF) {  // row_ptr() addresses the tile of it_nxt
     it_nxt = item_of(grp);
-    it_n2 = item_of(grp + gridDim.x);
+    it_n2 = item_of(grp + bgrid);
   }
   const half8* xp = row_ptr(grp < ngroup ? grp : 0);
   if (grp < ngroup) load_chunk(a0, xp, 0);
 
-  for (int rnd = 0; grp < ngroup; grp += gridDim.x, ++rnd) {
-    const int64_t gnext = grp + gridDim.x;
+  for (int rnd = 0; grp < ngroup; grp += bgrid, ++rnd) {
+    const int64_t gnext = grp + bgrid;
     if (IVF) {
       it_cur = it_nxt;
       it_nxt = it_n2;
-      it_n2 = item_of(gnext + gridDim.x);
+      it_n2 = item_of(gnext + bgrid);
     }
     const half8* xnext = row_ptr(gnext < ngroup ? gnext : grp);
     float16v acc_h, acc_l;
@@ -304,7 +332,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-        if (row < row_lim && q_ok) range_s[(size_t)q * range_cap + row] = acc_h[r] + acc_l[r] * KNN_LO_INV;
+        if (row < row_lim && q_ok) range_s[(size_t)(32 * blk + q) * range_cap + row] = acc_h[r] + acc_l[r] * KNN_LO_INV;
       }
     } else {
 #pragma unroll
@@ -326,17 +354,18 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     __syncthreads();
     for (int qq = w; qq < NQ; qq += KNN_WAVES) prune_query(sm, qq, cap, k, lane, thr_g);
     __syncthreads();
-    // publish this workgroup's sorted lists
+    // publish this workgroup's sorted lists (nblk > 1: block-major -- the lists of block b are slots [b bgrid, (b + 1) bgrid))
+    const size_t slot = (size_t)blk * bgrid + bidx;
     for (int i = tid; i < NQ * k; i += KNN_WG) {
       const int qq = i / k, j = i - qq * k;
       const int n = sm.cnt[qq];
-      const size_t o = ((size_t)blockIdx.x * NQ + qq) * k + j;
+      const size_t o = (slot * NQ + qq) * k + j;
       if (j < n) {
         part_s[o] = sm.cand_s[(size_t)qq * cap + j];
         part_i[o] = sm.cand_i[(size_t)qq * cap + j];
       }
     }
-    if (tid < NQ) part_n[blockIdx.x * NQ + tid] = sm.cnt[tid];
+    if (tid < NQ) part_n[slot * NQ + tid] = sm.cnt[tid];
   }
 }
 
@@ -362,15 +391,23 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
                                                        const int* __restrict__ pn, int P, int nq_stride, int kin,
                                                        int k, int64_t id_base, const int64_t* __restrict__ idmap,
                                                        float* __restrict__ D, int64_t* __restrict__ I,
-                                                       const unsigned* __restrict__ gate) {
+                                                       const unsigned* __restrict__ gate, int blk_q) {
   if (gate && *gate == 0) return;
+  // blk_q > 0 (multi-block scans): query blockIdx.x is query blockIdx.x % blk_q of block blockIdx.x / blk_q, whose P partial lists
+  // start P * nq_stride lists into the arrays per block
+  if (blk_q > 0) {
+    const size_t b = blockIdx.x / (unsigned)blk_q;
+    ps += b * P * nq_stride * kin;
+    pi += b * P * nq_stride * kin;
+    if (pn) pn += b * P * nq_stride;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
   unsigned* s_u = reinterpret_cast<unsigned*>(merge_smem);             // [P*kin] order-encoded score, 0 = empty
   const int ncand = P * kin;
   long long* sel_i = reinterpret_cast<long long*>(s_u + ((ncand + 3) & ~3));  // [64], 16-B aligned
   float* sel_s = reinterpret_cast<float*>(sel_i + 64);                        // [64]
   int* red = reinterpret_cast<int*>(sel_s + 64);                              // [4] + counter
-  const int qq = blockIdx.x, tid = threadIdx.x;
+  const int qout = blockIdx.x, qq = blk_q > 0 ? (int)(blockIdx.x % (unsigned)blk_q) : (int)blockIdx.x, tid = threadIdx.x;
 
   auto gidx = [&](int c) -> size_t { return ((size_t)(c / kin) * nq_stride + qq) * kin + (c % kin); };
   // IVF: candidate ids are positions in the list-sorted arena; idmap gives the id the row was added with
@@ -445,11 +482,11 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
         const long long ij = sel_i[j];
         r += ((sj > se) || (sj == se && ij < ie)) ? 1 : 0;
       }
-      D[(size_t)qq * k + r] = se;
-      I[(size_t)qq * k + r] = ie;
+      D[(size_t)qout * k + r] = se;
+      I[(size_t)qout * k + r] = ie;
     }
   }
-  for (int j = kk + tid; j < k; j += 256) { D[(size_t)qq * k + j] = -FLT_MAX; I[(size_t)qq * k + j] = -1; }
+  for (int j = kk + tid; j < k; j += 256) { D[(size_t)qout * k + j] = -FLT_MAX; I[(size_t)qout * k + j] = -1; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -871,11 +908,13 @@ __global__ void knn_select_kernel(const unsigned* __restrict__ need, int q0, int
 // matrix; the kernels below turn its [nq, nprobe] list ids into the work list the IVF scan walks.
 //   list l occupies tiles [tile0[l], tile0[l] + ntile[l]) of the list-sorted, tile-padded arena; size[l] rows are real.
 // ---------------------------------------------------------------------------------------------
+// (more than 32 queries -- the multi-block pass: query q marks bit q % 32 of masks[q / 32][l])
 __global__ void ivf_mark_kernel(const int64_t* __restrict__ Ic, int nq, int nprobe, int nlist, unsigned* __restrict__ masks) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq * nprobe) return;
   const int64_t l = Ic[i];
-  if (l >= 0 && l < nlist) atomicOr(&masks[l], 1u << (i / nprobe));
+  const int qi = i / nprobe;
+  if (l >= 0 && l < nlist) atomicOr(&masks[(size_t)(qi >> 5) * nlist + l], 1u << (qi & 31));
 }
 
 // single workgroup: exclusive prefix sum of (mask[l] ? ntile[l] : 0) -> off[l]; total -> *nwork
@@ -884,6 +923,9 @@ __global__ __launch_bounds__(1024) void ivf_offsets_kernel(const unsigned* __res
   __shared__ unsigned red[1024];
   __shared__ unsigned carry;
   const int tid = threadIdx.x;
+  masks += (size_t)blockIdx.x * nlist;  // one workgroup per query block (the multi-block pass; a single block otherwise)
+  off += (size_t)blockIdx.x * nlist;
+  nwork += blockIdx.x;
   if (tid == 0) carry = 0;
   __syncthreads();
   for (int base = 0; base < nlist; base += 1024) {
@@ -908,11 +950,14 @@ __global__ __launch_bounds__(1024) void ivf_offsets_kernel(const unsigned* __res
 // one workgroup per list: writes the list's tiles into the work list
 __global__ __launch_bounds__(256) void ivf_expand_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ tile0,
                                                         const unsigned* __restrict__ ntile, const unsigned* __restrict__ size,
-                                                        const unsigned* __restrict__ off, uint4* __restrict__ work) {
+                                                        const unsigned* __restrict__ off, uint4* __restrict__ work,
+                                                        unsigned work_stride) {
   const int l = blockIdx.x;
-  const unsigned m = masks[l];
+  const size_t b = blockIdx.y;  // query block (the multi-block pass)
+  const unsigned m = masks[b * gridDim.x + l];
   if (!m) return;
-  const unsigned nt = ntile[l], t0 = tile0[l], o = off[l], sz = size[l];
+  work += b * work_stride;
+  const unsigned nt = ntile[l], t0 = tile0[l], o = off[b * gridDim.x + l], sz = size[l];
   for (unsigned t = threadIdx.x; t < nt; t += 256) {
     const unsigned valid = (t + 1 < nt) ? 32u : sz - 32u * (nt - 1);
     work[o + t] = make_uint4(t0 + t, m, valid, 0u);
@@ -987,7 +1032,7 @@ __global__ __launch_bounds__(256) void ivf_select_mark_kernel(const float* __res
   }
   for (int l = tid; l < nlist; l += 256) {
     const unsigned u = enc(s[l]);
-    if (u > V || (u == V && l <= X)) atomicOr(&masks[l], 1u << qq);
+    if (u > V || (u == V && l <= X)) atomicOr(&masks[(size_t)(qq >> 5) * nlist + l], 1u << (qq & 31));
   }
 }
 
@@ -1092,25 +1137,46 @@ hipError_t launch_ivf_hist(const int32_t* lists, int64_t n, int nlist, unsigned 
   return hipGetLastError();
 }
 
+// nq > 32 (the multi-block pass): masks / off are [nblk, nlist], nwork [nblk], work [nblk, work_stride], nblk = ceil(nq / 32)
 hipError_t launch_ivf_worklist_from_scores(const float* scores, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
                                            const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
-                                           hipStream_t st) {
-  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nlist * sizeof(unsigned), st);
+                                           hipStream_t st, unsigned work_stride) {
+  const int nblk = (nq + 31) / 32;
+  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_select_mark_kernel, dim3(nq), dim3(256), 0, st, scores, nlist, nprobe, masks);
-  hipLaunchKernelGGL(ivf_offsets_kernel, dim3(1), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
-  hipLaunchKernelGGL(ivf_expand_kernel, dim3(nlist), dim3(256), 0, st, masks, tile0, ntile, size, off, work);
+  hipLaunchKernelGGL(ivf_offsets_kernel, dim3(nblk), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3(nlist, nblk), dim3(256), 0, st, masks, tile0, ntile, size, off, work, work_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
                                const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
-                               hipStream_t st) {
-  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nlist * sizeof(unsigned), st);
+                               hipStream_t st, unsigned work_stride) {
+  const int nblk = (nq + 31) / 32;
+  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_mark_kernel, dim3((nq * nprobe + 255) / 256), dim3(256), 0, st, Ic, nq, nprobe, nlist, masks);
-  hipLaunchKernelGGL(ivf_offsets_kernel, dim3(1), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
-  hipLaunchKernelGGL(ivf_expand_kernel, dim3(nlist), dim3(256), 0, st, masks, tile0, ntile, size, off, work);
+  hipLaunchKernelGGL(ivf_offsets_kernel, dim3(nblk), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3(nlist, nblk), dim3(256), 0, st, masks, tile0, ntile, size, off, work, work_stride);
+  return hipGetLastError();
+}
+// tiles of the lists at least one of the nblk query blocks probes -> *out
+__global__ __launch_bounds__(256) void ivf_union_tiles_kernel(const unsigned* __restrict__ masks, int nblk, int nlist,
+                                                             const unsigned* __restrict__ ntile, unsigned* __restrict__ out) {
+  unsigned t = 0;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < nlist; l += gridDim.x * 256) {
+    unsigned m = 0;
+    for (int b = 0; b < nblk; ++b) m |= masks[(size_t)b * nlist + l];
+    if (m) t += ntile[l];
+  }
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  if ((threadIdx.x & 63) == 0 && t) atomicAdd(out, t);
+}
+hipError_t launch_ivf_union_tiles(const unsigned* masks, int nblk, int nlist, const unsigned* ntile, unsigned* out, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ivf_union_tiles_kernel, dim3(std::min((nlist + 255) / 256, 256)), dim3(256), 0, st, masks, nblk, nlist, ntile, out);
   return hipGetLastError();
 }
 hipError_t launch_ivf_relayout(const _Float16* src, _Float16* dst, int d, int nlist, const int64_t* src0, const unsigned* tile0,
@@ -1134,7 +1200,14 @@ size_t scan_smem_bytes(int d, int cap, int nqs) { return (size_t)d * 128 + (size
 
 hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_g, unsigned* range_cnt, int wide,
                        const unsigned* gate, hipStream_t st) {
-  hipLaunchKernelGGL(knn_prep_queries_kernel, dim3(d / 16), dim3(64), 0, st, q_dev, nq, d, qfrag, thr_g, range_cnt, wide, gate);
+  hipLaunchKernelGGL(knn_prep_queries_kernel, dim3(d / 16), dim3(64), 0, st, q_dev, nq, d, qfrag, thr_g, range_cnt, wide, gate,
+                     (int*)nullptr);
+  return hipGetLastError();
+}
+// ceil(nq / 32) blocks of 32 queries: fragment images [nblk][d * 64 halves], thresholds thr_a / thr_b [32 nblk] reset
+hipError_t launch_prep_blocks(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_a, int* thr_b, hipStream_t st) {
+  hipLaunchKernelGGL(knn_prep_queries_kernel, dim3(d / 16, (nq + 31) / 32), dim3(64), 0, st, q_dev, nq, d, qfrag, thr_a,
+                     (unsigned*)nullptr, 0, (const unsigned*)nullptr, thr_b);
   return hipGetLastError();
 }
 hipError_t launch_maxnorm(const _Float16* X, int64_t n, int d, int* maxnorm, hipStream_t st) {
@@ -1168,7 +1241,8 @@ static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;                                                                              \
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(KNN_WG), smem, st, a.X, a.N, a.qfrag, a.nq, a.k, a.cap,         \
                        a.thr_g, a.part_s, a.part_i, a.part_n, a.range_thr, a.range_cnt, a.range_cap, a.range_s, \
-                       a.range_i, a.work, a.nwork, a.gate, a.tstride > 1 ? a.tstride : 1);                      \
+                       a.range_i, a.work, a.nwork, a.gate, a.tstride > 1 ? a.tstride : 1, a.nblk > 1 ? a.nblk : 1, \
+                       a.work_stride);                                                                           \
     return hipGetLastError();                                                                                   \
   }
   switch (a.d) {
@@ -1182,6 +1256,7 @@ static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
+  if (a.nblk > 1 && (a.wide || a.mode == 1 || a.grid % a.nblk != 0)) return hipErrorInvalidValue;
   if (a.wide) return (a.mode == 0 && !a.work) ? launch_scan_mode<0, false, false, 2>(a, st) : hipErrorInvalidValue;
   if (a.work) {  // IVF work list: top-k (mode 0) or range (mode 1) over the rows of the probed lists
     if (a.mode == 0) return launch_scan_mode<0, false, true>(a, st);
@@ -1194,13 +1269,13 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
 
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
                             int nq, int k, int64_t id_base, const int64_t* idmap, float* D, int64_t* I,
-                            const unsigned* gate, hipStream_t st) {
+                            const unsigned* gate, hipStream_t st, int blk_q) {
   if (k > 64) return hipErrorInvalidValue;
   const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
   auto kern = knn_merge_kernel<uint32_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I, gate);
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I, gate, blk_q);
   return hipGetLastError();
 }
 hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
@@ -1212,7 +1287,7 @@ hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, i
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, (const int*)nullptr, P, nq, kin, k, (int64_t)0,
-                     (const int64_t*)nullptr, D, I, (const unsigned*)nullptr);
+                     (const int64_t*)nullptr, D, I, (const unsigned*)nullptr, 0);
   return hipGetLastError();
 }
 // P-way merge of P sorted lists per query (score desc, id asc; id < 0 = padding at the tail of a list) -> the sorted top-k.

@@ -92,6 +92,18 @@ struct knnx_index {
   int64_t* ivf_Ic = nullptr;     // [KNN_NQ, KNNX_MAX_K_FAST] coarse result
   float* ivf_Dc = nullptr;
   float* ivf_scores = nullptr;   // [KNN_NQ, nlist] coarse scores (nprobe > 64 only; allocated on first use)
+  // multi-block pass (scan_topk_ivf_multi): up to IVFM_BLK blocks of 32 queries in ONE coarse scan + ONE list scan; allocated on
+  // first use, ivfm_ok = 0 (KNNX_IVF_MULTI=0, or an allocation failed) keeps the 32-queries-per-pass path
+  int ivfm_ok = 1;
+  int ivfm_last_blk = 0;           // blocks of the most recent IVF scan (0: the single-block path) -- knnx_ivf_last_scan_tiles
+  _Float16* ivfm_qfrag = nullptr;  // [IVFM_BLK][d * 64] fragment images
+  int *ivfm_thr_c = nullptr, *ivfm_thr_f = nullptr;  // [32 IVFM_BLK] thresholds of the coarse / the list scan
+  unsigned *ivfm_masks = nullptr, *ivfm_off = nullptr, *ivfm_nwork = nullptr;  // [IVFM_BLK][nlist] x 2, [IVFM_BLK + 1] (last: union tiles)
+  uint4* ivfm_work = nullptr;      // [IVFM_BLK][ivfm_stride]
+  unsigned ivfm_stride = 0;
+  int64_t* ivfm_Ic = nullptr;      // [32 IVFM_BLK, KNNX_MAX_K_FAST] coarse result
+  float* ivfm_Dc = nullptr;
+  float* ivfm_scores = nullptr;    // [32 IVFM_BLK, nlist] (nprobe > 64 only; allocated on first use)
   // streaming build (knnx_ivf_begin .. knnx_ivf_end)
   int ivfb_nlist = 0;
   int64_t ivfb_total = 0, ivfb_added = 0;
@@ -268,6 +280,8 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
     const char* i8b = getenv("KNNX_I8_MAX_BYTES");
     ix->i8_budget = i8b ? std::max<int64_t>(0, atoll(i8b)) : 0;
   }
+  const char* im = getenv("KNNX_IVF_MULTI");
+  ix->ivfm_ok = (im && im[0] == '0') ? 0 : 1;
   const char* rqm = getenv("KNNX_RQ_MIN_ROWS");
   if (rqm && rqm[0]) ix->rq_min_rows = atoll(rqm);
   const char* sg = getenv("KNNX_RQ_SAMPLE_GRID");
@@ -375,6 +389,16 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->ivf_Ic);
   hipFree(ix->ivf_Dc);
   hipFree(ix->ivf_scores);
+  hipFree(ix->ivfm_qfrag);
+  hipFree(ix->ivfm_thr_c);
+  hipFree(ix->ivfm_thr_f);
+  hipFree(ix->ivfm_masks);
+  hipFree(ix->ivfm_off);
+  hipFree(ix->ivfm_nwork);
+  hipFree(ix->ivfm_work);
+  hipFree(ix->ivfm_Ic);
+  hipFree(ix->ivfm_Dc);
+  hipFree(ix->ivfm_scores);
   hipFree(ix->ivfb_rows);
   hipFree(ix->ivfb_ids);
   hipFree(ix->ivfb_lists);
@@ -585,6 +609,7 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
   if (ix->ivf_nlist) {
     int r = ivf_build_worklist(ix, q_dev, nq, st, gate);
     if (r) return r;
+    ix->ivfm_last_blk = 0;
   }
   HIPCHK(launch_prep(q_dev, nq, ix->d, ix->qfrag, ix->thr_g, nullptr, 0, gate, st));
   ScanArgs a{};
@@ -619,6 +644,135 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
   }
   HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, ix->n_cu, KNN_NQ, k, nq, k, ix->id_base,
                           ix->ivf_nlist ? ix->ivf_idmap : nullptr, D_out, I_out, gate, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// IVF, more than 32 queries: the multi-block pass.  The 32-query scan keeps one block's hi / lo fragments in the LDS (d * 128 B:
+// 128 KiB at d = 1024), so a batch of B queries used to be ceil(B / 32) passes, each with its own coarse scan, work-list kernels,
+// list scan and merge (~0.55 ms of small kernels and launch gaps per pass on config 5's shard: 4.4 of the 7.2 ms of a 256-query
+// batch at nprobe 16).  Here the blocks run SIDE BY SIDE: one prep, one coarse scan, one work-list build, one list scan, one merge
+// for up to IVFM_BLK x 32 queries; workgroup g of a scan serves block g % nblk (knn_kernels.hip: knn_scan_kernel, nblk).  A list
+// probed by queries of one block is read once (as before); probed from two blocks it is read by both (the L2 / MALL may catch the
+// second read: the blocks walk their lists at the same time).  Results are those of the 32-query path, bit for bit: every block
+// runs the same exact hi / lo scan over the same candidate set (reference call: clip_back.py:357-369, nprobe on the IVF branch).
+// ---------------------------------------------------------------------------------------------
+constexpr int IVFM_BLK = 8;
+
+static bool ivfm_usable(const knnx_index* ix, int nq, int k) {
+  return ix->ivf_nlist && ix->ivfm_ok && ix->cent && nq > KNN_NQ && k <= KNNX_MAX_K_FAST && scan_cap(ix->d, k) > 0 &&
+         (ix->ivf_nprobe > KNNX_MAX_K_FAST || scan_cap(ix->d, std::min(ix->ivf_nprobe, ix->ivf_nlist)) > 0);
+}
+
+// 0: buffers are there; 1: not available (the caller falls back to the 32-query passes; ivfm_ok is cleared)
+static int ivfm_alloc(knnx_index* ix, bool need_scores) {
+  const size_t nl = (size_t)ix->ivf_nlist;
+  hipError_t e = hipSuccess;
+  if (!ix->ivfm_qfrag) {
+    const size_t tiles = (size_t)std::max<int64_t>(ix->capacity / 32, 1);
+    ix->ivfm_stride = (unsigned)tiles;
+    e = hipMalloc(&ix->ivfm_qfrag, (size_t)IVFM_BLK * ix->d * 128);
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_thr_c, (size_t)IVFM_BLK * 32 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_thr_f, (size_t)IVFM_BLK * 32 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_masks, (size_t)IVFM_BLK * nl * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_off, (size_t)IVFM_BLK * nl * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_nwork, (size_t)(IVFM_BLK + 1) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_work, (size_t)IVFM_BLK * tiles * sizeof(uint4));
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_Ic, (size_t)IVFM_BLK * 32 * KNNX_MAX_K_FAST * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_Dc, (size_t)IVFM_BLK * 32 * KNNX_MAX_K_FAST * sizeof(float));
+  }
+  if (e == hipSuccess && need_scores && !ix->ivfm_scores) e = hipMalloc(&ix->ivfm_scores, (size_t)IVFM_BLK * 32 * nl * sizeof(float));
+  if (e == hipSuccess) return 0;
+  (void)hipGetLastError();
+  hipFree(ix->ivfm_qfrag); ix->ivfm_qfrag = nullptr;
+  hipFree(ix->ivfm_thr_c); ix->ivfm_thr_c = nullptr;
+  hipFree(ix->ivfm_thr_f); ix->ivfm_thr_f = nullptr;
+  hipFree(ix->ivfm_masks); ix->ivfm_masks = nullptr;
+  hipFree(ix->ivfm_off); ix->ivfm_off = nullptr;
+  hipFree(ix->ivfm_nwork); ix->ivfm_nwork = nullptr;
+  hipFree(ix->ivfm_work); ix->ivfm_work = nullptr;
+  hipFree(ix->ivfm_Ic); ix->ivfm_Ic = nullptr;
+  hipFree(ix->ivfm_Dc); ix->ivfm_Dc = nullptr;
+  hipFree(ix->ivfm_scores); ix->ivfm_scores = nullptr;
+  ix->ivfm_ok = 0;
+  return 1;
+}
+
+// one pass of 33 .. 32 IVFM_BLK queries already in HBM
+static int scan_topk_ivf_multi(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st) {
+  const int cap = scan_cap(ix->d, k);
+  const int nblk = (nq + KNN_NQ - 1) / KNN_NQ;
+  const int grid = std::max(1, ix->n_cu / nblk) * nblk;  // (part_* hold n_cu x 64 lists: grid <= n_cu whenever n_cu >= nblk)
+  if (cap < 0 || nblk > IVFM_BLK || grid > std::max(ix->n_cu, nblk)) return fail(KNNX_E_STATE, "internal: multi-block IVF pass misuse");
+  knnx_index* c = ix->cent;
+  const int np = std::min(ix->ivf_nprobe, ix->ivf_nlist);
+  HIPCHK(launch_prep_blocks(q_dev, nq, ix->d, ix->ivfm_qfrag, ix->ivfm_thr_c, ix->ivfm_thr_f, st));
+  // coarse quantiser: every block's top-nprobe centroids in one scan over the centroid rows
+  ScanArgs ca{};
+  ca.X = c->rows;
+  ca.N = c->ntotal;
+  ca.d = c->d;
+  ca.qfrag = ix->ivfm_qfrag;
+  ca.nq = nq;
+  ca.grid = grid;
+  ca.thr_g = ix->ivfm_thr_c;
+  ca.nblk = nblk;
+  if (np <= KNNX_MAX_K_FAST) {
+    ca.k = np;
+    ca.cap = scan_cap(c->d, np);
+    ca.mode = 0;
+    ca.part_s = ix->part_s;
+    ca.part_i = ix->part_i;
+    ca.part_n = ix->part_n;
+    HIPCHK(launch_scan(ca, st));
+    HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, grid / nblk, KNN_NQ, np, nq, np, c->id_base, nullptr, ix->ivfm_Dc,
+                            ix->ivfm_Ic, nullptr, st, KNN_NQ));
+    HIPCHK(launch_ivf_worklist(ix->ivfm_Ic, nq, np, ix->ivf_nlist, ix->ivfm_masks, ix->ivf_tile0, ix->ivf_ntile, ix->ivf_size,
+                               ix->ivfm_off, ix->ivfm_work, ix->ivfm_nwork, st, ix->ivfm_stride));
+  } else {
+    ca.k = 1;
+    ca.cap = 2;
+    ca.mode = 2;
+    ca.range_cap = (unsigned)ix->ivf_nlist;
+    ca.range_s = ix->ivfm_scores;
+    HIPCHK(launch_scan(ca, st));
+    HIPCHK(launch_ivf_worklist_from_scores(ix->ivfm_scores, nq, np, ix->ivf_nlist, ix->ivfm_masks, ix->ivf_tile0, ix->ivf_ntile,
+                                           ix->ivf_size, ix->ivfm_off, ix->ivfm_work, ix->ivfm_nwork, st, ix->ivfm_stride));
+  }
+  if (ix->prof)  // tiles of the union of the blocks' lists (what one pass over shared lists would read): knnx_ivf_last_scan_tiles
+    HIPCHK(launch_ivf_union_tiles(ix->ivfm_masks, nblk, ix->ivf_nlist, ix->ivf_ntile, ix->ivfm_nwork + IVFM_BLK, st));
+  ScanArgs a{};
+  a.X = ix->rows;
+  a.N = ix->capacity;
+  a.d = ix->d;
+  a.qfrag = ix->ivfm_qfrag;
+  a.nq = nq;
+  a.k = k;
+  a.cap = cap;
+  a.grid = grid;
+  a.mode = 0;
+  a.thr_g = ix->ivfm_thr_f;
+  a.part_s = ix->part_s;
+  a.part_i = ix->part_i;
+  a.part_n = ix->part_n;
+  a.work = ix->ivfm_work;
+  a.nwork = ix->ivfm_nwork;
+  a.nblk = nblk;
+  a.work_stride = ix->ivfm_stride;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ix->prof) {
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st));
+  }
+  HIPCHK(launch_scan(a, st));
+  if (ix->prof) {
+    HIPCHK(hipEventRecord(e1, st));
+    ix->prof_events.emplace_back(e0, e1);
+  }
+  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, grid / nblk, KNN_NQ, k, nq, k, ix->id_base, ix->ivf_idmap, D_out, I_out,
+                          nullptr, st, KNN_NQ));
+  ix->ivfm_last_blk = nblk;
   return 0;
 }
 
@@ -1030,6 +1184,7 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
 
 // how many of `remaining` queries the next scan step takes (the same choice scan_step makes)
 static int step_queries(knnx_index* ix, int remaining, int k) {
+  if (ivfm_usable(ix, remaining, k)) return std::min(IVFM_BLK * KNN_NQ, remaining);
   // (two planes: 128 queries per int8 pass -- a batch of more goes to the fp16 register-stationary pass, 36 ms for 256 against 2 x 19.6)
   if (i8_usable(ix, remaining, k) && !(ix->i8_planes == 2 && remaining > 128 && rq_usable(ix, remaining, k)))
     return std::min(ix->i8_planes == 2 ? 128 : KNN_RQ_MAX, remaining);
@@ -1042,6 +1197,12 @@ static int step_queries(knnx_index* ix, int remaining, int k) {
 static int scan_step(knnx_index* ix, const float* q_dev, int remaining, int k, float* D_out, int64_t* I_out, hipStream_t st,
                      int* taken) {
   int nq, r;
+  if (ivfm_usable(ix, remaining, k) && ivfm_alloc(ix, ix->ivf_nprobe > KNNX_MAX_K_FAST) == 0) {
+    nq = std::min(IVFM_BLK * KNN_NQ, remaining);
+    r = scan_topk_ivf_multi(ix, q_dev, nq, k, D_out, I_out, st);
+    *taken = nq;
+    return r;
+  }
   if (i8_usable(ix, remaining, k)) {
     r = i8_ensure(ix, st);
     if (r < 0) return r;
@@ -2429,11 +2590,38 @@ extern "C" int knnx_ivf_last_scan_tiles(knnx_index* ix, int64_t* tiles) {
   std::lock_guard<std::mutex> lk(ix->mu);
   if (!ix->ivf_nlist) return fail(KNNX_E_STATE, "not an IVF index");
   if (set_dev(ix)) return KNNX_E_HIP;
-  unsigned n = 0;
   HIPCHK(hipStreamSynchronize(ix->stream));
+  if (ix->ivfm_last_blk > 0) {  // the multi-block pass: every block walks its own list of tiles
+    unsigned n[IVFM_BLK] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpy(n, ix->ivfm_nwork, (size_t)ix->ivfm_last_blk * sizeof(unsigned), hipMemcpyDeviceToHost));
+    *tiles = 0;
+    for (int b = 0; b < ix->ivfm_last_blk; ++b) *tiles += (int64_t)n[b];
+    return KNNX_OK;
+  }
+  unsigned n = 0;
   HIPCHK(hipMemcpy(&n, ix->ivf_nwork, sizeof(unsigned), hipMemcpyDeviceToHost));
   *tiles = (int64_t)n;
   return KNNX_OK;
+}
+
+// the same for the UNION of the lists the blocks of the most recent multi-block pass probed (a list counted once however many
+// blocks read it): the bytes a single pass over shared lists would have read.  Needs profiling on (knnx_profile_enable) during the
+// search; a single-block scan reports its own tiles.
+extern "C" int knnx_ivf_last_scan_union_tiles(knnx_index* ix, int64_t* tiles) {
+  if (!ix || !tiles) return fail(KNNX_E_ARG, "bad ivf_last_scan_union_tiles arguments");
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->ivf_nlist) return fail(KNNX_E_STATE, "not an IVF index");
+    if (ix->ivfm_last_blk > 0) {
+      if (set_dev(ix)) return KNNX_E_HIP;
+      HIPCHK(hipStreamSynchronize(ix->stream));
+      unsigned n = 0;
+      HIPCHK(hipMemcpy(&n, ix->ivfm_nwork + IVFM_BLK, sizeof(unsigned), hipMemcpyDeviceToHost));
+      *tiles = (int64_t)n;
+      return KNNX_OK;
+    }
+  }
+  return knnx_ivf_last_scan_tiles(ix, tiles);
 }
 
 extern "C" int knnx_profile_enable(knnx_index* ix, int on) {

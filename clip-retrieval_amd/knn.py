@@ -212,6 +212,12 @@ class Mi355xIndex(_FaissShaped):
         check(self._lib, self._lib.knnx_ivf_last_scan_tiles(self._h, C.byref(t)), "knnx")
         return int(t.value)
 
+    def last_scan_union_tiles(self):
+        """IVF: tiles of the union of the lists the most recent (multi-block) pass probed, each list counted once (profiling on)."""
+        t = C.c_int64(0)
+        check(self._lib, self._lib.knnx_ivf_last_scan_union_tiles(self._h, C.byref(t)), "knnx")
+        return int(t.value)
+
     # ------------------------------------------------------------------ searching
     def _search_raw(self, q, k, want_r):
         n = q.shape[0]

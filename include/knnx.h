@@ -191,9 +191,13 @@ int knnx_shards_range_search(knnx_shards* s, const float* q, int n, float thresh
  * exactness proof failed and were re-run by the exact 32-query scan (each failure costs one more pass over HBM). */
 int knnx_get_stats(knnx_index* ix, int64_t* proof_queries, int64_t* proof_failures);
 
-/* IVF: number of 32-row tiles the most recent scan walked (the probed lists of its <= 32 queries, padded to tiles);
- * bytes read from HBM = tiles * 32 * d * 2, to be compared with (nprobe / nlist) * N * d * 2. */
+/* IVF: number of 32-row tiles the most recent scan walked (the probed lists of its queries, padded to tiles; a call of more than
+ * 32 queries is ONE multi-block pass of up to 256 -- every block of 32 walks the union of its own queries' lists, and the sum over
+ * the blocks is reported); bytes read from HBM = tiles * 32 * d * 2, to be compared with (nprobe / nlist) * N * d * 2. */
 int knnx_ivf_last_scan_tiles(knnx_index* ix, int64_t* tiles);
+/* The same for the union over ALL queries of that pass (a list counted once however many blocks read it): the bytes one pass over
+ * shared lists would read.  Collected only while profiling is enabled (knnx_profile_enable) during the search. */
+int knnx_ivf_last_scan_union_tiles(knnx_index* ix, int64_t* tiles);
 
 /* Live kernel timing for bench.py: when enabled, every scan launch is bracketed with
  * hipEvents on its own stream; get returns launches and summed milliseconds, then resets. */

@@ -509,7 +509,8 @@ def test_ivf_flat_parity(n, d, nlist, nprobe):
     ix = build_ivf_index(x, nlist, nprobe=nprobe, centroids=cent)
     assert ix.ntotal == n and ix.nlist == nlist
     o = IVFFlatOracle(d, cent, ix.ivf_lists, x)
-    for nq, k in [(1, 40), (7, 10), (32, 64), (45, 40)]:
+    # more than 32 queries = ONE multi-block pass of up to 256 (round 6: knnx_api.hip scan_topk_ivf_multi); 300 = a pass of 256 + one of 44
+    for nq, k in [(1, 40), (7, 10), (32, 64), (45, 40), (64, 40), (200, 20), (256, 40), (300, 64)]:
         q = _queries(nq, d, seed=k + nq, x=x)
         D, I = ix.search(q, k)
         Do, Io = o.search(q, k, nprobe)
@@ -1335,11 +1336,43 @@ def test_ivf_nprobe_above_64(nprobe):
     cent = x[np.random.default_rng(1).choice(n, nlist, replace=False)]
     ix = build_ivf_index(x, nlist, nprobe=min(nprobe, nlist), centroids=cent)
     ora = IVFFlatOracle(d, cent, ix.ivf_lists, x)
-    q = _queries(37, d, seed=5, x=x)
-    D, I = ix.search(q, 40)
-    Do, Io = ora.search(q, 40, min(nprobe, nlist))
-    _check(D, I, Do, Io, f"ivf nprobe={nprobe}")
+    for nq in (37, 64, 256):  # (more than 32: the multi-block pass, whose coarse scan dumps the scores of every block at once)
+        q = _queries(nq, d, seed=5 + nq, x=x)
+        D, I = ix.search(q, 40)
+        Do, Io = ora.search(q, 40, min(nprobe, nlist))
+        _check(D, I, Do, Io, f"ivf nprobe={nprobe} nq={nq}")
     ix.close()
+
+
+@pytest.mark.parametrize("nprobe", [4, 70])
+def test_ivf_multi_block_pass_equals_the_32_query_passes(nprobe, monkeypatch):
+    """Round 6: a call of up to 256 queries is ONE pass -- every 32-query block runs the same exact scan side by side
+    in one launch.  Its D / I must be those of the 32-queries-per-pass path (KNNX_IVF_MULTI=0, read at index creation) bit for bit,
+    and the tiles it reports: sum over the blocks >= union over all queries >= the largest single block."""
+    from clip_retrieval_amd.knn import build_ivf_index
+
+    d, n, nlist = 768, 40_000, 200
+    x = _data(n, d, seed=13)
+    cent = x[np.random.default_rng(2).choice(n, nlist, replace=False)]
+    q = _queries(231, d, seed=99, x=x)
+    ix = build_ivf_index(x, nlist, nprobe=nprobe, centroids=cent)
+    ix.profile(True)
+    D, I = ix.search(q, 40)
+    tiles, union = ix.last_scan_tiles(), ix.last_scan_union_tiles()
+    ix.profile(False)
+    ix.profile_get()
+    per_block = []
+    for o in range(0, 231, 32):
+        ix.search(q[o:o + 32], 40)
+        per_block.append(ix.last_scan_tiles())
+    assert tiles == sum(per_block), (tiles, per_block)
+    assert max(per_block) <= union <= tiles
+    ix.close()
+    monkeypatch.setenv("KNNX_IVF_MULTI", "0")
+    ix0 = build_ivf_index(x, nlist, nprobe=nprobe, centroids=cent)
+    D0, I0 = ix0.search(q, 40)
+    ix0.close()
+    assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32))
 
 
 # ------------------------------------------------------------------------------------------------------------

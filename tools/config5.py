@@ -143,14 +143,28 @@ def run(rows=125_000_000, d=1024, nlist=65536, clusters=0, nprobes=(16, 64, 256)
                "served": []}
         log(f"nprobe {npb:4d}: recall@{k} {rec:.4f} (planted top-1 {top1:.4f}); B=32 {n_queries / el:9.1f} QPS, scan {ms / max(nl, 1):.3f} ms, "
             f"{gbs:.0f} GB/s; n=1 {lat1 * 1e3:.3f} ms, {tiles1 * 32 * d * 2 / 64 / 1e6:.1f} MB scanned vs model {model1 / 1e6:.1f} MB")
-        # one call of 256 queries (bench.py --ivf row at B = 256): the IVF scan serves them 32 per pass
-        ix.search(q[:256], k)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            ix.search(q[:256], k)
-        el256 = (time.perf_counter() - t1) / 3
-        row["batch256"] = {"qps": round(256 / el256, 1), "ms_per_batch": round(el256 * 1e3, 3), "passes": 8}
-        log(f"    B=256: {256 / el256:9.1f} QPS, {el256 * 1e3:.3f} ms per batch (8 passes of 32 queries)")
+        # one call of 64 / 256 queries (bench.py --ivf rows): ONE multi-block pass each since round 6 (every block of
+        # 32 queries runs its exact scan side by side in one launch); bytes walked (sum over the blocks) against the union of the
+        # lists of all its queries (each list once) and against the balanced-list model
+        for B in (64, 256):
+            ix.profile(True)
+            Db, Ib = ix.search(q[:B], k)
+            tb, ub = ix.last_scan_tiles(), ix.last_scan_union_tiles()
+            ix.profile(False)
+            nlb, msb = ix.profile_get()
+            same = bool(np.array_equal(Ib, I[:B]) and np.array_equal(Db, D[:B]))
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ix.search(q[:B], k)
+            elb = (time.perf_counter() - t1) / 5
+            row[f"batch{B}"] = {"qps": round(B / elb, 1), "ms_per_batch": round(elb * 1e3, 3), "passes": int(nlb), "scan_ms": round(msb, 3),
+                                "scan_GBps": round(tb * 32 * d * 2 / (msb * 1e-3) / 1e9, 1) if msb > 0 else 0.0,
+                                "bytes_scanned": int(tb * 32 * d * 2), "bytes_union_of_lists": int(ub * 32 * d * 2),
+                                "bytes_model": int(B * model1), "scanned_over_union": round(tb / max(ub, 1), 3),
+                                "equals_32_query_passes": same}
+            log(f"    B={B}: {B / elb:9.1f} QPS, {elb * 1e3:.3f} ms per batch ({nlb} pass, list scan {msb:.3f} ms = "
+                f"{row[f'batch{B}']['scan_GBps']:.0f} GB/s; {tb * 32 * d * 2 / 1e9:.2f} GB walked = {tb / max(ub, 1):.3f} x the union of its lists, "
+                f"{tb * 32 * d * 2 / (B * model1):.3f} x the balanced model; equals the 32-query passes: {same})")
         legs = [(T, False) for T in threads]
         if dedup_leg:
             legs.append((threads[-1], True))
