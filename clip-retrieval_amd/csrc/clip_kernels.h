@@ -44,6 +44,11 @@ struct GemmArgs {
                           // m-tiles are computed inside the same launch, 32 x (tail_nb x 32) per workgroup (0: none)
   int f16;                // A and W hold IEEE fp16 instead of bf16 (v_mfma_f32_32x32x16_f16, same rate): the LayerNorm-folded
                           // GEMMs, whose A operand is the fp16 residual stream itself.  bf16-output epilogues (0..2) and RAW only.
+  float stats_eps;        // > 0 (f16, 16-bit-output epilogues, K = the row length): the GEMM is LayerNorm-folded and rowscale is NOT an
+                          // input -- it is the [M] buffer that receives 1 / sqrt(var(A[m, :]) + stats_eps) where a separate pass has to
+                          // compute it (launch_gemm runs launch_rowstats on those rows); the rows the 4-wave 256x256 kernel takes get
+                          // their statistics from the A fragments inside its K loop instead (gemm256w4.hip, STATS) and are not written
+  int* range_flag;        // (stats_eps > 0) raised when a row of A holds inf / NaN (launch_rowstats)
 };
 
 // number of 256-row m-tiles variant 3 hands to the 256x256 kernel for an [M, N] output
@@ -59,7 +64,8 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
                             int d, float eps, hipStream_t st, bf16* y16 = nullptr);
 
 // LayerNorm statistics of the 16-bit residual stream rows (f16 != 0: IEEE fp16, else bf16): rstd[m] = 1 / sqrt(var(x16[m, :]) + eps)
-// (two-pass, fp32).  The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias
+// (bf16: two-pass, fp32; fp16: ONE pass in the canonical order of gemm_common.h ln_rstd_onepass -- the order the 4-wave GEMM kernel
+// accumulates the same sums in from its A fragments, so that a row's rstd does not depend on which of the two computed it).  The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias
 // absorbs beta: clipx_api.hip fold_layernorm), whose epilogue multiplies by rstd[m].  One wave per row.
 hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16 = 0, int* range_flag = nullptr);
 

@@ -531,11 +531,31 @@ int gemm256_tail_blocks(int N, int K, int n_cu) {
   return 0;
 }
 
-hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+hipError_t launch_gemm(const GemmArgs& g0, hipStream_t st) {
+  GemmArgs g = g0;
   if (g.M <= 0 || g.N % G_TN != 0 || g.K % G_BK != 0 || g.K <= 0) return hipErrorInvalidValue;
   const bool out16 = g.epi == EPI_BIAS_BF16 || g.epi == EPI_BIAS_QGELU_BF16 || g.epi == EPI_BIAS_GELU_BF16 || g.epi == EPI_BIAS_F16;
   if (out16 && !g.rowscale) return hipErrorInvalidValue;
   if (g.f16 && !out16) return hipErrorInvalidValue;
+  if (g.stats_eps > 0.f) {
+    // LayerNorm-folded GEMM that owns its row statistics: rowscale is the buffer a separate pass fills -- for the rows the 4-wave
+    // kernel does not cover (it takes the sums from its own A fragments: gemm256w4.hip STATS).  Decided here, with the dispatch below.
+    if (!g.f16 || !out16) return hipErrorInvalidValue;
+    int fused_rows = 0;
+    if (g.variant == 6 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
+      const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
+      const int cu = (g.n_cu > 0 ? g.n_cu : 256);
+      GemmArgs b = g;
+      b.M = bulk * 256;
+      if (bulk > 0 && (int64_t)bulk * (g.N / 256) >= cu / 2 && gemm256w4_fuses_stats(b)) fused_rows = b.M;
+    }
+    if (fused_rows < g.M) {
+      hipError_t e = launch_rowstats(reinterpret_cast<const char*>(g.A) + (size_t)fused_rows * g.K * 2, const_cast<float*>(g.rowscale) + fused_rows,
+                                     g.M - fused_rows, g.K, g.stats_eps, st, 1, g.range_flag);
+      if (e != hipSuccess) return e;
+    }
+    if (fused_rows == 0) g.stats_eps = 0.f;  // (every row scale is in the buffer: a plain folded GEMM from here on)
+  }
   if (g.variant >= 2 && g.N % 256 == 0 && g.K % 128 == 0 && g.M >= 256) {
     const int bulk = gemm256_bulk_mtiles(g.M, g.N, g.n_cu);
     // small problems (query-side B = 1: M = 257 or 77 rows) would put one 256x256 tile on each of a handful of CUs;
@@ -557,6 +577,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       if (b.M == g.M || tail_inside) return hipSuccess;
       GemmArgs r = g;  // remaining rows [bulk*256, M)
       r.variant = 1;
+      r.stats_eps = 0.f;  // (their row scales were written above)
       r.splitk_ws = nullptr;  // rows of one large batch are computed the same way whichever kernel they land in
       r.A = g.A + (size_t)b.M * g.K;
       r.M = g.M - b.M;
@@ -570,6 +591,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   }
   GemmArgs r = g;
   if (r.variant >= 2) r.variant = 1;
+  r.stats_eps = 0.f;
   return launch_gemm128(r, st);
 }
 
@@ -673,8 +695,55 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const void* __restrict__ 
   if (lane == 0) rstd[row] = 1.f / sqrtf(q * (1.f / d) + eps);
 }
 
+// The fp16 stream: ONE pass in the canonical order (gemm_common.h: ln_rstd_onepass) -- four lanes per row (lane = r16 + 16 q4, the
+// fragment layout of the 4-wave GEMM kernel, which computes the same sums for the rows it multiplies), lane part q4 takes the 16-B
+// chunks q4, q4 + 4, ..; a wave covers 16 rows, a workgroup 64.
+template <int NV2>  // d = NV2 * 256
+__global__ __launch_bounds__(256) void rowstats_f16_kernel(const void* __restrict__ x16, float* __restrict__ rstd, int M, float eps,
+                                                           int* __restrict__ range_flag) {
+  constexpr int d = NV2 * 256, NCH = d / 8;
+  const int lane = threadIdx.x & 63, q4 = lane >> 4, r16 = lane & 15;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + r16;
+  const uint4* xr = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x16) + (size_t)(row < M ? row : M - 1) * d);
+  const unsigned ones2 = __builtin_amdgcn_readfirstlane(0x3c003c00u);
+  float s1 = 0.f, s2 = 0.f;
+  constexpr int U = 8;  // chunks in flight per lane
+  static_assert((NCH / 4) % U == 0, "row length");
+  for (int j0 = 0; j0 < NCH / 4; j0 += U) {
+    uint4 c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) c[u] = xr[q4 + 4 * (j0 + u)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      CLIPX_DOT2_SQ(s2, c[u].x); CLIPX_DOT2_SQ(s2, c[u].y); CLIPX_DOT2_SQ(s2, c[u].z); CLIPX_DOT2_SQ(s2, c[u].w);
+      CLIPX_DOT2_SUM(s1, c[u].x, ones2); CLIPX_DOT2_SUM(s1, c[u].y, ones2); CLIPX_DOT2_SUM(s1, c[u].z, ones2); CLIPX_DOT2_SUM(s1, c[u].w, ones2);
+    }
+  }
+  s1 += __shfl_xor(s1, 16);
+  s2 += __shfl_xor(s2, 16);
+  s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 32);
+  if (row >= M || q4 != 0) return;
+  // range guard of the fp16 residual stream (see rowstats_kernel): a row holding inf / NaN has a non-finite sum
+  if (range_flag && !(fabsf(s1) <= 3.0e38f)) atomicOr(range_flag, 1);
+  rstd[row] = ln_rstd_onepass(s1, s2, 1.f / (float)d, eps);
+}
+
 hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16, int* range_flag) {
   if (M <= 0) return hipSuccess;
+  if (f16) {
+    const dim3 grid((M + 63) / 64), block(256);
+#define RSH_CASE(NV)                                                                                           \
+  case NV * 256:                                                                                               \
+    hipLaunchKernelGGL((rowstats_f16_kernel<NV>), grid, block, 0, st, x16, rstd, M, eps, range_flag);          \
+    break;
+    switch (d) {
+      RSH_CASE(1) RSH_CASE(2) RSH_CASE(3) RSH_CASE(4) RSH_CASE(5) RSH_CASE(6) RSH_CASE(7) RSH_CASE(8)
+      default: return hipErrorInvalidValue;
+    }
+#undef RSH_CASE
+    return hipGetLastError();
+  }
   const dim3 grid((M + 3) / 4), block(256);
 #define RS_CASE(NV)                                                                                        \
   case NV * 256:                                                                                           \

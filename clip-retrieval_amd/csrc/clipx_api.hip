@@ -137,6 +137,7 @@ struct clipx_handle {
   // sum(eot_i + 1) rows instead of B x ctx_len.  Per call: lens / offsets / row map / pooled rows, built on the host from the
   // token ids, in a ring of RG_SLOTS page-locked + device buffers (a slot is reused when the event of its upload has passed).
   static constexpr int RG_SLOTS = 4;
+  bool ln_fused = true;  // LayerNorm statistics of the folded GEMMs inside the 4-wave GEMM kernel (CLIPX_LN_FUSED=0: a separate pass)
   bool ragged_text = true;
   int* rg_host[RG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   int* rg_dev[RG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
@@ -342,6 +343,8 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   h->host_chunk = std::min(h->host_chunk, h->max_batch);
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   if (gv) h->gemm_variant = std::min(6, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
+  const char* lf = getenv("CLIPX_LN_FUSED");
+  if (lf && lf[0] == '0') h->ln_fused = false;
   const char* rgt = getenv("CLIPX_RAGGED_TEXT");
   if (rgt && rgt[0] == '0') h->ragged_text = false;
   const char* fl = getenv("CLIPX_FULL_LAST_BLOCK");
@@ -434,11 +437,15 @@ struct ProfScope {
 };
 
 static int run_gemm(clipx_handle* h, hipStream_t st, const bf16* A, const bf16* W, const float* bias, void* out,
-                    const float* table, int T, int M, int N, int K, int epi, const float* rowscale = nullptr, bool f16 = false) {
+                    const float* table, int T, int M, int N, int K, int epi, const float* rowscale = nullptr, bool f16 = false,
+                    float stats_eps = 0.f) {
   GemmArgs g{};
   g.A = A; g.W = W; g.bias = bias; g.out = out; g.table = table; g.T = T;
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.variant = h->gemm_variant; g.n_cu = h->n_cu; g.row0 = 0;
   g.rowscale = rowscale; g.out16 = nullptr; g.f16 = f16 ? 1 : 0;
+  // stats_eps > 0: a LayerNorm-folded GEMM that computes the row scales itself -- inside the 4-wave kernel for the rows it takes, by
+  // launch_rowstats into `rowscale` for the others (launch_gemm decides)
+  g.stats_eps = stats_eps; g.range_flag = stats_eps > 0.f ? h->cur_flag : nullptr;
   // split-K only on the single-query path (B == 1, KnnService.compute_query): every batch of two or more samples is computed
   // by the unsplit kernels, whose rows do not depend on the batch they travel in (bitwise); a B = 1 row differs from the same
   // sample inside a batch by f32 summation order only
@@ -479,8 +486,9 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& L = t.L[l];
     int r;
-    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1, h->cur_flag)); }
-    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_F16, h->rstd, true))) return r;
+    // (LayerNorm statistics: inside the GEMM -- run_gemm's stats_eps -- unless CLIPX_LN_FUSED=0 asks for the separate pass of rounds 2 - 5)
+    if (!h->ln_fused) { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1, h->cur_flag)); }
+    if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_F16, h->rstd, true, h->ln_fused ? eps : 0.f))) return r;
     // last block of the image tower: only token 0's attention row is read afterwards -> query block 0 only (same arithmetic)
     const bool pool_here = l == t.layers - 1 && h->pool_last_block && t.T > 1;
     const int q_blocks = pool_here && !ids ? 1 : 0;
@@ -496,15 +504,15 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
       void* xc = reinterpret_cast<char*>(h->x) + (((size_t)B * w * sizeof(bf16) + 255) & ~(size_t)255);
       { ProfScope ps(h, st, 3, 0); HIPCHK(launch_gather_pooled(h->att, h->xn, ids, attc, xc, B, t.T, w, st, rg ? rg->poolrows : nullptr)); }
       if ((r = run_gemm(h, st, attc, L.out_w, L.out_b, xc, nullptr, 1, B, w, w, EPI_BIAS_RESID_H16))) return r;
-      { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(xc, h->rstd, B, w, eps, st, 1, h->cur_flag)); }
-      if ((r = run_gemm(h, st, reinterpret_cast<const bf16*>(xc), L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, B, t.mlp, w, act, h->rstd, true))) return r;
+      if (!h->ln_fused) { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(xc, h->rstd, B, w, eps, st, 1, h->cur_flag)); }
+      if ((r = run_gemm(h, st, reinterpret_cast<const bf16*>(xc), L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, B, t.mlp, w, act, h->rstd, true, h->ln_fused ? eps : 0.f))) return r;
       if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, xc, nullptr, 1, B, w, t.mlp, EPI_BIAS_RESID_H16))) return r;
       *pooled = true;
       return 0;
     }
     if ((r = run_gemm(h, st, h->att, L.out_w, L.out_b, h->xn, nullptr, 1, M, w, w, EPI_BIAS_RESID_H16))) return r;
-    { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1, h->cur_flag)); }
-    if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, M, t.mlp, w, act, h->rstd, true))) return r;
+    if (!h->ln_fused) { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1, h->cur_flag)); }
+    if ((r = run_gemm(h, st, h->xn, L.fc1_w, L.fc1_c, h->hbuf, nullptr, 1, M, t.mlp, w, act, h->rstd, true, h->ln_fused ? eps : 0.f))) return r;
     if ((r = run_gemm(h, st, h->hbuf, L.fc2_w, L.fc2_b, h->xn, nullptr, 1, M, w, t.mlp, EPI_BIAS_RESID_H16))) return r;
   }
   *pooled = false;

@@ -50,14 +50,21 @@ typedef unsigned w4_u32x4 __attribute__((ext_vector_type(4)));
 typedef int w4_i32x4 __attribute__((ext_vector_type(4)));
 
 // DBG 16: phase timer (correct results): [0] epilogues, [1] first K-tile after an epilogue, [3] other K-tiles, [5] their number, [6] tiles, [7] kernel
-template <int EPI, bool F16, int DBG>
+// STATS (fp16 operands, 16-bit-output epilogues: the LayerNorm-folded QKV / fc1): the row scale of the epilogue is not read from
+// `rowscale` but computed here -- 1 / sqrt(var(A[m, :]) + stats_eps) over the K = row-length columns of the A rows the workgroup
+// holds, from the A fragments of the K loop, in the canonical order of gemm_common.h (ln_rstd_onepass): per unit one fragment
+// (16 B per lane) goes through 4 + 4 v_dot2_f32_f16, one behind each MFMA of the unit, into 16 running sums per lane.  (The rows
+// of the ragged tail tile still take theirs from `rowscale`.)
+template <int EPI, bool F16, int DBG, bool STATS = false>
 __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ outp, int N, int K,
-                                                          int ntm, int ntn, const float* __restrict__ rowscale, int tail_m0, int tail_nb, int stagger) {
+                                                          int ntm, int ntn, const float* __restrict__ rowscale, int tail_m0, int tail_nb, int stagger,
+                                                          float stats_eps, int* __restrict__ range_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool DBG_TIMER = DBG == 16;
   constexpr bool OUT16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F16;
   static_assert(OUT16 || EPI == EPI_BIAS_RESID_H16, "epilogue not built for the 4-wave kernel");
+  static_assert(!STATS || (OUT16 && F16), "in-kernel LayerNorm statistics: fp16 operands and a 16-bit-output epilogue");
   constexpr int PFD = 4;  // L2 prefetch distance in K-tiles
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,6 +150,8 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
     fM[sl] = lds0 + (wr * 128 + l15) * 128 + xk;              // + buf * W4_OPB + blk * 2048
     fN[sl] = lds0 + W4_NBASE + (wc * 128 + l15) * 128 + xk;
   }
+  float ssq[8], ssum[8];  // STATS: running sum of x^2 / of x of this lane's 8-value k-chunks of row l15 of activation block mi
+  const unsigned ones2 = __builtin_amdgcn_readfirstlane(0x3c003c00u);  // (1.0h, 1.0h)
   f32x4 acc[8][8];  // [activation block mi][weight block ni]: a 16 x 16 MFMA block each
   w4_i32x4 Nd[2][8], Md[8];  // Md: a ring -- the fragment of unit U sits in slot U & 7 (requested at unit U - 6, when unit U - 8 is long done)
 #define W4_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
@@ -183,8 +192,20 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
     if (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(accv) : "v"(a_), "v"(b_));                             \
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accv) : "v"(a_), "v"(b_));                                \
   }
+// STATS: statistic step j = 0..7 of unit u, issued behind the unit's j-th MFMA (steps 0..3: x . x of dword j of the unit's activation
+// fragment, 4..7: x . 1 of dword j - 4); ZERO (the tile's first K-tile, slab 0): steps 0 / 4 start their sum from zero
+#define W4_STAT_OP(u, j, ZERO)                                                                                                   \
+  if (STATS) {                                                                                                                   \
+    if ((j) == 0 && (ZERO)) asm volatile("v_dot2_f32_f16 %0, %1, %1, 0" : "=v"(ssq[(u) & 7]) : "v"(Md[(u) & 7][0]));             \
+    else if ((j) < 4) { CLIPX_DOT2_SQ(ssq[(u) & 7], Md[(u) & 7][(j) & 3]); }                                                     \
+    else if ((j) == 4 && (ZERO)) asm volatile("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(ssum[(u) & 7]) : "v"(Md[(u) & 7][0]), "s"(ones2)); \
+    else { CLIPX_DOT2_SUM(ssum[(u) & 7], Md[(u) & 7][(j) & 3], ones2); }                                                         \
+  }
 #define W4_MFMA4(u, n0_, ZERO)                                                                                           \
-  _Pragma("unroll") for (int ni = (n0_); ni < (n0_) + 4; ++ni) { W4_MFMA_ASM(acc[(u) & 7][ni], Nd[(u) >> 3][ni], Md[(u) & 7], ZERO) }
+  _Pragma("unroll") for (int ni = (n0_); ni < (n0_) + 4; ++ni) {                                                         \
+    W4_MFMA_ASM(acc[(u) & 7][ni], Nd[(u) >> 3][ni], Md[(u) & 7], ZERO)                                                   \
+    W4_STAT_OP(u, ni, ZERO)                                                                                              \
+  }
 // one unit: hook (a trickled store of the previous tile / an early load for this tile's epilogue), requests, wait, 4 MFMAs, X (a DMA
 // piece or nothing), 4 MFMAs, Y
 #define W4_UNIT(u, buf, ZERO, RD, X, Y, HK)  \
@@ -251,7 +272,8 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
 #define W4_POFF(k_, i_) ((size_t)(((k_) >> 1) * 16 + 8 * (i_)) * N * 2 + ((k_) & 1) * 128)
   // HS = 2: every second pass is held (16 slots: 64 VGPRs), HS = 4: three of four (24 slots: 96 VGPRs -- hipcc then spills 60 - 130
   // registers around the epilogue: not used).  Held slot s <-> (pass k with k % HS != 0, row group i).
-  constexpr int HS = 2, NH = HS == 2 ? 16 : 24, NE = 16 / HS;
+  // STATS: 12 slots (the odd passes 1, 3, 5; pass 7 is stored from the epilogue) -- the 16 running sums need the registers.
+  constexpr int HS = 2, NH = STATS ? 12 : (HS == 2 ? 16 : 24), NE = 16 / HS;
 #define W4_HIDX(k_, i_) (HS == 2 ? ((k_) >> 1) * 2 + (i_) : (((k_) >> 2) * 3 + ((k_) & 3) - 1) * 2 + (i_))
 #define W4_HELD_K(s_) (HS == 2 ? 2 * ((s_) >> 1) + 1 : 4 * (((s_) >> 1) / 3) + (((s_) >> 1) % 3) + 1)
 #define W4_CLAMP(s_) ((s_) < NH ? ((s_) < 0 ? 0 : (s_)) : NH - 1)
@@ -278,7 +300,10 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
   // loads of units 0..9 (10) -- and its second sync (vmcnt 0) also lands the bias and every early load issued before it; after an
   // epilogue its 2 NE stores + the prefetch + the trickled stores of units 1, 3, .. 9 (the residual's in-pass loads were consumed, i.e.
   // have retired); at the second K-tile's sync its prefetch + its trickled stores of units 1, 3, .. 9.
-  constexpr int EPI_VM = 2 * NE + 1 + 5, EPI_VM1 = 1 + 5;
+  // (exact counts: a wait that allows MORE outstanding operations than were issued behind the pieces would let a piece be in flight)
+  constexpr int EPI_STORES = 2 * NE + (16 - NH < 0 ? 0 : 16 - NH);       // stores issued by an epilogue (16-bit outputs: 16 + the un-held odd rows)
+  constexpr int TR0 = NH < 5 ? NH : 5, TR1 = NH - 8 < 0 ? 0 : (NH - 8 < 5 ? NH - 8 : 5);  // trickled stores of units 1, 3, .. 9 of the first / second K-tile
+  constexpr int EPI_VM = EPI_STORES + 1 + TR0, EPI_VM1 = 1 + TR1;
 
   // ---- prologue: K-tiles 0, 1 of the first tile; K-tile 0 landed; the requests units 10..15 of a previous K-tile would have made
 #pragma unroll
@@ -301,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
   // 0..31) and the 128 row scales of its rows (lanes 32..63) into its scratch; inline asm: hipcc must not know about it
   const unsigned bias_m0 = scr_m0 + 4096;
   auto load_bias = [&]() {
-    const float* p = (OUT16 && lane >= 32) ? rowscale + m0 + wr * 128 + (lane - 32) * 4 : bias + n0 + wc * 128 + (lane & 31) * 4;
+    const float* p = (OUT16 && !STATS && lane >= 32) ? rowscale + m0 + wr * 128 + (lane - 32) * 4 : bias + n0 + wc * 128 + (lane & 31) * 4;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(p), "s"(bias_m0) : "memory");
   };
 
@@ -401,8 +426,30 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) b4[nb] = *reinterpret_cast<const float4*>(scr + 4096 + (nb * 16 + 4 * q4) * 4);
         float rr[8];
+        if (STATS) {
+          // the four k-parts of a row sit in lanes l15 + 16 q4: xor-16 / xor-32 butterfly, then the canonical closing formula
+          const float inv_d = 1.f / (float)K;
+          bool bad = false;
 #pragma unroll
-        for (int pq = 0; pq < 8; ++pq) rr[pq] = *reinterpret_cast<const float*>(scr + 4096 + 512 + (pq * 16 + l15) * 4);
+          for (int pq = 0; pq < 8; ++pq) {
+            float s1 = ssum[pq], s2 = ssq[pq];
+            s1 += __shfl_xor(s1, 16);
+            s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            bad |= !(fabsf(s1) <= 3.0e38f);  // inf / NaN in the row (clipx.h: CLIPX_E_RANGE; rowstats_kernel has the same guard)
+            rr[pq] = ln_rstd_onepass(s1, s2, inv_d, stats_eps);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the shuffles are LDS-queue operations: none may be in flight when the counted waits below start)
+          if (bad) {  // error path: the batch is reported invalid
+            if (range_flag) atomicOr(range_flag, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the atomic counts in vmcnt: nothing assumes a number of outstanding operations across it)
+          }
+          W4_FENCE();
+        } else {
+#pragma unroll
+          for (int pq = 0; pq < 8; ++pq) rr[pq] = *reinterpret_cast<const float*>(scr + 4096 + 512 + (pq * 16 + l15) * 4);
+        }
         unsigned qpos[8], rp16[4];
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) qpos[nb] = lds0 + W4_SCR + w * W4_SCRW + l15 * 256 + (((2 * nb + (q4 >> 1)) ^ l15) << 4) + (q4 & 1) * 8;
@@ -460,7 +507,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
           W4_FENCE();
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if (p & 1) {
+            if ((p & 1) && (p >> 1) * 4 + i < NH) {
               held[W4_CLAMP((p >> 1) * 4 + i)] = qd[p & 1][i];
               asm volatile("" : "+v"(held[W4_CLAMP((p >> 1) * 4 + i)]));  // here, not sunk to its store in the next tile's K-loop
             } else {
@@ -633,14 +680,21 @@ static int w4_stagger() {
   return 0;
 }
 
-template <int EPI, bool F16, int DBG = 0>
+template <int EPI, bool F16, int DBG = 0, bool STATS = false>
 static hipError_t launch_w4_epi(const GemmArgs& g, int grid, hipStream_t st) {
   const size_t smem = W4_SCR + 4 * W4_SCRW;  // 160 KiB: the whole LDS of the CU
-  auto kern = gemm256w4_kernel<EPI, F16, DBG>;
+  auto kern = gemm256w4_kernel<EPI, F16, DBG, STATS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g.A, g.W, g.bias, g.out, g.N, g.K, g.M / 256, g.N / 256, g.rowscale, g.tail_m0, g.tail_nb, w4_stagger());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g.A, g.W, g.bias, g.out, g.N, g.K, g.M / 256, g.N / 256, g.rowscale, g.tail_m0, g.tail_nb, w4_stagger(),
+                     g.stats_eps, g.range_flag);
   return hipGetLastError();
+}
+
+// true when the 4-wave kernel computes the LayerNorm row scales of this GEMM itself (GemmArgs.stats_eps > 0)
+bool gemm256w4_fuses_stats(const GemmArgs& g) {
+  return g.stats_eps > 0.f && g.f16 && gemm256w4_supports(g) &&
+         (g.epi == EPI_BIAS_BF16 || g.epi == EPI_BIAS_F16 || g.epi == EPI_BIAS_QGELU_BF16 || g.epi == EPI_BIAS_GELU_BF16);
 }
 
 // true when the 4-wave kernel has this (epilogue, operand type, shape)
@@ -665,6 +719,15 @@ hipError_t launch_gemm256w4(const GemmArgs& g, int n_cu, hipStream_t st) {
     }
   }
 #endif
+  if (gemm256w4_fuses_stats(g)) {
+    switch (g.epi) {
+      case EPI_BIAS_BF16: return launch_w4_epi<EPI_BIAS_BF16, true, 0, true>(g, grid, st);
+      case EPI_BIAS_F16: return launch_w4_epi<EPI_BIAS_F16, true, 0, true>(g, grid, st);
+      case EPI_BIAS_QGELU_BF16: return launch_w4_epi<EPI_BIAS_QGELU_BF16, true, 0, true>(g, grid, st);
+      case EPI_BIAS_GELU_BF16: return launch_w4_epi<EPI_BIAS_GELU_BF16, true, 0, true>(g, grid, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   if (g.f16) {
     switch (g.epi) {
       case EPI_BIAS_BF16: return launch_w4_epi<EPI_BIAS_BF16, true>(g, grid, st);

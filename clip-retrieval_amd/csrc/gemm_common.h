@@ -59,6 +59,25 @@ __device__ __forceinline__ void mfma_block16(f32x4 (&q)[4], frag_t wf0, frag_t w
 __device__ __forceinline__ int quad_m(int g, int lane) { return CLIPX_MFMA16 ? 16 * (g >> 1) + (lane & 15) : (lane & 31); }
 __device__ __forceinline__ int quad_n(int g, int lane) { return CLIPX_MFMA16 ? 16 * (g & 1) + 4 * (lane >> 4) : 8 * g + 4 * (lane >> 5); }
 
+// ---- LayerNorm statistics of an fp16 row, one pass, in ONE canonical order (round 6).  The folded GEMMs (QKV, fc1) multiply their
+// accumulators by the row's 1 / sqrt(var + eps).  The 4-wave 256x256 kernel takes the two sums it needs from the A fragments it
+// holds anyway (gemm256w4.hip, STATS: v_dot2_f32_f16 in the MFMA shadow) instead of a separate pass over the stream (48 launches and
+// 1.1 - 1.4 ms per ViT-L/14 step in rounds 2 - 5); rows that reach another kernel get them from rowstats_f16_kernel.  Both follow:
+//   lane part q4 = 0..3 of a row:  S1[q4], S2[q4] accumulate the 16-B chunks c = q4, q4 + 4, q4 + 8, .. of the row in ascending
+//   order, the four dwords of a chunk in ascending order, one v_dot2_f32_f16 each (x . 1 resp. x . x added to the running sum);
+//   row sums = (S[q4] + S[q4 ^ 1]) + (S[q4 ^ 2] + S[q4 ^ 3])   (the xor-16 / xor-32 butterfly of lanes l15 + 16 q4);
+//   rstd = ln_rstd_onepass(S1, S2, 1 / d, eps).
+// Same instructions in the same order = the same bits whichever kernel computes a row.
+__device__ __forceinline__ float ln_rstd_onepass(float s1, float s2, float inv_d, float eps) {
+  const float mean = s1 * inv_d;
+  const float ex2 = s2 * inv_d;
+  float var = __builtin_fmaf(-mean, mean, ex2);
+  var = var > 0.f ? var : 0.f;
+  return 1.f / sqrtf(var + eps);
+}
+#define CLIPX_DOT2_SQ(acc, w) asm volatile("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(acc) : "v"(w))
+#define CLIPX_DOT2_SUM(acc, w, ones) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "s"(ones))
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -150,6 +169,7 @@ __device__ __forceinline__ void gemm_store_quad(float4 v, int m, int n, int N, c
 hipError_t launch_gemm256sp(const GemmArgs& g, int n_cu, hipStream_t st);
 // the 4-wave form of the same tile (gemm256w4.hip): 16-bit-output epilogues and the fp16 in-place residual, K >= 256
 bool gemm256w4_supports(const GemmArgs& g);
+bool gemm256w4_fuses_stats(const GemmArgs& g);  // GemmArgs.stats_eps > 0 and the form has the STATS kernel
 hipError_t launch_gemm256w4(const GemmArgs& g, int n_cu, hipStream_t st);
 
 }  // namespace clipx

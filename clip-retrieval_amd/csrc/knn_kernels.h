@@ -60,7 +60,9 @@ hipError_t launch_select(const unsigned* need, int q0, int nq, int k, const floa
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st);
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
                             int nq, int k, int64_t id_base, const int64_t* idmap_or_null, float* D, int64_t* I,
-                            const unsigned* gate_or_null, hipStream_t st, int blk_q = 0);  // blk_q = 32: block-major partial lists
+                            const unsigned* gate_or_null, hipStream_t st, int blk_q = 0,  // blk_q = 32: block-major partial lists, or
+                            const unsigned* blk_work = nullptr, int nblk = 0, int G = 0);  // (after a multi-block list scan of G
+                            // workgroups) block b's lists are the slots of the workgroups that served it: P = upper bound (LDS size)
 // IVF-Flat helpers (see knn_kernels.hip)
 hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist, unsigned* masks, const unsigned* tile0,
                                const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,

@@ -149,6 +149,23 @@ __device__ __forceinline__ void prune_query(const ScanSmem& sm, int qq, int cap,
   if (lane == 0) sm.cnt[qq] = n < k ? n : k;
 }
 
+// Multi-block IVF pass: the workgroups [s, e) of a G-workgroup launch that serve query block b, given the blocks' work-list
+// lengths wk[0 .. nblk): every block owns one workgroup plus a share of the other G - nblk proportional to its tiles (blocks of a
+// batch differ by +-10 % in tiles; an equal split leaves the chip waiting for the longest).  The list scan and the merge of its
+// partial lists compute the same ranges from the same array.
+__device__ __forceinline__ void ivfm_range(const unsigned* __restrict__ wk, int nblk, int G, int b, int& s, int& e) {
+  unsigned long long tot = 0, cum = 0, upto = 0;
+  for (int i = 0; i < nblk; ++i) {
+    const unsigned v = wk[i];
+    tot += v;
+    if (i < b) cum += v;
+    if (i <= b) upto += v;
+  }
+  const unsigned long long Gf = (unsigned long long)(G - nblk);
+  s = b + (tot ? (int)(Gf * cum / tot) : 0);
+  e = b + 1 + (tot ? (int)(Gf * upto / tot) : 0);
+}
+
 // IVF = true: instead of all row tiles 0..N/32, the waves walk a WORK LIST of 32-row tiles (the tiles of the inverted
 // lists probed by at least one query of this scan, built by ivf_expand_kernel); item = {tile, query mask, valid rows}:
 // a lane (= query column) only admits a score when its query probes that tile's list -- exactly the candidate set
@@ -180,9 +197,28 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
   // nblk > 1 (QB = 1 only): SEVERAL 32-query blocks in one launch -- the IVF pass of a batch of up to 32 nblk queries.  Workgroup g
   // serves query block g % nblk (its own fragment image, thresholds, work list, result slots) as member g / nblk of that block's
   // gridDim.x / nblk workgroups: nblk independent scans side by side, one launch and one set of small kernels around it.
-  const int blk = nblk > 1 ? (int)(blockIdx.x % (unsigned)nblk) : 0;
-  const int bidx = nblk > 1 ? (int)(blockIdx.x / (unsigned)nblk) : (int)blockIdx.x;
-  const int bgrid = nblk > 1 ? (int)(gridDim.x / (unsigned)nblk) : (int)gridDim.x;
+  // Which block: the list scan (IVF) splits the workgroups in proportion to the blocks' work (ivfm_range); the flat scan (the
+  // coarse quantiser: equal work) puts the nblk workgroups that visit the same row tiles on ONE XCD (workgroup g runs on XCD g % 8)
+  // when the grid allows it, so that a centroid tile is read from HBM once and from that XCD's L2 by the other blocks.
+  int blk = 0, bidx = (int)blockIdx.x, bgrid = (int)gridDim.x;
+  size_t slot = blockIdx.x;  // where this workgroup's partial lists go
+  if (nblk > 1) {
+    const int g = (int)blockIdx.x, G = (int)gridDim.x;
+    if (IVF) {
+      bgrid = 0;
+      for (int b = 0; b < nblk; ++b) {
+        int s_, e_;
+        ivfm_range(nwork_ptr, nblk, G, b, s_, e_);
+        if (g >= s_ && g < e_) { blk = b; bidx = g - s_; bgrid = e_ - s_; }
+      }
+      if (bgrid == 0) return;  // (no work at all: only the first workgroup of every block stays, to publish empty lists)
+    } else {
+      bgrid = G / nblk;
+      if (G % (8 * nblk) == 0) { blk = (g >> 3) % nblk; bidx = (g / (8 * nblk)) * 8 + (g & 7); }
+      else { blk = g % nblk; bidx = g / nblk; }
+      slot = (size_t)blk * bgrid + bidx;
+    }
+  }
   if (nblk > 1) {
     qfrag += (size_t)blk * D * 64;
     nq = nq - 32 * blk < 32 ? nq - 32 * blk : 32;
@@ -354,8 +390,8 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
     __syncthreads();
     for (int qq = w; qq < NQ; qq += KNN_WAVES) prune_query(sm, qq, cap, k, lane, thr_g);
     __syncthreads();
-    // publish this workgroup's sorted lists (nblk > 1: block-major -- the lists of block b are slots [b bgrid, (b + 1) bgrid))
-    const size_t slot = (size_t)blk * bgrid + bidx;
+    // publish this workgroup's sorted lists (nblk > 1, flat: block-major -- the lists of block b are slots [b bgrid, (b + 1) bgrid);
+    // IVF: slot = workgroup, block b owns the slots of ivfm_range)
     for (int i = tid; i < NQ * k; i += KNN_WG) {
       const int qq = i / k, j = i - qq * k;
       const int n = sm.cnt[qq];
@@ -391,15 +427,24 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
                                                        const int* __restrict__ pn, int P, int nq_stride, int kin,
                                                        int k, int64_t id_base, const int64_t* __restrict__ idmap,
                                                        float* __restrict__ D, int64_t* __restrict__ I,
-                                                       const unsigned* __restrict__ gate, int blk_q) {
+                                                       const unsigned* __restrict__ gate, int blk_q,
+                                                       const unsigned* __restrict__ blk_work, int nblk, int G) {
   if (gate && *gate == 0) return;
   // blk_q > 0 (multi-block scans): query blockIdx.x is query blockIdx.x % blk_q of block blockIdx.x / blk_q, whose P partial lists
-  // start P * nq_stride lists into the arrays per block
+  // start P * nq_stride lists into the arrays per block -- or, after a list scan (blk_work = the blocks' work-list lengths), are the
+  // lists of the workgroups ivfm_range gave that block (P = the launch's upper bound, for the LDS size only)
   if (blk_q > 0) {
-    const size_t b = blockIdx.x / (unsigned)blk_q;
-    ps += b * P * nq_stride * kin;
-    pi += b * P * nq_stride * kin;
-    if (pn) pn += b * P * nq_stride;
+    const int b = (int)(blockIdx.x / (unsigned)blk_q);
+    size_t first = (size_t)b * P;
+    if (blk_work) {
+      int s_, e_;
+      ivfm_range(blk_work, nblk, G, b, s_, e_);
+      first = (size_t)s_;
+      P = e_ - s_;
+    }
+    ps += first * nq_stride * kin;
+    pi += first * nq_stride * kin;
+    if (pn) pn += first * nq_stride;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
   unsigned* s_u = reinterpret_cast<unsigned*>(merge_smem);             // [P*kin] order-encoded score, 0 = empty
@@ -917,48 +962,73 @@ __global__ void ivf_mark_kernel(const int64_t* __restrict__ Ic, int nq, int npro
   if (l >= 0 && l < nlist) atomicOr(&masks[(size_t)(qi >> 5) * nlist + l], 1u << (qi & 31));
 }
 
-// single workgroup: exclusive prefix sum of (mask[l] ? ntile[l] : 0) -> off[l]; total -> *nwork
+// one workgroup per query block: exclusive prefix sum of (mask[l] ? ntile[l] : 0) -> off[l]; total -> *nwork.  Chunks of 16 rounds of
+// 1024 lists: the 32 loads of a chunk are issued together (a round at a time they were 64 dependent L2 round trips: 80 us for 65 536
+// lists), a shuffle scan inside each wave, the 16 x 16 wave totals through the LDS, two barriers per chunk.  (The Hillis-Steele
+// scan over the LDS of rounds 3-5 took 150 us: profiles/r06k_*.)
 __global__ __launch_bounds__(1024) void ivf_offsets_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ ntile,
                                                           int nlist, unsigned* __restrict__ off, unsigned* __restrict__ nwork) {
-  __shared__ unsigned red[1024];
-  __shared__ unsigned carry;
-  const int tid = threadIdx.x;
-  masks += (size_t)blockIdx.x * nlist;  // one workgroup per query block (the multi-block pass; a single block otherwise)
+  constexpr int R = 16;
+  __shared__ unsigned wsum[R][16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  masks += (size_t)blockIdx.x * nlist;  // (the multi-block pass; a single block otherwise)
   off += (size_t)blockIdx.x * nlist;
   nwork += blockIdx.x;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nlist; base += 1024) {
-    const int l = base + tid;
-    const unsigned v = (l < nlist && masks[l]) ? ntile[l] : 0u;
-    red[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-      const unsigned t = tid >= o ? red[tid - o] : 0u;
-      __syncthreads();
-      red[tid] += t;
-      __syncthreads();
+  unsigned carry = 0;  // every thread keeps the running total
+  for (int base = 0; base < nlist; base += R * 1024) {
+    unsigned m[R], t[R], inc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int l = base + r * 1024 + tid;
+      m[r] = l < nlist ? masks[l] : 0u;
+      t[r] = l < nlist ? ntile[l] : 0u;
     }
-    if (l < nlist) off[l] = carry + red[tid] - v;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned v = m[r] ? t[r] : 0u;
+      t[r] = v;
+      unsigned x = v;  // inclusive scan inside the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+      }
+      inc[r] = x;
+      if (lane == 63) wsum[r][wv] = x;
+    }
     __syncthreads();
-    if (tid == 1023) carry += red[1023];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      unsigned before = 0, total = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned y = wsum[r][i];
+        before += i < wv ? y : 0u;
+        total += y;
+      }
+      const int l = base + r * 1024 + tid;
+      if (l < nlist) off[l] = carry + before + inc[r] - t[r];
+      carry += total;
+    }
     __syncthreads();
   }
   if (tid == 0) *nwork = carry;
 }
 
-// one workgroup per list: writes the list's tiles into the work list
+// one THREAD per list (blockIdx.y = query block): a probed list writes its tiles into the block's work list.  (One workgroup per
+// list -- 65 536 x nblk workgroups, nearly all of which find their list unprobed and leave -- took 30 us.)
 __global__ __launch_bounds__(256) void ivf_expand_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ tile0,
                                                         const unsigned* __restrict__ ntile, const unsigned* __restrict__ size,
                                                         const unsigned* __restrict__ off, uint4* __restrict__ work,
-                                                        unsigned work_stride) {
-  const int l = blockIdx.x;
-  const size_t b = blockIdx.y;  // query block (the multi-block pass)
-  const unsigned m = masks[b * gridDim.x + l];
+                                                        unsigned work_stride, int nlist) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= nlist) return;
+  const size_t b = blockIdx.y;
+  const unsigned m = masks[b * nlist + l];
   if (!m) return;
   work += b * work_stride;
-  const unsigned nt = ntile[l], t0 = tile0[l], o = off[b * gridDim.x + l], sz = size[l];
-  for (unsigned t = threadIdx.x; t < nt; t += 256) {
+  const unsigned nt = ntile[l], t0 = tile0[l], o = off[b * nlist + l], sz = size[l];
+  for (unsigned t = 0; t < nt; ++t) {
     const unsigned valid = (t + 1 < nt) ? 32u : sz - 32u * (nt - 1);
     work[o + t] = make_uint4(t0 + t, m, valid, 0u);
   }
@@ -997,42 +1067,144 @@ __global__ void knn_gather_rows_inv_kernel(const _Float16* __restrict__ X, int d
   for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)i * d + c] = ok ? (float)X[r * d + c] : __int_as_float(-1);
 }
 
-// Coarse quantiser for nprobe > 64: scores [nq, nlist] (dumped by the MODE 2 scan over the centroids) -> masks[l] |= 1 << q
-// for the nprobe best lists of query q, (score desc, list id asc) -- the selection rule of the top-k path.  One workgroup
-// per query: 32-step bisection on the order-encoded score for the nprobe-th value V, a second bisection over list ids
-// among the ties at V, then one marking pass.  The score row (<= 1 MiB) is re-read from the L2 in every step.
-__global__ __launch_bounds__(256) void ivf_select_mark_kernel(const float* __restrict__ scores, int nlist, int nprobe,
-                                                             unsigned* __restrict__ masks) {
-  __shared__ int red[8];
+// Coarse quantiser from a score matrix: scores [nq, nlist] (dumped by the MODE 2 scan over the centroids) -> bit q % 32 of
+// masks[q / 32][l] for the nprobe best lists of query q, (score desc, list id asc) -- the selection rule of the top-k path.  One
+// 1024-thread workgroup per query.
+//   * radix_select_1024: the need-th largest of n order-encoded keys by three levels (11 + 11 + 10 bits) of an LDS histogram over the
+//     keys that share the prefix found so far -> that value V and how many of the entries equal to V belong to the selection.
+//   * fast path (nprobe <= 512): T0 = the nprobe-th largest of the 1024 per-thread maxima (a radix select over 1024 keys: one LDS
+//     atomic per thread and level) is a lower bound of V -- nprobe distinct entries are >= T0 --, so only the entries >= T0 can be
+//     selected: a few hundred at most for random scores (~1.1 nprobe at nprobe 16, ~1.4 nprobe at 512).  They are collected in the
+//     LDS and ranked against each other.  Two reads of the score row (256 KiB at nlist 65 536, the second from the L2).
+//   * general path (more than SV_CAP entries >= T0: duplicate / zero centroids; nprobe > 512): the radix select over the whole row
+//     (65 536 LDS atomics per level into a handful of hot bins: ~17 us per level), ties at V resolved by a bisection over list
+//     ids.  The 32-step bisection over scores this replaces read the row 33 times (the nprobe > 64 path of rounds 3-5).
+__device__ __forceinline__ int block_count_1024(int v, int* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += red[i];
+  return t;
+}
+// hist: 2048 words of LDS, sh: 2 words; every thread of the 1024 calls it; returns with V / need_out valid in every thread and
+// hist holding the last level's histogram (bin = key & 1023 among the keys that share V's upper 22 bits)
+template <class KeyFn>
+__device__ __forceinline__ void radix_select_1024(KeyFn key, int n, unsigned need, unsigned* hist, unsigned* sh, unsigned& V,
+                                                  unsigned& need_out) {
+  const int tid = threadIdx.x;
+  unsigned prefix = 0;  // keys with this prefix: `need` of them (the largest) are still to be taken
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    const int shift = lvl == 0 ? 21 : (lvl == 1 ? 10 : 0);
+    const int nb = lvl == 2 ? 1024 : 2048;
+    const unsigned himask = lvl == 0 ? 0u : (lvl == 1 ? 0xffe00000u : 0xfffffc00u);
+    for (int b = tid; b < 2048; b += 1024) hist[b] = 0u;
+    __syncthreads();
+    for (int l = tid; l < n; l += 1024) {
+      const unsigned u = key(l);
+      if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & (unsigned)(nb - 1)], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // the bin b with count(bins > b) < need <= count(bins >= b): lane L owns bins [L per, (L + 1) per)
+      const int per = nb / 64;
+      unsigned mine = 0;
+      for (int i = 0; i < per; ++i) mine += hist[tid * per + i];
+      unsigned suf = mine;  // inclusive suffix sum over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(suf, o);
+        if (tid + o < 64) suf += t;
+      }
+      const unsigned above = suf - mine;
+      if (above < need && need <= suf) {  // exactly one lane
+        unsigned acc = above;
+        int b = per - 1;
+        for (; b > 0; --b) {
+          const unsigned c = hist[tid * per + b];
+          if (acc + c >= need) break;
+          acc += c;
+        }
+        sh[0] = prefix | ((unsigned)(tid * per + b) << shift);
+        sh[1] = need - acc;
+      }
+    }
+    __syncthreads();
+    prefix = sh[0];
+    need = sh[1];
+    __syncthreads();  // (hist is cleared / sh rewritten only after everyone has read them)
+  }
+  V = prefix;
+  need_out = need;
+}
+__global__ __launch_bounds__(1024) void ivf_select_mark_kernel(const float* __restrict__ scores, int nlist, int nprobe,
+                                                              unsigned* __restrict__ masks) {
+  constexpr int SV_CAP = 2048;
+  __shared__ unsigned hist[2048];
+  __shared__ unsigned sv_key[SV_CAP];
+  __shared__ int sv_id[SV_CAP];
+  __shared__ unsigned sh[2];
+  __shared__ int sh_cnt;
+  __shared__ int red[16];
   const int qq = blockIdx.x, tid = threadIdx.x;
   const float* s = scores + (size_t)qq * nlist;
+  unsigned* mk = masks + (size_t)(qq >> 5) * nlist;
+  const unsigned bit = 1u << (qq & 31);
   auto enc = [](float f) -> unsigned { return (unsigned)enc_f(f) ^ 0x80000000u; };  // unsigned order == float order
   const int np = nprobe < nlist ? nprobe : nlist;
-  unsigned V = 0;
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned cand = V | (1u << bit);
-    int c = 0;
-    for (int l = tid; l < nlist; l += 256) c += enc(s[l]) >= cand ? 1 : 0;
-    if (block_count_256(c, red) >= np) V = cand;
+  if (np <= 512) {
+    unsigned mx = 0;
+    for (int l = tid; l < nlist; l += 1024) {
+      const unsigned u = enc(s[l]);
+      mx = u > mx ? u : mx;
+    }
+    sv_key[tid] = mx;  // (the survivor arrays are free until T0 is known)
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    unsigned T0, unused;
+    radix_select_1024([&](int i) -> unsigned { return sv_key[i]; }, 1024, (unsigned)np, hist, sh, T0, unused);
+    for (int l = tid; l < nlist; l += 1024) {
+      const unsigned u = enc(s[l]);
+      if (u >= T0) {
+        const int pos = atomicAdd(&sh_cnt, 1);
+        if (pos < SV_CAP) { sv_key[pos] = u; sv_id[pos] = l; }
+      }
+    }
+    __syncthreads();
+    const int S = sh_cnt;
+    if (S <= SV_CAP) {
+      for (int i = tid; i < S; i += 1024) {
+        const unsigned ki = sv_key[i];
+        const int li = sv_id[i];
+        int r = 0;
+        for (int j = 0; j < S; ++j) {
+          const unsigned kj = sv_key[j];
+          r += (kj > ki || (kj == ki && sv_id[j] < li)) ? 1 : 0;
+        }
+        if (r < np) atomicOr(&mk[li], bit);
+      }
+      return;
+    }
+    __syncthreads();  // (everyone has read sh_cnt; the general path reuses the LDS)
   }
-  int cg = 0, ce = 0;
-  for (int l = tid; l < nlist; l += 256) { const unsigned u = enc(s[l]); cg += u > V ? 1 : 0; ce += u == V ? 1 : 0; }
-  const int m1 = block_count_256(cg, red);
-  const int ceq = block_count_256(ce, red);
-  const int t = np - m1;  // lists to take among the ties at V, smallest ids first
+  unsigned V, need;
+  radix_select_1024([&](int l) -> unsigned { return enc(s[l]); }, nlist, (unsigned)np, hist, sh, V, need);
+  const int t = (int)need;                   // entries to take among the ties at V, smallest list ids first
+  const int ceq = (int)hist[V & 1023u];      // entries equal to V (the last level's histogram)
   int X = 0x7fffffff;
   if (ceq > t) {
     X = 0;
-    for (int bit = 30; bit >= 0; --bit) {
-      const int hi = X | ((1 << bit) - 1);
+    for (int b = 30; b >= 0; --b) {
+      const int hi = X | ((1 << b) - 1);
       int c = 0;
-      for (int l = tid; l < nlist; l += 256) c += (enc(s[l]) == V && l <= hi) ? 1 : 0;
-      if (block_count_256(c, red) < t) X |= (1 << bit);
+      for (int l = tid; l < nlist; l += 1024) c += (enc(s[l]) == V && l <= hi) ? 1 : 0;
+      if (block_count_1024(c, red) < t) X |= (1 << b);
     }
   }
-  for (int l = tid; l < nlist; l += 256) {
+  for (int l = tid; l < nlist; l += 1024) {
     const unsigned u = enc(s[l]);
-    if (u > V || (u == V && l <= X)) atomicOr(&masks[(size_t)(qq >> 5) * nlist + l], 1u << (qq & 31));
+    if (u > V || (u == V && l <= X)) atomicOr(&mk[l], bit);
   }
 }
 
@@ -1144,9 +1316,9 @@ hipError_t launch_ivf_worklist_from_scores(const float* scores, int nq, int npro
   const int nblk = (nq + 31) / 32;
   hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ivf_select_mark_kernel, dim3(nq), dim3(256), 0, st, scores, nlist, nprobe, masks);
+  hipLaunchKernelGGL(ivf_select_mark_kernel, dim3(nq), dim3(1024), 0, st, scores, nlist, nprobe, masks);
   hipLaunchKernelGGL(ivf_offsets_kernel, dim3(nblk), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
-  hipLaunchKernelGGL(ivf_expand_kernel, dim3(nlist, nblk), dim3(256), 0, st, masks, tile0, ntile, size, off, work, work_stride);
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, off, work, work_stride, nlist);
   return hipGetLastError();
 }
 
@@ -1158,7 +1330,7 @@ hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist,
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_mark_kernel, dim3((nq * nprobe + 255) / 256), dim3(256), 0, st, Ic, nq, nprobe, nlist, masks);
   hipLaunchKernelGGL(ivf_offsets_kernel, dim3(nblk), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
-  hipLaunchKernelGGL(ivf_expand_kernel, dim3(nlist, nblk), dim3(256), 0, st, masks, tile0, ntile, size, off, work, work_stride);
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, off, work, work_stride, nlist);
   return hipGetLastError();
 }
 // tiles of the lists at least one of the nblk query blocks probes -> *out
@@ -1269,13 +1441,14 @@ hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
 
 hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, int P, int nq_stride, int kin,
                             int nq, int k, int64_t id_base, const int64_t* idmap, float* D, int64_t* I,
-                            const unsigned* gate, hipStream_t st, int blk_q) {
+                            const unsigned* gate, hipStream_t st, int blk_q, const unsigned* blk_work, int nblk, int G) {
   if (k > 64) return hipErrorInvalidValue;
   const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
   auto kern = knn_merge_kernel<uint32_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I, gate, blk_q);
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I, gate, blk_q, blk_work,
+                     nblk, G);
   return hipGetLastError();
 }
 hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
@@ -1287,7 +1460,7 @@ hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, i
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, (const int*)nullptr, P, nq, kin, k, (int64_t)0,
-                     (const int64_t*)nullptr, D, I, (const unsigned*)nullptr, 0);
+                     (const int64_t*)nullptr, D, I, (const unsigned*)nullptr, 0, (const unsigned*)nullptr, 0, 0);
   return hipGetLastError();
 }
 // P-way merge of P sorted lists per query (score desc, id asc; id < 0 = padding at the tail of a list) -> the sorted top-k.

@@ -101,9 +101,7 @@ struct knnx_index {
   unsigned *ivfm_masks = nullptr, *ivfm_off = nullptr, *ivfm_nwork = nullptr;  // [IVFM_BLK][nlist] x 2, [IVFM_BLK + 1] (last: union tiles)
   uint4* ivfm_work = nullptr;      // [IVFM_BLK][ivfm_stride]
   unsigned ivfm_stride = 0;
-  int64_t* ivfm_Ic = nullptr;      // [32 IVFM_BLK, KNNX_MAX_K_FAST] coarse result
-  float* ivfm_Dc = nullptr;
-  float* ivfm_scores = nullptr;    // [32 IVFM_BLK, nlist] (nprobe > 64 only; allocated on first use)
+  float* ivfm_scores = nullptr;    // [32 IVFM_BLK, nlist] coarse scores of one pass
   // streaming build (knnx_ivf_begin .. knnx_ivf_end)
   int ivfb_nlist = 0;
   int64_t ivfb_total = 0, ivfb_added = 0;
@@ -396,8 +394,6 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->ivfm_off);
   hipFree(ix->ivfm_nwork);
   hipFree(ix->ivfm_work);
-  hipFree(ix->ivfm_Ic);
-  hipFree(ix->ivfm_Dc);
   hipFree(ix->ivfm_scores);
   hipFree(ix->ivfb_rows);
   hipFree(ix->ivfb_ids);
@@ -660,12 +656,12 @@ static int scan_topk(knnx_index* ix, const float* q_dev, int nq, int k, float* D
 constexpr int IVFM_BLK = 8;
 
 static bool ivfm_usable(const knnx_index* ix, int nq, int k) {
-  return ix->ivf_nlist && ix->ivfm_ok && ix->cent && nq > KNN_NQ && k <= KNNX_MAX_K_FAST && scan_cap(ix->d, k) > 0 &&
-         (ix->ivf_nprobe > KNNX_MAX_K_FAST || scan_cap(ix->d, std::min(ix->ivf_nprobe, ix->ivf_nlist)) > 0);
+  // (any batch size since the coarse quantiser of this pass is the score dump + radix select: at 32 queries and fewer it is one block)
+  return ix->ivf_nlist && ix->ivfm_ok && ix->cent && nq >= 1 && k <= KNNX_MAX_K_FAST && scan_cap(ix->d, k) > 0;
 }
 
 // 0: buffers are there; 1: not available (the caller falls back to the 32-query passes; ivfm_ok is cleared)
-static int ivfm_alloc(knnx_index* ix, bool need_scores) {
+static int ivfm_alloc(knnx_index* ix) {
   const size_t nl = (size_t)ix->ivf_nlist;
   hipError_t e = hipSuccess;
   if (!ix->ivfm_qfrag) {
@@ -678,10 +674,8 @@ static int ivfm_alloc(knnx_index* ix, bool need_scores) {
     if (e == hipSuccess) e = hipMalloc(&ix->ivfm_off, (size_t)IVFM_BLK * nl * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&ix->ivfm_nwork, (size_t)(IVFM_BLK + 1) * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&ix->ivfm_work, (size_t)IVFM_BLK * tiles * sizeof(uint4));
-    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_Ic, (size_t)IVFM_BLK * 32 * KNNX_MAX_K_FAST * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_Dc, (size_t)IVFM_BLK * 32 * KNNX_MAX_K_FAST * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_scores, (size_t)IVFM_BLK * 32 * nl * sizeof(float));
   }
-  if (e == hipSuccess && need_scores && !ix->ivfm_scores) e = hipMalloc(&ix->ivfm_scores, (size_t)IVFM_BLK * 32 * nl * sizeof(float));
   if (e == hipSuccess) return 0;
   (void)hipGetLastError();
   hipFree(ix->ivfm_qfrag); ix->ivfm_qfrag = nullptr;
@@ -691,14 +685,12 @@ static int ivfm_alloc(knnx_index* ix, bool need_scores) {
   hipFree(ix->ivfm_off); ix->ivfm_off = nullptr;
   hipFree(ix->ivfm_nwork); ix->ivfm_nwork = nullptr;
   hipFree(ix->ivfm_work); ix->ivfm_work = nullptr;
-  hipFree(ix->ivfm_Ic); ix->ivfm_Ic = nullptr;
-  hipFree(ix->ivfm_Dc); ix->ivfm_Dc = nullptr;
   hipFree(ix->ivfm_scores); ix->ivfm_scores = nullptr;
   ix->ivfm_ok = 0;
   return 1;
 }
 
-// one pass of 33 .. 32 IVFM_BLK queries already in HBM
+// one pass of 1 .. 32 IVFM_BLK queries already in HBM
 static int scan_topk_ivf_multi(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st) {
   const int cap = scan_cap(ix->d, k);
   const int nblk = (nq + KNN_NQ - 1) / KNN_NQ;
@@ -707,7 +699,9 @@ static int scan_topk_ivf_multi(knnx_index* ix, const float* q_dev, int nq, int k
   knnx_index* c = ix->cent;
   const int np = std::min(ix->ivf_nprobe, ix->ivf_nlist);
   HIPCHK(launch_prep_blocks(q_dev, nq, ix->d, ix->ivfm_qfrag, ix->ivfm_thr_c, ix->ivfm_thr_f, st));
-  // coarse quantiser: every block's top-nprobe centroids in one scan over the centroid rows
+  // coarse quantiser: ONE scan over the centroid rows dumps every block's scores (mode 2: no queues -- a top-nprobe queue scan of
+  // 65 536 centroids spends its time pruning cold queues: 245 us for two blocks, profiles/r06k_*), a radix select marks the nprobe
+  // best lists of every query (knn_kernels.hip: ivf_select_mark_kernel), whatever nprobe is
   ScanArgs ca{};
   ca.X = c->rows;
   ca.N = c->ntotal;
@@ -717,28 +711,14 @@ static int scan_topk_ivf_multi(knnx_index* ix, const float* q_dev, int nq, int k
   ca.grid = grid;
   ca.thr_g = ix->ivfm_thr_c;
   ca.nblk = nblk;
-  if (np <= KNNX_MAX_K_FAST) {
-    ca.k = np;
-    ca.cap = scan_cap(c->d, np);
-    ca.mode = 0;
-    ca.part_s = ix->part_s;
-    ca.part_i = ix->part_i;
-    ca.part_n = ix->part_n;
-    HIPCHK(launch_scan(ca, st));
-    HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, grid / nblk, KNN_NQ, np, nq, np, c->id_base, nullptr, ix->ivfm_Dc,
-                            ix->ivfm_Ic, nullptr, st, KNN_NQ));
-    HIPCHK(launch_ivf_worklist(ix->ivfm_Ic, nq, np, ix->ivf_nlist, ix->ivfm_masks, ix->ivf_tile0, ix->ivf_ntile, ix->ivf_size,
-                               ix->ivfm_off, ix->ivfm_work, ix->ivfm_nwork, st, ix->ivfm_stride));
-  } else {
-    ca.k = 1;
-    ca.cap = 2;
-    ca.mode = 2;
-    ca.range_cap = (unsigned)ix->ivf_nlist;
-    ca.range_s = ix->ivfm_scores;
-    HIPCHK(launch_scan(ca, st));
-    HIPCHK(launch_ivf_worklist_from_scores(ix->ivfm_scores, nq, np, ix->ivf_nlist, ix->ivfm_masks, ix->ivf_tile0, ix->ivf_ntile,
-                                           ix->ivf_size, ix->ivfm_off, ix->ivfm_work, ix->ivfm_nwork, st, ix->ivfm_stride));
-  }
+  ca.k = 1;
+  ca.cap = 2;
+  ca.mode = 2;
+  ca.range_cap = (unsigned)ix->ivf_nlist;
+  ca.range_s = ix->ivfm_scores;
+  HIPCHK(launch_scan(ca, st));
+  HIPCHK(launch_ivf_worklist_from_scores(ix->ivfm_scores, nq, np, ix->ivf_nlist, ix->ivfm_masks, ix->ivf_tile0, ix->ivf_ntile,
+                                         ix->ivf_size, ix->ivfm_off, ix->ivfm_work, ix->ivfm_nwork, st, ix->ivfm_stride));
   if (ix->prof)  // tiles of the union of the blocks' lists (what one pass over shared lists would read): knnx_ivf_last_scan_tiles
     HIPCHK(launch_ivf_union_tiles(ix->ivfm_masks, nblk, ix->ivf_nlist, ix->ivf_ntile, ix->ivfm_nwork + IVFM_BLK, st));
   ScanArgs a{};
@@ -770,8 +750,8 @@ static int scan_topk_ivf_multi(knnx_index* ix, const float* q_dev, int nq, int k
     HIPCHK(hipEventRecord(e1, st));
     ix->prof_events.emplace_back(e0, e1);
   }
-  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, grid / nblk, KNN_NQ, k, nq, k, ix->id_base, ix->ivf_idmap, D_out, I_out,
-                          nullptr, st, KNN_NQ));
+  HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, grid - nblk + 1, KNN_NQ, k, nq, k, ix->id_base, ix->ivf_idmap, D_out, I_out,
+                          nullptr, st, KNN_NQ, ix->ivfm_nwork, nblk, grid));
   ix->ivfm_last_blk = nblk;
   return 0;
 }
@@ -1197,7 +1177,7 @@ static int step_queries(knnx_index* ix, int remaining, int k) {
 static int scan_step(knnx_index* ix, const float* q_dev, int remaining, int k, float* D_out, int64_t* I_out, hipStream_t st,
                      int* taken) {
   int nq, r;
-  if (ivfm_usable(ix, remaining, k) && ivfm_alloc(ix, ix->ivf_nprobe > KNNX_MAX_K_FAST) == 0) {
+  if (ivfm_usable(ix, remaining, k) && ivfm_alloc(ix) == 0) {
     nq = std::min(IVFM_BLK * KNN_NQ, remaining);
     r = scan_topk_ivf_multi(ix, q_dev, nq, k, D_out, I_out, st);
     *taken = nq;

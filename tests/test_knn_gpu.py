@@ -1373,6 +1373,13 @@ def test_ivf_multi_block_pass_equals_the_32_query_passes(nprobe, monkeypatch):
     D0, I0 = ix0.search(q, 40)
     ix0.close()
     assert np.array_equal(I, I0) and np.array_equal(D.view(np.uint32), D0.view(np.uint32))
+    # (32 queries and fewer are one block of the same pass: its coarse quantiser is the score dump + radix select, the old path's the
+    # top-nprobe queue scan)
+    ix = build_ivf_index(x, nlist, nprobe=nprobe, centroids=cent)
+    for nq in (1, 20, 32):
+        D1, I1 = ix.search(q[:nq], 40)
+        assert np.array_equal(I1, I0[:nq]) and np.array_equal(D1.view(np.uint32), D0[:nq].view(np.uint32)), nq
+    ix.close()
 
 
 # ------------------------------------------------------------------------------------------------------------

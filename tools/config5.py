@@ -32,7 +32,8 @@ HBM_PEAK_GBS = 8000.0
 
 
 def run(rows=125_000_000, d=1024, nlist=65536, clusters=0, nprobes=(16, 64, 256), threads=(1, 8, 64), seconds=3.0, k=40,
-        n_queries=1024, seed=5, niter=8, device=0, chunk=1 << 20, points_per_centroid=64, log=print, dedup_leg=True):
+        n_queries=1024, seed=5, niter=8, device=0, chunk=1 << 20, points_per_centroid=64, log=print, dedup_leg=True,
+        profile_batches=0):
     import numpy as np
     import torch
 
@@ -78,6 +79,15 @@ def run(rows=125_000_000, d=1024, nlist=65536, clusters=0, nprobes=(16, 64, 256)
     planted = qstride // 2 + qstride * np.arange(n_queries, dtype=np.int64)
     q = perturbed_queries(qrows.float().cpu().numpy(), noise=0.1, seed=4)
     del qrows
+
+    if profile_batches:  # rocprofv3 --kernel-trace --stats runs: only the B = 256 / 64 calls, a few of each per nprobe
+        for npb in nprobes:
+            ix.nprobe = npb
+            for B in (256, 64):
+                for _ in range(profile_batches):
+                    ix.search(q[:B], k)
+        ix.close()
+        return {"profile_batches": profile_batches}
 
     def search_all(B=32):
         D = np.empty((n_queries, k), np.float32)
@@ -224,10 +234,11 @@ def main():
     ap.add_argument("--niter", type=int, default=8)
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--points-per-centroid", type=int, default=64)
+    ap.add_argument("--profile-batches", type=int, default=0, help="build, then ONLY this many B = 256 and B = 64 calls per nprobe (for rocprofv3 --kernel-trace --stats)")
     a = ap.parse_args()
     out = run(rows=a.rows, d=a.d, nlist=a.nlist, clusters=a.clusters, nprobes=tuple(int(x) for x in a.nprobe.split(",")),
               threads=tuple(int(x) for x in a.threads.split(",")), seconds=a.seconds, niter=a.niter, n_queries=a.queries,
-              points_per_centroid=a.points_per_centroid, log=lambda m: print(m, flush=True))
+              points_per_centroid=a.points_per_centroid, log=lambda m: print(m, flush=True), profile_batches=a.profile_batches)
     print("CONFIG5 " + json.dumps(out), flush=True)
 
 
