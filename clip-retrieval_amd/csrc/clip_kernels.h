@@ -64,10 +64,13 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
                             int d, float eps, hipStream_t st, bf16* y16 = nullptr);
 
 // LayerNorm statistics of the 16-bit residual stream rows (f16 != 0: IEEE fp16, else bf16): rstd[m] = 1 / sqrt(var(x16[m, :]) + eps)
-// (bf16: two-pass, fp32; fp16: ONE pass in the canonical order of gemm_common.h ln_rstd_onepass -- the order the 4-wave GEMM kernel
-// accumulates the same sums in from its A fragments, so that a row's rstd does not depend on which of the two computed it).  The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias
+// (two-pass, fp32; or, for fp16 rows on request, ONE pass in the canonical order of gemm_common.h ln_rstd_onepass -- the order the
+// 4-wave GEMM kernel accumulates the same sums in from its A fragments, so that a row's rstd does not depend on which of the two
+// computed it: the CLIPX_LN_FUSED=1 experiment of round 6).  The LayerNorm itself is folded into the GEMM that follows (weights scaled by gamma and row-centred, bias
 // absorbs beta: clipx_api.hip fold_layernorm), whose epilogue multiplies by rstd[m].  One wave per row.
-hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16 = 0, int* range_flag = nullptr);
+// canonical != 0 (fp16 rows): the one-pass form of a GEMM that owns its statistics (GemmArgs.stats_eps)
+hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16 = 0, int* range_flag = nullptr,
+                           int canonical = 0);
 
 // LayerNorm-folded weights: Wf[n, k] = r16(W[n,k] gamma[k] - mean_k(W[n,:] gamma)), cf[n] = bias[n] + sum_k beta[k] W[n,k];
 // r16 = bf16 rounding, or IEEE fp16 when f16 != 0

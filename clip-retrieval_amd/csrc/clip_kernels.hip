@@ -551,7 +551,7 @@ hipError_t launch_gemm(const GemmArgs& g0, hipStream_t st) {
     }
     if (fused_rows < g.M) {
       hipError_t e = launch_rowstats(reinterpret_cast<const char*>(g.A) + (size_t)fused_rows * g.K * 2, const_cast<float*>(g.rowscale) + fused_rows,
-                                     g.M - fused_rows, g.K, g.stats_eps, st, 1, g.range_flag);
+                                     g.M - fused_rows, g.K, g.stats_eps, st, 1, g.range_flag, 1);
       if (e != hipSuccess) return e;
     }
     if (fused_rows == 0) g.stats_eps = 0.f;  // (every row scale is in the buffer: a plain folded GEMM from here on)
@@ -729,9 +729,9 @@ __global__ __launch_bounds__(256) void rowstats_f16_kernel(const void* __restric
   rstd[row] = ln_rstd_onepass(s1, s2, 1.f / (float)d, eps);
 }
 
-hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16, int* range_flag) {
+hipError_t launch_rowstats(const void* x16, float* rstd, int M, int d, float eps, hipStream_t st, int f16, int* range_flag, int canonical) {
   if (M <= 0) return hipSuccess;
-  if (f16) {
+  if (f16 && canonical) {
     const dim3 grid((M + 63) / 64), block(256);
 #define RSH_CASE(NV)                                                                                           \
   case NV * 256:                                                                                               \

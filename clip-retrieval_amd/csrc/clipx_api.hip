@@ -137,7 +137,10 @@ struct clipx_handle {
   // sum(eot_i + 1) rows instead of B x ctx_len.  Per call: lens / offsets / row map / pooled rows, built on the host from the
   // token ids, in a ring of RG_SLOTS page-locked + device buffers (a slot is reused when the event of its upload has passed).
   static constexpr int RG_SLOTS = 4;
-  bool ln_fused = true;  // LayerNorm statistics of the folded GEMMs inside the 4-wave GEMM kernel (CLIPX_LN_FUSED=0: a separate pass)
+  // LayerNorm statistics of the folded GEMMs inside the 4-wave GEMM kernel instead of a pass of their own: CLIPX_LN_FUSED=1, OFF by
+  // default -- measured 50.5 ms per ViT-L/14 step against 42.6 (profiles/r06o_ab_ln_fused.log): the 128 v_dot2_f32_f16 per K-tile do
+  // not hide behind the MFMAs of a one-wave-per-SIMD kernel (~8 cycles of issue each), they cost 8 ms to save 1.2
+  bool ln_fused = false;
   bool ragged_text = true;
   int* rg_host[RG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   int* rg_dev[RG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
@@ -344,7 +347,7 @@ extern "C" int clipx_create(const clipx_model_desc* desc, const float* blob, siz
   const char* gv = getenv("CLIPX_GEMM_VARIANT");
   if (gv) h->gemm_variant = std::min(6, std::max(0, atoi(gv)));  // 5: tools build only (falls back to 3 in the product)
   const char* lf = getenv("CLIPX_LN_FUSED");
-  if (lf && lf[0] == '0') h->ln_fused = false;
+  if (lf) h->ln_fused = lf[0] == '1';
   const char* rgt = getenv("CLIPX_RAGGED_TEXT");
   if (rgt && rgt[0] == '0') h->ragged_text = false;
   const char* fl = getenv("CLIPX_FULL_LAST_BLOCK");
@@ -486,7 +489,7 @@ static int run_layers(clipx_handle* h, hipStream_t st, const Tower& t, int B, in
   for (int l = 0; l < t.layers; ++l) {
     const LayerW& L = t.L[l];
     int r;
-    // (LayerNorm statistics: inside the GEMM -- run_gemm's stats_eps -- unless CLIPX_LN_FUSED=0 asks for the separate pass of rounds 2 - 5)
+    // (LayerNorm statistics: the separate pass of rounds 2 - 5, or with CLIPX_LN_FUSED=1 inside the GEMM -- run_gemm's stats_eps)
     if (!h->ln_fused) { ProfScope ps(h, st, 2, 0); HIPCHK(launch_rowstats(h->xn, h->rstd, M, w, eps, st, 1, h->cur_flag)); }
     if ((r = run_gemm(h, st, h->xn, L.qkv_w, L.qkv_c, h->qkv, nullptr, 1, M, 3 * w, w, EPI_BIAS_F16, h->rstd, true, h->ln_fused ? eps : 0.f))) return r;
     // last block of the image tower: only token 0's attention row is read afterwards -> query block 0 only (same arithmetic)
@@ -923,7 +926,7 @@ extern "C" int clipx_wait(clipx_ticket* t) {
 }
 
 static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const float* bias, void* out, int M, int N, int K, int epi,
-                     const float* rowscale, void* out16, void* stream, int f16 = 0) {
+                     const float* rowscale, void* out16, void* stream, int f16 = 0, float stats_eps = 0.f) {
   if (!A_bf16 || !W_bf16 || !out || M <= 0 || N <= 0 || K <= 0) return fail(CLIPX_E_ARG, "bad gemm arguments");
   if (!((epi >= 0 && epi <= 3) || epi == EPI_BIAS_RESID_H16 || epi == EPI_BIAS_F16) || !bias) return fail(CLIPX_E_ARG, "epi must be 0..3, 6 or 7 and bias non-null");
   if (f16 && epi > 2 && epi != EPI_BIAS_F16) return fail(CLIPX_E_ARG, "fp16 operands go with the 16-bit-output epilogues 0..2 and 7 only");
@@ -935,6 +938,8 @@ static int gemm_hook(int device, const void* A_bf16, const void* W_bf16, const f
   g.rowscale = rowscale;
   g.out16 = epi == 3 ? (bf16*)out16 : nullptr;
   g.f16 = f16;
+  g.stats_eps = stats_eps;
+  if (stats_eps > 0.f && !g.rowscale) return fail(CLIPX_E_ARG, "a GEMM that owns its LayerNorm statistics needs the [M] row-scale buffer");
   if (!g.rowscale) {  // bf16-output epilogues scale rows (LayerNorm-folded GEMMs of the encoder); a plain GEMM uses ones
     static std::mutex ones_mu;
     static float* ones[64] = {};
@@ -976,6 +981,12 @@ extern "C" int clipx_gemm_f16_device(int device, const void* A_f16, const void* 
   return gemm_hook(device, A_f16, W_f16, bias, out_bf16, M, N, K, epi, rowscale_or_null, nullptr, stream, 1);
 }
 
+extern "C" int clipx_gemm_f16_ln_device(int device, const void* A_f16, const void* W_f16, const float* bias, void* out_16bit, int M, int N,
+                                        int K, int epi, float* rstd_buf, float eps, void* stream) {
+  if (!(eps > 0.f)) return fail(CLIPX_E_ARG, "eps must be positive");
+  return gemm_hook(device, A_f16, W_f16, bias, out_16bit, M, N, K, epi, rstd_buf, nullptr, stream, 1, eps);
+}
+
 extern "C" int clipx_attention_device(int device, const void* qkv_bf16, void* out_bf16, int B, int T, int H, int causal,
                                       void* stream) {
   if (!qkv_bf16 || !out_bf16 || B <= 0 || T <= 0 || H <= 0) return fail(CLIPX_E_ARG, "bad attention arguments");
@@ -1010,7 +1021,7 @@ extern "C" int clipx_rowstats_device(int device, const void* x16, int is_f16, fl
   if (!x16 || !rstd || M <= 0) return fail(CLIPX_E_ARG, "bad rowstats arguments");
   if (d % 256 || d > 2048) return fail(CLIPX_E_UNSUPPORTED, "d must be a multiple of 256, <= 2048");
   HIPCHK(hipSetDevice(device));
-  HIPCHK(launch_rowstats(x16, rstd, M, d, eps, (hipStream_t)stream, is_f16 ? 1 : 0));
+  HIPCHK(launch_rowstats(x16, rstd, M, d, eps, (hipStream_t)stream, is_f16 ? 1 : 0, nullptr, is_f16 == 2 ? 1 : 0));
   return CLIPX_OK;
 }
 

@@ -184,6 +184,13 @@ int clipx_gemm_bf16_ex_device(int device, const void* A_bf16, const void* W_bf16
 int clipx_gemm_f16_device(int device, const void* A_f16, const void* W_f16, const float* bias, void* out_16bit, int M, int N, int K,
                           int epi, const float* rowscale_or_null, void* stream);
 
+/* The same GEMM as the encoder's folded layers run it since round 6 (mapper.py:57,65 -> the LayerNorm in front of QKV / fc1): the row
+ * scales are NOT an input but 1 / sqrt(var(A[m, :]) + eps) of the fp16 rows of A itself (K = the row length), computed inside the
+ * 4-wave 256x256 kernel for the rows it multiplies and by the statistics pass into rstd_buf [M] (scratch; only those rows are
+ * written) for the others -- the same bits either way (csrc/gemm_common.h: ln_rstd_onepass). */
+int clipx_gemm_f16_ln_device(int device, const void* A_f16, const void* W_f16, const float* bias, void* out_16bit, int M, int N, int K,
+                             int epi, float* rstd_buf, float eps, void* stream);
+
 /* The attention and LayerNorm kernels in isolation (device pointers), for per-kernel parity tests:
  * qkv IEEE fp16 [B*T, 3*H*64] (q | k | v as the QKV projection's epi 7 writes them; the products run on fp16 MFMA, P is
  * rounded to fp16) -> out bf16 [B*T, H*64];  x f32 [M, d] -> y (bf16 if out_bf16 else f32). */
@@ -195,7 +202,8 @@ int clipx_attention_dh_device(int device, const void* qkv_f16, void* out_bf16, i
 int clipx_layernorm_device(int device, const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
                            int M, int d, float eps, void* stream);
 /* LayerNorm statistics of the residual stream as the LayerNorm-folded GEMMs consume them (per-kernel parity test):
- * rstd[m] = 1 / sqrt(var(x16[m, :]) + eps) by a pass over the 16-bit rows (is_f16: IEEE fp16, else bf16). */
+ * rstd[m] = 1 / sqrt(var(x16[m, :]) + eps) by a pass over the 16-bit rows (is_f16: IEEE fp16, else bf16; is_f16 = 2: fp16 rows by the
+ * one-pass canonical form that clipx_gemm_f16_ln_device uses for the rows its 4-wave kernel does not take). */
 int clipx_rowstats_device(int device, const void* x16, int is_f16, float* rstd, int M, int d, float eps, void* stream);
 
 /* Live per-kernel timing for bench.py: launches of the enabled kinds are bracketed by hipEvents on

@@ -701,6 +701,58 @@ def test_large_batch_persistent_kernel_path_equals_128_path():
     full.close()
 
 
+@pytest.mark.parametrize("M,N,K", [(65792, 3072, 1024), (10547, 2304, 768), (16384, 4096, 1024), (256, 4096, 1024), (1000, 1024, 1024),
+                                   (33024, 1280, 1280)])
+def test_gemm_with_layernorm_statistics_inside(lib, M, N, K):
+    """Round 6, an experiment kept behind CLIPX_LN_FUSED=1 (it measured SLOWER: profiles/r06o_ab_ln_fused.log): the
+    LayerNorm-folded GEMMs (QKV, fc1) take the row scale 1 / sqrt(var(x) + eps) from the A fragments of their own K loop
+    (gemm256w4.hip, STATS) for the rows the 4-wave kernel multiplies; the other rows (ragged tail, small M, the other kernels) get
+    it from the one-pass statistics kernel, which sums in the same canonical order.  (1) the statistics pass against torch;
+    (2) the GEMM with the statistics inside equals -- bit for bit -- the GEMM given the pass's row scales, with every kernel variant;
+    (3) against torch fp32 on the same operands."""
+    from clip_retrieval_amd._lib import check
+
+    g = torch.Generator(device="cuda").manual_seed(M + 5 * N)
+    Ah = (torch.randn(M, K, generator=g, device="cuda") * 2.0 + 0.3).to(torch.float16)  # un-normalised rows with a mean
+    Ah[:, 7] += 60.0                                                                     # and a 'massive activation' channel
+    Ah[:, 1] += (torch.arange(M, device="cuda") % 113).to(torch.float16) * 0.02
+    Wh = (torch.randn(N, K, generator=g, device="cuda") * 0.04).to(torch.float16)
+    bias = torch.randn(N, generator=g, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    eps = 1e-5
+    rstd = torch.empty(M, device="cuda")
+    check(lib, lib.clipx_rowstats_device(0, _ptr(Ah), 2, _ptr(rstd), M, K, C.c_float(eps), C.c_void_p(st)), "clipx")  # 2: the canonical one-pass form
+    torch.cuda.synchronize()
+    want_r = 1.0 / torch.sqrt(Ah.double().var(dim=1, unbiased=False) + eps)
+    assert torch.allclose(rstd.double(), want_r, rtol=2e-5, atol=0), float(((rstd.double() - want_r) / want_r).abs().max())
+    ref = (Ah.float() @ Wh.float().T) * want_r.float()[:, None] + bias
+    outs = {}
+    for variant in (6, 3, 1):
+        os.environ["CLIPX_GEMM_VARIANT"] = str(variant)
+        for epi in (7, 1):
+            dt = torch.float16 if epi == 7 else torch.bfloat16
+            y_in = torch.empty(M, N, device="cuda", dtype=dt)
+            scratch = torch.full((M,), float("nan"), device="cuda")
+            check(lib, lib.clipx_gemm_f16_ln_device(0, _ptr(Ah), _ptr(Wh), _ptr(bias), _ptr(y_in), M, N, K, epi, _ptr(scratch), C.c_float(eps),
+                                                    C.c_void_p(st)), "clipx")
+            y_ex = torch.empty(M, N, device="cuda", dtype=dt)
+            check(lib, lib.clipx_gemm_f16_device(0, _ptr(Ah), _ptr(Wh), _ptr(bias), _ptr(y_ex), M, N, K, epi, _ptr(rstd), C.c_void_p(st)), "clipx")
+            torch.cuda.synchronize()
+            bad = (y_in.view(torch.int16) != y_ex.view(torch.int16)).nonzero()
+            assert bad.numel() == 0, f"variant {variant} epi {epi}: statistics inside != statistics pass at {bad[:5].tolist()} ({bad.shape[0]} elements)"
+            outs[(variant, epi)] = y_in
+            if variant == 6 and M >= 16384:  # the rows the 4-wave kernel took were never written by a pass
+                assert bool(torch.isnan(scratch[0])) and bool(torch.isnan(scratch[255]))
+    os.environ.pop("CLIPX_GEMM_VARIANT")
+    for epi in (7, 1):
+        for variant in (3, 1):
+            assert torch.equal(outs[(6, epi)].view(torch.int16), outs[(variant, epi)].view(torch.int16)), (variant, epi)
+        w = ref if epi == 7 else ref * torch.sigmoid(1.702 * ref)
+        e = (outs[(6, epi)].float() - w).abs()
+        t = (3e-4 + 6e-4 * w.abs()) if epi == 7 else (2e-3 + 4e-3 * w.abs())
+        assert (e <= t).all(), f"epi {epi}: max err {float(e.max()):.4g}"
+
+
 @pytest.mark.parametrize("M,N,K", [(16384, 1024, 1024), (65792, 1024, 4096), (19712, 768, 768), (1000, 1024, 1024), (257, 1280, 1280)])
 def test_gemm_fp16_residual_stream_hooks_both_kernels(lib, M, N, K):
     """Round 3: the residual stream lives in IEEE fp16.  (1) epi 6, out16 = fp16(f32(out16) + acc + bias) in place (bf16
