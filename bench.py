@@ -37,13 +37,29 @@ def refuse_debug_environment():
         raise SystemExit(f"bench.py refuses to run with debug/ablation switches set: {sorted(bad)}")
 
 
+def counters_match(j):
+    """A committed counter file belongs beside this run's timings only if it was measured on THIS tree's kernels: the summaries are
+    stamped with a digest of csrc/ + include/ (tools/source_digest.py); a file of another tree (or an unstamped one) is ignored and
+    the line says traffic / mfma_busy_frac null rather than quoting stale counters (VERDICT r5 #9)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_digest import source_digest  # pylint: disable=import-outside-toplevel
+
+        return j.get("source_digest") == source_digest()
+    except Exception:  # pylint: disable=broad-except
+        return False
+
+
 def pmc_traffic(kernel):
     """HBM bytes per STEP (encode kernels) / per scan (kNN) from the rocprofv3 --pmc passes of this same command
     (tools/gpu_round.sh -> tools/traffic_summary.py -> profiles/traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes,
     kernel-trace only).  Counters cannot be read from inside the run that is being timed; None when the file is absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            k = json.load(f)["kernels"][kernel]
+            j = json.load(f)
+        if not counters_match(j):
+            return None, None
+        k = j["kernels"][kernel]
         return int(k["bytes_per_unit"]), k["unit"]
     except (OSError, KeyError, ValueError):
         return None, None
@@ -55,7 +71,10 @@ def pmc_mfma_busy(family):
     the file is absent.  The `frac` beside it is arithmetic (flops / time / peak): the two differ by the clock the part sustained."""
     try:
         with open(os.path.join(ROOT, "profiles", "mfma_busy.json")) as f:
-            k = json.load(f)["families"][family]
+            j = json.load(f)
+        if not counters_match(j):
+            return None, None
+        k = j["families"][family]
         return k["mfma_busy_frac"], k["effective_clock_ghz"]
     except (OSError, KeyError, ValueError):
         return None, None
@@ -377,7 +396,7 @@ def main():
     # the committed counter passes were taken on the default workload only
     traffic, traffic_unit = pmc_traffic("gemm") if (args.model == "ViT-L/14" and B == 256) else (None, None)
     # one denominator throughout: everything below is PER STEP (one batch of 256 through both towers)
-    roofline = {"bound": "mfma", "kernel": "gemm256sp_kernel (+ gemm_bf16_kernel on the peeled 257th m-tile); bf16 / fp16 operands, f32 accumulate", "achieved": round(gemm_tflops, 1),
+    roofline = {"bound": "mfma", "kernel": "gemm256w4_kernel (4-wave 256x256, the 16-bit-output and fp16-residual forms) + gemm256sp_kernel / gemm_bf16_kernel on the other forms and ragged rows; bf16 / fp16 operands, f32 accumulate", "achieved": round(gemm_tflops, 1),
                 "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / BF16_PEAK_TFLOPS, 4),
                 "per": "step", "launches_per_step": g["launches"] // max(args.steps, 1), "ms_per_step": round(g["ms"] / max(args.steps, 1), 3),
                 "algorithmic_tflop_per_step": round(gemm_tflops * g["ms"] / max(args.steps, 1) / 1e3, 3),

@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
                                                           int ntm, int ntn, const float* __restrict__ rowscale, int tail_m0, int tail_nb, int stagger,
                                                           float stats_eps, int* __restrict__ range_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool DBG_TIMER = DBG == 16;
+  // DBG (tools build only): 16 = phase timer, results correct.  19 .. 23 = the timer + an ABLATION of the K loop (results are garbage,
+  // the timings say what each ingredient costs): 19 no operand DMAs, 20 no fragment reads, 21 neither, 22 no s_barrier, 23 no L2 prefetch
+  constexpr bool DBG_TIMER = DBG >= 16;
+  constexpr bool AB_NODMA = DBG == 19 || DBG == 21, AB_NOREAD = DBG == 20 || DBG == 21, AB_NOBAR = DBG == 22, AB_NOPF = DBG == 23;
   constexpr bool OUT16 = EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_F16;
   static_assert(OUT16 || EPI == EPI_BIAS_RESID_H16, "epilogue not built for the 4-wave kernel");
   static_assert(!STATS || (OUT16 && F16), "in-kernel LayerNorm statistics: fp16 operands and a 16-bit-output epilogue");
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
   const unsigned dmw = lds_base + w * 8192;  // this wave's first piece inside an operand tile
 #define W4_DMA(off, base, cimm)                                                                             \
-  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dmw), "n"(cimm) \
+  if (!AB_NODMA) asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dmw), "n"(cimm) \
                : "memory", "scc")
 // piece d of a stage: d & 1 = operand (0: M, 1: N), d >> 1 = which 8 rows
 #define W4_PIECE(pM, pN, buf, d)                                                          \
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
   const unsigned scr_m0 = lds_base + W4_SCR + w * W4_SCRW;
   const unsigned pf_m0 = scr_m0 + 7936;
 #define W4_PF(ptr) \
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(ptr), "s"(pf_m0) : "memory");
+  if (!AB_NOPF) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(ptr), "s"(pf_m0) : "memory");
 
   // ---- fragment read addresses: row l15 of a 16-row block (+ 2 KiB per block), k-chunk 4 sl + q4 of the 32-deep slab sl
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
   const unsigned ones2 = __builtin_amdgcn_readfirstlane(0x3c003c00u);  // (1.0h, 1.0h)
   f32x4 acc[8][8];  // [activation block mi][weight block ni]: a 16 x 16 MFMA block each
   w4_i32x4 Nd[2][8], Md[8];  // Md: a ring -- the fragment of unit U sits in slot U & 7 (requested at unit U - 6, when unit U - 8 is long done)
-#define W4_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define W4_DSREAD(dst, addr, off) \
+  if (AB_NOREAD) asm volatile("" : "+v"(dst)); else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define W4_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory");
 // the fragment requests at the top of unit u of the K-tile in buffer `buf`
 #define W4_READS(u, buf)                                                                          \
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16* __restric
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vm) : "memory");  \
   W4_FENCE();                                                \
-  __builtin_amdgcn_s_barrier();                              \
+  if (!AB_NOBAR) __builtin_amdgcn_s_barrier();               \
   W4_FENCE();
 #define W4_NOP
 #define W4_HK_NONE(u)
@@ -716,6 +720,15 @@ hipError_t launch_gemm256w4(const GemmArgs& g, int n_cu, hipStream_t st) {
       if (g.f16 && g.epi == EPI_BIAS_QGELU_BF16) return launch_w4_epi<EPI_BIAS_QGELU_BF16, true, 16>(g, grid, st);
       if (!g.f16 && g.epi == EPI_BIAS_BF16) return launch_w4_epi<EPI_BIAS_BF16, false, 16>(g, grid, st);
       if (!g.f16 && g.epi == EPI_BIAS_RESID_H16) return launch_w4_epi<EPI_BIAS_RESID_H16, false, 16>(g, grid, st);
+    }
+    if (dbg && atoi(dbg) >= 19 && atoi(dbg) <= 23 && g.f16 && g.epi == EPI_BIAS_F16) {  // K-loop ablations: the QKV form only
+      switch (atoi(dbg)) {
+        case 19: return launch_w4_epi<EPI_BIAS_F16, true, 19>(g, grid, st);
+        case 20: return launch_w4_epi<EPI_BIAS_F16, true, 20>(g, grid, st);
+        case 21: return launch_w4_epi<EPI_BIAS_F16, true, 21>(g, grid, st);
+        case 22: return launch_w4_epi<EPI_BIAS_F16, true, 22>(g, grid, st);
+        default: return launch_w4_epi<EPI_BIAS_F16, true, 23>(g, grid, st);
+      }
     }
   }
 #endif

@@ -10,7 +10,10 @@ import json
 import re
 import sys
 
-FAMILIES = {"gemm256sp_kernel": "gemm", "gemm_bf16_kernel": "gemm", "attention_pk_kernel": "attention", "attention_kernel": "attention",
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from source_digest import source_digest  # noqa: E402
+
+FAMILIES = {"gemm256sp_kernel": "gemm", "gemm256w4_kernel": "gemm", "gemm_bf16_kernel": "gemm", "attention_pk_kernel": "attention", "attention_kernel": "attention",
             "knn_rq8_scan_kernel": "knn_rq8_scan_kernel", "knn_rq_scan_kernel": "knn_rq_scan_kernel", "knn_scan_kernel": "knn_scan_kernel",
             "knn_assign_kernel": "knn_assign_kernel"}
 rows = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -57,4 +60,5 @@ for f, v in fam.items():
                           "mfma_busy_frac": round(sum(x[0] * x[2] for x in v) / us, 4)}
 out["note"] = ("SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over the 1024 SIMDs; kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter "
                "comes back summed over the 8 XCDs); profiled passes clock ~3 % lower than un-profiled ones (MI355X_MICROARCH.md, DVFS): compare fractions, not times")
+out["source_digest"] = source_digest()
 json.dump(out, sys.stdout, indent=1)

@@ -18,7 +18,10 @@ import csv
 import json
 import sys
 
-GROUPS = {"knn_rq8_scan_kernel": "knn_rq8_scan_kernel", "knn_rq_scan_kernel": "knn_rq_scan_kernel", "knn_scan_kernel": "knn_scan_kernel", "gemm256sp_kernel": "gemm", "gemm_bf16_kernel": "gemm",
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from source_digest import source_digest  # noqa: E402
+
+GROUPS = {"knn_rq8_scan_kernel": "knn_rq8_scan_kernel", "knn_rq_scan_kernel": "knn_rq_scan_kernel", "knn_scan_kernel": "knn_scan_kernel", "gemm256sp_kernel": "gemm", "gemm256w4_kernel": "gemm", "gemm_bf16_kernel": "gemm",
           "attention_kernel": "attention", "attention_pk_kernel": "attention", "layernorm_kernel": "layernorm"}
 SCANS = ("knn_scan_kernel", "knn_rq_scan_kernel", "knn_rq8_scan_kernel")
 
@@ -61,4 +64,4 @@ for k in sorted(set(fetch) | set(write)):
               "bytes_per_unit": round((fb + wb) / units)}
 json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE uncorrected; "
                    "counts are L2 <-> fabric requests (Infinity Cache hits included)",
-           "command": f"bench.py --steps {a.steps} --warmup {a.warmup}", "kernels": out}, sys.stdout, indent=1)
+           "command": f"bench.py --steps {a.steps} --warmup {a.warmup}", "source_digest": source_digest(), "kernels": out}, sys.stdout, indent=1)
