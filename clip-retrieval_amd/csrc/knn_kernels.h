@@ -41,8 +41,8 @@ struct ScanArgs {
   int wide;              // 1: QB = 2 wide scan (64 queries, approximate scores; flat top-k only)
   const unsigned* gate;  // run only if *gate != 0 (null: always)
   int tstride;           // flat scans: visit every tstride-th 32-row tile only (0 / 1 = all): the sample pass of the RQ scan
-  // nblk > 1: ceil(nq / 32) blocks of 32 queries side by side in ONE launch (modes 0 and 2, not wide; grid % nblk == 0): qfrag
-  // [nblk][d * 64], thr_g [32 nblk], work [nblk][work_stride], nwork [nblk], part_* block-major (knn_kernels.hip: knn_scan_kernel)
+  // nblk > 1: blocks of 32 (wide: 64) queries side by side in ONE launch (modes 0 and 2; grid % nblk == 0): qfrag [nblk][d * 64],
+  // thr_g [32 nblk] (wide: [64 nblk]), work [nblk][work_stride], nwork [nblk], part_* block-major (knn_kernels.hip: knn_scan_kernel)
   int nblk;
   unsigned work_stride;
 };
@@ -50,7 +50,8 @@ struct ScanArgs {
 size_t scan_smem_bytes(int d, int cap, int nq_slots);
 hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_g, unsigned* range_cnt, int wide,
                        const unsigned* gate, hipStream_t st);
-hipError_t launch_prep_blocks(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_a, int* thr_b_or_null, hipStream_t st);
+// (wide: blocks of 64 queries, the fp16-hi fragment images of the QB = 2 scan)
+hipError_t launch_prep_blocks(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_a, int* thr_b_or_null, hipStream_t st, int wide = 0);
 hipError_t launch_maxnorm(const _Float16* X, int64_t n, int d, int* maxnorm_enc, hipStream_t st);
 hipError_t launch_rescore(const _Float16* X, int d, const float* q, const int64_t* cand, const float* approx, int nq, int kw,
                           int k, int64_t id_base, const int* maxnorm_enc, float* D, int64_t* I, unsigned* need, unsigned* gate,

@@ -51,8 +51,9 @@ __device__ __forceinline__ bool better(float sa, uint32_t ia, float sb, uint32_t
 // query preparation: f32 [nq, d] -> hi/lo fp16 MFMA fragments; resets the per-scan global state
 // ---------------------------------------------------------------------------------------------
 // wide = 1: slot 1 holds the fp16 hi part of query n + 32 instead of the lo part of query n (QB = 2 scan)
-// gridDim.y > 1 (the multi-block IVF pass): block b = blockIdx.y prepares queries [32 b, 32 b + 32) into the b-th fragment image
-// and resets thresholds [32 b, 32 b + 32) of thr_g and of thr_g2 (the coarse and the fine scan of one pass: two arrays).
+// gridDim.y > 1 (the multi-block IVF pass; the sample scans of a register-stationary batch): block b = blockIdx.y prepares queries
+// [32 b, 32 b + 32) (wide: [64 b, 64 b + 64)) into the b-th fragment image and resets their thresholds in thr_g and in thr_g2 (the
+// coarse and the fine scan of one IVF pass: two arrays).
 __global__ void knn_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
                                         _Float16* __restrict__ qfrag, int* __restrict__ thr_g,
                                         unsigned* __restrict__ range_cnt, int wide, const unsigned* __restrict__ gate,
@@ -60,13 +61,14 @@ __global__ void knn_prep_queries_kernel(const float* __restrict__ q, int nq, int
   if (gate && *gate == 0) return;
   const int s = blockIdx.x;  // k-step
   const int lane = threadIdx.x;
+  const int qpb = wide ? KNN_NQ_MAX : KNN_NQ;  // queries per block (a wide block: the hi parts of 64 queries)
   if (gridDim.y > 1) {
     const int b = blockIdx.y;
-    q += (size_t)b * 32 * d;
-    nq -= 32 * b;
+    q += (size_t)b * qpb * d;
+    nq -= qpb * b;
     qfrag += (size_t)b * d * 64;
-    thr_g += 32 * b;
-    if (thr_g2) thr_g2 += 32 * b;
+    thr_g += qpb * b;
+    if (thr_g2) thr_g2 += qpb * b;
   }
   const int n = lane & 31, h = lane >> 5;
   half8 hi, lo;
@@ -82,7 +84,7 @@ __global__ void knn_prep_queries_kernel(const float* __restrict__ q, int nq, int
   half8* out = reinterpret_cast<half8*>(qfrag);
   out[(size_t)(s * 2 + 0) * 64 + lane] = hi;
   out[(size_t)(s * 2 + 1) * 64 + lane] = lo;
-  if (s == 0 && lane < (gridDim.y > 1 ? KNN_NQ : KNN_NQ_MAX)) {
+  if (s == 0 && lane < (gridDim.y > 1 ? qpb : KNN_NQ_MAX)) {
     thr_g[lane] = enc_f(-INFINITY);
     if (thr_g2) thr_g2[lane] = enc_f(-INFINITY);
     if (range_cnt && lane < KNN_NQ) range_cnt[lane] = 0u;
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
   const int lane = tid & 63, w = tid >> 6;
   const int q = lane & 31, hb = lane >> 5;
 
-  // nblk > 1 (QB = 1 only): SEVERAL 32-query blocks in one launch -- the IVF pass of a batch of up to 32 nblk queries.  Workgroup g
+  // nblk > 1: SEVERAL query blocks (32 queries; QB = 2: 64) in one launch -- the IVF pass of a batch of up to 32 nblk queries, the
+  // four 64-query sample scans of a 256-query register-stationary batch.  Workgroup g
   // serves query block g % nblk (its own fragment image, thresholds, work list, result slots) as member g / nblk of that block's
   // gridDim.x / nblk workgroups: nblk independent scans side by side, one launch and one set of small kernels around it.
   // Which block: the list scan (IVF) splits the workgroups in proportion to the blocks' work (ivfm_range); the flat scan (the
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
   size_t slot = blockIdx.x;  // where this workgroup's partial lists go
   if (nblk > 1) {
     const int g = (int)blockIdx.x, G = (int)gridDim.x;
-    if (IVF) {
+    if (IVF && MODE != 2) {
       bgrid = 0;
       for (int b = 0; b < nblk; ++b) {
         int s_, e_;
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
   }
   if (nblk > 1) {
     qfrag += (size_t)blk * D * 64;
-    nq = nq - 32 * blk < 32 ? nq - 32 * blk : 32;
-    thr_g += 32 * blk;
+    nq = nq - NQ * blk < NQ ? nq - NQ * blk : NQ;
+    thr_g += NQ * blk;
     if (IVF) {
       work += (size_t)blk * work_stride;
       nwork_ptr += blk;
@@ -1377,9 +1380,10 @@ hipError_t launch_prep(const float* q_dev, int nq, int d, _Float16* qfrag, int* 
   return hipGetLastError();
 }
 // ceil(nq / 32) blocks of 32 queries: fragment images [nblk][d * 64 halves], thresholds thr_a / thr_b [32 nblk] reset
-hipError_t launch_prep_blocks(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_a, int* thr_b, hipStream_t st) {
-  hipLaunchKernelGGL(knn_prep_queries_kernel, dim3(d / 16, (nq + 31) / 32), dim3(64), 0, st, q_dev, nq, d, qfrag, thr_a,
-                     (unsigned*)nullptr, 0, (const unsigned*)nullptr, thr_b);
+hipError_t launch_prep_blocks(const float* q_dev, int nq, int d, _Float16* qfrag, int* thr_a, int* thr_b, hipStream_t st, int wide) {
+  const int qpb = wide ? KNN_NQ_MAX : KNN_NQ;
+  hipLaunchKernelGGL(knn_prep_queries_kernel, dim3(d / 16, (nq + qpb - 1) / qpb), dim3(64), 0, st, q_dev, nq, d, qfrag, thr_a,
+                     (unsigned*)nullptr, wide ? 1 : 0, (const unsigned*)nullptr, thr_b);
   return hipGetLastError();
 }
 hipError_t launch_maxnorm(const _Float16* X, int64_t n, int d, int* maxnorm, hipStream_t st) {
@@ -1428,7 +1432,7 @@ static hipError_t launch_scan_mode(const ScanArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_scan(const ScanArgs& a, hipStream_t st) {
-  if (a.nblk > 1 && (a.wide || a.mode == 1 || a.grid % a.nblk != 0)) return hipErrorInvalidValue;
+  if (a.nblk > 1 && (a.mode == 1 || a.grid % a.nblk != 0)) return hipErrorInvalidValue;
   if (a.wide) return (a.mode == 0 && !a.work) ? launch_scan_mode<0, false, false, 2>(a, st) : hipErrorInvalidValue;
   if (a.work) {  // IVF work list: top-k (mode 0) or range (mode 1) over the rows of the probed lists
     if (a.mode == 0) return launch_scan_mode<0, false, true>(a, st);

@@ -92,6 +92,15 @@ struct knnx_index {
   int64_t* ivf_Ic = nullptr;     // [KNN_NQ, KNNX_MAX_K_FAST] coarse result
   float* ivf_Dc = nullptr;
   float* ivf_scores = nullptr;   // [KNN_NQ, nlist] coarse scores (nprobe > 64 only; allocated on first use)
+  // Unproven queries of the proof-based scans (wide / RQ / int8) get the exact 32-query scan of their group.  On the device-buffer
+  // entry point that scan is launched for every group, gated on the device (no host round trip); the host-buffer entry points
+  // (search_fast_locked) read the gates back with the results instead and launch it only for a group that needs it -- 4 gated
+  // no-op kernels per group, 32 per 256-query batch, ~0.16 ms of launch slots (profiles/r06r_knn_b256_timeline.log).
+  int sample_one_launch = 1;  // the sample scans of a register-stationary batch as blocks of one launch (KNNX_SAMPLE_STREAMS=1: a stream each)
+  _Float16* rq_m_qfrag = nullptr;
+  int* rq_m_thr = nullptr;
+  bool defer_fb = false;
+  int defer_kind = 0, defer_nq = 0;  // set by the scan that skipped its fallback: 1 = rq_need / rq_gate, 2 = wide_need / wide_gate
   // multi-block pass (scan_topk_ivf_multi): up to IVFM_BLK blocks of 32 queries in ONE coarse scan + ONE list scan; allocated on
   // first use, ivfm_ok = 0 (KNNX_IVF_MULTI=0, or an allocation failed) keeps the 32-queries-per-pass path
   int ivfm_ok = 1;
@@ -278,6 +287,8 @@ extern "C" int knnx_create(int device, int d, int metric, knnx_index** out) {
     const char* i8b = getenv("KNNX_I8_MAX_BYTES");
     ix->i8_budget = i8b ? std::max<int64_t>(0, atoll(i8b)) : 0;
   }
+  const char* ss = getenv("KNNX_SAMPLE_STREAMS");
+  ix->sample_one_launch = (ss && ss[0] == '1') ? 0 : 1;
   const char* im = getenv("KNNX_IVF_MULTI");
   ix->ivfm_ok = (im && im[0] == '0') ? 0 : 1;
   const char* rqm = getenv("KNNX_RQ_MIN_ROWS");
@@ -360,6 +371,8 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->rq_hit_r);
   hipFree(ix->rq_samp);
   hipFree(ix->rq_samp_i);
+  hipFree(ix->rq_m_qfrag);
+  hipFree(ix->rq_m_thr);
   for (int i = 0; i < knnx_index::RQ_SIDE; ++i) {
     hipFree(ix->rq_s_qfrag[i]);
     hipFree(ix->rq_s_thr_g[i]);
@@ -756,6 +769,25 @@ static int scan_topk_ivf_multi(knnx_index* ix, const float* q_dev, int nq, int k
   return 0;
 }
 
+// the exact scan of every 32-query group of a proof-based scan, gated on the device by gate[g] -- or (ix->defer_fb) left to the host
+// entry point, which reads the gates back: see knnx_index::defer_fb
+static int fallback_groups(knnx_index* ix, const float* q_dev, int nq, int k, float* D_out, int64_t* I_out, hipStream_t st, int kind) {
+  unsigned* need = kind == 1 ? ix->rq_need : ix->wide_need;
+  unsigned* gate = kind == 1 ? ix->rq_gate : ix->wide_gate;
+  if (ix->defer_fb) {
+    ix->defer_kind = kind;
+    ix->defer_nq = nq;
+    return 0;
+  }
+  for (int g = 0; g * KNN_NQ < nq; ++g) {
+    const int q0 = g * KNN_NQ, n = std::min(KNN_NQ, nq - q0);
+    int r = scan_topk(ix, q_dev + (size_t)q0 * ix->d, n, k, ix->wide_Dfb, ix->wide_Ifb, st, gate + g);
+    if (r) return r;
+    HIPCHK(launch_select(need, q0, n, k, ix->wide_Dfb, ix->wide_Ifb, D_out, I_out, st));
+  }
+  return 0;
+}
+
 // LDS capacity of the 64-queue wide scan at this d
 static int wide_cap(int d) {
   long avail = (long)KNN_LDS_BYTES - (long)d * 128 - KNN_NQ_MAX * 8 - 16;
@@ -803,14 +835,7 @@ static int scan_topk_wide(knnx_index* ix, const float* q_dev, int nq, int k, flo
                           ix->wide_approx, ix->wide_cand, nullptr, st));
   HIPCHK(launch_rescore(ix->rows, ix->d, q_dev, ix->wide_cand, ix->wide_approx, nq, KNN_WIDE_KW, k, ix->id_base, ix->maxnorm,
                         D_out, I_out, ix->wide_need, ix->wide_gate, ix->stats, st));
-  for (int half = 0; half < 2; ++half) {
-    const int q0 = half * KNN_NQ, n = std::min(KNN_NQ, nq - q0);
-    if (n <= 0) break;
-    int r = scan_topk(ix, q_dev + (size_t)q0 * ix->d, n, k, ix->wide_Dfb, ix->wide_Ifb, st, ix->wide_gate + half);
-    if (r) return r;
-    HIPCHK(launch_select(ix->wide_need, q0, n, k, ix->wide_Dfb, ix->wide_Ifb, D_out, I_out, st));
-  }
-  return 0;
+  return fallback_groups(ix, q_dev, nq, k, D_out, I_out, st, 2);
 }
 
 
@@ -844,6 +869,8 @@ static int rq_alloc(knnx_index* ix) {
   HIPCHK(hipMalloc(&ix->rq_hit_r, Q * KNN_RQ_CAP * sizeof(uint32_t)));
   HIPCHK(hipMalloc(&ix->rq_samp, Q * KNN_WIDE_KW * sizeof(float)));
   HIPCHK(hipMalloc(&ix->rq_samp_i, Q * KNN_WIDE_KW * sizeof(int64_t)));
+  HIPCHK(hipMalloc(&ix->rq_m_qfrag, (Q / KNN_NQ) * (size_t)ix->d * 128));  // fragment images of the sample scans of one batch, side by side
+  HIPCHK(hipMalloc(&ix->rq_m_thr, Q * sizeof(int)));
   const size_t G = (size_t)ix->n_cu;
   HIPCHK(hipEventCreateWithFlags(&ix->rq_fork, hipEventDisableTiming));
   for (int i = 0; i < knnx_index::RQ_SIDE; ++i) {
@@ -873,6 +900,46 @@ static int rq_sample_pass(knnx_index* ix, const float* q_dev, int nq, int k, int
   // them needs a whole CU's LDS per workgroup.  So the groups of a batch run side by side, each on its own quarter of the CUs
   // (own stream, own scratch): 4 x (prep + scan + merge) in the time of one.
   const int ngroups = (nq + gsz - 1) / gsz;
+  // Round 6: the groups of a batch as blocks of ONE launch (knn_scan_kernel, nblk: workgroup g serves group g % ngroups) instead of
+  // one stream each -- four streams only run side by side while the runtime has four hardware queues to give them: in
+  // profiles/r06r_knn_b256_timeline.log the fourth scan starts when the first three have finished (0.5 ms of a 256-query batch).
+  // KNNX_SAMPLE_STREAMS=1 keeps the streams.
+  if (ngroups > 1 && ix->sample_one_launch && ngroups <= KNN_RQ_MAX / KNN_NQ) {
+    const int grid = std::max(1, ix->n_cu / ngroups) * ngroups;
+    // only the J-th best sample score of a query is used: the queues keep J entries (>= 8), not 64 -- their thresholds rise sooner and
+    // the cold-queue pruning that makes up most of this scan's time (see above) ends sooner
+    const int jf0 = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
+    const int Jq = tstride <= 128 ? jf0 : std::max(6, std::min(jf0, (jf0 * 128 + tstride - 1) / tstride));
+    const int ks = std::min(KNN_WIDE_KW, std::max(8, Jq));
+    if (grid <= ix->n_cu) {
+      HIPCHK(launch_prep_blocks(q_dev, nq, d, ix->rq_m_qfrag, ix->rq_m_thr, nullptr, st, wide_samp ? 1 : 0));
+      ScanArgs a{};
+      a.X = ix->rows;
+      a.N = ix->ntotal;
+      a.d = d;
+      a.qfrag = ix->rq_m_qfrag;
+      a.nq = nq;
+      a.k = ks;
+      a.cap = wide_samp ? wide_cap(d) : scan_cap(d, KNN_WIDE_KW);
+      a.grid = grid;
+      a.mode = 0;
+      a.wide = wide_samp ? 1 : 0;
+      a.tstride = tstride;
+      a.thr_g = ix->rq_m_thr;
+      a.part_s = ix->part_s;
+      a.part_i = ix->part_i;
+      a.part_n = ix->part_n;
+      a.nblk = ngroups;
+      HIPCHK(launch_scan(a, st));
+      HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, grid / ngroups, gsz, ks, nq, KNN_WIDE_KW, 0, nullptr, ix->rq_samp,
+                              ix->rq_samp_i, nullptr, st, gsz));  // (rows of 64 with the entries past ks padded: the preps read entry J - 1)
+      const int jf = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
+      *tstride_out = tstride;
+      *J_out = tstride <= 128 ? jf : std::max(6, std::min(jf, (jf * 128 + tstride - 1) / tstride));
+      *wide_samp_out = wide_samp;
+      return 0;
+    }
+  }
   const int lanes = std::min(ngroups, 1 + knnx_index::RQ_SIDE);
   const int sgrid = std::max(1, std::min(ix->n_cu, ix->rq_sample_grid > 0 ? ix->rq_sample_grid : ix->n_cu / lanes));
   if (lanes > 1) HIPCHK(hipEventRecord(ix->rq_fork, st));
@@ -948,14 +1015,8 @@ static int scan_topk_rq(knnx_index* ix, const float* q_dev, int nq, int k, float
                           nullptr, st));
   HIPCHK(launch_rq_proof(q_dev, nq, d, k, D_out, ix->rq_thr, ix->rq_cnt, KNN_RQ_CAP, ix->rq_lost, ix->maxnorm, ix->rq_need,
                          ix->rq_gate, ix->stats, st));
-  // 4. unproven queries: the exact scan of their 32-query group, gated on the device
-  for (int g = 0; g * KNN_NQ < nq; ++g) {
-    const int q0 = g * KNN_NQ, n = std::min(KNN_NQ, nq - q0);
-    r = scan_topk(ix, q_dev + (size_t)q0 * d, n, k, ix->wide_Dfb, ix->wide_Ifb, st, ix->rq_gate + g);
-    if (r) return r;
-    HIPCHK(launch_select(ix->rq_need, q0, n, k, ix->wide_Dfb, ix->wide_Ifb, D_out, I_out, st));
-  }
-  return 0;
+  // 4. unproven queries: the exact scan of their 32-query group, gated on the device (or left to the host entry point)
+  return fallback_groups(ix, q_dev, nq, k, D_out, I_out, st, 1);
 }
 
 // ---- int8 first stage (knn_rq_kernels.hip, "int8 first stage"): 1 .. 256 queries in ONE pass over the int8 copy of the rows
@@ -1151,15 +1212,10 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
   HIPCHK(launch_merge_u32(ix->i8_hit_s, ix->i8_hit_r, ix->rq_cntc, 1, nq, (int)KNN_I8_CAP, nq, k, ix->id_base, nullptr, D_out, I_out,
                           nullptr, st));
   HIPCHK(launch_i8_proof(nq, k, D_out, ix->i8_lb, ix->rq_cnt, KNN_I8_CAP, ix->rq_lost, ix->rq_need, ix->rq_gate, ix->stats, st));
-  // 4. unproven queries (a hit list overflowed): the exact scan of their 32-query group, gated on the device
-  for (int g = 0; g * KNN_NQ < nq; ++g) {
-    const int q0 = g * KNN_NQ, n = std::min(KNN_NQ, nq - q0);
-    r = scan_topk(ix, q_dev + (size_t)q0 * d, n, k, ix->wide_Dfb, ix->wide_Ifb, st, ix->rq_gate + g);
-    if (r) return r;
-    HIPCHK(launch_select(ix->rq_need, q0, n, k, ix->wide_Dfb, ix->wide_Ifb, D_out, I_out, st));
-  }
+  // 4. unproven queries (a hit list overflowed): the exact scan of their 32-query group, gated on the device (or left to the host
+  // entry point)
   ix->i8_served += (unsigned long long)nq;
-  return 0;
+  return fallback_groups(ix, q_dev, nq, k, D_out, I_out, st, 1);
 }
 
 // how many of `remaining` queries the next scan step takes (the same choice scan_step makes)
@@ -1259,7 +1315,7 @@ static int search_fast_locked(knnx_index* ix, const float* q, int n, int k, floa
   const size_t QM = KNN_RQ_MAX;  // the widest scan's query count: staging is sized for it
   const size_t qb = QM * ix->d * sizeof(float);
   const size_t db = QM * k * sizeof(float), ib = QM * k * sizeof(int64_t);
-  int r = ensure_pin(ix, qb + db + ib);
+  int r = ensure_pin(ix, qb + db + ib + 64);
   if (r) return r;
   char* pin = (char*)ix->pin;
   if (scratch_acquire(ix, st)) return KNNX_E_HIP;
@@ -1269,13 +1325,35 @@ static int search_fast_locked(knnx_index* ix, const float* q, int n, int k, floa
     memcpy(pin, q + (size_t)o * ix->d, (size_t)nq * ix->d * sizeof(float));
     HIPCHK(hipMemcpyAsync(ix->q_dev, pin, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
     int took = 0;
+    // the proof-based scans leave their fallback to this function (knnx_index::defer_fb): the gates come back with the results
+    ix->defer_fb = true;
+    ix->defer_kind = 0;
     r = scan_step(ix, ix->q_dev, nq, k, ix->D_dev, ix->I_dev, st, &took);
+    ix->defer_fb = false;
     if (r) return r;
     // (the step may take fewer than were staged: the int8 path can turn itself off -- out of memory -- between the two decisions)
     if (took <= 0 || took > nq) return fail(KNNX_E_STATE, "internal: scan step size mismatch");
+    unsigned* gates = reinterpret_cast<unsigned*>(pin + qb + db + ib);
+    const int kind = ix->defer_kind, ngroup = kind ? (ix->defer_nq + KNN_NQ - 1) / KNN_NQ : 0;
+    if (kind) HIPCHK(hipMemcpyAsync(gates, kind == 1 ? ix->rq_gate : ix->wide_gate, (size_t)ngroup * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(pin + qb, ix->D_dev, (size_t)took * k * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(pin + qb + db, ix->I_dev, (size_t)took * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    bool again = false;
+    for (int g = 0; g < ngroup; ++g) {
+      if (!gates[g]) continue;
+      // a query of this group is unproven (rare: the bench counts them as fallbacks): its group's exact scan, then the rows again
+      const int q0 = g * KNN_NQ, m = std::min(KNN_NQ, ix->defer_nq - q0);
+      r = scan_topk(ix, ix->q_dev + (size_t)q0 * ix->d, m, k, ix->wide_Dfb, ix->wide_Ifb, st);
+      if (r) return r;
+      HIPCHK(launch_select(kind == 1 ? ix->rq_need : ix->wide_need, q0, m, k, ix->wide_Dfb, ix->wide_Ifb, ix->D_dev, ix->I_dev, st));
+      again = true;
+    }
+    if (again) {
+      HIPCHK(hipMemcpyAsync(pin + qb, ix->D_dev, (size_t)took * k * sizeof(float), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(pin + qb + db, ix->I_dev, (size_t)took * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
     memcpy(D + (size_t)o * k, pin + qb, (size_t)took * k * sizeof(float));
     memcpy(I + (size_t)o * k, pin + qb + db, (size_t)took * k * sizeof(int64_t));
     o += took;
