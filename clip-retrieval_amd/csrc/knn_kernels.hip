@@ -417,6 +417,74 @@ __global__ __launch_bounds__(KNN_WG, 2) void knn_scan_kernel(
 // LDS; a 32-step bisection finds the k-th largest value V, a second bisection over ids resolves ties at V
 // (ascending id), the exactly-k selected entries are compacted and rank-sorted.
 // ---------------------------------------------------------------------------------------------
+// RADIX select (round 6): the need-th largest of n order-encoded keys by three levels (11 + 11 + 10 bits) of an LDS histogram over the
+// keys that share the prefix found so far -> that value V and how many of the entries equal to V belong to the selection.  Takes
+// the place of the 32-step bisections (two barriers and a pass over the keys per step) of the merge and of the coarse quantiser.
+// hist: 2048 words of LDS, sh: 2 words; every thread of the NT-thread workgroup calls it; returns with V / need_out valid in every thread and
+// hist holding the last level's histogram (bin = key & 1023 among the keys that share V's upper 22 bits)
+// SKIP0: key 0 marks an empty slot that is never counted (the caller guarantees need <= the number of non-zero keys): the hit lists the
+// merge selects from are mostly empty slots, and 25 000 LDS atomics on ONE bin cost more than the rest of the kernel
+template <int NT, class KeyFn, bool SKIP0 = false>
+__device__ __forceinline__ void radix_select_block(KeyFn key, int n, unsigned need, unsigned* hist, unsigned* sh, unsigned& V,
+                                                  unsigned& need_out) {
+  const int tid = threadIdx.x;
+  unsigned prefix = 0;  // keys with this prefix: `need` of them (the largest) are still to be taken
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    const int shift = lvl == 0 ? 21 : (lvl == 1 ? 10 : 0);
+    const int nb = lvl == 2 ? 1024 : 2048;
+    const unsigned himask = lvl == 0 ? 0u : (lvl == 1 ? 0xffe00000u : 0xfffffc00u);
+    for (int b = tid; b < 2048; b += NT) hist[b] = 0u;
+    __syncthreads();
+    for (int l = tid; l < n; l += NT) {
+      const unsigned u = key(l);
+      const bool part = (u & himask) == prefix && !(SKIP0 && u == 0u);
+      const unsigned bin = (u >> shift) & (unsigned)(nb - 1);
+      // scores crowd into a few bins (every hit of a list lies within a narrow band above its threshold): same-address LDS atomics
+      // serialise -- 6 900 of them were 90 us of the merge.  The lanes that share the first participating lane's bin add ONE count.
+      const unsigned long long m = __ballot(part);
+      if (m != 0ull) {
+        const int leader = __ffsll((long long)m) - 1;
+        const unsigned b0 = (unsigned)__shfl((int)bin, leader);
+        const unsigned long long same = __ballot(part && bin == b0);
+        if (part && bin == b0) {
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+        } else if (part) {
+          atomicAdd(&hist[bin], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // the bin b with count(bins > b) < need <= count(bins >= b): lane L owns bins [L per, (L + 1) per)
+      const int per = nb / 64;
+      unsigned mine = 0;
+      for (int i = 0; i < per; ++i) mine += hist[tid * per + i];
+      unsigned suf = mine;  // inclusive suffix sum over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(suf, o);
+        if (tid + o < 64) suf += t;
+      }
+      const unsigned above = suf - mine;
+      if (above < need && need <= suf) {  // exactly one lane
+        unsigned acc = above;
+        int b = per - 1;
+        for (; b > 0; --b) {
+          const unsigned c = hist[tid * per + b];
+          if (acc + c >= need) break;
+          acc += c;
+        }
+        sh[0] = prefix | ((unsigned)(tid * per + b) << shift);
+        sh[1] = need - acc;
+      }
+    }
+    __syncthreads();
+    prefix = sh[0];
+    need = sh[1];
+    __syncthreads();  // (hist is cleared / sh rewritten only after everyone has read them)
+  }
+  V = prefix;
+  need_out = need;
+}
 __device__ __forceinline__ int block_count_256(int v, int* red) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __syncthreads();
@@ -451,8 +519,8 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
   unsigned* s_u = reinterpret_cast<unsigned*>(merge_smem);             // [P*kin] order-encoded score, 0 = empty
-  const int ncand = P * kin;
-  long long* sel_i = reinterpret_cast<long long*>(s_u + ((ncand + 3) & ~3));  // [64], 16-B aligned
+  const int ncap = P * kin;
+  long long* sel_i = reinterpret_cast<long long*>(s_u + ((ncap + 3) & ~3));  // [64], 16-B aligned
   float* sel_s = reinterpret_cast<float*>(sel_i + 64);                        // [64]
   int* red = reinterpret_cast<int*>(sel_s + 64);                              // [4] + counter
   const int qout = blockIdx.x, qq = blk_q > 0 ? (int)(blockIdx.x % (unsigned)blk_q) : (int)blockIdx.x, tid = threadIdx.x;
@@ -463,16 +531,45 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     return idmap ? (long long)idmap[(size_t)pi[gidx(c)]] : (long long)pi[gidx(c)] + id_base;
   };
 
+  // ONE list of up to kin entries (the hit lists of the register-stationary scans: kin = 32 768, a few thousand filled): only the
+  // filled part is walked -- by this loop and by every pass of the selection below.  (Walking all 32 768 slots with one dependent
+  // load per iteration was 0.1 ms of a 0.15 ms kernel: profiles/r06x_knn_b256_timeline.log.)
+  int ncand = ncap;
+  if (P == 1 && pn) {
+    const int nv = pn[qq];
+    ncand = nv < ncap ? (nv > 0 ? nv : 0) : ncap;
+  }
   int mine = 0;
+  if (P == 1 && pn) {
+    // every slot below ncand is filled: eight independent loads per thread in flight (the general loop below has two DEPENDENT global
+    // round trips per iteration -- the list's length, then the score -- and was ~4 us per iteration)
+    const float* pq = ps + (size_t)qq * kin;
+    for (int c0 = tid; c0 < ncand; c0 += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = pq[c0 + 256 * i < ncand ? c0 + 256 * i : c0];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (c0 + 256 * i < ncand) {
+          unsigned u = (unsigned)enc_f(v[i]) ^ 0x80000000u;
+          if (u == 0) u = 1;
+          s_u[c0 + 256 * i] = u;
+          ++mine;
+        }
+      }
+    }
+  } else
+#pragma unroll 4
   for (int c = tid; c < ncand; c += 256) {
     const int p = c / kin, j = c - p * kin;
     const size_t g = ((size_t)p * nq_stride + qq) * kin + j;
     bool ok;
     if (pn) ok = j < pn[p * nq_stride + qq];
     else ok = (long long)pi[g] >= 0;
+    const float sc = ps[ok ? g : 0];             // (unconditional: the loads of the unrolled iterations fly together)
     unsigned u = 0;
     if (ok) {
-      u = (unsigned)enc_f(ps[g]) ^ 0x80000000u;  // unsigned order == float order
+      u = (unsigned)enc_f(sc) ^ 0x80000000u;     // unsigned order == float order
       if (u == 0) u = 1;                         // (only a -NaN payload; keeps 0 = "empty")
     }
     s_u[c] = u;
@@ -482,19 +579,14 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
   const int ntot = block_count_256(mine, red);
   const int kk = ntot < k ? ntot : k;
   if (kk > 0) {
-    // V = kk-th largest encoded score
-    unsigned V = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-      const unsigned cand = V | (1u << bit);
-      int c = 0;
-      for (int e = tid; e < ncand; e += 256) c += s_u[e] >= cand ? 1 : 0;
-      if (block_count_256(c, red) >= kk) V = cand;
-    }
-    int cg = 0, ce = 0;
-    for (int e = tid; e < ncand; e += 256) { cg += s_u[e] > V ? 1 : 0; ce += s_u[e] == V ? 1 : 0; }
-    const int m1 = block_count_256(cg, red);
-    const int ceq = block_count_256(ce, red);
-    const int t = kk - m1;  // entries to take among the ties at V, smallest ids first
+    // V = kk-th largest encoded score (an empty slot is key 0 and kk <= the number of filled ones: V is a filled slot's key)
+    __shared__ unsigned m_hist[2048];
+    __shared__ unsigned m_sh[2];
+    unsigned V, need;
+    auto key_of = [&](int e) -> unsigned { return s_u[e]; };
+    radix_select_block<256, decltype(key_of), true>(key_of, ncand, (unsigned)kk, m_hist, m_sh, V, need);
+    const int ceq = (int)m_hist[V & 1023u];  // entries equal to V (the last level's histogram)
+    const int t = (int)need;                 // entries to take among the ties at V, smallest ids first
     long long X = 0x7fffffffffffffffll;
     if (ceq > t) {
       X = 0;
@@ -1092,55 +1184,6 @@ __device__ __forceinline__ int block_count_1024(int v, int* red) {
   for (int i = 0; i < 16; ++i) t += red[i];
   return t;
 }
-// hist: 2048 words of LDS, sh: 2 words; every thread of the 1024 calls it; returns with V / need_out valid in every thread and
-// hist holding the last level's histogram (bin = key & 1023 among the keys that share V's upper 22 bits)
-template <class KeyFn>
-__device__ __forceinline__ void radix_select_1024(KeyFn key, int n, unsigned need, unsigned* hist, unsigned* sh, unsigned& V,
-                                                  unsigned& need_out) {
-  const int tid = threadIdx.x;
-  unsigned prefix = 0;  // keys with this prefix: `need` of them (the largest) are still to be taken
-  for (int lvl = 0; lvl < 3; ++lvl) {
-    const int shift = lvl == 0 ? 21 : (lvl == 1 ? 10 : 0);
-    const int nb = lvl == 2 ? 1024 : 2048;
-    const unsigned himask = lvl == 0 ? 0u : (lvl == 1 ? 0xffe00000u : 0xfffffc00u);
-    for (int b = tid; b < 2048; b += 1024) hist[b] = 0u;
-    __syncthreads();
-    for (int l = tid; l < n; l += 1024) {
-      const unsigned u = key(l);
-      if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & (unsigned)(nb - 1)], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) {  // the bin b with count(bins > b) < need <= count(bins >= b): lane L owns bins [L per, (L + 1) per)
-      const int per = nb / 64;
-      unsigned mine = 0;
-      for (int i = 0; i < per; ++i) mine += hist[tid * per + i];
-      unsigned suf = mine;  // inclusive suffix sum over the lanes
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_down(suf, o);
-        if (tid + o < 64) suf += t;
-      }
-      const unsigned above = suf - mine;
-      if (above < need && need <= suf) {  // exactly one lane
-        unsigned acc = above;
-        int b = per - 1;
-        for (; b > 0; --b) {
-          const unsigned c = hist[tid * per + b];
-          if (acc + c >= need) break;
-          acc += c;
-        }
-        sh[0] = prefix | ((unsigned)(tid * per + b) << shift);
-        sh[1] = need - acc;
-      }
-    }
-    __syncthreads();
-    prefix = sh[0];
-    need = sh[1];
-    __syncthreads();  // (hist is cleared / sh rewritten only after everyone has read them)
-  }
-  V = prefix;
-  need_out = need;
-}
 __global__ __launch_bounds__(1024) void ivf_select_mark_kernel(const float* __restrict__ scores, int nlist, int nprobe,
                                                               unsigned* __restrict__ masks) {
   constexpr int SV_CAP = 2048;
@@ -1166,7 +1209,7 @@ __global__ __launch_bounds__(1024) void ivf_select_mark_kernel(const float* __re
     if (tid == 0) sh_cnt = 0;
     __syncthreads();
     unsigned T0, unused;
-    radix_select_1024([&](int i) -> unsigned { return sv_key[i]; }, 1024, (unsigned)np, hist, sh, T0, unused);
+    radix_select_block<1024>([&](int i) -> unsigned { return sv_key[i]; }, 1024, (unsigned)np, hist, sh, T0, unused);
     for (int l = tid; l < nlist; l += 1024) {
       const unsigned u = enc(s[l]);
       if (u >= T0) {
@@ -1192,7 +1235,7 @@ __global__ __launch_bounds__(1024) void ivf_select_mark_kernel(const float* __re
     __syncthreads();  // (everyone has read sh_cnt; the general path reuses the LDS)
   }
   unsigned V, need;
-  radix_select_1024([&](int l) -> unsigned { return enc(s[l]); }, nlist, (unsigned)np, hist, sh, V, need);
+  radix_select_block<1024>([&](int l) -> unsigned { return enc(s[l]); }, nlist, (unsigned)np, hist, sh, V, need);
   const int t = (int)need;                   // entries to take among the ties at V, smallest list ids first
   const int ceq = (int)hist[V & 1023u];      // entries equal to V (the last level's histogram)
   int X = 0x7fffffff;
@@ -1459,7 +1502,7 @@ hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, i
                             int64_t* I, hipStream_t st) {
   if (k > 64) return hipErrorInvalidValue;
   const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
-  if (smem > (size_t)KNN_LDS_BYTES) return hipErrorInvalidValue;
+  if (smem + 8256 > (size_t)KNN_LDS_BYTES) return hipErrorInvalidValue;  // (+ the kernel's static radix histogram)
   auto kern = knn_merge_kernel<int64_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
