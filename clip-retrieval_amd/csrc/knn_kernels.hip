@@ -558,13 +558,22 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
         }
       }
     }
-  } else
+  } else {
+  // the P list lengths once, into the LDS (they were a global load in front of every score load: two dependent round trips per
+  // iteration, 48 us for 128 lists of 40)
+  __shared__ int s_pn[256];
+  const bool pn_lds = pn && P <= 256;
+  if (pn_lds) {
+    if (tid < P) s_pn[tid] = pn[tid * nq_stride + qq];
+    __syncthreads();
+  }
 #pragma unroll 4
   for (int c = tid; c < ncand; c += 256) {
     const int p = c / kin, j = c - p * kin;
     const size_t g = ((size_t)p * nq_stride + qq) * kin + j;
     bool ok;
-    if (pn) ok = j < pn[p * nq_stride + qq];
+    if (pn_lds) ok = j < s_pn[p];
+    else if (pn) ok = j < pn[p * nq_stride + qq];
     else ok = (long long)pi[g] >= 0;
     const float sc = ps[ok ? g : 0];             // (unconditional: the loads of the unrolled iterations fly together)
     unsigned u = 0;
@@ -574,6 +583,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     }
     s_u[c] = u;
     mine += ok ? 1 : 0;
+  }
   }
   if (tid == 0) red[4] = 0;
   const int ntot = block_count_256(mine, red);
@@ -1057,75 +1067,34 @@ __global__ void ivf_mark_kernel(const int64_t* __restrict__ Ic, int nq, int npro
   if (l >= 0 && l < nlist) atomicOr(&masks[(size_t)(qi >> 5) * nlist + l], 1u << (qi & 31));
 }
 
-// one workgroup per query block: exclusive prefix sum of (mask[l] ? ntile[l] : 0) -> off[l]; total -> *nwork.  Chunks of 16 rounds of
-// 1024 lists: the 32 loads of a chunk are issued together (a round at a time they were 64 dependent L2 round trips: 80 us for 65 536
-// lists), a shuffle scan inside each wave, the 16 x 16 wave totals through the LDS, two barriers per chunk.  (The Hillis-Steele
-// scan over the LDS of rounds 3-5 took 150 us: profiles/r06k_*.)
-__global__ __launch_bounds__(1024) void ivf_offsets_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ ntile,
-                                                          int nlist, unsigned* __restrict__ off, unsigned* __restrict__ nwork) {
-  constexpr int R = 16;
-  __shared__ unsigned wsum[R][16];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  masks += (size_t)blockIdx.x * nlist;  // (the multi-block pass; a single block otherwise)
-  off += (size_t)blockIdx.x * nlist;
-  nwork += blockIdx.x;
-  unsigned carry = 0;  // every thread keeps the running total
-  for (int base = 0; base < nlist; base += R * 1024) {
-    unsigned m[R], t[R], inc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int l = base + r * 1024 + tid;
-      m[r] = l < nlist ? masks[l] : 0u;
-      t[r] = l < nlist ? ntile[l] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const unsigned v = m[r] ? t[r] : 0u;
-      t[r] = v;
-      unsigned x = v;  // inclusive scan inside the wave
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-      }
-      inc[r] = x;
-      if (lane == 63) wsum[r][wv] = x;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      unsigned before = 0, total = 0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const unsigned y = wsum[r][i];
-        before += i < wv ? y : 0u;
-        total += y;
-      }
-      const int l = base + r * 1024 + tid;
-      if (l < nlist) off[l] = carry + before + inc[r] - t[r];
-      carry += total;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) *nwork = carry;
-}
-
-// one THREAD per list (blockIdx.y = query block): a probed list writes its tiles into the block's work list.  (One workgroup per
-// list -- 65 536 x nblk workgroups, nearly all of which find their list unprobed and leave -- took 30 us.)
+// Work list of a query block (blockIdx.y): a thread looks at one list, and the WAVE writes the tiles of each probed list among its 64
+// (lane t -> tile t, t + 64, ..: whole lines of the work list) at a position it takes from the block's tile counter with ONE atomic
+// per probed list -- nwork[b], zeroed by the launcher, ends as the length of the list.  The order of the lists in the work list is
+// whatever order the atomics retire in: the scan's result does not depend on it (exact top-k, ties by id).  (Rounds 3 - 5: a prefix
+// sum over all lists -- a single-workgroup kernel of 60 - 150 us for 65 536 lists -- then one workgroup per list, 30 us.)
 __global__ __launch_bounds__(256) void ivf_expand_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ tile0,
                                                         const unsigned* __restrict__ ntile, const unsigned* __restrict__ size,
-                                                        const unsigned* __restrict__ off, uint4* __restrict__ work,
+                                                        unsigned* __restrict__ nwork, uint4* __restrict__ work,
                                                         unsigned work_stride, int nlist) {
-  const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= nlist) return;
+  const int l = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
   const size_t b = blockIdx.y;
-  const unsigned m = masks[b * nlist + l];
-  if (!m) return;
+  const unsigned m = l < nlist ? masks[b * nlist + l] : 0u;
+  unsigned long long probed = __ballot(m != 0u);
+  if (probed == 0ull) return;
+  const unsigned nt = m ? ntile[l] : 0u, t0 = m ? tile0[l] : 0u, sz = m ? size[l] : 0u;
   work += b * work_stride;
-  const unsigned nt = ntile[l], t0 = tile0[l], o = off[b * nlist + l], sz = size[l];
-  for (unsigned t = 0; t < nt; ++t) {
-    const unsigned valid = (t + 1 < nt) ? 32u : sz - 32u * (nt - 1);
-    work[o + t] = make_uint4(t0 + t, m, valid, 0u);
+  while (probed) {
+    const int src = __ffsll((long long)probed) - 1;
+    probed &= probed - 1;
+    const unsigned mm = (unsigned)__shfl((int)m, src), nn = (unsigned)__shfl((int)nt, src), tt = (unsigned)__shfl((int)t0, src),
+                   ss = (unsigned)__shfl((int)sz, src);
+    unsigned oo = 0;
+    if (lane == 0) oo = atomicAdd(&nwork[b], nn);
+    oo = (unsigned)__shfl((int)oo, 0);
+    for (unsigned t = lane; t < nn; t += 64) {
+      const unsigned valid = (t + 1 < nn) ? 32u : ss - 32u * (nn - 1);
+      work[oo + t] = make_uint4(tt + t, mm, valid, 0u);
+    }
   }
 }
 
@@ -1361,10 +1330,11 @@ hipError_t launch_ivf_worklist_from_scores(const float* scores, int nq, int npro
                                            hipStream_t st, unsigned work_stride) {
   const int nblk = (nq + 31) / 32;
   hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
+  if (e == hipSuccess) e = hipMemsetAsync(nwork, 0, (size_t)nblk * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_select_mark_kernel, dim3(nq), dim3(1024), 0, st, scores, nlist, nprobe, masks);
-  hipLaunchKernelGGL(ivf_offsets_kernel, dim3(nblk), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
-  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, off, work, work_stride, nlist);
+  (void)off;  // (the per-list offsets of rounds 3 - 5: positions now come from the blocks' tile counters, ivf_expand_kernel)
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, nwork, work, work_stride, nlist);
   return hipGetLastError();
 }
 
@@ -1373,10 +1343,11 @@ hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist,
                                hipStream_t st, unsigned work_stride) {
   const int nblk = (nq + 31) / 32;
   hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
+  if (e == hipSuccess) e = hipMemsetAsync(nwork, 0, (size_t)nblk * sizeof(unsigned), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_mark_kernel, dim3((nq * nprobe + 255) / 256), dim3(256), 0, st, Ic, nq, nprobe, nlist, masks);
-  hipLaunchKernelGGL(ivf_offsets_kernel, dim3(nblk), dim3(1024), 0, st, masks, ntile, nlist, off, nwork);
-  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, off, work, work_stride, nlist);
+  (void)off;  // (the per-list offsets of rounds 3 - 5: positions now come from the blocks' tile counters, ivf_expand_kernel)
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, nwork, work, work_stride, nlist);
   return hipGetLastError();
 }
 // tiles of the lists at least one of the nblk query blocks probes -> *out
@@ -1502,7 +1473,7 @@ hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, i
                             int64_t* I, hipStream_t st) {
   if (k > 64) return hipErrorInvalidValue;
   const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
-  if (smem + 8256 > (size_t)KNN_LDS_BYTES) return hipErrorInvalidValue;  // (+ the kernel's static radix histogram)
+  if (smem + 9472 > (size_t)KNN_LDS_BYTES) return hipErrorInvalidValue;  // (+ the kernel's static LDS: radix histogram, list lengths)
   auto kern = knn_merge_kernel<int64_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
