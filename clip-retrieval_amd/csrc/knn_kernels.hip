@@ -485,6 +485,16 @@ __device__ __forceinline__ void radix_select_block(KeyFn key, int n, unsigned ne
   V = prefix;
   need_out = need;
 }
+__device__ __forceinline__ int block_count_1024(int v, int* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += red[i];
+  return t;
+}
 __device__ __forceinline__ int block_count_256(int v, int* red) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __syncthreads();
@@ -493,8 +503,11 @@ __device__ __forceinline__ int block_count_256(int v, int* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// 1024 threads per query (round 6; 256 before): the kernel is a chain of short passes over a few thousand candidates with a barrier
+// between them, and a launch is one workgroup per query -- 64 workgroups of 256 threads left most of the chip idle for 43 us.
+constexpr int MERGE_NT = 1024;
 template <typename IdT>
-__global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict__ ps, const IdT* __restrict__ pi,
+__global__ __launch_bounds__(MERGE_NT) void knn_merge_kernel(const float* __restrict__ ps, const IdT* __restrict__ pi,
                                                        const int* __restrict__ pn, int P, int nq_stride, int kin,
                                                        int k, int64_t id_base, const int64_t* __restrict__ idmap,
                                                        float* __restrict__ D, int64_t* __restrict__ I,
@@ -522,7 +535,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
   const int ncap = P * kin;
   long long* sel_i = reinterpret_cast<long long*>(s_u + ((ncap + 3) & ~3));  // [64], 16-B aligned
   float* sel_s = reinterpret_cast<float*>(sel_i + 64);                        // [64]
-  int* red = reinterpret_cast<int*>(sel_s + 64);                              // [4] + counter
+  int* red = reinterpret_cast<int*>(sel_s + 64);                              // [16] + counter
   const int qout = blockIdx.x, qq = blk_q > 0 ? (int)(blockIdx.x % (unsigned)blk_q) : (int)blockIdx.x, tid = threadIdx.x;
 
   auto gidx = [&](int c) -> size_t { return ((size_t)(c / kin) * nq_stride + qq) * kin + (c % kin); };
@@ -544,16 +557,16 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     // every slot below ncand is filled: eight independent loads per thread in flight (the general loop below has two DEPENDENT global
     // round trips per iteration -- the list's length, then the score -- and was ~4 us per iteration)
     const float* pq = ps + (size_t)qq * kin;
-    for (int c0 = tid; c0 < ncand; c0 += 8 * 256) {
+    for (int c0 = tid; c0 < ncand; c0 += 8 * MERGE_NT) {
       float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = pq[c0 + 256 * i < ncand ? c0 + 256 * i : c0];
+      for (int i = 0; i < 8; ++i) v[i] = pq[c0 + MERGE_NT * i < ncand ? c0 + MERGE_NT * i : c0];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (c0 + 256 * i < ncand) {
+        if (c0 + MERGE_NT * i < ncand) {
           unsigned u = (unsigned)enc_f(v[i]) ^ 0x80000000u;
           if (u == 0) u = 1;
-          s_u[c0 + 256 * i] = u;
+          s_u[c0 + MERGE_NT * i] = u;
           ++mine;
         }
       }
@@ -568,7 +581,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     __syncthreads();
   }
 #pragma unroll 4
-  for (int c = tid; c < ncand; c += 256) {
+  for (int c = tid; c < ncand; c += MERGE_NT) {
     const int p = c / kin, j = c - p * kin;
     const size_t g = ((size_t)p * nq_stride + qq) * kin + j;
     bool ok;
@@ -585,8 +598,8 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     mine += ok ? 1 : 0;
   }
   }
-  if (tid == 0) red[4] = 0;
-  const int ntot = block_count_256(mine, red);
+  if (tid == 0) red[16] = 0;
+  const int ntot = block_count_1024(mine, red);
   const int kk = ntot < k ? ntot : k;
   if (kk > 0) {
     // V = kk-th largest encoded score (an empty slot is key 0 and kk <= the number of filled ones: V is a filled slot's key)
@@ -594,7 +607,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
     __shared__ unsigned m_sh[2];
     unsigned V, need;
     auto key_of = [&](int e) -> unsigned { return s_u[e]; };
-    radix_select_block<256, decltype(key_of), true>(key_of, ncand, (unsigned)kk, m_hist, m_sh, V, need);
+    radix_select_block<MERGE_NT, decltype(key_of), true>(key_of, ncand, (unsigned)kk, m_hist, m_sh, V, need);
     const int ceq = (int)m_hist[V & 1023u];  // entries equal to V (the last level's histogram)
     const int t = (int)need;                 // entries to take among the ties at V, smallest ids first
     long long X = 0x7fffffffffffffffll;
@@ -603,13 +616,13 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
       for (int bit = 62; bit >= 0; --bit) {
         const long long hi = X | ((1ll << bit) - 1);  // largest id with this prefix and the bit clear
         int c = 0;
-        for (int e = tid; e < ncand; e += 256)
+        for (int e = tid; e < ncand; e += MERGE_NT)
           if (s_u[e] == V) c += get_id(e) <= hi ? 1 : 0;
-        if (block_count_256(c, red) < t) X |= (1ll << bit);
+        if (block_count_1024(c, red) < t) X |= (1ll << bit);
       }
     }
     // compact the exactly-kk selected entries
-    for (int e = tid; e < ncand; e += 256) {
+    for (int e = tid; e < ncand; e += MERGE_NT) {
       const unsigned u = s_u[e];
       bool take = u > V;
       long long id = 0;
@@ -618,7 +631,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
         if (u == V) take = id <= X;
       }
       if (take) {
-        const int pos = atomicAdd(&red[4], 1);
+        const int pos = atomicAdd(&red[16], 1);
         if (pos < 64) { sel_s[pos] = ps[gidx(e)]; sel_i[pos] = id; }
       }
     }
@@ -636,7 +649,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
       I[(size_t)qout * k + r] = ie;
     }
   }
-  for (int j = kk + tid; j < k; j += 256) { D[(size_t)qout * k + j] = -FLT_MAX; I[(size_t)qout * k + j] = -1; }
+  for (int j = kk + tid; j < k; j += MERGE_NT) { D[(size_t)qout * k + j] = -FLT_MAX; I[(size_t)qout * k + j] = -1; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1143,16 +1156,6 @@ __global__ void knn_gather_rows_inv_kernel(const _Float16* __restrict__ X, int d
 //   * general path (more than SV_CAP entries >= T0: duplicate / zero centroids; nprobe > 512): the radix select over the whole row
 //     (65 536 LDS atomics per level into a handful of hot bins: ~17 us per level), ties at V resolved by a bisection over list
 //     ids.  The 32-step bisection over scores this replaces read the row 33 times (the nprobe > 64 path of rounds 3-5).
-__device__ __forceinline__ int block_count_1024(int v, int* red) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  int t = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) t += red[i];
-  return t;
-}
 __global__ __launch_bounds__(1024) void ivf_select_mark_kernel(const float* __restrict__ scores, int nlist, int nprobe,
                                                               unsigned* __restrict__ masks) {
   constexpr int SV_CAP = 2048;
@@ -1329,8 +1332,13 @@ hipError_t launch_ivf_worklist_from_scores(const float* scores, int nq, int npro
                                            const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
                                            hipStream_t st, unsigned work_stride) {
   const int nblk = (nq + 31) / 32;
-  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(nwork, 0, (size_t)nblk * sizeof(unsigned), st);
+  hipError_t e;
+  if (nwork + 16 == masks) {  // (the counters sit right in front of the masks: one fill)
+    e = hipMemsetAsync(nwork, 0, ((size_t)nblk * nlist + 16) * sizeof(unsigned), st);
+  } else {
+    e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
+    if (e == hipSuccess) e = hipMemsetAsync(nwork, 0, (size_t)nblk * sizeof(unsigned), st);
+  }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_select_mark_kernel, dim3(nq), dim3(1024), 0, st, scores, nlist, nprobe, masks);
   (void)off;  // (the per-list offsets of rounds 3 - 5: positions now come from the blocks' tile counters, ivf_expand_kernel)
@@ -1342,8 +1350,13 @@ hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist,
                                const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
                                hipStream_t st, unsigned work_stride) {
   const int nblk = (nq + 31) / 32;
-  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
-  if (e == hipSuccess) e = hipMemsetAsync(nwork, 0, (size_t)nblk * sizeof(unsigned), st);
+  hipError_t e;
+  if (nwork + 16 == masks) {  // (the counters sit right in front of the masks: one fill)
+    e = hipMemsetAsync(nwork, 0, ((size_t)nblk * nlist + 16) * sizeof(unsigned), st);
+  } else {
+    e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
+    if (e == hipSuccess) e = hipMemsetAsync(nwork, 0, (size_t)nblk * sizeof(unsigned), st);
+  }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_mark_kernel, dim3((nq * nprobe + 255) / 256), dim3(256), 0, st, Ic, nq, nprobe, nlist, masks);
   (void)off;  // (the per-list offsets of rounds 3 - 5: positions now come from the blocks' tile counters, ivf_expand_kernel)
@@ -1461,23 +1474,23 @@ hipError_t launch_merge_u32(const float* ps, const uint32_t* pi, const int* pn, 
                             int nq, int k, int64_t id_base, const int64_t* idmap, float* D, int64_t* I,
                             const unsigned* gate, hipStream_t st, int blk_q, const unsigned* blk_work, int nblk, int G) {
   if (k > 64) return hipErrorInvalidValue;
-  const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
+  const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 96;
   auto kern = knn_merge_kernel<uint32_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I, gate, blk_q, blk_work,
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(MERGE_NT), smem, st, ps, pi, pn, P, nq_stride, kin, k, id_base, idmap, D, I, gate, blk_q, blk_work,
                      nblk, G);
   return hipGetLastError();
 }
 hipError_t launch_merge_i64(const float* ps, const int64_t* pi, int P, int nq, int kin, int k, float* D,
                             int64_t* I, hipStream_t st) {
   if (k > 64) return hipErrorInvalidValue;
-  const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 32;
+  const size_t smem = (size_t)((P * kin + 3) & ~3) * 4 + 64 * 12 + 96;
   if (smem + 9472 > (size_t)KNN_LDS_BYTES) return hipErrorInvalidValue;  // (+ the kernel's static LDS: radix histogram, list lengths)
   auto kern = knn_merge_kernel<int64_t>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(nq), dim3(256), smem, st, ps, pi, (const int*)nullptr, P, nq, kin, k, (int64_t)0,
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(MERGE_NT), smem, st, ps, pi, (const int*)nullptr, P, nq, kin, k, (int64_t)0,
                      (const int64_t*)nullptr, D, I, (const unsigned*)nullptr, 0, (const unsigned*)nullptr, 0, 0);
   return hipGetLastError();
 }

@@ -105,9 +105,10 @@ struct knnx_index {
   // first use, ivfm_ok = 0 (KNNX_IVF_MULTI=0, or an allocation failed) keeps the 32-queries-per-pass path
   int ivfm_ok = 1;
   int ivfm_last_blk = 0;           // blocks of the most recent IVF scan (0: the single-block path) -- knnx_ivf_last_scan_tiles
+  bool ivfm_union_valid = false;   // the most recent pass also counted the union of its lists (profiling was on)
   _Float16* ivfm_qfrag = nullptr;  // [IVFM_BLK][d * 64] fragment images
   int *ivfm_thr_c = nullptr, *ivfm_thr_f = nullptr;  // [32 IVFM_BLK] thresholds of the coarse / the list scan
-  unsigned *ivfm_masks = nullptr, *ivfm_off = nullptr, *ivfm_nwork = nullptr;  // [IVFM_BLK][nlist] x 2, [IVFM_BLK + 1] (last: union tiles)
+  unsigned *ivfm_masks = nullptr, *ivfm_off = nullptr, *ivfm_nwork = nullptr;  // nwork: 16 counters (8: union tiles) + masks [IVFM_BLK][nlist] behind them (one allocation); off: unused since the atomic work list
   uint4* ivfm_work = nullptr;      // [IVFM_BLK][ivfm_stride]
   unsigned ivfm_stride = 0;
   float* ivfm_scores = nullptr;    // [32 IVFM_BLK, nlist] coarse scores of one pass
@@ -403,7 +404,6 @@ extern "C" void knnx_destroy(knnx_index* ix) {
   hipFree(ix->ivfm_qfrag);
   hipFree(ix->ivfm_thr_c);
   hipFree(ix->ivfm_thr_f);
-  hipFree(ix->ivfm_masks);
   hipFree(ix->ivfm_off);
   hipFree(ix->ivfm_nwork);
   hipFree(ix->ivfm_work);
@@ -683,9 +683,10 @@ static int ivfm_alloc(knnx_index* ix) {
     e = hipMalloc(&ix->ivfm_qfrag, (size_t)IVFM_BLK * ix->d * 128);
     if (e == hipSuccess) e = hipMalloc(&ix->ivfm_thr_c, (size_t)IVFM_BLK * 32 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&ix->ivfm_thr_f, (size_t)IVFM_BLK * 32 * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_masks, (size_t)IVFM_BLK * nl * sizeof(unsigned));
+    // (the tile counters sit in the 16 words in front of the masks: one memset clears both, knn_kernels.hip launch_ivf_worklist*)
+    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_nwork, ((size_t)IVFM_BLK * nl + 16) * sizeof(unsigned));
+    if (e == hipSuccess) ix->ivfm_masks = ix->ivfm_nwork + 16;
     if (e == hipSuccess) e = hipMalloc(&ix->ivfm_off, (size_t)IVFM_BLK * nl * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMalloc(&ix->ivfm_nwork, (size_t)(IVFM_BLK + 1) * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&ix->ivfm_work, (size_t)IVFM_BLK * tiles * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc(&ix->ivfm_scores, (size_t)IVFM_BLK * 32 * nl * sizeof(float));
   }
@@ -694,7 +695,7 @@ static int ivfm_alloc(knnx_index* ix) {
   hipFree(ix->ivfm_qfrag); ix->ivfm_qfrag = nullptr;
   hipFree(ix->ivfm_thr_c); ix->ivfm_thr_c = nullptr;
   hipFree(ix->ivfm_thr_f); ix->ivfm_thr_f = nullptr;
-  hipFree(ix->ivfm_masks); ix->ivfm_masks = nullptr;
+  ix->ivfm_masks = nullptr;  // (inside the ivfm_nwork allocation)
   hipFree(ix->ivfm_off); ix->ivfm_off = nullptr;
   hipFree(ix->ivfm_nwork); ix->ivfm_nwork = nullptr;
   hipFree(ix->ivfm_work); ix->ivfm_work = nullptr;
@@ -766,6 +767,7 @@ static int scan_topk_ivf_multi(knnx_index* ix, const float* q_dev, int nq, int k
   HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, grid - nblk + 1, KNN_NQ, k, nq, k, ix->id_base, ix->ivf_idmap, D_out, I_out,
                           nullptr, st, KNN_NQ, ix->ivfm_nwork, nblk, grid));
   ix->ivfm_last_blk = nblk;
+  ix->ivfm_union_valid = ix->prof;
   return 0;
 }
 
@@ -2671,6 +2673,7 @@ extern "C" int knnx_ivf_last_scan_union_tiles(knnx_index* ix, int64_t* tiles) {
     std::lock_guard<std::mutex> lk(ix->mu);
     if (!ix->ivf_nlist) return fail(KNNX_E_STATE, "not an IVF index");
     if (ix->ivfm_last_blk > 0) {
+      if (!ix->ivfm_union_valid) return fail(KNNX_E_STATE, "the union of the lists is counted only while profiling is enabled (knnx_profile_enable)");
       if (set_dev(ix)) return KNNX_E_HIP;
       HIPCHK(hipStreamSynchronize(ix->stream));
       unsigned n = 0;
