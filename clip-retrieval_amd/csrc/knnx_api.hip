@@ -888,8 +888,9 @@ static int rq_alloc(knnx_index* ix) {
 }
 // thresholds of a register-stationary pass: the 64-query scan over every S-th tile, S = min(stride_cap, tiles / 4096); the J-th best
 // sample score of query q -> ix->rq_samp[q * KNN_WIDE_KW + J - 1] (knn_kernels.h: KNN_RQ_STRIDE).  Returns S and J through the pointers.
+// hits_target > 0: J = hits_target / S (>= 6) instead of the rule above -- the threshold that leaves ~hits_target rows of the index above it
 static int rq_sample_pass(knnx_index* ix, const float* q_dev, int nq, int k, int stride_cap, hipStream_t st, int* tstride_out, int* J_out,
-                          bool* wide_samp_out) {
+                          bool* wide_samp_out, int hits_target = 0) {
   const int d = ix->d;
   const int64_t ntiles = (ix->ntotal + 31) / 32;
   const int tstride = (int)std::max<int64_t>(1, std::min<int64_t>(stride_cap, ntiles / 4096));
@@ -911,7 +912,8 @@ static int rq_sample_pass(knnx_index* ix, const float* q_dev, int nq, int k, int
     // only the J-th best sample score of a query is used: the queues keep J entries (>= 8), not 64 -- their thresholds rise sooner and
     // the cold-queue pruning that makes up most of this scan's time (see above) ends sooner
     const int jf0 = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
-    const int Jq = tstride <= 128 ? jf0 : std::max(6, std::min(jf0, (jf0 * 128 + tstride - 1) / tstride));
+    const int Jq = hits_target > 0 ? std::max(6, std::min(jf0, (hits_target + tstride - 1) / tstride))
+                                   : (tstride <= 128 ? jf0 : std::max(6, std::min(jf0, (jf0 * 128 + tstride - 1) / tstride)));
     const int ks = std::min(KNN_WIDE_KW, std::max(8, Jq));
     if (grid <= ix->n_cu) {
       HIPCHK(launch_prep_blocks(q_dev, nq, d, ix->rq_m_qfrag, ix->rq_m_thr, nullptr, st, wide_samp ? 1 : 0));
@@ -935,9 +937,8 @@ static int rq_sample_pass(knnx_index* ix, const float* q_dev, int nq, int k, int
       HIPCHK(launch_scan(a, st));
       HIPCHK(launch_merge_u32(ix->part_s, ix->part_i, ix->part_n, grid / ngroups, gsz, ks, nq, KNN_WIDE_KW, 0, nullptr, ix->rq_samp,
                               ix->rq_samp_i, nullptr, st, gsz));  // (rows of 64 with the entries past ks padded: the preps read entry J - 1)
-      const int jf = std::min(KNN_WIDE_KW, k + KNN_RQ_MARGIN);
       *tstride_out = tstride;
-      *J_out = tstride <= 128 ? jf : std::max(6, std::min(jf, (jf * 128 + tstride - 1) / tstride));
+      *J_out = Jq;
       *wide_samp_out = wide_samp;
       return 0;
     }
@@ -1163,7 +1164,18 @@ static int scan_topk_i8(knnx_index* ix, const float* q_dev, int nq, int k, float
   // side by side cost ~3 ms of a 25 ms batch, so the threshold comes in two levels -- the coarse exact sample of the fp16 path (every
   // 763rd tile), then an int8 pass over every 32nd tile with THAT threshold (one pass for all the queries: 2.4 GB), whose hits are
   // re-scored exactly; their J-th best score is the threshold of the pass over everything.
-  const bool two_level = nq > KNN_NQ_MAX && ntiles >= (int64_t)4096 * KNN_I8_STRIDE;
+  bool two_level = nq > KNN_NQ_MAX && ntiles >= (int64_t)4096 * KNN_I8_STRIDE;
+  // KNNX_I8_ONE_LEVEL=S (round 6 experiment, OFF by default): ONE exact sample over every S-th tile with J = 1536 / S instead of the two
+  // levels -- the same expected number of index rows above the threshold (J S = 48 x 32) from one scan instead of scan + int8 sample
+  // pass + re-score + merge + second prep.  S = 256 (J = 6): 20.2 against 21.3 ms per 256-query batch on the isotropic 100 M x 768 index,
+  // same ids and scores -- and 175 ms with 39 fallbacks on the corpus with dominant columns (profiles/r06af_*): the J-th best of a sparse
+  // sample is a NOISY threshold (S x Gamma(6): +-41 %), and where the score density near it is steep a threshold one sigma low admits
+  // several times the rows; the second level's threshold (48th best of a 1/32 sample: +-14 %) is what keeps the hit lists bounded.
+  static const int one_level = [] { const char* e = getenv("KNNX_I8_ONE_LEVEL"); return e ? atoi(e) : 0; }();
+  if (two_level && one_level > 0 && ix->sample_one_launch) {
+    two_level = false;
+    r = rq_sample_pass(ix, q_dev, nq, k, one_level, st, &tstride, &J, &wide_samp, 1536);
+  } else
   r = rq_sample_pass(ix, q_dev, nq, k, two_level ? KNN_RQ_STRIDE : KNN_I8_STRIDE, st, &tstride, &J, &wide_samp);
   if (r) return r;
   float* thr_rest = nrest > 0 ? ix->rq_thr : nullptr;

@@ -25,6 +25,11 @@ def run(rows, B):
     for _ in range(5):
         ix.search(q, 40)
     print(f"B={B}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms per batch, {B * 5 / (time.perf_counter() - t0):.1f} QPS", flush=True)
+    if os.environ.get("KNN_TRACE_SAVE"):  # the ids / scores of the batch, for a comparison between two settings of a switch
+        D, I = ix.search(q, 40)
+        np.save(os.environ["KNN_TRACE_SAVE"] + "_I.npy", I)
+        np.save(os.environ["KNN_TRACE_SAVE"] + "_D.npy", D)
+        print("stats (proof-served, fallbacks):", ix.stats(), flush=True)
     ix.close()
 
 
