@@ -670,7 +670,8 @@ constexpr int IVFM_BLK = 8;
 
 static bool ivfm_usable(const knnx_index* ix, int nq, int k) {
   // (any batch size since the coarse quantiser of this pass is the score dump + radix select: at 32 queries and fewer it is one block)
-  return ix->ivf_nlist && ix->ivfm_ok && ix->cent && nq >= 1 && k <= KNNX_MAX_K_FAST && scan_cap(ix->d, k) > 0;
+  // (n_cu >= IVFM_BLK: every block needs a workgroup of its own, and the partial-list arrays hold n_cu slots -- KNNX_GRID can set fewer)
+  return ix->ivf_nlist && ix->ivfm_ok && ix->cent && nq >= 1 && k <= KNNX_MAX_K_FAST && scan_cap(ix->d, k) > 0 && ix->n_cu >= IVFM_BLK;
 }
 
 // 0: buffers are there; 1: not available (the caller falls back to the 32-query passes; ivfm_ok is cleared)
@@ -907,7 +908,7 @@ static int rq_sample_pass(knnx_index* ix, const float* q_dev, int nq, int k, int
   // one stream each -- four streams only run side by side while the runtime has four hardware queues to give them: in
   // profiles/r06r_knn_b256_timeline.log the fourth scan starts when the first three have finished (0.5 ms of a 256-query batch).
   // KNNX_SAMPLE_STREAMS=1 keeps the streams.
-  if (ngroups > 1 && ix->sample_one_launch && ngroups <= KNN_RQ_MAX / KNN_NQ) {
+  if (ngroups > 1 && ix->sample_one_launch && ngroups <= KNN_RQ_MAX / KNN_NQ && ix->n_cu >= ngroups) {
     const int grid = std::max(1, ix->n_cu / ngroups) * ngroups;
     // only the J-th best sample score of a query is used: the queues keep J entries (>= 8), not 64 -- their thresholds rise sooner and
     // the cold-queue pruning that makes up most of this scan's time (see above) ends sooner
