@@ -1080,30 +1080,63 @@ __global__ void ivf_mark_kernel(const int64_t* __restrict__ Ic, int nq, int npro
   if (l >= 0 && l < nlist) atomicOr(&masks[(size_t)(qi >> 5) * nlist + l], 1u << (qi & 31));
 }
 
-// Work list of a query block (blockIdx.y): a thread looks at one list, and the WAVE writes the tiles of each probed list among its 64
-// (lane t -> tile t, t + 64, ..: whole lines of the work list) at a position it takes from the block's tile counter with ONE atomic
-// per probed list -- nwork[b], zeroed by the launcher, ends as the length of the list.  The order of the lists in the work list is
-// whatever order the atomics retire in: the scan's result does not depend on it (exact top-k, ties by id).  (Rounds 3 - 5: a prefix
-// sum over all lists -- a single-workgroup kernel of 60 - 150 us for 65 536 lists -- then one workgroup per list, 30 us.)
+// Work list of a query block b (blockIdx.y), SORTED (list order = arena order: the workgroups of a scan then walk neighbouring tiles at
+// the same time -- 3 - 5 % on the long scans against an arbitrary order), in two small kernels and no scan over all lists:
+//   ivf_wgsum_kernel   workgroup w of block b: the tiles of the probed lists among its 256 -> wgsum[b][w]
+//   ivf_expand_kernel  workgroup w: base = sum of wgsum[b][0 .. w) (every workgroup adds them up itself: a few hundred words), position
+//                      of a list = base + the exclusive prefix inside the workgroup (shuffles + the four wave totals); then the WAVE
+//                      writes the tiles of each probed list among its 64 (lane t -> tile t, t + 64, ..: whole lines of the work list);
+//                      the last workgroup leaves the length of the list in nwork[b].
+// (Rounds 3 - 5: a single-workgroup prefix sum over all 65 536 lists, 57 - 180 us in four variants, + one workgroup per list, 30 us;
+// one atomic per probed list on the block's tile counter: 15 us at 512 probed lists, 50 us at 2 048, and an arbitrary order.)
+__global__ __launch_bounds__(256) void ivf_wgsum_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ ntile, int nlist,
+                                                       unsigned* __restrict__ wgsum) {
+  __shared__ unsigned ws[4];
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  const size_t b = blockIdx.y;
+  unsigned v = (l < nlist && masks[b * nlist + l]) ? ntile[l] : 0u;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) wgsum[b * gridDim.x + blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
 __global__ __launch_bounds__(256) void ivf_expand_kernel(const unsigned* __restrict__ masks, const unsigned* __restrict__ tile0,
                                                         const unsigned* __restrict__ ntile, const unsigned* __restrict__ size,
                                                         unsigned* __restrict__ nwork, uint4* __restrict__ work,
-                                                        unsigned work_stride, int nlist) {
-  const int l = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+                                                        unsigned work_stride, int nlist, const unsigned* __restrict__ wgsum) {
+  __shared__ unsigned red[4], wtot[4];
+  const int l = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t b = blockIdx.y;
   const unsigned m = l < nlist ? masks[b * nlist + l] : 0u;
-  unsigned long long probed = __ballot(m != 0u);
-  if (probed == 0ull) return;
   const unsigned nt = m ? ntile[l] : 0u, t0 = m ? tile0[l] : 0u, sz = m ? size[l] : 0u;
+  // tiles in front of this workgroup
+  unsigned part = 0;
+  for (unsigned i = threadIdx.x; i < blockIdx.x; i += 256) part += wgsum[b * gridDim.x + i];
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  // exclusive prefix of the tiles inside the workgroup
+  unsigned inc = nt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned y = __shfl_up(inc, o);
+    if (lane >= o) inc += y;
+  }
+  if (lane == 0) red[wv] = part;
+  if (lane == 63) wtot[wv] = inc;
+  __syncthreads();
+  const unsigned base = red[0] + red[1] + red[2] + red[3];
+  unsigned before = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) before += i < wv ? wtot[i] : 0u;
+  const unsigned o = base + before + inc - nt;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) nwork[b] = o + nt;
+  unsigned long long probed = __ballot(m != 0u);
   work += b * work_stride;
   while (probed) {
     const int src = __ffsll((long long)probed) - 1;
     probed &= probed - 1;
     const unsigned mm = (unsigned)__shfl((int)m, src), nn = (unsigned)__shfl((int)nt, src), tt = (unsigned)__shfl((int)t0, src),
-                   ss = (unsigned)__shfl((int)sz, src);
-    unsigned oo = 0;
-    if (lane == 0) oo = atomicAdd(&nwork[b], nn);
-    oo = (unsigned)__shfl((int)oo, 0);
+                   ss = (unsigned)__shfl((int)sz, src), oo = (unsigned)__shfl((int)o, src);
     for (unsigned t = lane; t < nn; t += 64) {
       const unsigned valid = (t + 1 < nn) ? 32u : ss - 32u * (nn - 1);
       work[oo + t] = make_uint4(tt + t, mm, valid, 0u);
@@ -1332,17 +1365,12 @@ hipError_t launch_ivf_worklist_from_scores(const float* scores, int nq, int npro
                                            const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
                                            hipStream_t st, unsigned work_stride) {
   const int nblk = (nq + 31) / 32;
-  hipError_t e;
-  if (nwork + 16 == masks) {  // (the counters sit right in front of the masks: one fill)
-    e = hipMemsetAsync(nwork, 0, ((size_t)nblk * nlist + 16) * sizeof(unsigned), st);
-  } else {
-    e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
-    if (e == hipSuccess) e = hipMemsetAsync(nwork, 0, (size_t)nblk * sizeof(unsigned), st);
-  }
+  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);  // (nwork is written by ivf_expand_kernel)
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_select_mark_kernel, dim3(nq), dim3(1024), 0, st, scores, nlist, nprobe, masks);
-  (void)off;  // (the per-list offsets of rounds 3 - 5: positions now come from the blocks' tile counters, ivf_expand_kernel)
-  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, nwork, work, work_stride, nlist);
+  // (`off` [nblk][nlist] holds the per-workgroup tile sums: [nblk][ceil(nlist / 256)] of it)
+  hipLaunchKernelGGL(ivf_wgsum_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, ntile, nlist, off);
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, nwork, work, work_stride, nlist, off);
   return hipGetLastError();
 }
 
@@ -1350,17 +1378,12 @@ hipError_t launch_ivf_worklist(const int64_t* Ic, int nq, int nprobe, int nlist,
                                const unsigned* ntile, const unsigned* size, unsigned* off, uint4* work, unsigned* nwork,
                                hipStream_t st, unsigned work_stride) {
   const int nblk = (nq + 31) / 32;
-  hipError_t e;
-  if (nwork + 16 == masks) {  // (the counters sit right in front of the masks: one fill)
-    e = hipMemsetAsync(nwork, 0, ((size_t)nblk * nlist + 16) * sizeof(unsigned), st);
-  } else {
-    e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);
-    if (e == hipSuccess) e = hipMemsetAsync(nwork, 0, (size_t)nblk * sizeof(unsigned), st);
-  }
+  hipError_t e = hipMemsetAsync(masks, 0, (size_t)nblk * nlist * sizeof(unsigned), st);  // (nwork is written by ivf_expand_kernel)
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ivf_mark_kernel, dim3((nq * nprobe + 255) / 256), dim3(256), 0, st, Ic, nq, nprobe, nlist, masks);
-  (void)off;  // (the per-list offsets of rounds 3 - 5: positions now come from the blocks' tile counters, ivf_expand_kernel)
-  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, nwork, work, work_stride, nlist);
+  // (`off` [nblk][nlist] holds the per-workgroup tile sums: [nblk][ceil(nlist / 256)] of it)
+  hipLaunchKernelGGL(ivf_wgsum_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, ntile, nlist, off);
+  hipLaunchKernelGGL(ivf_expand_kernel, dim3((nlist + 255) / 256, nblk), dim3(256), 0, st, masks, tile0, ntile, size, nwork, work, work_stride, nlist, off);
   return hipGetLastError();
 }
 // tiles of the lists at least one of the nblk query blocks probes -> *out
